@@ -1,0 +1,731 @@
+/*
+ * refnerf_oracle.c -- CPU restatement of the Ref-NeRF rendering inner loop.
+ *
+ * TEST INFRASTRUCTURE ONLY (see refnerf_oracle.h).  Parity status: PINNED by
+ * tests/golden/*.npz (captured from the upstream reference in the build
+ * container by tests/golden/make_golden.py).
+ *
+ * Reference citations are file:line relative to the upstream repo root.
+ * fp32 IEEE arithmetic in the reference's operation order; compile with
+ *   gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC
+ */
+#include "refnerf_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define EPS32 1.1920928955078125e-07f /* torch.finfo(float32).eps */
+
+/* ------------------------------------------------------------------ */
+/* parameter blob layout = state_dict order (models.py:497-531)       */
+/* ------------------------------------------------------------------ */
+void rn_param_layout(rn_param_offsets *o) {
+  int p = 0;
+  for (int i = 0; i < RN_DEPTH; ++i) {
+    int in = (i == 0) ? RN_IPE_DIM
+                      : ((i - 1) % RN_SKIP == 0 && (i - 1) > 0 ? RN_WIDTH + RN_IPE_DIM
+                                                               : RN_WIDTH);
+    o->sp_in[i] = in;
+    o->sp_w[i] = p; p += RN_WIDTH * in;
+    o->sp_b[i] = p; p += RN_WIDTH;
+  }
+  o->density_w = p; p += RN_WIDTH;      o->density_b = p; p += 1;
+  o->gradpred_w = p; p += 3 * RN_WIDTH; o->gradpred_b = p; p += 3;
+  o->rough_w = p; p += RN_WIDTH;        o->rough_b = p; p += 1;
+  o->diffuse_w = p; p += 3 * RN_WIDTH;  o->diffuse_b = p; p += 3;
+  o->tint_w = p; p += 3 * RN_WIDTH;     o->tint_b = p; p += 3;
+  o->bneck_w = p; p += RN_BNECK * RN_WIDTH; o->bneck_b = p; p += RN_BNECK;
+  for (int i = 0; i < RN_DEPTH; ++i) {
+    int in = (i == 0) ? RN_DIR_IN
+                      : ((i - 1) % RN_SKIP == 0 && (i - 1) > 0 ? RN_WIDTH + RN_DIR_IN
+                                                               : RN_WIDTH);
+    o->vd_in[i] = in;
+    o->vd_w[i] = p; p += RN_WIDTH * in;
+    o->vd_b[i] = p; p += RN_WIDTH;
+  }
+  o->rgb_w = p; p += 3 * RN_WIDTH; o->rgb_b = p; p += 3;
+  o->total = p;
+}
+
+void rn_level_cfg_default(rn_level_cfg *c) {
+  memset(c, 0, sizeof(*c));
+  c->n_samples = 128; c->n_in = 1;
+  c->training = 0; c->compute_extras = 1;
+  c->srgb_mapping = 1; c->srgb_mapping_normalization = 1;
+  c->render_srgb_mode = RN_SRGB_NONE;
+  c->opaque_background = 0; c->ray_shape = 0; c->ide_mode = 0;
+  c->anneal = 1.0f; c->resample_padding = 0.01f;
+  c->s_near = 0.0f; c->s_far = 1.0f;
+  c->density_bias = 0.5f; c->roughness_bias = -1.0f;
+  c->rgb_premultiplier = 1.0f; c->rgb_bias = 0.0f; c->rgb_padding = 0.001f;
+  c->bg_rgb = 1.0f;
+}
+
+/* ------------------------------------------------------------------ */
+/* sampler                                                            */
+/* ------------------------------------------------------------------ */
+
+/* torch.linspace(start, end, n) for float32 (ATen RangeFactories: step in
+ * fp32, symmetric fill, fused multiply-add) as used by stepfun.py:199-204:
+ *   pad = 1/(2N); u = linspace(pad, 1 - pad - eps, N). */
+void rn_linspace_u(int n, float *u) {
+  double pad = 1.0 / (2.0 * n);
+  float start = (float)pad;
+  float end = (float)(1.0 - pad - (double)EPS32);
+  if (n == 1) { u[0] = start; return; }
+  float step = (end - start) / (float)(n - 1);
+  int half = n / 2;
+  for (int i = 0; i < n; ++i)
+    u[i] = (i < half) ? fmaf(step, (float)i, start)
+                      : fmaf(-step, (float)(n - 1 - i), end);
+}
+
+/* models.py:200-203 */
+void rn_resample_logits(const float *t, const float *w, int M, float anneal,
+                        float padding, float *logits) {
+  for (int i = 0; i < M; ++i)
+    logits[i] = (t[i + 1] > t[i]) ? anneal * logf(w[i] + padding) : -INFINITY;
+}
+
+static float nan_to_num0(float x) { /* torch.nan_to_num(x, 0) */
+  if (isnan(x)) return 0.0f;
+  if (isinf(x)) return x > 0 ? FLT_MAX : -FLT_MAX;
+  return x;
+}
+static float clip01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+/* stepfun.py:209-258 -> sample (168-206) -> invert_cdf (157-165)
+ * -> integrate_weights (134-154) -> math.sorted_interp (math.py:88-111). */
+void rn_sample_intervals(const float *t, const float *w_logits, int M, int N,
+                         float smin, float smax, float *sdist, int32_t *bin_idx) {
+  float *p = (float *)malloc(sizeof(float) * (size_t)(M + (M + 1) + N + N));
+  float *cw = p + M, *u = cw + (M + 1), *c = u + N;
+  /* softmax (stepfun.py:160) */
+  float mx = -INFINITY;
+  for (int i = 0; i < M; ++i) mx = fmaxf(mx, w_logits[i]);
+  float sum = 0.0f;
+  for (int i = 0; i < M; ++i) { p[i] = expf(w_logits[i] - mx); sum += p[i]; }
+  for (int i = 0; i < M; ++i) p[i] = p[i] / sum;
+  /* integrate_weights: cw = [0, min(1, cumsum(w[:-1])), 1]; torch.cumsum on
+   * CPU accumulates float in double (at::acc_type<float,false>). */
+  cw[0] = 0.0f;
+  double acc = 0.0;
+  for (int i = 0; i < M - 1; ++i) {
+    acc += (double)p[i];
+    cw[i + 1] = fminf(1.0f, (float)acc);
+  }
+  cw[M] = 1.0f;
+  rn_linspace_u(N, u);
+  /* sorted_interp: for each u find the bracketing CDF knots by value. */
+  for (int k = 0; k < N; ++k) {
+    float x = u[k];
+    int lo = -1;
+    for (int j = 0; j <= M; ++j) if (x >= cw[j]) lo = j;  /* mask is monotone */
+    float xp0, fp0, xp1, fp1;
+    /* max over masked entries, default element 0 */
+    xp0 = cw[0]; fp0 = t[0];
+    for (int j = 0; j <= M; ++j) if (x >= cw[j]) { xp0 = fmaxf(xp0, cw[j]); fp0 = fmaxf(fp0, t[j]); }
+    xp1 = cw[M]; fp1 = t[M];
+    for (int j = 0; j <= M; ++j) if (!(x >= cw[j])) { xp1 = fminf(xp1, cw[j]); fp1 = fminf(fp1, t[j]); }
+    float off = clip01(nan_to_num0((x - xp0) / (xp1 - xp0)));
+    c[k] = fp0 + off * (fp1 - fp0);
+    if (bin_idx) bin_idx[k] = lo < 0 ? 0 : lo;
+  }
+  /* stepfun.py:247-257: midpoints + reflected, clamped end fenceposts */
+  for (int k = 0; k < N - 1; ++k) sdist[k + 1] = (c[k + 1] + c[k]) / 2.0f;
+  sdist[0] = fmaxf(smin, 2.0f * c[0] - sdist[1]);
+  sdist[N] = fminf(smax, 2.0f * c[N - 1] - sdist[N - 1]);
+  free(p);
+}
+
+/* coord.py:96-98 (fn=None): t = s*far + (1-s)*near */
+float rn_s_to_t(float s, float near, float far) {
+  float a = s * far;
+  float b = (1.0f - s) * near;
+  return a + b;
+}
+
+/* ------------------------------------------------------------------ */
+/* ray casting                                                        */
+/* ------------------------------------------------------------------ */
+
+/* render.py:105-129 (cast_rays) -> 46-80 (conical_frustum_to_gaussian,
+ * stable) / 83-102 (cylinder) -> 22-43 (lift_gaussian, diag=False), then
+ * coord.py:129-133 (lift_and_diagonalize) with the octahedron/1 basis
+ * pos_basis_t = [[0,0,-1],[0,-1,0],[-1,0,0]] (geopoly.py:78-123), which makes
+ * lifted mean = (-z,-y,-x) and lifted var = (C_zz, C_yy, C_xx) exactly. */
+void rn_cast_sample(const float *o, const float *d, float radius, float t0,
+                    float t1, int ray_shape, float *lmean, float *lvar,
+                    float *mean_xyz) {
+  float t_mean, t_var, r_var;
+  if (ray_shape == 0) {
+    float mu = (t0 + t1) / 2.0f;
+    float hw = (t1 - t0) / 2.0f;
+    float hw2 = hw * hw, mu2 = mu * mu;
+    float den = fmaxf(EPS32, 3.0f * mu2 + hw2);
+    t_mean = mu + ((2.0f * mu) * hw2) / den;
+    /* hw**4 is torch.pow(x, 4) (Sleef powf, <=1 ulp); use the correctly
+     * rounded value. */
+    float hw4 = (float)((double)hw * (double)hw * (double)hw * (double)hw);
+    float c415 = (float)(4.0 / 15.0);
+    t_var = hw2 / 3.0f - ((c415 * hw4) * (12.0f * mu2 - hw2)) / (den * den);
+    r_var = (mu2 / 4.0f + (float)(5.0 / 12.0) * hw2) - (c415 * hw4) / den;
+    r_var = r_var * (radius * radius);
+  } else {
+    t_mean = (t0 + t1) / 2.0f;
+    r_var = (radius * radius) / 4.0f;
+    float dt = t1 - t0;
+    t_var = (dt * dt) / 12.0f;
+  }
+  float dms = fmaxf(1e-10f, (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+  float mean[3], cov_diag[3];
+  for (int i = 0; i < 3; ++i) {
+    mean[i] = d[i] * t_mean + o[i];
+    float d_outer = d[i] * d[i];
+    float null_outer = 1.0f - d[i] * (d[i] / dms);
+    cov_diag[i] = t_var * d_outer + r_var * null_outer;
+  }
+  lmean[0] = -mean[2]; lmean[1] = -mean[1]; lmean[2] = -mean[0];
+  lvar[0] = cov_diag[2]; lvar[1] = cov_diag[1]; lvar[2] = cov_diag[0];
+  if (mean_xyz) { mean_xyz[0] = mean[0]; mean_xyz[1] = mean[1]; mean_xyz[2] = mean[2]; }
+}
+
+/* math.py:22-34: sin(where(|x| < 100pi, x, x % 100pi)); torch `%` is the
+ * floored remainder, with the scalar cast to fp32. */
+static float safe_arg(float x) {
+  const float T = (float)(100.0 * M_PI);
+  if (fabsf(x) < T) return x;
+  float m = fmodf(x, T);
+  if (m != 0.0f && (m < 0.0f)) m += T;
+  return m;
+}
+
+/* coord.py:107-126 (integrated_pos_enc, min_deg=0, max_deg=16) + 102-104. */
+void rn_ipe(const float *lmean, const float *lvar, float *feat) {
+  const float HALF_PI = (float)(0.5 * M_PI);
+  for (int j = 0; j < RN_IPE_DEG; ++j) {
+    float sc = ldexpf(1.0f, j), sc2 = ldexpf(1.0f, 2 * j);
+    for (int b = 0; b < 3; ++b) {
+      float x = lmean[b] * sc;
+      float s = lvar[b] * sc2;
+      float e = expf(-0.5f * s);
+      feat[j * 3 + b] = e * sinf(safe_arg(x));
+      feat[48 + j * 3 + b] = e * sinf(safe_arg(x + HALF_PI));
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* integrated directional encoding                                    */
+/* ------------------------------------------------------------------ */
+
+static const int IDE_L[5] = {1, 2, 4, 8, 16};
+
+static double fact(int n) { double r = 1; for (int i = 2; i <= n; ++i) r *= i; return r; }
+
+/* ref_utils.py:53-81 */
+static double sph_harm_coeff(int l, int m, int k) {
+  double a = 0.5 * (l + k + m - 1.0);
+  double gb = 1.0;
+  for (int i = 0; i < l; ++i) gb *= (a - i);
+  gb /= fact(l);
+  double al = ((m & 1) ? -1.0 : 1.0) * pow(2.0, l) * fact(l) / fact(k) / fact(l - k - m) * gb;
+  return sqrt((2.0 * l + 1.0) * fact(l - m) / (4.0 * M_PI * fact(l + m))) * al;
+}
+
+/* ref_utils.py:98-161 evaluated in float64 (the "truth" used to gate both the
+ * reference's and the build's fp32 rounding error). */
+void rn_ide_f64(const double *xyz, double kappa_inv, double *out) {
+  double x = xyz[0], y = xyz[1], z = xyz[2];
+  double zp[17]; zp[0] = 1; for (int i = 1; i <= 16; ++i) zp[i] = zp[i - 1] * z;
+  double pr[17], pi[17]; pr[0] = 1; pi[0] = 0;
+  for (int m = 1; m <= 16; ++m) { pr[m] = pr[m - 1] * x - pi[m - 1] * y; pi[m] = pr[m - 1] * y + pi[m - 1] * x; }
+  int idx = 0;
+  for (int li = 0; li < 5; ++li) {
+    int l = IDE_L[li];
+    double att = exp(-0.5 * l * (l + 1) * kappa_inv);
+    for (int m = 0; m <= l; ++m, ++idx) {
+      double s = 0;
+      for (int k = 0; k <= l - m; ++k) s += zp[k] * sph_harm_coeff(l, m, k);
+      out[idx] = pr[m] * s * att;
+      out[RN_IDE_TERMS + idx] = pi[m] * s * att;
+    }
+  }
+}
+
+/* Reference-order fp32 evaluation: monomial Vandermonde in z times the fp32
+ * coefficient matrix (ref_utils.py:117-151), complex64 powers of (x+iy).
+ * Used only to pin the oracle against the golden IDE vectors. */
+void rn_ide_ref_f32(const float *xyz, float kappa_inv, float *out) {
+  static float mat[17][RN_IDE_TERMS];
+  static int init = 0;
+  if (!init) {
+    memset(mat, 0, sizeof(mat));
+    int idx = 0;
+    for (int li = 0; li < 5; ++li) for (int m = 0; m <= IDE_L[li]; ++m, ++idx)
+      for (int k = 0; k <= IDE_L[li] - m; ++k) mat[k][idx] = (float)sph_harm_coeff(IDE_L[li], m, k);
+    init = 1;
+  }
+  float x = xyz[0], y = xyz[1], z = xyz[2];
+  float zp[17];
+  for (int i = 0; i <= 16; ++i) zp[i] = (i == 0) ? 1.0f : (i == 1 ? z : (i == 2 ? z * z : (i == 3 ? z * z * z : powf(z, (float)i))));
+  float pr[17], pi[17]; pr[0] = 1; pi[0] = 0;
+  for (int m = 1; m <= 16; ++m) { pr[m] = pr[m - 1] * x - pi[m - 1] * y; pi[m] = pr[m - 1] * y + pi[m - 1] * x; }
+  int idx = 0;
+  for (int li = 0; li < 5; ++li) {
+    int l = IDE_L[li];
+    float sigma = (float)(0.5 * l * (l + 1));
+    float att = expf(-sigma * kappa_inv);
+    for (int m = 0; m <= l; ++m, ++idx) {
+      float s = 0.0f;
+      for (int k = 0; k <= 16; ++k) s = fmaf(zp[k], mat[k][idx], s);
+      out[idx] = (pr[m] * s) * att;
+      out[RN_IDE_TERMS + idx] = (pi[m] * s) * att;
+    }
+  }
+}
+
+/* Stable fp32 evaluation of the SAME polynomials (documented deviation from
+ * the reference's evaluation ORDER, not from its function -- SURVEY.md H2):
+ * T_l^m(z) = sum_k z^k mat[k,(l,m)] obeys the fully-normalised Legendre
+ * three-term recurrence
+ *   T_m^m = c_m,  T_l^m = a_lm * (z*T_{l-1}^m - b_lm*T_{l-2}^m)
+ * with a_lm = sqrt((4l^2-1)/(l^2-m^2)), b_lm = sqrt(((l-1)^2-m^2)/(4(l-1)^2-1)).
+ * Tables: tab_c[17], tab_a[17][17], tab_b[17][17] (double -> fp32). */
+static float g_ide_c[17], g_ide_a[17][17], g_ide_b[17][17];
+static int g_ide_init = 0;
+void rn_ide_tables(float *c, float *a, float *b) {
+  for (int m = 0; m <= 16; ++m) {
+    /* c_m = (-1)^m sqrt((2m+1)/(4pi (2m)!)) (2m-1)!! */
+    double df = 1; for (int i = 1; i <= m; ++i) df *= (2 * i - 1);
+    double cm = ((m & 1) ? -1.0 : 1.0) * sqrt((2.0 * m + 1.0) / (4.0 * M_PI * fact(2 * m))) * df;
+    c[m] = (float)cm;
+    for (int l = 0; l <= 16; ++l) {
+      a[m * 17 + l] = 0; b[m * 17 + l] = 0;
+      if (l > m) {
+        a[m * 17 + l] = (float)sqrt((4.0 * l * l - 1.0) / ((double)l * l - (double)m * m));
+        if (l > m + 1)
+          b[m * 17 + l] = (float)sqrt((((double)l - 1) * (l - 1) - (double)m * m) / (4.0 * (l - 1.0) * (l - 1.0) - 1.0));
+      }
+    }
+  }
+}
+static int ide_term_index(int l, int m) { /* position of (l,m) in the 36-list */
+  int base = 0;
+  for (int li = 0; li < 5; ++li) { if (IDE_L[li] == l) return base + m; base += IDE_L[li] + 1; }
+  return -1;
+}
+void rn_ide_stable_f32(const float *xyz, float kappa_inv, float *out) {
+  if (!g_ide_init) { rn_ide_tables(g_ide_c, &g_ide_a[0][0], &g_ide_b[0][0]); g_ide_init = 1; }
+  float x = xyz[0], y = xyz[1], z = xyz[2];
+  float att[17];
+  for (int li = 0; li < 5; ++li) {
+    int l = IDE_L[li];
+    att[l] = expf(-(float)(0.5 * l * (l + 1)) * kappa_inv);
+  }
+  float pr = 1.0f, pi = 0.0f;
+  for (int m = 0; m <= 16; ++m) {
+    if (m > 0) { float nr = pr * x - pi * y; float ni = pr * y + pi * x; pr = nr; pi = ni; }
+    float tm2 = 0.0f, tm1 = g_ide_c[m]; /* T_{l-2}, T_{l-1} with l-1 = m */
+    for (int l = m; l <= 16; ++l) {
+      float tl;
+      if (l == m) tl = g_ide_c[m];
+      else { tl = g_ide_a[m][l] * (z * tm1 - g_ide_b[m][l] * tm2); tm2 = tm1; tm1 = tl; }
+      if (l >= 1 && (l & (l - 1)) == 0) {
+        int idx = ide_term_index(l, m);
+        float s = tl * att[l];
+        out[idx] = pr * s;
+        out[RN_IDE_TERMS + idx] = pi * s;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* per-sample MLP                                                     */
+/* ------------------------------------------------------------------ */
+
+static float softplus_t(float x) { /* F.softplus beta=1 threshold=20 */
+  return x > 20.0f ? x : log1pf(expf(x));
+}
+static float sigmoid_t(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+/* image.py:51-59 */
+float rn_linear_to_srgb(float x) {
+  float srgb0 = (float)(323.0 / 25.0) * x;
+  float srgb1 = (211.0f * powf(fmaxf(EPS32, x), (float)(5.0 / 12.0)) - 11.0f) / 200.0f;
+  return (x <= 0.0031308f) ? srgb0 : srgb1;
+}
+
+/* ---- dense layers -------------------------------------------------------
+ * y[s][o] = b[o] + sum_k W[o][k] x[s][k] as a k-ordered fmaf chain seeded with
+ * the bias (nn.Linear = addmm(bias, x, W^T)).  Weights are held transposed
+ * ([in][out]) so the chain vectorises across outputs; the per-output
+ * summation order (k ascending, one rounding per fma) is unchanged. */
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#endif
+#define RN_SB 8 /* samples per block */
+
+typedef struct rn_model {
+  rn_param_offsets L;
+  const float *P;    /* canonical blob */
+  float *T;          /* transposed copies, same offsets, [in][out] */
+} rn_model;
+
+static void model_init(rn_model *m, const float *P) {
+  rn_param_layout(&m->L);
+  m->P = P;
+  m->T = (float *)malloc(sizeof(float) * (size_t)m->L.total);
+  memcpy(m->T, P, sizeof(float) * (size_t)m->L.total);
+#define TR(off, out, in) do { for (int o_ = 0; o_ < (out); ++o_) for (int k_ = 0; k_ < (in); ++k_) m->T[(off) + (size_t)k_ * (out) + o_] = P[(off) + (size_t)o_ * (in) + k_]; } while (0)
+  for (int i = 0; i < RN_DEPTH; ++i) { TR(m->L.sp_w[i], RN_WIDTH, m->L.sp_in[i]); TR(m->L.vd_w[i], RN_WIDTH, m->L.vd_in[i]); }
+  TR(m->L.gradpred_w, 3, RN_WIDTH); TR(m->L.diffuse_w, 3, RN_WIDTH); TR(m->L.tint_w, 3, RN_WIDTH);
+  TR(m->L.bneck_w, RN_BNECK, RN_WIDTH); TR(m->L.rgb_w, 3, RN_WIDTH);
+#undef TR
+}
+static void model_free(rn_model *m) { free(m->T); }
+
+/* X: [S][ldx], Y: [S][ldy]; Wt: [in][out]; out multiple of 16 uses AVX2. */
+static void dense_block(const float *Wt, const float *b, const float *X, int ldx, int in,
+                        int out, float *Y, int ldy, int S, int relu) {
+#if defined(__AVX2__) && defined(__FMA__)
+  if (out % 16 == 0) {
+    for (int ob = 0; ob < out; ob += 16) {
+      __m256 a0[RN_SB], a1[RN_SB];
+      __m256 b0 = _mm256_loadu_ps(b + ob), b1 = _mm256_loadu_ps(b + ob + 8);
+      for (int s = 0; s < S; ++s) { a0[s] = b0; a1[s] = b1; }
+      for (int k = 0; k < in; ++k) {
+        __m256 w0 = _mm256_loadu_ps(Wt + (size_t)k * out + ob);
+        __m256 w1 = _mm256_loadu_ps(Wt + (size_t)k * out + ob + 8);
+        for (int s = 0; s < S; ++s) {
+          __m256 xs = _mm256_broadcast_ss(X + (size_t)s * ldx + k);
+          a0[s] = _mm256_fmadd_ps(w0, xs, a0[s]);
+          a1[s] = _mm256_fmadd_ps(w1, xs, a1[s]);
+        }
+      }
+      __m256 z = _mm256_setzero_ps();
+      for (int s = 0; s < S; ++s) {
+        if (relu) { a0[s] = _mm256_max_ps(a0[s], z); a1[s] = _mm256_max_ps(a1[s], z); }
+        _mm256_storeu_ps(Y + (size_t)s * ldy + ob, a0[s]);
+        _mm256_storeu_ps(Y + (size_t)s * ldy + ob + 8, a1[s]);
+      }
+    }
+    return;
+  }
+#endif
+  for (int s = 0; s < S; ++s)
+    for (int o = 0; o < out; ++o) {
+      float a = b[o];
+      for (int k = 0; k < in; ++k) a = fmaf(Wt[(size_t)k * out + o], X[(size_t)s * ldx + k], a);
+      Y[(size_t)s * ldy + o] = relu ? fmaxf(a, 0.0f) : a;
+    }
+}
+
+/* models.py:533-750 for a block of S <= RN_SB samples of one ray (Ref-NeRF flag
+ * set of configs/blender_refnerf.gin:34-52). lmean/lvar: [S][3]. */
+static void mlp_block(const rn_model *M, const rn_level_cfg *cfg, const float *lmean,
+                      const float *lvar, const float *v, int S, rn_sample_out *outs) {
+  const rn_param_offsets *L = &M->L;
+  const float *P = M->P, *T = M->T;
+  enum { LDX = RN_WIDTH + RN_DIR_IN };
+  float ipe[RN_SB][RN_IPE_DIM];
+  float x[RN_SB][LDX], y[RN_SB][RN_WIDTH];
+  static __thread float act[RN_DEPTH][RN_SB][RN_WIDTH];     /* post-ReLU, for the VJP */
+  for (int s = 0; s < S; ++s) {
+    rn_ipe(lmean + 3 * s, lvar + 3 * s, ipe[s]);             /* models.py:566-571 */
+    memcpy(x[s], ipe[s], sizeof(ipe[s]));
+  }
+  for (int i = 0; i < RN_DEPTH; ++i) {                       /* models.py:576-580 */
+    dense_block(T + L->sp_w[i], P + L->sp_b[i], &x[0][0], LDX, L->sp_in[i], RN_WIDTH, &y[0][0], RN_WIDTH, S, 1);
+    for (int s = 0; s < S; ++s) {
+      memcpy(act[i][s], y[s], sizeof(y[s]));
+      memcpy(x[s], y[s], sizeof(y[s]));
+      if (i % RN_SKIP == 0 && i > 0) memcpy(x[s] + RN_WIDTH, ipe[s], sizeof(ipe[s]));
+    }
+  }
+  float bneck[RN_SB][RN_BNECK];
+  dense_block(T + L->bneck_w, P + L->bneck_b, &x[0][0], LDX, RN_WIDTH, RN_BNECK, &bneck[0][0], RN_BNECK, S, 0); /* :645 */
+  for (int s = 0; s < S; ++s) {
+    rn_sample_out *out = &outs[s];
+    float raw_density, gp[3], raw_rough, raw_diff[3], raw_tint[3];
+    dense_block(P + L->density_w, P + L->density_b, x[s], LDX, RN_WIDTH, 1, &raw_density, 1, 1, 0);  /* :582 */
+    dense_block(T + L->gradpred_w, P + L->gradpred_b, x[s], LDX, RN_WIDTH, 3, gp, 3, 1, 0);          /* :613 */
+    dense_block(T + L->diffuse_w, P + L->diffuse_b, x[s], LDX, RN_WIDTH, 3, raw_diff, 3, 1, 0);      /* :634 */
+    dense_block(T + L->tint_w, P + L->tint_b, x[s], LDX, RN_WIDTH, 3, raw_tint, 3, 1, 0);            /* :637 */
+    dense_block(P + L->rough_w, P + L->rough_b, x[s], LDX, RN_WIDTH, 1, &raw_rough, 1, 1, 0);        /* :640 */
+
+    /* density-gradient normals (models.py:603-609), training only: VJP of
+     * sum(raw_density) w.r.t. the (un-lifted) sample mean; detached. */
+    out->normals[0] = out->normals[1] = out->normals[2] = 0.0f;
+    if (cfg->training) {
+      float g[RN_WIDTH + RN_IPE_DIM], gi[RN_WIDTH + RN_IPE_DIM], gipe[RN_IPE_DIM];
+      memset(gipe, 0, sizeof(gipe));
+      for (int k = 0; k < RN_WIDTH; ++k) g[k] = P[L->density_w + k];
+      for (int i = RN_DEPTH - 1; i >= 0; --i) {
+        int in = L->sp_in[i];
+        const float *W = P + L->sp_w[i];
+        for (int k = 0; k < in; ++k) gi[k] = 0.0f;
+        for (int o = 0; o < RN_WIDTH; ++o) {
+          if (!(act[i][s][o] > 0.0f)) continue;              /* relu'(0) = 0 */
+          float go = g[o];
+          const float *w = W + (size_t)o * in;
+          for (int k = 0; k < in; ++k) gi[k] = fmaf(w[k], go, gi[k]);
+        }
+        if (i == 0) { for (int k = 0; k < RN_IPE_DIM; ++k) gipe[k] += gi[k]; }
+        else {
+          if (in > RN_WIDTH) for (int k = 0; k < RN_IPE_DIM; ++k) gipe[k] += gi[RN_WIDTH + k];
+          memcpy(g, gi, sizeof(float) * RN_WIDTH);
+        }
+      }
+      /* through the IPE (coord.py:119-126): d/dx sin(r(x)) = cos(r(x)) */
+      const float HALF_PI = (float)(0.5 * M_PI);
+      float gl[3] = {0, 0, 0};
+      for (int j = 0; j < RN_IPE_DEG; ++j) {
+        float sc = ldexpf(1.0f, j), sc2 = ldexpf(1.0f, 2 * j);
+        for (int b = 0; b < 3; ++b) {
+          float xx = lmean[3 * s + b] * sc;
+          float e = expf(-0.5f * (lvar[3 * s + b] * sc2));
+          gl[b] += ((gipe[j * 3 + b] * e) * cosf(safe_arg(xx))) * sc;
+          gl[b] += ((gipe[48 + j * 3 + b] * e) * cosf(safe_arg(xx + HALF_PI))) * sc;
+        }
+      }
+      float gx[3] = {-gl[2], -gl[1], -gl[0]};                 /* basis^T */
+      float n2g = fmaxf((gx[0] * gx[0] + gx[1] * gx[1]) + gx[2] * gx[2], EPS32);
+      float ng = sqrtf(n2g);
+      for (int i = 0; i < 3; ++i) out->normals[i] = -(gx[i] / ng);
+    }
+
+    /* models.py:611-616 */
+    float n2 = fmaxf((gp[0] * gp[0] + gp[1] * gp[1]) + gp[2] * gp[2], EPS32);
+    float nrm = sqrtf(n2);
+    float np_[3];
+    for (int i = 0; i < 3; ++i) { np_[i] = -(gp[i] / nrm); out->normals_pred[i] = np_[i]; out->grad_pred[i] = gp[i]; }
+    out->density = softplus_t(raw_density + cfg->density_bias);                  /* :623 */
+    for (int i = 0; i < 3; ++i) out->tint[i] = sigmoid_t(raw_tint[i]);
+    float rough = softplus_t(raw_rough + cfg->roughness_bias);                   /* :640-641 */
+    out->roughness = rough;
+    /* reflect(-viewdirs, normals_pred) (models.py:662-663, ref_utils.py:36-37) */
+    float w[3] = {-v[0], -v[1], -v[2]};
+    float dot = (np_[0] * w[0] + np_[1] * w[1]) + np_[2] * w[2];
+    float refdir[3];
+    for (int i = 0; i < 3; ++i) refdir[i] = (2.0f * dot) * np_[i] - w[i];
+    float *din = x[s] + RN_WIDTH;                 /* [bottleneck | ide | n.v] (:686) */
+    memcpy(din, bneck[s], sizeof(bneck[s]));
+    if (cfg->ide_mode == 1) rn_ide_ref_f32(refdir, rough, din + RN_BNECK);
+    else rn_ide_stable_f32(refdir, rough, din + RN_BNECK);                        /* :665 */
+    din[RN_DIR_IN - 1] = (np_[0] * v[0] + np_[1] * v[1]) + np_[2] * v[2];        /* :679-683 */
+    /* raw diffuse is parked in `out` until the colour head below */
+    out->diffuse[0] = raw_diff[0]; out->diffuse[1] = raw_diff[1]; out->diffuse[2] = raw_diff[2];
+  }
+  /* directional MLP (models.py:690-694); x[s][256..456] keeps the 201-vector */
+  float xin[RN_SB][LDX];
+  for (int s = 0; s < S; ++s) memcpy(xin[s], x[s] + RN_WIDTH, sizeof(float) * RN_DIR_IN);
+  for (int i = 0; i < RN_DEPTH; ++i) {
+    if (i == 0)
+      dense_block(T + L->vd_w[i], P + L->vd_b[i], &xin[0][0], LDX, L->vd_in[i], RN_WIDTH, &y[0][0], RN_WIDTH, S, 1);
+    else
+      dense_block(T + L->vd_w[i], P + L->vd_b[i], &x[0][0], LDX, L->vd_in[i], RN_WIDTH, &y[0][0], RN_WIDTH, S, 1);
+    for (int s = 0; s < S; ++s) memcpy(x[s], y[s], sizeof(y[s]));   /* skip input already sits at x[s]+256 */
+  }
+  const float LOG3 = 1.0986122886681098f;
+  for (int s = 0; s < S; ++s) {
+    rn_sample_out *out = &outs[s];
+    float raw_rgb[3];
+    dense_block(T + L->rgb_w, P + L->rgb_b, x[s], LDX, RN_WIDTH, 3, raw_rgb, 3, 1, 0);
+    float spec_lin[3], diff_lin[3], rgb[3];
+    for (int i = 0; i < 3; ++i) {
+      float sg = sigmoid_t(cfg->rgb_premultiplier * raw_rgb[i] + cfg->rgb_bias);  /* :699-700 */
+      diff_lin[i] = sigmoid_t(out->diffuse[i] - LOG3);                            /* :705-706 */
+      spec_lin[i] = out->tint[i] * sg;                                            /* :708 */
+      rgb[i] = spec_lin[i] + diff_lin[i];
+    }
+    if (cfg->srgb_mapping) {                                                      /* :712-723 */
+      if (cfg->srgb_mapping_normalization) {
+        float mxc = fmaxf(fmaxf(rgb[0], rgb[1]), rgb[2]);
+        float norm = fmaxf(mxc, 1.0f);
+        for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] / norm;
+      }
+      for (int i = 0; i < 3; ++i) {
+        rgb[i] = clip01(rn_linear_to_srgb(rgb[i]));
+        out->diffuse[i] = clip01(rn_linear_to_srgb(diff_lin[i]));
+        out->specular[i] = clip01(rn_linear_to_srgb(spec_lin[i]));
+      }
+    } else {
+      for (int i = 0; i < 3; ++i) { out->diffuse[i] = diff_lin[i]; out->specular[i] = spec_lin[i]; }
+    }
+    float pad_scale = (float)(1.0 + 2.0 * (double)cfg->rgb_padding);
+    for (int i = 0; i < 3; ++i) out->rgb[i] = rgb[i] * pad_scale - cfg->rgb_padding; /* :729 */
+  }
+}
+
+void rn_mlp_sample(const float *P, const rn_level_cfg *cfg, const float *lmean,
+                   const float *lvar, const float *v, rn_sample_out *out) {
+  rn_model M;
+  model_init(&M, P);
+  mlp_block(&M, cfg, lmean, lvar, v, 1, out);
+  model_free(&M);
+}
+
+/* ------------------------------------------------------------------ */
+/* compositing                                                        */
+/* ------------------------------------------------------------------ */
+
+/* render.py:132-149 */
+void rn_alpha_weights(const float *density, const float *tdist, const float *dir,
+                      int N, int opaque_background, float *weights) {
+  float norm = sqrtf((dir[0] * dir[0] + dir[1] * dir[1]) + dir[2] * dir[2]);
+  double cum = 0.0;
+  for (int i = 0; i < N; ++i) {
+    float t_delta = tdist[i + 1] - tdist[i];
+    float delta = t_delta * norm;
+    float dd = density[i] * delta;
+    if (opaque_background && i == N - 1) dd = INFINITY;
+    float alpha = 1.0f - expf(-dd);
+    float trans = expf(-(float)cum);
+    weights[i] = alpha * trans;
+    cum += (double)dd;    /* torch.cumsum: double accumulator, fp32 outputs */
+  }
+}
+
+static void render_map(int mode, float *rgb, float *dif, float *spc) {
+  if (mode == RN_SRGB_NONE) return;
+  if (mode == RN_SRGB_NORM_LINEAR || mode == RN_SRGB_NORM_SRGB) {
+    float norm = fmaxf(fmaxf(fmaxf(rgb[0], rgb[1]), rgb[2]), 1.0f);
+    for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] / norm;
+  }
+  for (int i = 0; i < 3; ++i) {
+    if (mode == RN_SRGB_SRGB || mode == RN_SRGB_NORM_SRGB) {
+      rgb[i] = rn_linear_to_srgb(rgb[i]); dif[i] = rn_linear_to_srgb(dif[i]); spc[i] = rn_linear_to_srgb(spc[i]);
+    }
+    rgb[i] = clip01(rgb[i]); dif[i] = clip01(dif[i]); spc[i] = clip01(spc[i]);
+  }
+}
+
+/* stepfun.py:294-307 (weighted_percentile) + math.py:114-142 (interp, fp64) */
+static void percentiles(const float *tdist, const float *w, int N, float bg_w, float far, double *out3) {
+  int n = N + 2; /* knots */
+  double *xp = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+  double *fp = xp + n;
+  xp[0] = 0.0;
+  double acc = 0.0;
+  for (int i = 0; i < N; ++i) { acc += (double)w[i]; xp[i + 1] = (double)fminf(1.0f, (float)acc); }
+  (void)bg_w; /* weights_aug[-1] is dropped by integrate_weights */
+  xp[N + 1] = 1.0;
+  for (int i = 0; i <= N; ++i) fp[i] = (double)tdist[i];
+  fp[N + 1] = (double)far;
+  const float ps[3] = {5.0f / 100.0f, 50.0f / 100.0f, 95.0f / 100.0f};
+  for (int q = 0; q < 3; ++q) {
+    double x = (double)ps[q];
+    int cnt = 0;
+    for (int j = 0; j < n; ++j) cnt += (x >= xp[j]);
+    int idx = cnt - 1; if (idx < 0) idx = 0; if (idx > n - 2) idx = n - 2;
+    double m = (fp[idx + 1] - fp[idx]) / (xp[idx + 1] - xp[idx]);
+    double b = fp[idx] - m * xp[idx];
+    out3[q] = m * x + b;
+  }
+  free(xp);
+}
+
+/* ------------------------------------------------------------------ */
+/* one level                                                          */
+/* ------------------------------------------------------------------ */
+
+#define ST3(ptr, r, i, N, val3) do { if (ptr) { float *q_ = (ptr) + ((size_t)(r) * (N) + (i)) * 3; q_[0] = (val3)[0]; q_[1] = (val3)[1]; q_[2] = (val3)[2]; } } while (0)
+
+int rn_level_forward(const float *params, const rn_level_cfg *cfg, const rn_rays *rays,
+                     int R, const float *sdist_in, const float *weights_in,
+                     rn_level_out *out, int n_threads) {
+  const int N = cfg->n_samples, M = cfg->n_in;
+  if (N <= 1) return -1;                           /* stepfun.py:234-235 */
+  if (cfg->ray_shape != 0 && cfg->ray_shape != 1) return -2; /* render.py:126 */
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+  rn_model model;
+  model_init(&model, params);
+#pragma omp parallel
+  {
+    float *logits = (float *)malloc(sizeof(float) * (size_t)(M + (N + 1) * 2 + N * 2));
+    float *sd = logits + M, *td = sd + (N + 1), *dens = td + (N + 1), *wts = dens + N;
+    rn_sample_out *so = (rn_sample_out *)malloc(sizeof(rn_sample_out) * (size_t)N);
+    int32_t *bidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
+#pragma omp for schedule(dynamic, 1)
+    for (int r = 0; r < R; ++r) {
+      const float *o = rays->origins + 3 * r, *d = rays->directions + 3 * r, *v = rays->viewdirs + 3 * r;
+      float near = rays->near[r], far = rays->far[r], radius = rays->radii[r];
+      /* models.py:200-215 */
+      rn_resample_logits(sdist_in + (size_t)r * (M + 1), weights_in + (size_t)r * M, M, cfg->anneal, cfg->resample_padding, logits);
+      rn_sample_intervals(sdist_in + (size_t)r * (M + 1), logits, M, N, cfg->s_near, cfg->s_far, sd, bidx);
+      for (int i = 0; i <= N; ++i) td[i] = rn_s_to_t(sd[i], near, far);          /* :218 */
+      for (int i0 = 0; i0 < N; i0 += RN_SB) {                                     /* :221-241 */
+        float lm[RN_SB][3], lv[RN_SB][3];
+        int S = (N - i0 < RN_SB) ? (N - i0) : RN_SB;
+        for (int s = 0; s < S; ++s)
+          rn_cast_sample(o, d, radius, td[i0 + s], td[i0 + s + 1], cfg->ray_shape, lm[s], lv[s], NULL);
+        mlp_block(&model, cfg, &lm[0][0], &lv[0][0], v, S, &so[i0]);
+        for (int s = 0; s < S; ++s) dens[i0 + s] = so[i0 + s].density;
+      }
+      rn_alpha_weights(dens, td, d, N, cfg->opaque_background, wts);              /* :244-249 */
+      /* ---- history ---- */
+      if (out->sdist) memcpy(out->sdist + (size_t)r * (N + 1), sd, sizeof(float) * (N + 1));
+      if (out->bin_idx) memcpy(out->bin_idx + (size_t)r * N, bidx, sizeof(int32_t) * N);
+      for (int i = 0; i < N; ++i) {
+        if (out->density) out->density[(size_t)r * N + i] = dens[i];
+        if (out->weights) out->weights[(size_t)r * N + i] = wts[i];
+        if (out->roughness) out->roughness[(size_t)r * N + i] = so[i].roughness;
+        ST3(out->rgb, r, i, N, so[i].rgb);
+        if (cfg->training) ST3(out->normals, r, i, N, so[i].normals);
+        ST3(out->normals_pred, r, i, N, so[i].normals_pred);
+        ST3(out->grad_pred, r, i, N, so[i].grad_pred);
+        ST3(out->tint, r, i, N, so[i].tint);
+        ST3(out->diffuse, r, i, N, so[i].diffuse);
+        ST3(out->specular, r, i, N, so[i].specular);
+      }
+      /* ---- render.py:152-254 ---- */
+      float acc = 0.0f, rgb[3] = {0, 0, 0}, dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
+      float dist = 0.0f, nrm[3] = {0, 0, 0}, nrp[3] = {0, 0, 0}, tnt[3] = {0, 0, 0}, rgh = 0.0f, logd = 0.0f;
+      for (int i = 0; i < N; ++i) {
+        float w = wts[i];
+        acc += w;
+        float tmid = 0.5f * (td[i] + td[i + 1]);
+        dist += w * tmid;
+        logd += w * logf(tmid);
+        rgh += w * so[i].roughness;
+        for (int c = 0; c < 3; ++c) {
+          rgb[c] += w * so[i].rgb[c]; dif[c] += w * so[i].diffuse[c]; spc[c] += w * so[i].specular[c];
+          nrm[c] += w * so[i].normals[c]; nrp[c] += w * so[i].normals_pred[c]; tnt[c] += w * so[i].tint[c];
+        }
+      }
+      float bg_w = fmaxf(0.0f, 1.0f - acc);
+      for (int c = 0; c < 3; ++c) { rgb[c] += bg_w * cfg->bg_rgb; dif[c] += bg_w * cfg->bg_rgb; spc[c] += bg_w * cfg->bg_rgb; }
+      render_map(cfg->render_srgb_mode, rgb, dif, spc);
+      if (out->r_rgb) memcpy(out->r_rgb + 3 * (size_t)r, rgb, 12);
+      if (out->r_diffuse) memcpy(out->r_diffuse + 3 * (size_t)r, dif, 12);
+      if (out->r_specular) memcpy(out->r_specular + 3 * (size_t)r, spc, 12);
+      if (out->r_distance) out->r_distance[r] = dist;
+      if (out->r_acc) out->r_acc[r] = acc;
+      if (cfg->compute_extras) {
+        if (out->r_normals && cfg->training) memcpy(out->r_normals + 3 * (size_t)r, nrm, 12);
+        if (out->r_normals_pred) memcpy(out->r_normals_pred + 3 * (size_t)r, nrp, 12);
+        if (out->r_tint) memcpy(out->r_tint + 3 * (size_t)r, tnt, 12);
+        if (out->r_roughness) out->r_roughness[r] = rgh;
+        if (out->r_distance_mean) {
+          float e = expf(logd / fmaxf(EPS32, acc));
+          if (isnan(e)) e = INFINITY;              /* nan_to_num(x, inf) */
+          if (isinf(e)) e = e > 0 ? FLT_MAX : -FLT_MAX;
+          out->r_distance_mean[r] = fminf(fmaxf(e, td[0]), td[N]);
+        }
+        if (out->r_percentiles) percentiles(td, wts, N, bg_w, far, out->r_percentiles + 3 * (size_t)r);
+      }
+    }
+    free(logits); free(so); free(bidx);
+  }
+  model_free(&model);
+  return 0;
+}

@@ -1,0 +1,176 @@
+/*
+ * refnerf_oracle.h -- CPU restatement of the Ref-NeRF rendering inner loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle for the HIP path in
+ * refnerf-pl_amd/csrc; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product path never calls it.
+ *
+ * Parity status: PINNED.  Every stage below is checked against vectors
+ * captured from the upstream reference itself (tests/golden/make_golden.py
+ * imports /root/reference in the build container and writes the .npz files
+ * that tests/test_oracle_golden.py replays).
+ *
+ * Each function cites the reference lines (relative to the upstream repo
+ * root) it restates.  All arithmetic is IEEE fp32 in the reference's operation
+ * order unless stated; build with -ffp-contract=off.
+ */
+#ifndef REFNERF_ORACLE_H
+#define REFNERF_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- fixed Ref-NeRF architecture (configs/blender_refnerf.gin:34-52) ---- */
+#define RN_WIDTH 256        /* NerfMLP.net_width = net_width_viewdirs        */
+#define RN_DEPTH 8          /* NerfMLP.net_depth = net_depth_viewdirs        */
+#define RN_SKIP 4           /* MLP.skip_layer (models.py:357,579,693)        */
+#define RN_IPE_DEG 16       /* NerfMLP.max_deg_point                          */
+#define RN_IPE_DIM 96       /* 2 * 16 degrees * 3 basis dirs                  */
+#define RN_BNECK 128        /* NerfMLP.bottleneck_width                       */
+#define RN_IDE_TERMS 36     /* (l,m) pairs for deg_view = 5                   */
+#define RN_IDE_DIM 72
+#define RN_DIR_IN 201       /* 128 + 72 + 1                                   */
+#define RN_NUM_PARAMS 1110158
+
+/* Offsets (in floats) into the canonical parameter blob = the reference's
+ * state_dict order for `nerf_mlp.*` (models.py:497-531): every tensor is
+ * row-major [out][in], weight followed by bias. */
+typedef struct rn_param_offsets {
+  int sp_w[RN_DEPTH], sp_b[RN_DEPTH], sp_in[RN_DEPTH];
+  int density_w, density_b;
+  int gradpred_w, gradpred_b;
+  int rough_w, rough_b;
+  int diffuse_w, diffuse_b;
+  int tint_w, tint_b;
+  int bneck_w, bneck_b;
+  int vd_w[RN_DEPTH], vd_b[RN_DEPTH], vd_in[RN_DEPTH];
+  int rgb_w, rgb_b;
+  int total;
+} rn_param_offsets;
+
+void rn_param_layout(rn_param_offsets *o);
+
+enum { RN_SRGB_NONE = 0, RN_SRGB_LINEAR = 1, RN_SRGB_NORM_LINEAR = 2,
+       RN_SRGB_SRGB = 3, RN_SRGB_NORM_SRGB = 4 };
+
+typedef struct rn_level_cfg {
+  int32_t n_samples;          /* N: intervals produced at this level          */
+  int32_t n_in;               /* M: intervals of the incoming step function   */
+  int32_t training;           /* 1: also produce density-gradient normals     */
+  int32_t compute_extras;
+  int32_t srgb_mapping;       /* MLP.srgb_mapping (models.py:712)             */
+  int32_t srgb_mapping_normalization;
+  int32_t render_srgb_mode;   /* RN_SRGB_* (render.py:186-216)                */
+  int32_t opaque_background;
+  int32_t ray_shape;          /* 0 cone, 1 cylinder (render.py:121-126)       */
+  int32_t ide_mode;           /* 0 stable recurrence, 1 reference-order fp32  */
+  float anneal;               /* models.py:190-195 (1.0 in shipped configs)   */
+  float resample_padding;
+  float s_near, s_far;        /* Model.init_s_near / init_s_far               */
+  float density_bias, roughness_bias;
+  float rgb_premultiplier, rgb_bias, rgb_padding;
+  float bg_rgb;
+} rn_level_cfg;
+
+void rn_level_cfg_default(rn_level_cfg *c);
+
+/* Per-ray inputs (SoA, fp32). */
+typedef struct rn_rays {
+  const float *origins;     /* [R,3] */
+  const float *directions;  /* [R,3] */
+  const float *viewdirs;    /* [R,3] */
+  const float *radii;       /* [R]   */
+  const float *near;        /* [R]   */
+  const float *far;         /* [R]   */
+} rn_rays;
+
+/* All outputs are optional (NULL = do not store). */
+typedef struct rn_level_out {
+  /* sampler */
+  float *sdist;        /* [R,N+1] */
+  int32_t *bin_idx;    /* [R,N] CDF bin chosen for each centre (the "sample index") */
+  /* per-sample history (models.py:731-750, 304-305) */
+  float *density;      /* [R,N]   */
+  float *rgb;          /* [R,N,3] */
+  float *normals;      /* [R,N,3] training only */
+  float *normals_pred; /* [R,N,3] */
+  float *grad_pred;    /* [R,N,3] */
+  float *tint;         /* [R,N,3] */
+  float *diffuse;      /* [R,N,3] */
+  float *specular;     /* [R,N,3] */
+  float *roughness;    /* [R,N]   */
+  float *weights;      /* [R,N]   */
+  /* per-ray renderings (render.py:152-254) */
+  float *r_rgb, *r_diffuse, *r_specular;  /* [R,3] */
+  float *r_distance;   /* [R] */
+  float *r_acc;        /* [R] */
+  float *r_normals, *r_normals_pred, *r_tint; /* [R,3] (extras) */
+  float *r_roughness;  /* [R] */
+  float *r_distance_mean; /* [R] */
+  double *r_percentiles;  /* [R,3] = 5, 50, 95 */
+} rn_level_out;
+
+/* ---- stage functions (each is what one golden fixture pins) ---- */
+
+/* torch.linspace(pad, 1-pad-eps, N) in fp32 (stepfun.py:199-204). */
+void rn_linspace_u(int n, float *u);
+
+/* stepfun.sample_intervals (stepfun.py:209-258) on one ray.
+ * t[M+1], w_logits[M] -> sdist[N+1]; bin_idx[N] optional. scratch-free. */
+void rn_sample_intervals(const float *t, const float *w_logits, int M, int N,
+                         float smin, float smax, float *sdist, int32_t *bin_idx);
+
+/* models.py:200-203: logits from (sdist, weights). */
+void rn_resample_logits(const float *t, const float *w, int M, float anneal,
+                        float padding, float *logits);
+
+/* coord.py:96-98 with fn=None. */
+float rn_s_to_t(float s, float near, float far);
+
+/* render.py:105-129 + coord.py:129-133 for the octahedron/1 basis:
+ * lifted mean[3] and lifted diagonal variance[3] of one interval; also the
+ * un-lifted mean (xyz) when mean_xyz != NULL. */
+void rn_cast_sample(const float *o, const float *d, float radius, float t0,
+                    float t1, int ray_shape, float *lmean, float *lvar,
+                    float *mean_xyz);
+
+/* coord.py:107-126 + math.py:22-34. feat[96]. */
+void rn_ipe(const float *lmean, const float *lvar, float *feat);
+
+/* ref_utils.py:98-161 for deg_view=5. out[72] = [Re x36 | Im x36]. */
+void rn_ide_stable_f32(const float *xyz, float kappa_inv, float *out);
+void rn_ide_ref_f32(const float *xyz, float kappa_inv, float *out);
+void rn_ide_f64(const double *xyz, double kappa_inv, double *out);
+
+/* image.py:51-59 */
+float rn_linear_to_srgb(float x);
+
+/* One full MLP.__call__ (models.py:533-750) for one sample.
+ * out13 layout documented in refnerf_oracle.c (rn_sample_out). */
+typedef struct rn_sample_out {
+  float density, roughness;
+  float rgb[3], normals[3], normals_pred[3], grad_pred[3], tint[3], diffuse[3],
+      specular[3];
+} rn_sample_out;
+
+void rn_mlp_sample(const float *params, const rn_level_cfg *cfg,
+                   const float *lmean, const float *lvar, const float *viewdir,
+                   rn_sample_out *out);
+
+/* render.py:132-149 on one ray. */
+void rn_alpha_weights(const float *density, const float *tdist, const float *dir,
+                      int N, int opaque_background, float *weights);
+
+/* One level of Model.__call__ (models.py:162-306) for R rays.
+ * sdist_in[R,M+1], weights_in[R,M]. Returns 0 or a negative error code. */
+int rn_level_forward(const float *params, const rn_level_cfg *cfg,
+                     const rn_rays *rays, int R, const float *sdist_in,
+                     const float *weights_in, rn_level_out *out, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

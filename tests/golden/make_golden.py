@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the upstream reference (build container only).
+
+Run:  python tests/golden/make_golden.py
+Needs /root/reference (read-only).  Writes tests/golden/*.npz: INPUTS and the
+reference's OUTPUTS only -- no reference source travels.  Weights are not
+stored: every fixture records the (seed, bias_scale, sharpen, roughness_bias)
+arguments of refnerf_pl_amd.synthetic.make_params that regenerate them.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import _ref_harness  # noqa: E402
+
+_ref_harness.install()
+import torch  # noqa: E402
+import gin  # noqa: E402
+
+import refnerf_pl_amd  # noqa: E402,F401
+from refnerf_pl_amd import layout, synthetic  # noqa: E402
+
+from internal import configs, coord, models, ref_utils, render, stepfun, train_utils, utils  # noqa: E402
+
+torch.set_num_threads(8)
+REF_CFG = os.path.join(_ref_harness.REFERENCE_ROOT, "configs", "blender_refnerf.gin")
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def to_rays(d):
+    return utils.Rays(**{k: torch.tensor(v) for k, v in d.items()})
+
+
+def build_model(bindings=(), param_kw=None):
+    gin.clear_config()
+    gin.parse_config_files_and_bindings([REF_CFG], list(bindings))
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg)
+    blob = synthetic.make_params(**(param_kw or {}))
+    sd = model.nerf_mlp.state_dict()
+    for spec in layout.PARAM_SPECS:
+        w = blob[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim].reshape(spec.out_dim, spec.in_dim)
+        b = blob[spec.b_off:spec.b_off + spec.out_dim]
+        assert tuple(sd[spec.name + ".weight"].shape) == w.shape, spec
+        sd[spec.name + ".weight"].copy_(torch.tensor(w))
+        sd[spec.name + ".bias"].copy_(torch.tensor(b))
+    return model, cfg
+
+
+# --------------------------------------------------------------------------
+def golden_sampler():
+    out = {}
+    rng = np.random.default_rng(7)
+    cases = []
+    # (a) level-0 degenerate step function
+    cases.append((np.tile(np.array([[0.0, 1.0]], np.float32), (3, 1)), np.ones((3, 1), np.float32), 128))
+    cases.append((np.tile(np.array([[0.0, 1.0]], np.float32), (2, 1)), np.ones((2, 1), np.float32), 64))
+    # (b) peaky weights on a 128-bin histogram (what level 1 sees)
+    t = np.sort(rng.random((6, 129)).astype(np.float32), axis=-1)
+    t[:, 0] = 0.0
+    t[:, -1] = 1.0
+    w = (rng.random((6, 128)) ** 8).astype(np.float32)
+    w[0, 40:44] = 5.0
+    w[1, :] = 1e-6
+    w[1, 100] = 0.9
+    cases.append((t, w, 128))
+    cases.append((t[:, ::2][:, :33].copy(), w[:, :32].copy(), 48))
+    # (c) zero-width intervals and exact-zero weights
+    t2 = t.copy()
+    t2[:, 10:20] = t2[:, 10:11]
+    w2 = w.copy()
+    w2[:, 60:70] = 0.0
+    cases.append((t2, w2, 192))
+    # (d) uniform weights, exact binary fractions: ties u == cw happen here
+    t3 = np.tile(np.linspace(0, 1, 65, dtype=np.float32), (2, 1))
+    w3 = np.full((2, 64), 1.0 / 64, np.float32)
+    cases.append((t3, w3, 64))
+    for i, (t, w, n) in enumerate(cases):
+        tt, ww = torch.tensor(t), torch.tensor(w)
+        logits = torch.where(tt[..., 1:] > tt[..., :-1], 1.0 * torch.log(ww + 0.01), -float("inf"))
+        sd = stepfun.sample_intervals(tt, logits, n, single_jitter=False, domain=(0.0, 1.0), use_gpu_resampling=False)
+        # bin index implied by math.sorted_interp's mask (math.py:93)
+        eps = torch.finfo(torch.float32).eps
+        pad = 1 / (2 * n)
+        u = torch.linspace(pad, 1.0 - pad - eps, n)
+        cw = stepfun.integrate_weights(torch.softmax(logits, dim=-1))
+        idx = (u[None, None, :] >= cw[:, :, None]).sum(dim=1) - 1
+        out[f"c{i}_t"], out[f"c{i}_w"], out[f"c{i}_n"] = t, w, n
+        out[f"c{i}_logits"], out[f"c{i}_sdist"] = logits.numpy(), sd.numpy()
+        out[f"c{i}_idx"], out[f"c{i}_u"], out[f"c{i}_cw"] = idx.numpy().astype(np.int32), u.numpy(), cw.numpy()
+    out["num_cases"] = len(cases)
+    save("sampler", **out)
+
+
+def golden_cast_ipe():
+    out = {}
+    for fam, rays in (("blender", synthetic.blender_rays(12, seed=3)), ("llff", synthetic.llff_rays(12, seed=4))):
+        r = to_rays(rays)
+        n = 32
+        sd = np.sort(np.random.default_rng(5).random((12, n + 1)).astype(np.float32), axis=-1)
+        sd[:, 0], sd[:, -1] = 0.0, 1.0
+        _, s_to_t = coord.construct_ray_warps(None, r.near, r.far)
+        tdist = s_to_t(torch.tensor(sd))
+        means, covs = render.cast_rays(tdist, r.origins, r.directions, r.radii, "cone", diag=False)
+        basis_t = torch.tensor([[0.0, 0.0, -1.0], [0.0, -1.0, 0.0], [-1.0, 0.0, 0.0]])
+        lm, lv = coord.lift_and_diagonalize(means, covs, basis_t)
+        feat = coord.integrated_pos_enc(lm, lv, 0, 16)
+        mc, cc = render.cast_rays(tdist, r.origins, r.directions, r.radii, "cylinder", diag=False)
+        lmc, lvc = coord.lift_and_diagonalize(mc, cc, basis_t)
+        for k, v in dict(sdist=sd, tdist=tdist, means=means, covs=covs, lmean=lm, lvar=lv, ipe=feat,
+                         cyl_lmean=lmc, cyl_lvar=lvc, origins=r.origins, directions=r.directions,
+                         radii=r.radii, near=r.near, far=r.far).items():
+            out[f"{fam}_{k}"] = v.numpy() if isinstance(v, torch.Tensor) else v
+    # safe_sin straddling 100*pi and big arguments
+    x = torch.tensor(np.concatenate([np.linspace(-330, 330, 41), [314.15924, 314.15927, 314.1593, -314.15927, 1e4, -1e4, 2.5e5, -2.5e5]]).astype(np.float32))
+    from internal import math as rmath
+    out["safe_sin_x"], out["safe_sin_y"] = x.numpy(), rmath.safe_sin(x).numpy()
+    save("cast_ipe", **out)
+
+
+def golden_ide():
+    fn = ref_utils.generate_ide_fn(5)
+    rng = np.random.default_rng(11)
+    d = rng.normal(size=(64, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    d[:4] *= np.array([[0.5], [0.9], [1.05], [0.0]])       # non-unit + zero vector
+    d[4] = [0, 0, 1]
+    d[5] = [0, 0, -1]
+    d[6] = [1, 0, 0]
+    d = d.astype(np.float32)
+    out = {"xyz": d}
+    for kap in (0.0, 0.01, 0.1, 0.3, 1.0):
+        k = torch.full((64, 1), kap)
+        out[f"ide_{kap}"] = fn(torch.tensor(d), k).numpy()
+    save("ide", **out)
+
+
+def golden_mlp():
+    out = {}
+    pk = dict(seed=0, bias_scale=0.1)
+    model, cfg = build_model(param_kw=pk)
+    out["param_kw"] = np.array([pk["seed"], pk["bias_scale"], 1.0, 0.0])
+    mlp = model.nerf_mlp
+    rays = synthetic.blender_rays(6, seed=9)
+    r = to_rays(rays)
+    n = 8
+    sd = torch.linspace(0, 1, n + 1)[None].repeat(6, 1)
+    _, s_to_t = coord.construct_ray_warps(None, r.near, r.far)
+    tdist = s_to_t(sd)
+    means, covs = render.cast_rays(tdist, r.origins, r.directions, r.radii, "cone", diag=False)
+    basis_t = torch.tensor([[0.0, 0.0, -1.0], [0.0, -1.0, 0.0], [-1.0, 0.0, 0.0]])
+    lm, lv = coord.lift_and_diagonalize(means, covs, basis_t)
+    out["lmean"], out["lvar"], out["viewdirs"] = lm.numpy(), lv.numpy(), r.viewdirs.numpy()
+    mlp.eval()
+    with torch.no_grad():
+        res = mlp((means, covs), viewdirs=r.viewdirs)
+    for k, v in res.items():
+        if v is not None:
+            out["eval_" + k] = v.numpy()
+    mlp.train()
+    res = mlp((means.clone(), covs), viewdirs=r.viewdirs)
+    for k, v in res.items():
+        if v is not None:
+            out["train_" + k] = v.detach().numpy()
+    save("mlp", **out)
+
+
+def golden_render():
+    out = {}
+    rng = np.random.default_rng(13)
+    R, N = 10, 48
+    density = (rng.random((R, N)) ** 4 * 30).astype(np.float32)
+    density[0] = 0.0
+    density[1] = 1e4
+    tdist = np.sort(rng.random((R, N + 1)).astype(np.float32) * 4 + 2, axis=-1)
+    dirs = rng.normal(size=(R, 3)).astype(np.float32)
+    rgbs = rng.random((R, N, 3)).astype(np.float32) * 1.4
+    dif = rng.random((R, N, 3)).astype(np.float32)
+    spc = rng.random((R, N, 3)).astype(np.float32)
+    extras = dict(normals=rng.normal(size=(R, N, 3)).astype(np.float32),
+                  normals_pred=rng.normal(size=(R, N, 3)).astype(np.float32),
+                  roughness=rng.random((R, N, 1)).astype(np.float32),
+                  tint=rng.random((R, N, 3)).astype(np.float32))
+    far = np.full((R, 1), 6.0, np.float32)
+    for k, v in dict(density=density, tdist=tdist, dirs=dirs, rgbs=rgbs, dif=dif, spc=spc, far=far, **extras).items():
+        out[k] = v
+    for opaque in (False, True):
+        w, a, tr = render.compute_alpha_weights(torch.tensor(density), torch.tensor(tdist), torch.tensor(dirs), opaque_background=opaque)
+        out[f"weights_opaque{int(opaque)}"] = w.numpy()
+    w = torch.tensor(out["weights_opaque0"])
+    for mode in ("none", "linear", "norm_linear", "srgb", "norm_srgb"):
+        rend = render.volumetric_rendering(torch.tensor(rgbs), torch.tensor(dif), torch.tensor(spc), w, torch.tensor(tdist),
+                                           1.0, torch.tensor(far), True, extras={k: torch.tensor(v) for k, v in extras.items()},
+                                           srgb_mapping=mode)
+        for k, v in rend.items():
+            out[f"{mode}_{k}"] = v.numpy()
+    save("render", **out)
+
+
+def run_model(model, cfg, rays, train, gt=None):
+    r = to_rays(rays)
+    res = {}
+    if not train:
+        model.eval()
+        with torch.no_grad():
+            rend, hist = model(r, 1.0, True)
+    else:
+        model.train()
+        model.zero_grad()
+        rend, hist = model(r, 1.0, True)
+        batch = utils.Batch(rays=r, rgb=gt)
+        data_loss, stats = train_utils.compute_data_loss(batch, rend, r, cfg)
+        o_loss = train_utils.orientation_loss(r, model, hist, cfg)
+        n_loss = train_utils.predicted_normal_loss(model, hist, cfg)
+        loss = data_loss + o_loss + n_loss
+        loss.backward()
+        res["loss_data"], res["loss_orientation"], res["loss_normal"] = data_loss.item(), o_loss.item(), n_loss.item()
+        res["loss_total"] = loss.item()
+        grads = np.zeros(layout.NUM_PARAMS, np.float32)
+        named = dict(model.nerf_mlp.named_parameters())
+        for spec in layout.PARAM_SPECS:
+            grads[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = named[spec.name + ".weight"].grad.numpy().reshape(-1)
+            grads[spec.b_off:spec.b_off + spec.out_dim] = named[spec.name + ".bias"].grad.numpy()
+        res["grads"] = grads
+    for lvl, (rd, hs) in enumerate(zip(rend, hist)):
+        for k, v in rd.items():
+            res[f"L{lvl}_r_{k}"] = v.detach().numpy()
+        for k, v in hs.items():
+            if v is not None:
+                res[f"L{lvl}_h_{k}"] = v.detach().numpy()
+    return res
+
+
+def golden_models():
+    cases = {
+        # name: (gin bindings, param kw, rays, train)
+        "model_blender_eval": ([], dict(seed=0, bias_scale=0.05), synthetic.blender_rays(24, seed=1, center_frac=0.4), False),
+        "model_blender_sharp_eval": ([], dict(seed=0, bias_scale=0.05, sharpen=20.0), synthetic.blender_rays(24, seed=1, center_frac=0.4), False),
+        "model_c1_eval": (["Model.num_levels = 1", "Model.num_nerf_samples = 64"], dict(seed=3, bias_scale=0.05, sharpen=10.0),
+                          synthetic.blender_rays(16, seed=2, center_frac=0.4), False),
+        "model_llff_linear_eval": (["NerfMLP.srgb_mapping = False", "Config.srgb_mapping_when_rendering = True",
+                                    "Config.srgb_mapping_type = 'norm_linear'", "Config.near = 0.", "Config.far = 1."],
+                                   dict(seed=4, bias_scale=0.05, sharpen=20.0), synthetic.llff_rays(16, seed=5), False),
+        "model_blender_sharp_train": ([], dict(seed=0, bias_scale=0.05, sharpen=20.0), synthetic.blender_rays(16, seed=6, center_frac=0.4), True),
+        "model_llff_linear_train": (["NerfMLP.srgb_mapping = False", "Config.srgb_mapping_when_rendering = True",
+                                     "Config.srgb_mapping_type = 'norm_linear'", "Config.near = 0.", "Config.far = 1.",
+                                     "Model.num_prop_samples = 64", "Model.num_nerf_samples = 96"],
+                                    dict(seed=4, bias_scale=0.05, sharpen=20.0), synthetic.llff_rays(12, seed=7), True),
+    }
+    for name, (bindings, pk, rays, train) in cases.items():
+        model, cfg = build_model(bindings, pk)
+        gt = synthetic.target_rgb(rays["origins"].shape[0], seed=2)
+        res = run_model(model, cfg, rays, train, gt)
+        res["bindings"] = np.array(bindings if bindings else [""])
+        res["param_kw"] = np.array([pk.get("seed", 0), pk.get("bias_scale", 0.0), pk.get("sharpen", 1.0), pk.get("roughness_bias", 0.0)])
+        for k, v in rays.items():
+            res["rays_" + k] = v
+        res["gt_rgb"] = gt
+        # keep fixtures small: grads are big (4.4 MB) -> store a strided subsample + per-tensor norms
+        if "grads" in res:
+            g = res.pop("grads")
+            res["grads_sub"] = g[::97].copy()
+            res["grads_tensor_l2"] = np.array([[np.linalg.norm(g[s.w_off:s.w_off + s.out_dim * s.in_dim]),
+                                                np.linalg.norm(g[s.b_off:s.b_off + s.out_dim])] for s in layout.PARAM_SPECS])
+        save(name, **res)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models"]
+    for w in which:
+        globals()["golden_" + w]()

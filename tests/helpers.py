@@ -1,0 +1,45 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+
+import refnerf_pl_amd  # noqa: F401
+from refnerf_pl_amd import synthetic
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def params_from_golden(g):
+    pk = g["param_kw"]
+    return synthetic.make_params(int(pk[0]), float(pk[1]), float(pk[2]), float(pk[3]))
+
+
+def rays_from_golden(g):
+    return {k[5:]: g[k] for k in g.files if k.startswith("rays_")}
+
+
+def cfg_from_bindings(bindings):
+    """Translate the gin bindings stored in a model fixture into
+    (level-cfg kwargs, Model kwargs)."""
+    kw, lv = {}, {}
+    for s in bindings:
+        s = str(s)
+        if "NerfMLP.srgb_mapping = False" in s:
+            kw["srgb_mapping"] = 0
+        if "srgb_mapping_type" in s:
+            kw["render_srgb_mode"] = s.split("'")[1]
+        for key in ("num_levels", "num_nerf_samples", "num_prop_samples"):
+            if "Model." + key in s:
+                lv[key] = int(s.split("=")[1])
+    return kw, lv
+
+
+MODEL_CASES = ["model_blender_eval", "model_blender_sharp_eval", "model_c1_eval",
+               "model_llff_linear_eval", "model_blender_sharp_train", "model_llff_linear_train"]
+
+HIST_KEYS = ("sdist", "weights", "density", "rgb", "normals_pred", "roughness", "diffuse", "specular", "tint")
+REND_KEYS = ("rgb", "diffuse", "specular", "distance", "acc", "normals_pred", "tint", "roughness", "distance_mean")
