@@ -1,0 +1,55 @@
+/*
+ * refnerf_detmath.h -- bit-reproducible fp32 helpers shared by the HIP kernels
+ * and the CPU oracle.
+ *
+ * The resampler's CDF-bin index ("sample index") must be
+ * bit-exact between implementations on identical (t, logits) inputs.  libm's
+ * expf differs by an ulp between glibc, Sleef (torch) and ocml (device), and an
+ * ulp in the softmax is enough to flip a bin at a near-tie, so the softmax of
+ * stepfun.invert_cdf (stepfun.py:157-165) uses this exp instead: only IEEE
+ * fma/mul/add and integer ops, hence identical bits on x86 and gfx950.
+ * Accuracy: ~1 ulp on [-86, 0]; inputs below -86 return 0 (softmax terms
+ * below 1.6e-38 carry no weight).
+ */
+#ifndef REFNERF_DETMATH_H
+#define REFNERF_DETMATH_H
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define RN_HD __host__ __device__ inline
+#else
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#define RN_HD static inline
+#endif
+
+/* exp(x) for x <= 0 (softmax arguments after subtracting the row max). */
+RN_HD float rn_det_expf(float x) {
+  if (!(x > -86.0f)) return (x != x) ? x : 0.0f;
+  if (x > 88.0f) x = 88.0f;
+  /* n = round(x / ln2); r = x - n*ln2 in two steps (Cody-Waite) */
+  const float LOG2E = 1.44269504088896341f;
+  const float LN2_HI = 0.693145751953125f;        /* 0x3f317200 */
+  const float LN2_LO = 1.42860682030941723212e-6f;
+  float fn = x * LOG2E;
+  /* round to nearest, ties away is fine (any consistent choice works) */
+  fn = (float)(int)(fn + (fn < 0.0f ? -0.5f : 0.5f));
+  float r = fmaf(-fn, LN2_HI, x);
+  r = fmaf(-fn, LN2_LO, r);
+  /* exp(r), |r| <= ln2/2: degree-6 minimax-ish Taylor/Remez blend */
+  float p = 1.9875691500e-4f;
+  p = fmaf(p, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  float r2 = r * r;
+  float e = fmaf(p, r2, r) + 1.0f;
+  /* scale by 2^n through the exponent field; n in [-126, 127] here */
+  int n = (int)fn;
+  union { float f; unsigned u; } s;
+  s.u = (unsigned)(n + 127) << 23;
+  return e * s.f;
+}
+
+#endif

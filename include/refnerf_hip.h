@@ -1,0 +1,159 @@
+/*
+ * refnerf_hip.h -- C ABI of the MI355X (gfx950) Ref-NeRF rendering inner loop.
+ *
+ * Shared library: refnerf-pl_amd/csrc/librefnerf_hip.so.  Plain pointers and
+ * sizes only; every `d_*` pointer is DEVICE memory owned by the caller; every
+ * call is asynchronous on `stream` (a hipStream_t passed as void*, NULL = the
+ * default stream) and returns 0 or a negative REFNERF_E* code (message via
+ * refnerf_last_error()).  No global state besides the per-thread error string;
+ * re-entrant.
+ *
+ * The upstream reference (minfenli/refnerf-pl) has no FFI: its boundary is the
+ * Python call surface of internal/models.py.  Each entry point below names the
+ * reference function (file:line, relative to the upstream repo root) whose
+ * ATen op sequence it replaces; INTEGRATION.md shows the ctypes binding a
+ * maintainer adds on the reference side.
+ */
+#ifndef REFNERF_HIP_H
+#define REFNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REFNERF_ABI_VERSION 1
+#define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
+
+enum {
+  REFNERF_OK = 0,
+  REFNERF_EINVAL = -1,      /* bad argument / unsupported configuration     */
+  REFNERF_ENOGPU = -2,      /* no gfx950 device                             */
+  REFNERF_EHIP = -3,        /* HIP runtime error                            */
+  REFNERF_EUNSUPPORTED = -4 /* valid in the reference, not built here yet   */
+};
+
+/* arithmetic of the MLP contractions */
+enum {
+  REFNERF_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains (parity mode) */
+  REFNERF_PREC_BF16 = 1  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate                   */
+};
+
+enum { REFNERF_SRGB_NONE = 0, REFNERF_SRGB_LINEAR = 1, REFNERF_SRGB_NORM_LINEAR = 2,
+       REFNERF_SRGB_SRGB = 3, REFNERF_SRGB_NORM_SRGB = 4 };
+
+/* One sampling level of Model.__call__ (internal/models.py:162-306).
+ * Field-for-field the knobs the reference reads on this path. */
+typedef struct refnerf_level_cfg {
+  int32_t n_samples;          /* Model.num_prop_samples / num_nerf_samples (models.py:164) */
+  int32_t n_in;               /* intervals of the incoming step function (1 at level 0)    */
+  int32_t training;           /* MLP.training: also emit density-gradient normals (:603)   */
+  int32_t compute_extras;     /* models.py:133                                             */
+  int32_t srgb_mapping;       /* MLP.srgb_mapping (:712)                                   */
+  int32_t srgb_mapping_normalization; /* (:718)                                           */
+  int32_t render_srgb_mode;   /* Config.srgb_mapping_type if srgb_mapping_when_rendering (:285-287) */
+  int32_t opaque_background;  /* Model.opaque_background (render.py:139-143)               */
+  int32_t ray_shape;          /* 0 'cone', 1 'cylinder' (render.py:121-126)                */
+  int32_t precision;          /* REFNERF_PREC_*                                            */
+  float anneal;               /* models.py:190-195                                         */
+  float resample_padding;     /* Model.resample_padding (:202)                             */
+  float s_near, s_far;        /* Model.init_s_near / init_s_far (:213)                     */
+  float density_bias;         /* MLP.density_bias (:623)                                   */
+  float roughness_bias;       /* MLP.roughness_bias (:641)                                 */
+  float rgb_premultiplier, rgb_bias, rgb_padding; /* (:700, :729)                          */
+  float bg_rgb;               /* Model.bg_intensity_range midpoint (:261-267)              */
+} refnerf_level_cfg;
+
+void refnerf_level_cfg_default(refnerf_level_cfg *cfg);
+
+/* utils.Rays (internal/utils.py:51-93): the six fields the path reads. */
+typedef struct refnerf_rays {
+  const float *d_origins;    /* [R,3] */
+  const float *d_directions; /* [R,3] */
+  const float *d_viewdirs;   /* [R,3] */
+  const float *d_radii;      /* [R]   */
+  const float *d_near;       /* [R]   */
+  const float *d_far;        /* [R]   */
+} refnerf_rays;
+
+/* Outputs of one level; any pointer may be NULL (not stored).
+ * Per-sample = ray_history[l] (models.py:731-750, 304-305),
+ * per-ray = renderings[l] (render.py:152-254). */
+typedef struct refnerf_level_out {
+  float *d_sdist;        /* [R,N+1] */
+  int32_t *d_bin_idx;    /* [R,N]   CDF bin of each sample centre (math.py:93) */
+  float *d_density;      /* [R,N]   */
+  float *d_rgb;          /* [R,N,3] */
+  float *d_normals;      /* [R,N,3] training only */
+  float *d_normals_pred; /* [R,N,3] */
+  float *d_grad_pred;    /* [R,N,3] */
+  float *d_tint;         /* [R,N,3] */
+  float *d_diffuse;      /* [R,N,3] */
+  float *d_specular;     /* [R,N,3] */
+  float *d_roughness;    /* [R,N]   */
+  float *d_weights;      /* [R,N]   */
+  float *d_r_rgb, *d_r_diffuse, *d_r_specular; /* [R,3] */
+  float *d_r_distance;   /* [R] */
+  float *d_r_acc;        /* [R] */
+  float *d_r_normals, *d_r_normals_pred, *d_r_tint; /* [R,3] extras */
+  float *d_r_roughness;  /* [R] */
+  float *d_r_distance_mean; /* [R] */
+  double *d_r_percentiles;  /* [R,3] float64: 5 / 50 / 95 (math.py:133-135) */
+} refnerf_level_out;
+
+/* Library / device probe.  refnerf_device_ok() returns REFNERF_OK only when
+ * the current HIP device is gfx950. */
+int refnerf_abi_version(void);
+int refnerf_device_ok(void);
+const char *refnerf_last_error(void);
+
+/* Bytes of the kernel-side weight image for a precision mode. */
+size_t refnerf_packed_weights_bytes(int precision);
+
+/* Re-layout the 46 nn.Parameters of NerfMLP (canonical blob, device) into the
+ * MFMA operand image the level kernel streams.  Replaces nothing in the
+ * reference (its weights are consumed in place by nn.Linear, models.py:576-
+ * 700); must be re-run after every optimiser step. */
+int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, void *stream);
+
+/* One fused launch = one iteration of the level loop of Model.__call__
+ * (models.py:162-306): resample (stepfun.py:209-258) -> s_to_t (coord.py:96-98)
+ * -> cast_rays (render.py:105-129) -> MLP.__call__ (models.py:533-750) ->
+ * compute_alpha_weights (render.py:132-149) -> volumetric_rendering
+ * (render.py:152-254).  d_sdist_in [R,n_in+1], d_weights_in [R,n_in]. */
+int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg,
+                          const refnerf_rays *rays, int32_t R,
+                          const float *d_sdist_in, const float *d_weights_in,
+                          const refnerf_level_out *out, void *stream);
+
+/* Stage entry points (same device code as the fused kernel; used by the
+ * parity tests and for drop-in use of the individual reference functions). */
+
+/* stepfun.sample_intervals (stepfun.py:209-258) with deterministic centres.
+ * d_t [R,M+1], d_logits [R,M] -> d_sdist [R,N+1], d_bin_idx [R,N] (optional). */
+int refnerf_sample_intervals(const float *d_t, const float *d_logits, int32_t R, int32_t M,
+                             int32_t N, float s_min, float s_max, float *d_sdist,
+                             int32_t *d_bin_idx, void *stream);
+
+/* coord.integrated_pos_enc(min_deg=0,max_deg=16) on lifted Gaussians
+ * (coord.py:107-126): d_lmean/d_lvar [n,3] -> d_feat [n,96]. */
+int refnerf_integrated_pos_enc(const float *d_lmean, const float *d_lvar, int32_t n,
+                               float *d_feat, void *stream);
+
+/* ref_utils.generate_ide_fn(5) (ref_utils.py:98-161): d_xyz [n,3],
+ * d_kappa_inv [n] -> d_ide [n,72]. */
+int refnerf_integrated_dir_enc(const float *d_xyz, const float *d_kappa_inv, int32_t n,
+                               float *d_ide, void *stream);
+
+/* Average duration (ms) of the last `refnerf_level_forward` kernels measured
+ * with HIP events on their own stream; enabled by refnerf_set_timing(1).
+ * Used by bench.py for the roofline line. */
+int refnerf_set_timing(int enable);
+int refnerf_get_timing(double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

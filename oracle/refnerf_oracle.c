@@ -10,6 +10,7 @@
  *   gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC
  */
 #include "refnerf_oracle.h"
+#include "../include/refnerf_detmath.h"
 
 #include <float.h>
 #include <math.h>
@@ -105,11 +106,12 @@ void rn_sample_intervals(const float *t, const float *w_logits, int M, int N,
                          float smin, float smax, float *sdist, int32_t *bin_idx) {
   float *p = (float *)malloc(sizeof(float) * (size_t)(M + (M + 1) + N + N));
   float *cw = p + M, *u = cw + (M + 1), *c = u + N;
-  /* softmax (stepfun.py:160) */
+  /* softmax (stepfun.py:160); exp through the shared bit-reproducible
+   * rn_det_expf so that the HIP path can match the CDF bit for bit. */
   float mx = -INFINITY;
   for (int i = 0; i < M; ++i) mx = fmaxf(mx, w_logits[i]);
   float sum = 0.0f;
-  for (int i = 0; i < M; ++i) { p[i] = expf(w_logits[i] - mx); sum += p[i]; }
+  for (int i = 0; i < M; ++i) { p[i] = rn_det_expf(w_logits[i] - mx); sum += p[i]; }
   for (int i = 0; i < M; ++i) p[i] = p[i] / sum;
   /* integrate_weights: cw = [0, min(1, cumsum(w[:-1])), 1]; torch.cumsum on
    * CPU accumulates float in double (at::acc_type<float,false>). */

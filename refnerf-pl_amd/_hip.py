@@ -1,0 +1,221 @@
+"""ctypes binding of librefnerf_hip.so (include/refnerf_hip.h).
+
+PyTorch is used only for device memory and streams: every call takes raw
+device pointers (``tensor.data_ptr()``) and the current HIP stream.  There is
+no CPU fallback -- if the library or a gfx950 device is missing the call
+raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
+
+PREC_F32, PREC_BF16 = 0, 1
+SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 4}
+
+_FP = C.c_void_p
+
+
+class LevelCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_samples", "n_in", "training", "compute_extras", "srgb_mapping",
+        "srgb_mapping_normalization", "render_srgb_mode", "opaque_background",
+        "ray_shape", "precision")] + [(n, C.c_float) for n in (
+            "anneal", "resample_padding", "s_near", "s_far", "density_bias",
+            "roughness_bias", "rgb_premultiplier", "rgb_bias", "rgb_padding", "bg_rgb")]
+
+
+class RaysStruct(C.Structure):
+    _fields_ = [(n, _FP) for n in ("d_origins", "d_directions", "d_viewdirs", "d_radii", "d_near", "d_far")]
+
+
+OUT_FIELDS = ("d_sdist", "d_bin_idx", "d_density", "d_rgb", "d_normals", "d_normals_pred", "d_grad_pred",
+              "d_tint", "d_diffuse", "d_specular", "d_roughness", "d_weights", "d_r_rgb", "d_r_diffuse",
+              "d_r_specular", "d_r_distance", "d_r_acc", "d_r_normals", "d_r_normals_pred", "d_r_tint",
+              "d_r_roughness", "d_r_distance_mean", "d_r_percentiles")
+
+
+class LevelOut(C.Structure):
+    _fields_ = [(n, _FP) for n in OUT_FIELDS]
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile the library in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC] + (["-B"] if force else []) + ["librefnerf_hip.so"]
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the library; raises HipLibraryError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the Ref-NeRF hot path has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.refnerf_last_error.restype = C.c_char_p
+        L.refnerf_packed_weights_bytes.restype = C.c_size_t
+        L.refnerf_packed_weights_bytes.argtypes = [C.c_int]
+        L.refnerf_pack_weights.argtypes = [_FP, _FP, C.c_int, _FP]
+        L.refnerf_level_forward.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
+                                            _FP, _FP, C.POINTER(LevelOut), _FP]
+        L.refnerf_sample_intervals.argtypes = [_FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                               _FP, _FP, _FP]
+        L.refnerf_integrated_pos_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
+        L.refnerf_integrated_dir_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
+        L.refnerf_get_timing.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        if L.refnerf_abi_version() != 1:
+            raise HipLibraryError("librefnerf_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc == 0:
+        return
+    msg = lib().refnerf_last_error().decode()
+    if rc == -1:
+        raise ValueError(msg)      # same exception type the reference raises for bad arguments
+    raise HipLibraryError(f"librefnerf_hip error {rc}: {msg}")
+
+
+def require_device():
+    """Fail loudly unless the current device is an MI355X-class (gfx950) GPU."""
+    if not torch.cuda.is_available():
+        raise HipLibraryError("no HIP device visible: the Ref-NeRF hot path needs a gfx950 GPU (no CPU fallback)")
+    check(lib().refnerf_device_ok())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def default_cfg(**kw) -> LevelCfg:
+    c = LevelCfg()
+    lib().refnerf_level_cfg_default(C.byref(c))
+    for k, v in kw.items():
+        if k == "render_srgb_mode" and isinstance(v, str):
+            v = SRGB_MODES[v]
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def packed_weights_bytes(precision=PREC_F32) -> int:
+    return int(lib().refnerf_packed_weights_bytes(precision))
+
+
+def pack_weights(params: torch.Tensor, packed: torch.Tensor = None, precision=PREC_F32) -> torch.Tensor:
+    """canonical fp32 blob (device) -> MFMA operand image (device)."""
+    require_device()
+    assert params.dtype == torch.float32 and params.numel() == 1110158
+    nbytes = packed_weights_bytes(precision)
+    if nbytes == 0:
+        raise HipLibraryError("precision mode not built")
+    if packed is None:
+        packed = torch.empty(nbytes // 4, dtype=torch.float32, device=params.device)
+    check(lib().refnerf_pack_weights(ptr(params), ptr(packed), precision, stream_ptr()))
+    return packed
+
+
+def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, history=True):
+    """One fused level.  rays: dict of device tensors (origins, directions,
+    viewdirs [R,3]; radii, near, far [R] or [R,1]).  Returns dict of tensors."""
+    require_device()
+    dev = sdist_in.device
+    R = rays["origins"].shape[0]
+    N = cfg.n_samples
+    rs = RaysStruct()
+    keep = []
+    for name in ("origins", "directions", "viewdirs", "radii", "near", "far"):
+        t = rays[name].to(torch.float32).contiguous()
+        keep.append(t)
+        setattr(rs, "d_" + name, t.data_ptr())
+    f32 = dict(dtype=torch.float32, device=dev)
+    res = {
+        "sdist": torch.empty((R, N + 1), **f32), "bin_idx": torch.empty((R, N), dtype=torch.int32, device=dev),
+        "weights": torch.empty((R, N), **f32),
+        "r_rgb": torch.empty((R, 3), **f32), "r_diffuse": torch.empty((R, 3), **f32),
+        "r_specular": torch.empty((R, 3), **f32), "r_distance": torch.empty((R,), **f32),
+        "r_acc": torch.empty((R,), **f32),
+    }
+    if history:
+        for k in ("rgb", "normals_pred", "grad_pred", "tint", "diffuse", "specular"):
+            res[k] = torch.empty((R, N, 3), **f32)
+        res["density"] = torch.empty((R, N), **f32)
+        res["roughness"] = torch.empty((R, N), **f32)
+        if cfg.training:
+            res["normals"] = torch.empty((R, N, 3), **f32)
+    if cfg.compute_extras:
+        res["r_normals_pred"] = torch.empty((R, 3), **f32)
+        res["r_tint"] = torch.empty((R, 3), **f32)
+        res["r_roughness"] = torch.empty((R,), **f32)
+        res["r_distance_mean"] = torch.empty((R,), **f32)
+        res["r_percentiles"] = torch.empty((R, 3), dtype=torch.float64, device=dev)
+        if cfg.training:
+            res["r_normals"] = torch.empty((R, 3), **f32)
+    out = LevelOut()
+    for k, t in res.items():
+        setattr(out, "d_" + k, t.data_ptr())
+    sd = sdist_in.to(torch.float32).contiguous()
+    w = weights_in.to(torch.float32).contiguous()
+    check(lib().refnerf_level_forward(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out), stream_ptr()))
+    return res
+
+
+def sample_intervals(t, logits, n, smin=0.0, smax=1.0):
+    require_device()
+    R, M = logits.shape
+    sd = torch.empty((R, n + 1), dtype=torch.float32, device=t.device)
+    bi = torch.empty((R, n), dtype=torch.int32, device=t.device)
+    check(lib().refnerf_sample_intervals(ptr(t.contiguous()), ptr(logits.contiguous()), R, M, n, smin, smax,
+                                         ptr(sd), ptr(bi), stream_ptr()))
+    return sd, bi
+
+
+def integrated_pos_enc(lmean, lvar):
+    require_device()
+    n = lmean.numel() // 3
+    out = torch.empty(lmean.shape[:-1] + (96,), dtype=torch.float32, device=lmean.device)
+    check(lib().refnerf_integrated_pos_enc(ptr(lmean.contiguous()), ptr(lvar.contiguous()), n, ptr(out), stream_ptr()))
+    return out
+
+
+def integrated_dir_enc(xyz, kappa_inv):
+    require_device()
+    n = xyz.numel() // 3
+    out = torch.empty(xyz.shape[:-1] + (72,), dtype=torch.float32, device=xyz.device)
+    k = kappa_inv.to(torch.float32).expand(xyz.shape[:-1] + (1,)).contiguous()
+    check(lib().refnerf_integrated_dir_enc(ptr(xyz.contiguous()), ptr(k), n, ptr(out), stream_ptr()))
+    return out
+
+
+def set_timing(enable: bool):
+    lib().refnerf_set_timing(int(enable))
+
+
+def get_timing():
+    ms, n = C.c_double(0), C.c_int64(0)
+    lib().refnerf_get_timing(C.byref(ms), C.byref(n))
+    return ms.value, n.value

@@ -1,0 +1,143 @@
+/*
+ * refnerf_device_math.h -- per-sample device math of the Ref-NeRF path.
+ *
+ * Every function restates the cited reference lines in the reference's fp32
+ * operation order (build with -ffp-contract=off: no implicit fma), so that the
+ * sample means that feed the (chaotic, up to 2^15 x) IPE sines are bit-equal
+ * to the reference CPU path.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "refnerf_detmath.h"
+#include "refnerf_layout.h"
+
+namespace rn {
+
+constexpr float EPS32 = 1.1920928955078125e-07f; /* torch.finfo(float32).eps */
+constexpr float HALF_PI_F = 1.57079637050628662109375f;   /* fl32(0.5*pi) */
+constexpr float T100PI = 314.159271240234375f;            /* fl32(100*pi) */
+constexpr float LOG3_F = 1.09861228466033935546875f;      /* fl32(log 3)  */
+
+/* IDE recurrence tables (see oracle rn_ide_stable_f32): c[17], a[17*17], b[17*17] */
+__constant__ float g_ide_c[17];
+__constant__ float g_ide_a[17 * 17];
+__constant__ float g_ide_b[17 * 17];
+
+__device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+/* coord.py:96-98 (fn=None) */
+__device__ __forceinline__ float s_to_t(float s, float nearv, float farv) {
+  float a = s * farv;
+  float b = (1.0f - s) * nearv;
+  return a + b;
+}
+
+/* torch.linspace(pad, 1-pad-eps, N)[k] (stepfun.py:199-204; ATen fills
+ * symmetrically with fused multiply-adds). */
+__device__ __forceinline__ float linspace_u(int k, int n) {
+  double pad = 1.0 / (2.0 * (double)n);
+  float start = (float)pad;
+  float end = (float)(1.0 - pad - (double)EPS32);
+  float step = (end - start) / (float)(n - 1);
+  return (k < n / 2) ? fmaf(step, (float)k, start) : fmaf(-step, (float)(n - 1 - k), end);
+}
+
+/* render.py:46-80 / 83-102 + 22-43 + coord.py:129-133 (octahedron/1 basis):
+ * lifted mean (-z,-y,-x) and lifted variance (C_zz,C_yy,C_xx). */
+__device__ __forceinline__ void cast_sample(const float o[3], const float d[3], float radius, float t0,
+                                            float t1, int ray_shape, float lmean[3], float lvar[3]) {
+  float t_mean, t_var, r_var;
+  if (ray_shape == 0) {
+    float mu = (t0 + t1) / 2.0f;
+    float hw = (t1 - t0) / 2.0f;
+    float hw2 = hw * hw, mu2 = mu * mu;
+    float den = fmaxf(EPS32, 3.0f * mu2 + hw2);
+    t_mean = mu + ((2.0f * mu) * hw2) / den;
+    float hw4 = (float)((double)hw * (double)hw * (double)hw * (double)hw);
+    const float c415 = (float)(4.0 / 15.0);
+    t_var = hw2 / 3.0f - ((c415 * hw4) * (12.0f * mu2 - hw2)) / (den * den);
+    r_var = (mu2 / 4.0f + (float)(5.0 / 12.0) * hw2) - (c415 * hw4) / den;
+    r_var = r_var * (radius * radius);
+  } else {
+    t_mean = (t0 + t1) / 2.0f;
+    r_var = (radius * radius) / 4.0f;
+    float dt = t1 - t0;
+    t_var = (dt * dt) / 12.0f;
+  }
+  float dms = fmaxf(1e-10f, (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+  float mean[3], cd[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    mean[i] = d[i] * t_mean + o[i];
+    float d_outer = d[i] * d[i];
+    float null_outer = 1.0f - d[i] * (d[i] / dms);
+    cd[i] = t_var * d_outer + r_var * null_outer;
+  }
+  lmean[0] = -mean[2]; lmean[1] = -mean[1]; lmean[2] = -mean[0];
+  lvar[0] = cd[2]; lvar[1] = cd[1]; lvar[2] = cd[0];
+}
+
+/* math.py:22-34: where(|x| < 100pi, x, x % 100pi), floored remainder */
+__device__ __forceinline__ float safe_arg(float x) {
+  if (fabsf(x) < T100PI) return x;
+  float m = fmodf(x, T100PI);
+  if (m != 0.0f && m < 0.0f) m += T100PI;
+  return m;
+}
+
+/* One IPE feature (coord.py:119-126): block 0 = sin, block 1 = "cos" =
+ * sin(fl(x + pi/2)). */
+__device__ __forceinline__ float ipe_feature(float lm, float lv, int j, int cos_block) {
+  float sc = __builtin_ldexpf(1.0f, j), sc2 = __builtin_ldexpf(1.0f, 2 * j);
+  float x = lm * sc;
+  if (cos_block) x = x + HALF_PI_F;
+  float e = expf(-0.5f * (lv * sc2));
+  return e * sinf(safe_arg(x));
+}
+
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_t(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+/* image.py:51-59 */
+__device__ __forceinline__ float linear_to_srgb(float x) {
+  float srgb0 = (float)(323.0 / 25.0) * x;
+  float srgb1 = (211.0f * powf(fmaxf(EPS32, x), (float)(5.0 / 12.0)) - 11.0f) / 200.0f;
+  return (x <= 0.0031308f) ? srgb0 : srgb1;
+}
+
+/* ref_utils.py:98-161, deg_view = 5, evaluated with the stable normalised
+ * Legendre recurrence (same polynomials as the reference's Vandermonde form;
+ * SURVEY.md H2).  part = 0: real parts (out[0..35]), 1: imaginary parts.
+ * `emit(q, value)` receives term index q in the reference's (l,m) order. */
+template <typename Emit>
+__device__ __forceinline__ void ide_eval(float x, float y, float z, float kappa_inv, int part, Emit emit) {
+  float att1 = expf(-1.0f * kappa_inv), att2 = expf(-3.0f * kappa_inv), att4 = expf(-10.0f * kappa_inv);
+  float att8 = expf(-36.0f * kappa_inv), att16 = expf(-136.0f * kappa_inv);
+  float pr = 1.0f, pi = 0.0f;
+#pragma unroll 1
+  for (int m = 0; m <= 16; ++m) {
+    if (m > 0) { float nr = pr * x - pi * y; float ni = pr * y + pi * x; pr = nr; pi = ni; }
+    const float pw = part ? pi : pr;
+    const float cm = g_ide_c[m];
+    float tm2 = 0.0f, tm1 = cm;
+    /* l == m term */
+    if (m == 1) emit(0 + m, pw * (cm * att1));
+    if (m == 2) emit(2 + m, pw * (cm * att2));
+    if (m == 4) emit(5 + m, pw * (cm * att4));
+    if (m == 8) emit(10 + m, pw * (cm * att8));
+    if (m == 16) emit(19 + m, pw * (cm * att16));
+#pragma unroll 1
+    for (int l = m + 1; l <= 16; ++l) {
+      float tl = g_ide_a[m * 17 + l] * (z * tm1 - g_ide_b[m * 17 + l] * tm2);
+      tm2 = tm1; tm1 = tl;
+      if ((l & (l - 1)) == 0) {                 /* l in {1,2,4,8,16} */
+        float att = (l == 1) ? att1 : (l == 2) ? att2 : (l == 4) ? att4 : (l == 8) ? att8 : att16;
+        int base = (l == 1) ? 0 : (l == 2) ? 2 : (l == 4) ? 5 : (l == 8) ? 10 : 19;
+        emit(base + m, pw * (tl * att));
+      }
+    }
+  }
+}
+
+}  // namespace rn

@@ -1,0 +1,99 @@
+/*
+ * refnerf_layout.h -- compile-time layouts shared by the pack kernel, the level
+ * kernels and the host side of librefnerf_hip.so.
+ *
+ * (1) canonical parameter blob = the reference's state_dict order for
+ *     nerf_mlp.* (internal/models.py:497-531), row-major [out][in];
+ * (2) fp32 MFMA operand image ("packed weights") streamed by the level kernel.
+ */
+#pragma once
+
+namespace rn {
+
+constexpr int WIDTH = 256;
+constexpr int DEPTH = 8;
+constexpr int IPE_DIM = 96;
+constexpr int BNECK = 128;
+constexpr int IDE_TERMS = 36;
+constexpr int IDE_DIM = 72;
+constexpr int DIR_IN = 201;   /* bottleneck 128 | IDE 72 | n.v 1            */
+constexpr int DIR_PAD = 204;  /* padded: 102 K=2 steps, a multiple of the prefetch depth */
+constexpr int NUM_PARAMS = 1110158;
+
+/* ---------------- canonical blob ---------------- */
+struct Canon {
+  int sp_w[DEPTH], sp_b[DEPTH], sp_in[DEPTH];
+  int density_w, density_b, gradpred_w, gradpred_b, rough_w, rough_b;
+  int diffuse_w, diffuse_b, tint_w, tint_b, bneck_w, bneck_b;
+  int vd_w[DEPTH], vd_b[DEPTH], vd_in[DEPTH];
+  int rgb_w, rgb_b, total;
+};
+
+constexpr Canon make_canon() {
+  Canon c{};
+  int p = 0;
+  for (int i = 0; i < DEPTH; ++i) {
+    int in = (i == 0) ? IPE_DIM : (i == 5 ? WIDTH + IPE_DIM : WIDTH);
+    c.sp_in[i] = in; c.sp_w[i] = p; p += WIDTH * in; c.sp_b[i] = p; p += WIDTH;
+  }
+  c.density_w = p; p += WIDTH; c.density_b = p; p += 1;
+  c.gradpred_w = p; p += 3 * WIDTH; c.gradpred_b = p; p += 3;
+  c.rough_w = p; p += WIDTH; c.rough_b = p; p += 1;
+  c.diffuse_w = p; p += 3 * WIDTH; c.diffuse_b = p; p += 3;
+  c.tint_w = p; p += 3 * WIDTH; c.tint_b = p; p += 3;
+  c.bneck_w = p; p += BNECK * WIDTH; c.bneck_b = p; p += BNECK;
+  for (int i = 0; i < DEPTH; ++i) {
+    int in = (i == 0) ? DIR_IN : (i == 5 ? WIDTH + DIR_IN : WIDTH);
+    c.vd_in[i] = in; c.vd_w[i] = p; p += WIDTH * in; c.vd_b[i] = p; p += WIDTH;
+  }
+  c.rgb_w = p; p += 3 * WIDTH; c.rgb_b = p; p += 3;
+  c.total = p;
+  return c;
+}
+constexpr Canon CANON = make_canon();
+static_assert(CANON.total == NUM_PARAMS, "canonical layout");
+
+/* ---------------- fp32 MFMA operand image ----------------
+ * 18 GEMM ops per sample block.  Each op computes D[out][sample] =
+ * W[out][k] * X[k][sample] with v_mfma_f32_32x32x2_f32 (A = W, B = X), so a
+ * lane (sample = lane&31, half h = lane>>5) ends up holding output rows
+ * row(reg,h) = (reg&3) + 8*(reg>>2) + 4*h of every 32-row block -- exactly the
+ * (k = row) values the next op needs as its B operand for the K=2 step
+ * (block kb, reg r).  The weight image is therefore stored per step as
+ *   A[step][lane][ob] = W[32*ob + (lane&31)][ kidx(step, lane>>5) ]
+ * "register" steps (kb,r): kidx = 32*kb + (r&3) + 8*(r>>2) + 4*h,
+ * "LDS" steps s (encoded inputs staged in LDS): kidx = 2*s + h.
+ * Bias image: B[ob][h][reg] = bias[32*ob + row(reg,h)] (accumulator seed). */
+constexpr int NUM_OPS = 18;
+constexpr int OP_HEADS = 8;
+constexpr int OP_RGB = 17;
+constexpr int REG_STEPS = 128;   /* 256 inputs / 2 */
+
+struct Op { int nob; int stride; int reg_steps; int lds_k; int lds_steps; int a_off; int b_off; };
+struct Packed { Op op[NUM_OPS]; int total; };
+
+constexpr Packed make_packed() {
+  Packed P{};
+  int p = 0;
+  for (int i = 0; i < NUM_OPS; ++i) {
+    Op o{};
+    o.nob = (i == OP_HEADS) ? 5 : (i == OP_RGB ? 1 : 8);
+    o.stride = (i == OP_RGB) ? 1 : 8;
+    bool has_reg = !(i == 0 || i == 9);
+    o.reg_steps = has_reg ? REG_STEPS : 0;
+    o.lds_k = (i == 0 || i == 5) ? IPE_DIM : ((i == 9 || i == 14) ? DIR_PAD : 0);
+    o.lds_steps = o.lds_k / 2;
+    o.a_off = p; p += (o.reg_steps + o.lds_steps) * 64 * o.stride;
+    o.b_off = p; p += o.nob * 32;
+    p = (p + 3) & ~3;
+    P.op[i] = o;
+  }
+  P.total = p + 4 * 64 * 8;   /* tail pad: the A prefetch runs PF steps past an op */
+  return P;
+}
+constexpr Packed PACKED = make_packed();
+
+/* head rows inside op 8 (5 blocks of 32): 0..127 bottleneck, then */
+constexpr int HROW_DENSITY = 128, HROW_GRAD = 129, HROW_ROUGH = 132, HROW_DIFFUSE = 133, HROW_TINT = 136, HROWS = 139;
+
+}  // namespace rn
