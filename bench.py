@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- Ref-NeRF rendering inner loop on MI355X.
+
+One "step" = one ``Model.__call__`` (eval forward, compute_extras=True) over a
+synthetic Blender-style batch of 4096 rays x 128 samples x 2 levels
+(BASELINE.json configs[1]) through the fused HIP path.  Prints ONE JSON line.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: rays shard by rank (each rank renders its own 4096-ray tile, weights
+replicated, no data-path collective) -> weak scaling; RCCL is used only for the
+timing barrier / max-over-ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_PER_SAMPLE = 2211840            # MLP contractions only
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-image", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def build_model(args, dev):
+    import refnerf_pl_amd  # noqa: F401
+    from refnerf_pl_amd import configs, models, synthetic
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", "refnerf_blender.gin")], [
+        f"Model.num_prop_samples = {args.samples}", f"Model.num_nerf_samples = {args.samples}",
+        f"Config.batch_size = {args.rays}", f"Config.hip_precision = '{args.precision}'"])
+    cfg = configs.Config()
+    model = models.construct_model(None, cfg).to(dev)
+    model.eval()
+    blob = synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0)
+    model.nerf_mlp.load_flat_params(blob)
+    return model, cfg, blob
+
+
+def cpu_baseline(blob, args, target_seconds):
+    """Time the CPU oracle (a from-scratch C port, OpenMP over rays, all host
+    cores) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from refnerf_pl_amd import synthetic
+    cores = os.cpu_count() or 1
+    probe = synthetic.blender_rays(64, seed=1, center_frac=0.5)
+    O.model_forward(blob, probe, num_prop_samples=args.samples, num_nerf_samples=args.samples, n_threads=cores, history=True)
+    t0 = time.time()
+    O.model_forward(blob, probe, num_prop_samples=args.samples, num_nerf_samples=args.samples, n_threads=cores, history=True)
+    rate = 64 * args.samples * 2 / max(time.time() - t0, 1e-6)
+    n_rays = int(min(args.rays, max(64, rate * target_seconds / (args.samples * 2))))
+    n_rays = max(64, (n_rays // 64) * 64)
+    rays = synthetic.blender_rays(n_rays, seed=1, center_frac=0.5)
+    t0 = time.time()
+    O.model_forward(blob, rays, num_prop_samples=args.samples, num_nerf_samples=args.samples, n_threads=cores, history=True)
+    dt = time.time() - t0
+    return {"value": n_rays * args.samples * 2 / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n_rays} of {args.rays} rays x {args.samples} samples x 2 levels, eval forward, fp32, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from refnerf_pl_amd import _hip, synthetic, utils
+    _hip.require_device()
+    model, cfg, blob = build_model(args, dev)
+    # ray-tile data parallel: rank r renders its own tile of the (virtual) image
+    rays = utils.rays_from_dict(synthetic.blender_rays(args.rays, seed=1 + rank, center_frac=0.5), dev)
+
+    def step():
+        with torch.no_grad():
+            return model(rays, 1.0, True)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    _hip.set_timing(True)          # HIP events on the kernel's own stream, inside the library
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = _hip.get_timing()
+    _hip.set_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    rgb = out[0][-1]["rgb"]
+    assert torch.isfinite(rgb).all()
+
+    samples_per_step = args.rays * args.samples * 2
+    value = world * samples_per_step * args.steps / elapsed
+    line = {
+        "metric": "ray-samples/s (4096 rays x 128 samples x 2 levels, Ref-NeRF Blender, eval forward)",
+        "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"blender_refnerf.gin, {args.rays} rays x {args.samples} samples, 2-level, "
+                               "Model.__call__ eval forward with compute_extras + full ray_history",
+                   "rays_per_gpu": args.rays, "parallelism": f"ray-tile dp{world}"},
+    }
+    if launches:
+        avg_ms = kern_ms / launches
+        flop_per_launch = args.rays * args.samples * FLOP_PER_SAMPLE
+        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+        line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
+                            "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": None,
+                            "kernel": "rn::level_fwd_f32", "avg_launch_ms": avg_ms, "launches": launches}
+    if rank == 0 and world == 1 and not args.no_image:
+        # full-image render ms: 800x800 Blender view, 157 chunks of 4096 rays (models.render_image)
+        from refnerf_pl_amd import models
+        img = utils.rays_from_dict({k: v.reshape(800, 800, -1) for k, v in synthetic.blender_rays(0, seed=1, full_image=True).items()}, dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            rendering = models.render_image(lambda r: model(r, 1.0, True), img, cfg, verbose=False, device=dev)
+        torch.cuda.synchronize()
+        line["full_image_render_ms"] = 1e3 * (time.perf_counter() - t0)
+        assert rendering["rgb"].shape == (800, 800, 3)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(blob, args, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -147,8 +147,8 @@ int refnerf_integrated_pos_enc(const float *d_lmean, const float *d_lvar, int32_
 int refnerf_integrated_dir_enc(const float *d_xyz, const float *d_kappa_inv, int32_t n,
                                float *d_ide, void *stream);
 
-/* Average duration (ms) of the last `refnerf_level_forward` kernels measured
- * with HIP events on their own stream; enabled by refnerf_set_timing(1).
+/* Total duration (ms) and count of the `refnerf_level_forward` kernels launched
+ * since refnerf_set_timing(1), from HIP event pairs on the launch stream.
  * Used by bench.py for the roofline line. */
 int refnerf_set_timing(int enable);
 int refnerf_get_timing(double *total_ms, int64_t *launches);

@@ -1,0 +1,219 @@
+"""Config dataclass + a minimal gin-syntax loader.
+
+Mirror of the reference's ``internal/configs.py:28-194`` for the fields the hot
+path and its callers read.  gin-config / absl are not installable in the build
+image, so ``parse_config_files_and_bindings`` implements exactly the syntax the
+shipped ``configs/*.gin`` use: ``Name.param = <python literal>``, ``#``
+comments and backslash line continuations.
+"""
+import ast
+import dataclasses
+from typing import Any, Callable, Dict, Optional, Tuple
+
+import numpy as np
+
+_BINDINGS: Dict[str, Dict[str, Any]] = {}
+
+
+def clear_config():
+    _BINDINGS.clear()
+
+
+def bindings_for(name: str) -> Dict[str, Any]:
+    return dict(_BINDINGS.get(name, {}))
+
+
+def parse_config_files_and_bindings(files=None, bindings=None, skip_unknown=True):
+    text = []
+    for f in (files or []):
+        with open(f) as fh:
+            text.append(fh.read())
+    text.extend(bindings or [])
+    src = "\n".join(text).replace("\\\n", " ")
+    for raw in src.splitlines():
+        line = _strip_comment(raw).strip()
+        if not line or "=" not in line:
+            continue
+        lhs, rhs = line.split("=", 1)
+        lhs = lhs.strip()
+        if "." not in lhs:
+            continue
+        name, param = lhs.rsplit(".", 1)
+        name = name.split("/")[-1]          # drop gin scopes
+        try:
+            val = ast.literal_eval(rhs.strip())
+        except (ValueError, SyntaxError):
+            val = rhs.strip()               # e.g. @function references: kept as text
+        _BINDINGS.setdefault(name, {})[param] = val
+
+
+def _strip_comment(line: str) -> str:
+    out, quote = [], None
+    for ch in line:
+        if quote:
+            if ch == quote:
+                quote = None
+        elif ch in "'\"":
+            quote = ch
+        elif ch == "#":
+            break
+        out.append(ch)
+    return "".join(out)
+
+
+def configurable(cls):
+    """Class decorator: constructor kwargs default to the parsed gin bindings."""
+    name = cls.__name__
+    orig = cls.__init__
+
+    def __init__(self, *a, **k):
+        merged = bindings_for(name)
+        if dataclasses.is_dataclass(cls):
+            known = {f.name for f in dataclasses.fields(cls)}
+            merged = {kk: vv for kk, vv in merged.items() if kk in known}
+        merged.update(k)
+        orig(self, *a, **merged)
+
+    cls.__init__ = __init__
+    return cls
+
+
+def config_str() -> str:
+    lines = []
+    for name in sorted(_BINDINGS):
+        for p in sorted(_BINDINGS[name]):
+            lines.append(f"{name}.{p} = {_BINDINGS[name][p]!r}")
+    return "\n".join(lines) + "\n"
+
+
+@configurable
+@dataclasses.dataclass
+class Config:
+    """configs.py:28-172 (fields kept verbatim; dataset/render-path-only knobs included
+    so shipped .gin files parse without unknown-field errors)."""
+    exp_name: str = 'exp'
+    seed: int = 20230227
+    num_workers: int = 4
+    num_gpus: int = 1
+    val_sample_num: int = 3
+    sample_angle_range: float = 5
+    n_input_views: int = 0
+    dataset_loader: str = 'llff'
+    dataset_debug_mode: bool = False
+    batching: str = 'all_images'
+    batch_size: int = 16384
+    patch_size: int = 1
+    factor: int = 0
+    load_alphabetical: bool = True
+    forward_facing: bool = False
+    render_path: bool = False
+    llffhold: int = 8
+    llff_use_all_images_for_training: bool = False
+    use_tiffs: bool = False
+    compute_disp_metrics: bool = False
+    compute_normal_metrics: bool = False
+    gc_every: int = 10000
+    disable_multiscale_loss: bool = False
+    randomized: bool = True
+    near: float = 2.
+    far: float = 6.
+    checkpoint_dir: Optional[str] = None
+    render_dir: Optional[str] = None
+    data_dir: Optional[str] = None
+    vocab_tree_path: Optional[str] = None
+    render_chunk_size: int = 16384
+    num_showcase_images: int = 5
+    deterministic_showcase: bool = True
+    vis_num_rays: int = 16
+    vis_decimate: int = 0
+    save_top_k: int = 5
+    resume_path: Optional[str] = None
+    max_steps: int = 250000
+    early_exit_steps: Optional[int] = None
+    checkpoint_every: int = 25000
+    print_every: int = 100
+    train_render_every: int = 5000
+    cast_rays_in_train_step: bool = False
+    data_loss_type: str = 'charb'
+    charb_padding: float = 0.001
+    data_loss_mult: float = 1.0
+    data_coarse_loss_mult: float = 0.
+    interlevel_loss_mult: float = 1.0
+    orientation_loss_mult: float = 0.0
+    orientation_coarse_loss_mult: float = 0.0
+    orientation_loss_target: str = 'normals_pred'
+    predicted_normal_loss_mult: float = 0.0
+    predicted_normal_coarse_loss_mult: float = 0.0
+    sample_noise_size: int = 128
+    sample_noise_angles: int = 1
+    consistency_warmup_steps: float = 0.
+    consistency_decay_steps: float = 1.
+    consistency_normal_loss_mult: float = 0.0
+    consistency_normal_coarse_loss_mult: float = 0.0
+    consistency_normal_loss_target: str = 'normals_pred'
+    consistency_diffuse_loss_type: str = 'mse'
+    consistency_diffuse_loss_mult: float = 0.0
+    consistency_diffuse_coarse_loss_mult: float = 0.0
+    consistency_specular_loss_type: str = 'mse'
+    consistency_specular_loss_mult: float = 0.0
+    consistency_specular_coarse_loss_mult: float = 0.0
+    accumulated_weights_loss_mult: float = 0.0
+    srgb_mapping_when_rendering: bool = False
+    srgb_mapping_type: str = 'linear'
+    supervised_by_linear_rgb: bool = False
+    render_with_specular_density: bool = False
+    noise_background: bool = False
+    depth_smoothness_loss_mult: float = 0.0
+    depth_smoothness_coarse_loss_mult: float = 0.0
+    consistency_distance_loss_type: str = 'mse'
+    consistency_distance_loss_mult: float = 0.0
+    consistency_distance_coarse_loss_mult: float = 0.0
+    acc_threshold_for_consistency_loss: float = 0.0
+    weights_entropy_loss_mult: float = 0.0
+    weights_entropy_coarse_loss_mult: float = 0.0
+    acc_threshold_for_weights_entropy_loss: float = 0.0
+    lr_init: float = 0.002
+    lr_final: float = 0.00002
+    lr_delay_steps: int = 512
+    lr_delay_mult: float = 0.01
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_eps: float = 1e-6
+    grad_max_norm: float = 0.001
+    grad_max_val: float = 0.
+    distortion_loss_mult: float = 0.01
+    eval_only_once: bool = True
+    eval_save_output: bool = True
+    eval_save_ray_data: bool = False
+    eval_render_interval: int = 1
+    eval_dataset_limit: int = np.iinfo(np.int32).max
+    eval_quantize_metrics: bool = True
+    eval_crop_borders: int = 0
+    render_video_fps: int = 60
+    render_video_crf: int = 18
+    render_path_frames: int = 120
+    z_variation: float = 0.
+    z_phase: float = 0.
+    render_dist_percentile: float = 0.5
+    render_dist_curve_fn: Callable[..., Any] = np.log
+    render_path_file: Optional[str] = None
+    render_job_id: int = 0
+    render_num_jobs: int = 1
+    render_resolution: Optional[Tuple[int, int]] = None
+    render_focal: Optional[float] = None
+    render_camtype: Optional[str] = None
+    render_spherical: bool = False
+    render_save_async: bool = True
+    render_spline_keyframes: Optional[str] = None
+    render_spline_n_interp: int = 30
+    render_spline_degree: int = 5
+    render_spline_smoothness: float = .03
+    # build-side knob (not in the reference): arithmetic of the MLP contractions,
+    # 'f32' (exact fp32 MFMA, the parity mode) or 'bf16'.
+    hip_precision: str = 'f32'
+
+
+def load_config(gin_configs=None, gin_bindings=None) -> Config:
+    """configs.py:182-194 without the absl flags / config dump side effects."""
+    parse_config_files_and_bindings(gin_configs, gin_bindings, skip_unknown=True)
+    return Config()

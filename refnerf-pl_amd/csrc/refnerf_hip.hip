@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 #include "refnerf_hip.h"
 #include "refnerf_device_math.h"
@@ -714,10 +716,11 @@ int fail(int code, const char *fmt, const char *detail = "") {
 
 std::once_flag g_tab_once;
 int g_tab_status = 0;
+/* kernel timing: event pairs recorded on the launch stream, resolved lazily in
+ * refnerf_get_timing() so the timed region is not serialised by event syncs */
 bool g_timing = false;
-double g_time_ms = 0.0;
-int64_t g_time_launches = 0;
-hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
+size_t g_events_used = 0;
 
 double fact(int n) { double r = 1; for (int i = 2; i <= n; ++i) r *= i; return r; }
 
@@ -831,19 +834,21 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
   a.out = *out;
   int grid = (R + rpw - 1) / rpw;
   hipStream_t st = (hipStream_t)stream;
-  if (g_timing) {
-    if (!g_ev0) { HIP_TRY(hipEventCreate(&g_ev0)); HIP_TRY(hipEventCreate(&g_ev1)); }
-    HIP_TRY(hipEventRecord(g_ev0, st));
+  const bool timed = g_timing && g_events_used < 65536;
+  if (timed) {
+    if (g_events_used == g_events.size()) {
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      g_events.emplace_back(e0, e1);
+    }
+    HIP_TRY(hipEventRecord(g_events[g_events_used].first, st));
   }
   hipLaunchKernelGGL(rn::level_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());
-  if (g_timing) {
-    HIP_TRY(hipEventRecord(g_ev1, st));
-    HIP_TRY(hipEventSynchronize(g_ev1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, g_ev0, g_ev1));
-    g_time_ms += ms;
-    g_time_launches += 1;
+  if (timed) {
+    HIP_TRY(hipEventRecord(g_events[g_events_used].second, st));
+    g_events_used += 1;
   }
   return REFNERF_OK;
 }
@@ -883,13 +888,19 @@ int refnerf_integrated_dir_enc(const float *d_xyz, const float *d_kappa_inv, int
 
 int refnerf_set_timing(int enable) {
   g_timing = enable != 0;
-  g_time_ms = 0.0;
-  g_time_launches = 0;
+  g_events_used = 0;
   return REFNERF_OK;
 }
 int refnerf_get_timing(double *total_ms, int64_t *launches) {
-  if (total_ms) *total_ms = g_time_ms;
-  if (launches) *launches = g_time_launches;
+  double tot = 0.0;
+  for (size_t i = 0; i < g_events_used; ++i) {
+    HIP_TRY(hipEventSynchronize(g_events[i].second));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, g_events[i].first, g_events[i].second));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int64_t)g_events_used;
   return REFNERF_OK;
 }
 

@@ -1,0 +1,392 @@
+"""Host-side mirror of the reference's ``internal/models.py`` call surface.
+
+``Model``, ``MLP``, ``NerfMLP``, ``PropMLP``, ``construct_model`` and
+``render_image`` keep the reference's names, constructor parameters, gin
+names, ``state_dict`` keys and return contract, but the level
+loop body of ``Model.__call__`` (models.py:162-306) is ONE fused HIP launch per
+level through the C ABI of include/refnerf_hip.h.  There is no PyTorch / CPU
+fallback: without the library or a gfx950 device the call raises.
+"""
+import math as python_math
+from typing import Any, Callable, List, Mapping, MutableMapping, Optional, Text, Tuple
+
+import torch
+from torch import nn
+
+from . import _hip, configs, layout, utils
+
+
+def _reset_parameters(linear: nn.Linear):
+    """models.py:38-47: U(+-1/sqrt(fan_in)) weights, zero bias."""
+    nn.init.kaiming_uniform_(linear.weight, a=python_math.sqrt(5))
+    if linear.bias is not None:
+        nn.init.constant_(linear.bias, val=0)
+
+
+def _linear(in_f, out_f):
+    lin = nn.Linear(in_f, out_f)
+    _reset_parameters(lin)
+    return lin
+
+
+class MLP(nn.Module):
+    """A PosEnc MLP (models.py:343-750): parameter container + configuration.
+
+    Only the Ref-NeRF architecture family of the shipped refnerf configs is built
+    as a fused kernel; other flag combinations raise ``ValueError`` at
+    construction (they are valid in the reference).
+    """
+
+    def __init__(
+            self,
+            net_depth: int = 8,
+            net_width: int = 256,
+            bottleneck_width: int = 256,
+            net_depth_viewdirs: int = 1,
+            net_width_viewdirs: int = 128,
+            net_activation: Callable[..., Any] = torch.nn.functional.relu,
+            min_deg_point: int = 0,
+            max_deg_point: int = 12,
+            weight_init: str = 'he_uniform',
+            skip_layer: int = 4,
+            skip_layer_dir: int = 4,
+            num_rgb_channels: int = 3,
+            deg_view: int = 4,
+            use_reflections: bool = False,
+            use_directional_enc: bool = False,
+            enable_pred_roughness: bool = False,
+            roughness_activation: Callable[..., Any] = torch.nn.functional.softplus,
+            roughness_bias: float = -1.,
+            use_diffuse_color: bool = False,
+            use_specular_tint: bool = False,
+            use_n_dot_v: bool = False,
+            enable_pred_specular_density: bool = False,
+            bottleneck_noise: float = 0.0,
+            density_activation: Callable[..., Any] = torch.nn.functional.softplus,
+            density_bias: float = -1.,
+            density_noise: float = 0.,
+            rgb_premultiplier: float = 1.,
+            rgb_activation: Callable[..., Any] = torch.sigmoid,
+            rgb_bias: float = 0.,
+            rgb_padding: float = 0.001,
+            enable_pred_normals: bool = False,
+            disable_density_normals: bool = False,
+            disable_rgb: bool = False,
+            srgb_mapping: bool = True,
+            srgb_mapping_normalization: bool = True,
+            warp_fn: Callable[..., Any] = None,
+            basis_shape: str = 'icosahedron',
+            basis_subdivisions: int = 2,
+    ):
+        super().__init__()
+        for k, v in list(locals().items()):
+            if k not in ("self", "__class__"):
+                setattr(self, k, v)
+
+        # models.py:471-480 (same errors as the reference)
+        if self.use_reflections and not (self.enable_pred_normals or not self.disable_density_normals):
+            raise ValueError('Normals must be computed for reflection directions.')
+        if self.enable_pred_specular_density and not self.use_diffuse_color:
+            raise ValueError('Specular density is useless if not using diffuse color.')
+        self._check_supported()
+
+        # same module names / shapes as the reference after its lazy init (models.py:497-531)
+        W = self.net_width
+        sp_in = [layout.IPE_DIM if i == 0 else (W + layout.IPE_DIM if i == self.skip_layer + 1 else W)
+                 for i in range(self.net_depth)]
+        self.spatial_net = nn.ModuleList([_linear(sp_in[i], W) for i in range(self.net_depth)])
+        self.raw_density = _linear(W, 1)
+        self.grad_pred = _linear(W, 3)
+        self.raw_roughness = _linear(W, 1)
+        self.raw_rgb_diffuse = _linear(W, self.num_rgb_channels)
+        self.raw_tint = _linear(W, 3)
+        self.bottleneck = _linear(W, self.bottleneck_width)
+        vd_in = [layout.DIR_IN if i == 0 else (W + layout.DIR_IN if i == self.skip_layer + 1 else W)
+                 for i in range(self.net_depth_viewdirs)]
+        self.viewdir_mlp = nn.ModuleList([_linear(vd_in[i], self.net_width_viewdirs)
+                                          for i in range(self.net_depth_viewdirs)])
+        self.rgb = _linear(self.net_width_viewdirs, self.num_rgb_channels)
+
+        self._flat = None          # canonical blob the parameters alias
+        self._packed = None        # MFMA operand image
+        self._packed_key = None
+
+    # ---- supported-configuration gate ------------------------------------
+    def _check_supported(self):
+        want = dict(net_depth=8, net_width=256, bottleneck_width=128, net_depth_viewdirs=8,
+                    net_width_viewdirs=256, min_deg_point=0, max_deg_point=16, skip_layer=4,
+                    num_rgb_channels=3, deg_view=5, use_reflections=True, use_directional_enc=True,
+                    enable_pred_roughness=True, use_diffuse_color=True, use_specular_tint=True,
+                    use_n_dot_v=True, enable_pred_specular_density=False, bottleneck_noise=0.0,
+                    density_noise=0., enable_pred_normals=True, disable_density_normals=False,
+                    disable_rgb=False, warp_fn=None, basis_shape='octahedron', basis_subdivisions=1)
+        bad = {k: getattr(self, k) for k, v in want.items() if getattr(self, k) != v}
+        if bad:
+            raise ValueError(
+                "MLP configuration outside the fused Ref-NeRF family (configs/*refnerf*.gin): "
+                f"{bad}; expected {({k: want[k] for k in bad})}")
+        if self.net_activation is not torch.nn.functional.relu:
+            raise ValueError("net_activation must be relu")
+        if self.density_activation is not torch.nn.functional.softplus or \
+                self.roughness_activation is not torch.nn.functional.softplus or \
+                self.rgb_activation is not torch.sigmoid:
+            raise ValueError("density/roughness activations must be softplus and rgb_activation sigmoid")
+
+    # ---- flat canonical blob ----------------------------------------------
+    def _named_linears(self):
+        for spec in layout.PARAM_SPECS:
+            mod = self
+            for part in spec.name.split("."):
+                mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+            yield spec, mod
+
+    def flat_params(self) -> torch.Tensor:
+        """The 46 parameters as ONE canonical fp32 blob; the nn.Parameters are
+        re-pointed to views of it (so optimiser steps update the blob in place)."""
+        first = self.spatial_net[0].weight
+        ok = (self._flat is not None and self._flat.device == first.device)
+        if ok:
+            for spec, lin in self._named_linears():
+                if lin.weight.data_ptr() != self._flat.data_ptr() + 4 * spec.w_off or \
+                        lin.bias.data_ptr() != self._flat.data_ptr() + 4 * spec.b_off:
+                    ok = False
+                    break
+        if not ok:
+            flat = torch.empty(layout.NUM_PARAMS, dtype=torch.float32, device=first.device)
+            with torch.no_grad():
+                for spec, lin in self._named_linears():
+                    n = spec.out_dim * spec.in_dim
+                    flat[spec.w_off:spec.w_off + n].copy_(lin.weight.detach().reshape(-1))
+                    flat[spec.b_off:spec.b_off + spec.out_dim].copy_(lin.bias.detach())
+                    lin.weight.data = flat[spec.w_off:spec.w_off + n].view(spec.out_dim, spec.in_dim)
+                    lin.bias.data = flat[spec.b_off:spec.b_off + spec.out_dim]
+            self._flat = flat
+            self._packed_key = None
+        return self._flat
+
+    def load_flat_params(self, blob):
+        """Copy a canonical blob (numpy / tensor) into the parameters."""
+        flat = self.flat_params()
+        with torch.no_grad():
+            flat.copy_(torch.as_tensor(blob, dtype=torch.float32).to(flat.device))
+        self._packed_key = None
+
+    def _param_version(self):
+        return tuple(p._version for p in self.parameters())
+
+    def packed_weights(self, precision: int) -> torch.Tensor:
+        flat = self.flat_params()
+        key = (precision, flat.data_ptr(), self._param_version(), flat._version)
+        if self._packed is None or self._packed_key != key:
+            self._packed = _hip.pack_weights(flat, None if self._packed is None or
+                                             self._packed.device != flat.device else self._packed, precision)
+            self._packed_key = key
+        return self._packed
+
+    def __call__(self, gaussians, viewdirs=None, imageplane=None):
+        raise _hip.HipLibraryError(
+            "MLP.__call__ on caller-supplied Gaussians is not a separate entry point of the fused "
+            "path: the MLP runs inside refnerf_level_forward (Model.__call__).")
+
+
+@configs.configurable
+class NerfMLP(MLP):
+    pass
+
+
+@configs.configurable
+class PropMLP(MLP):
+    pass
+
+
+_PREC = {"f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16}
+
+
+@configs.configurable
+class Model(nn.Module):
+    """A mip-NeRF-360 style model holding the MLPs (models.py:50-321)."""
+
+    def __init__(
+            self,
+            config: Any = None,
+            num_prop_samples: int = 64,
+            num_nerf_samples: int = 32,
+            num_levels: int = 3,
+            bg_intensity_range: Tuple[float] = (1., 1.),
+            anneal_slope: float = 10,
+            use_viewdirs: bool = True,
+            raydist_fn: Callable[..., Any] = None,
+            ray_shape: str = 'cone',
+            disable_integration: bool = False,
+            single_jitter: bool = True,
+            dilation_bias: float = 0.0025,
+            dilation_multiplier: float = 0.5,
+            single_mlp: bool = False,
+            resample_padding: float = 0.0,
+            opaque_background: bool = False,
+            init_s_near: float = 0.,
+            init_s_far: float = 1.,
+    ):
+        super().__init__()
+        for k, v in list(locals().items()):
+            if k not in ("self", "__class__"):
+                setattr(self, k, v)
+        # models.py:120-123
+        self.nerf_mlp = NerfMLP()
+        self.prop_mlp = self.nerf_mlp if self.single_mlp else PropMLP()
+        unsupported = {}
+        if self.dilation_bias > 0 or self.dilation_multiplier > 0:
+            unsupported["dilation"] = (self.dilation_bias, self.dilation_multiplier)
+        if self.raydist_fn is not None:
+            unsupported["raydist_fn"] = self.raydist_fn
+        if self.disable_integration:
+            unsupported["disable_integration"] = True
+        if not self.use_viewdirs:
+            unsupported["use_viewdirs"] = False
+        if unsupported:
+            raise ValueError(f"Model options outside the fused Ref-NeRF path: {unsupported}")
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def _level_cfg(self, mlp: MLP, n_samples, n_in, train_frac, compute_extras):
+        cfg = self.config
+        if self.ray_shape not in ('cone', 'cylinder'):
+            raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')      # render.py:126
+        if cfg.render_with_specular_density:
+            raise ValueError('Specular density prediction from mlps should be enabled.')  # models.py:250-252
+        if self.anneal_slope > 0:                                               # models.py:190-195
+            s = self.anneal_slope
+            anneal = (s * train_frac) / ((s - 1) * train_frac + 1)
+        else:
+            anneal = 1.
+        if self.bg_intensity_range[0] == self.bg_intensity_range[1]:            # models.py:261-267
+            bg = self.bg_intensity_range[0]
+        else:
+            bg = (self.bg_intensity_range[0] + self.bg_intensity_range[1]) / 2
+        mode = cfg.srgb_mapping_type if cfg.srgb_mapping_when_rendering else 'none'
+        if mode not in _hip.SRGB_MODES:
+            raise ValueError('Mapping types are none, linear, norm_linear, srgb, norm_srgb')  # render.py:218
+        prec = getattr(cfg, "hip_precision", "f32")
+        return _hip.default_cfg(
+            n_samples=int(n_samples), n_in=int(n_in), training=int(self.training),
+            compute_extras=int(bool(compute_extras)), srgb_mapping=int(mlp.srgb_mapping),
+            srgb_mapping_normalization=int(mlp.srgb_mapping_normalization), render_srgb_mode=mode,
+            opaque_background=int(self.opaque_background), ray_shape=0 if self.ray_shape == 'cone' else 1,
+            precision=_PREC[prec], anneal=float(anneal), resample_padding=float(self.resample_padding),
+            s_near=float(self.init_s_near), s_far=float(self.init_s_far), density_bias=float(mlp.density_bias),
+            roughness_bias=float(mlp.roughness_bias), rgb_premultiplier=float(mlp.rgb_premultiplier),
+            rgb_bias=float(mlp.rgb_bias), rgb_padding=float(mlp.rgb_padding), bg_rgb=float(bg))
+
+    def __call__(self, rays, train_frac, compute_extras):
+        """The Ref-NeRF model (models.py:129-321).
+
+        Returns (renderings, ray_history): per level a dict of per-ray tensors
+        and a dict of per-sample tensors, keys/shapes/dtypes as in the reference.
+        """
+        _hip.require_device()
+        dev = self.device
+        batch_shape = tuple(rays.origins.shape[:-1])
+
+        def flat(x, c):
+            return torch.as_tensor(x, dtype=torch.float32, device=dev).reshape(-1, c)
+        r = {"origins": flat(rays.origins, 3), "directions": flat(rays.directions, 3),
+             "viewdirs": flat(rays.viewdirs, 3), "radii": flat(rays.radii, 1).reshape(-1),
+             "near": flat(rays.near, 1).reshape(-1), "far": flat(rays.far, 1).reshape(-1)}
+        R = r["origins"].shape[0]
+        # models.py:153-157
+        sdist = torch.cat([torch.full((R, 1), float(self.init_s_near), device=dev),
+                           torch.full((R, 1), float(self.init_s_far), device=dev)], dim=-1)
+        weights = torch.ones((R, 1), device=dev)
+        if self.training:
+            raise _hip.HipLibraryError("training-mode forward/backward is not built yet in this round")
+
+        renderings, ray_history = [], []
+        for i_level in range(self.num_levels):
+            is_prop = i_level < (self.num_levels - 1)
+            num_samples = self.num_prop_samples if is_prop else self.num_nerf_samples
+            if num_samples <= 1:
+                raise ValueError(f'num_samples must be > 1, is {num_samples}.')   # stepfun.py:234-235
+            mlp = self.prop_mlp if is_prop else self.nerf_mlp
+            cfg = self._level_cfg(mlp, num_samples, weights.shape[-1], train_frac, compute_extras)
+            res = _hip.level_forward(mlp.packed_weights(cfg.precision), cfg, r, sdist, weights, history=True)
+            sdist, weights = res["sdist"], res["weights"]
+
+            def rs(x, *tail):
+                return x.reshape(batch_shape + tuple(tail))
+            N = num_samples
+            rendering = {"rgb": rs(res["r_rgb"], 3), "diffuse": rs(res["r_diffuse"], 3),
+                         "specular": rs(res["r_specular"], 3), "distance": rs(res["r_distance"], 1),
+                         "acc": rs(res["r_acc"])}
+            if compute_extras:                                                   # render.py:227-254
+                if self.training:
+                    rendering["normals"] = rs(res["r_normals"], 3)
+                rendering["normals_pred"] = rs(res["r_normals_pred"], 3)
+                rendering["tint"] = rs(res["r_tint"], 3)
+                rendering["roughness"] = rs(res["r_roughness"], 1)
+                rendering["distance_mean"] = rs(res["r_distance_mean"])
+                pct = res["r_percentiles"]
+                rendering["distance_percentile_5"] = rs(pct[:, 0].contiguous())
+                rendering["distance_median"] = rs(pct[:, 1].contiguous())
+                rendering["distance_percentile_95"] = rs(pct[:, 2].contiguous())
+                n = self.config.vis_num_rays                                     # models.py:290-301
+                rendering["ray_sdist"] = sdist[:n, :]
+                rendering["ray_weights"] = weights[:n, :]
+                rendering["ray_rgbs"] = res["rgb"][:n, :, :]
+            renderings.append(rendering)
+            ray_results = {"density": rs(res["density"], N), "rgb": rs(res["rgb"], N, 3),
+                           "normals": rs(res["normals"], N, 3) if self.training else None,
+                           "normals_pred": rs(res["normals_pred"], N, 3),
+                           "grad_pred": rs(res["grad_pred"], N, 3), "tint": rs(res["tint"], N, 3),
+                           "diffuse": rs(res["diffuse"], N, 3), "specular": rs(res["specular"], N, 3),
+                           "roughness": rs(res["roughness"], N, 1),
+                           "sdist": rs(sdist, N + 1).clone(), "weights": rs(weights, N).clone()}
+            ray_history.append(ray_results)
+
+        if compute_extras:                                                       # models.py:308-319
+            ws = [x['ray_weights'] for x in renderings]
+            rgbs = [x['ray_rgbs'] for x in renderings]
+            final_rgb = torch.sum(rgbs[-1] * ws[-1][..., None], dim=-2)
+            for i in range(len(rgbs) - 1):
+                renderings[i]['ray_rgbs'] = torch.broadcast_to(final_rgb[:, None, :], rgbs[i].shape)
+        return renderings, ray_history
+
+
+def construct_model(rays, config):
+    """models.py:324-340.  The reference needs one dummy forward to shape its
+    LazyLinear layers; here the shapes are known at construction, so `rays` is
+    only accepted for signature compatibility."""
+    del rays
+    return Model(config=config)
+
+
+def render_image(render_fn: Callable[[utils.Rays], Tuple[List[Mapping[Text, torch.Tensor]], List[Any]]],
+                 rays: utils.Rays, config: configs.Config, verbose: bool = True,
+                 device=torch.device('cuda')) -> MutableMapping[Text, Any]:
+    """Render all the pixels of an image in chunks (models.py:763-825)."""
+    torch.cuda.synchronize()
+    height, width = rays.origins.shape[:2]
+    num_rays = height * width
+    rays = rays.reshape(num_rays, -1)
+    chunks = []
+    for idx0 in range(0, num_rays, config.render_chunk_size):
+        chunk_rays = rays[idx0:idx0 + config.render_chunk_size]
+        chunk_rays.to(device)
+        chunk_renderings, _ = render_fn(chunk_rays)
+        chunk_rendering = chunk_renderings[-1]
+        for k in chunk_renderings[0]:
+            if k.startswith('ray_'):
+                chunk_rendering[k] = [r[k] for r in chunk_renderings]
+        chunks.append({k: utils.recursive_detach(v) for k, v in chunk_rendering.items()})
+    rendering = utils.merge_chunks(chunks)
+    for k, z in rendering.items():
+        if not k.startswith('ray_'):
+            rendering[k] = z.reshape((height, width) + z.shape[1:])
+    keys = [k for k in rendering if k.startswith('ray_')]
+    if keys:
+        temp_num_rays = rendering[keys[0]][0].shape[0]
+        ray_idx = torch.randperm(temp_num_rays)[:config.vis_num_rays]
+        for k in keys:
+            rendering[k] = [r[ray_idx.to(r.device)] for r in rendering[k]]
+    return rendering
