@@ -1,0 +1,225 @@
+"""GPU: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors captured from the reference.  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (HIST_KEYS, REND_KEYS, cfg_from_bindings, load_golden, params_from_golden,
+                     rays_from_golden)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import refnerf_pl_amd  # noqa: F401
+    from refnerf_pl_amd import _hip
+    _hip.require_device()          # fails loudly: no fallback
+    return _hip
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+DEV = "cuda:0"
+
+
+def dev_rays(rays):
+    out = {}
+    for k, v in rays.items():
+        t = torch.tensor(np.asarray(v, np.float32), device=DEV)
+        out[k] = t.reshape(-1) if k in ("radii", "near", "far") else t
+    return out
+
+
+def run_hip_model(hip, P, rays, kw, lv, precision=0):
+    packed = hip.pack_weights(torch.tensor(P, device=DEV), precision=precision)
+    r = dev_rays(rays)
+    R = rays["origins"].shape[0]
+    sdist = torch.tensor([[0.0, 1.0]], device=DEV).repeat(R, 1)
+    weights = torch.ones((R, 1), device=DEV)
+    nl = lv.get("num_levels", 2)
+    outs = []
+    for L in range(nl):
+        n = lv.get("num_prop_samples", 128) if L < nl - 1 else lv.get("num_nerf_samples", 128)
+        cfg = hip.default_cfg(n_samples=n, n_in=weights.shape[1], precision=precision, **kw)
+        res = hip.level_forward(packed, cfg, r, sdist, weights)
+        sdist, weights = res["sdist"], res["weights"]
+        outs.append({k: v.cpu().numpy() for k, v in res.items()})
+    return outs
+
+
+# ---------------------------------------------------------------- stages
+def test_sampler_bit_exact_vs_oracle_and_golden(hip, O):
+    """Identical (t, logits) in -> CDF bin indices AND sdist bit-identical to the
+    oracle (shared exp, sequential CDF), indices identical to the reference."""
+    g = load_golden("sampler")
+    for i in range(int(g["num_cases"])):
+        t, lg, n = g[f"c{i}_t"], g[f"c{i}_logits"], int(g[f"c{i}_n"])
+        sd, idx = hip.sample_intervals(torch.tensor(t, device=DEV), torch.tensor(lg, device=DEV), n)
+        sd_o, idx_o = O.sample_intervals(t, lg, n)
+        assert np.array_equal(idx.cpu().numpy(), idx_o), f"case {i}: bin indices differ from oracle"
+        assert np.array_equal(idx.cpu().numpy(), g[f"c{i}_idx"]), f"case {i}: bin indices differ from reference"
+        assert np.array_equal(sd.cpu().numpy(), sd_o), f"case {i}: sdist not bit-equal to oracle"
+
+
+def test_sampler_large_random_bit_exact(hip, O):
+    rng = np.random.default_rng(3)
+    R, M, N = 512, 128, 128
+    t = np.sort(rng.random((R, M + 1)).astype(np.float32), axis=-1)
+    t[:, 0], t[:, -1] = 0, 1
+    w = (rng.random((R, M)) ** 6).astype(np.float32)
+    lg = O.resample_logits(t, w)
+    sd, idx = hip.sample_intervals(torch.tensor(t, device=DEV), torch.tensor(lg, device=DEV), N)
+    sd_o, idx_o = O.sample_intervals(t, lg, N)
+    assert np.array_equal(idx.cpu().numpy(), idx_o)
+    assert np.array_equal(sd.cpu().numpy(), sd_o)
+    s = sd.cpu().numpy()
+    assert np.all(np.diff(s, axis=-1) >= 0) and s.min() >= 0 and s.max() <= 1
+
+
+def test_sampler_errors(hip):
+    t = torch.zeros((1, 2), device=DEV)
+    with pytest.raises(ValueError, match="num_samples must be > 1"):      # stepfun.py:234-235
+        hip.sample_intervals(t, torch.zeros((1, 1), device=DEV), 1)
+
+
+@pytest.mark.parametrize("fam", ["blender", "llff"])
+def test_ipe_stage(hip, fam):
+    g = load_golden("cast_ipe")
+    f = hip.integrated_pos_enc(torch.tensor(g[fam + "_lmean"], device=DEV), torch.tensor(g[fam + "_lvar"], device=DEV))
+    np.testing.assert_allclose(f.cpu().numpy(), g[fam + "_ipe"], rtol=0, atol=1e-6)
+
+
+def test_ide_stage_gated_by_fp64(hip, O):
+    """|hip - fp64| <= |reference - fp64| + 1e-5 at every roughness."""
+    g = load_golden("ide")
+    xyz = g["xyz"]
+    for kap in (0.0, 0.01, 0.1, 0.3, 1.0):
+        mine = hip.integrated_dir_enc(torch.tensor(xyz, device=DEV), torch.full((xyz.shape[0], 1), kap, device=DEV)).cpu().numpy()
+        truth = O.ide(xyz, kap, "f64")
+        ref = g[f"ide_{kap}"]
+        assert np.abs(mine - truth).max() <= np.abs(ref - truth).max() + 1e-5
+        assert np.abs(mine - truth).max() < 5e-6
+        np.testing.assert_allclose(mine, O.ide(xyz, kap, "stable"), rtol=0, atol=1e-6)
+
+
+# ---------------------------------------------------------------- end to end
+EVAL_CASES = ["model_blender_eval", "model_blender_sharp_eval", "model_c1_eval", "model_llff_linear_eval"]
+
+
+@pytest.mark.parametrize("name", EVAL_CASES)
+def test_level_forward_vs_oracle_and_reference(hip, O, name):
+    g = load_golden(name)
+    P = params_from_golden(g)
+    rays = rays_from_golden(g)
+    kw, lv = cfg_from_bindings(g["bindings"])
+    ref = O.model_forward(P, rays, **lv, **kw)
+    outs = run_hip_model(hip, P, rays, kw, lv)
+    for L, (res, orc) in enumerate(zip(outs, ref)):
+        if L == 0:
+            assert np.array_equal(res["sdist"], orc["sdist"])
+        # sample indices: identical to the oracle on this fixture (fp32 mode)
+        assert np.mean(res["bin_idx"] == orc["bin_idx"]) == 1.0
+        for k in HIST_KEYS:
+            tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 5e-6)
+            np.testing.assert_allclose(res[k], orc[k].reshape(res[k].shape), rtol=0, atol=tol, err_msg=f"L{L} {k}")
+            np.testing.assert_allclose(res[k], g[f"L{L}_h_{k}"].reshape(res[k].shape), rtol=0, atol=max(tol, 2e-5), err_msg=f"golden L{L} {k}")
+        for k in REND_KEYS:
+            np.testing.assert_allclose(res["r_" + k], orc["r_" + k], rtol=0, atol=1e-5, err_msg=f"L{L} r_{k}")
+            np.testing.assert_allclose(res["r_" + k], g[f"L{L}_r_{k}"].reshape(res["r_" + k].shape), rtol=0, atol=1e-5)
+        # headline bar: RGB L-inf <= 1e-4 vs the reference CPU path
+        assert np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max() <= 1e-4
+        pc = np.stack([g[f"L{L}_r_distance_percentile_5"], g[f"L{L}_r_distance_median"], g[f"L{L}_r_distance_percentile_95"]], -1)
+        assert res["r_percentiles"].dtype == np.float64
+        np.testing.assert_allclose(res["r_percentiles"], pc, rtol=0, atol=2e-5)
+
+
+def test_model_api_matches_reference_contract(hip):
+    """Model.__call__ through the host mirror: keys, shapes, dtypes and values."""
+    from refnerf_pl_amd import configs, models, utils
+    g = load_golden("model_blender_sharp_eval")
+    configs.clear_config()
+    import os
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")], [])
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).eval()
+    model.nerf_mlp.load_flat_params(params_from_golden(g))
+    rays = utils.rays_from_dict(rays_from_golden(g), DEV)
+    with torch.no_grad():
+        renderings, history = model(rays, 1.0, True)
+    assert len(renderings) == len(history) == 2
+    R = 24
+    expect_r = {"rgb": (R, 3), "diffuse": (R, 3), "specular": (R, 3), "distance": (R, 1), "acc": (R,),
+                "normals_pred": (R, 3), "tint": (R, 3), "roughness": (R, 1), "distance_mean": (R,),
+                "distance_percentile_5": (R,), "distance_median": (R,), "distance_percentile_95": (R,),
+                "ray_sdist": (16, 129), "ray_weights": (16, 128), "ray_rgbs": (16, 128, 3)}
+    for L in range(2):
+        assert list(renderings[L].keys()) == list(expect_r.keys())
+        for k, shp in expect_r.items():
+            assert tuple(renderings[L][k].shape) == shp, k
+            want = torch.float64 if "percentile" in k or "median" in k else torch.float32
+            assert renderings[L][k].dtype == want
+            np.testing.assert_allclose(renderings[L][k].cpu().numpy(), g[f"L{L}_r_{k}"], rtol=0, atol=2e-5, err_msg=k)
+        assert history[L]["normals"] is None
+        for k in ("density", "rgb", "normals_pred", "grad_pred", "tint", "diffuse", "specular", "roughness", "sdist", "weights"):
+            assert tuple(history[L][k].shape) == g[f"L{L}_h_{k}"].shape, k
+    # render_image on a tiny 6x4 "image" reuses the same rays
+    img = utils.rays_from_dict({k: v.reshape(6, 4, -1) for k, v in rays_from_golden(g).items()}, DEV)
+    cfg.render_chunk_size = 10
+    with torch.no_grad():
+        rendering = models.render_image(lambda r: model(r, 1.0, True), img, cfg, verbose=False, device=torch.device(DEV))
+    assert rendering["rgb"].shape == (6, 4, 3)
+    np.testing.assert_allclose(rendering["rgb"].reshape(-1, 3).cpu().numpy(), g["L1_r_rgb"], rtol=0, atol=2e-5)
+
+
+def test_edge_shapes_and_errors(hip, O):
+    """Ragged / edge sizes: R not a multiple of the workgroup tile, N in {2, 33,
+    64, 192, 256}, a single ray; and the reference's error cases."""
+    from refnerf_pl_amd import synthetic
+    P = synthetic.make_params(1, 0.05, 10.0)
+    packed = hip.pack_weights(torch.tensor(P, device=DEV))
+    for R, n0, n1 in ((1, 64, 64), (7, 33, 2), (5, 192, 256), (3, 256, 192)):
+        rays = synthetic.blender_rays(R, seed=R, center_frac=0.3)
+        ref = O.model_forward(P, rays, num_prop_samples=n0, num_nerf_samples=n1)
+        outs = run_hip_model(hip, P, rays, {}, dict(num_prop_samples=n0, num_nerf_samples=n1))
+        for L in range(2):
+            np.testing.assert_allclose(outs[L]["r_rgb"], ref[L]["r_rgb"], rtol=0, atol=1e-4, err_msg=f"R={R} L={L}")
+            np.testing.assert_allclose(outs[L]["weights"], ref[L]["weights"], rtol=0, atol=2e-5)
+            assert np.mean(outs[L]["bin_idx"] == ref[L]["bin_idx"]) > 0.999
+    r = dev_rays(synthetic.blender_rays(2, seed=1))
+    sd = torch.tensor([[0.0, 1.0]], device=DEV).repeat(2, 1)
+    w = torch.ones((2, 1), device=DEV)
+    with pytest.raises(ValueError, match="num_samples must be > 1"):
+        hip.level_forward(packed, hip.default_cfg(n_samples=1), r, sd, w)
+    with pytest.raises(ValueError, match="ray_shape"):
+        hip.level_forward(packed, hip.default_cfg(ray_shape=3), r, sd, w)
+
+
+def test_full_size_properties(hip):
+    """BASELINE configs[1] size (4096 x 128 x 2): size-independent properties --
+    weights >= 0, acc = sum(w) <= 1, sdist monotone in [0,1], level-0 sampling
+    exactly uniform, render = sum(w*c)+bg, determinism (two runs bit-equal)."""
+    from refnerf_pl_amd import synthetic
+    P = synthetic.make_params(0, 0.05, 20.0)
+    rays = synthetic.blender_rays(4096, seed=1, center_frac=0.5)
+    a = run_hip_model(hip, P, rays, {}, {})
+    b = run_hip_model(hip, P, rays, {}, {})
+    for L in range(2):
+        for k in a[L]:
+            assert np.array_equal(a[L][k], b[L][k]), f"non-deterministic {k}"
+        w, sd = a[L]["weights"], a[L]["sdist"]
+        assert np.all(np.isfinite(a[L]["r_rgb"]))
+        assert w.min() >= 0 and np.all(w.sum(-1) <= 1 + 1e-5)
+        assert np.all(np.diff(sd, axis=-1) >= 0) and sd.min() >= 0 and sd.max() <= 1
+        np.testing.assert_allclose(a[L]["r_acc"], w.sum(-1), rtol=0, atol=1e-5)
+        bg = np.maximum(0, 1 - a[L]["r_acc"])[:, None]
+        np.testing.assert_allclose(a[L]["r_rgb"], (w[..., None] * a[L]["rgb"]).sum(1) + bg, rtol=0, atol=2e-5)
+    from oracle import oracle as Orc
+    u = Orc.linspace_u(128)
+    mid = (u[1:] + u[:-1]) / 2
+    assert np.array_equal(a[0]["sdist"][0, 1:-1], mid.astype(np.float32))
+    assert np.all(a[0]["sdist"] == a[0]["sdist"][0:1])

@@ -1,0 +1,139 @@
+"""CPU: host logic of the drop-in boundary (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import refnerf_pl_amd  # noqa: F401
+from refnerf_pl_amd import _hip, configs, layout, models, synthetic, utils
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GIN = os.path.join(ROOT, "configs", "refnerf_blender.gin")
+
+
+@pytest.fixture()
+def cfg():
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([GIN], [])
+    yield configs.Config()
+    configs.clear_config()
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports exactly what include/refnerf_hip.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "refnerf_hip.h")).read()
+    names = set(re.findall(r"\b(refnerf_[a-z_0-9]+)\s*\(", hdr))
+    assert {"refnerf_level_forward", "refnerf_pack_weights", "refnerf_sample_intervals",
+            "refnerf_integrated_pos_enc", "refnerf_integrated_dir_enc"} <= names
+    lib = _hip.lib()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.refnerf_abi_version() == 1
+    assert _hip.packed_weights_bytes(_hip.PREC_F32) > 4 * layout.NUM_PARAMS
+    c = _hip.default_cfg()
+    assert (c.n_samples, c.resample_padding, c.density_bias) == (128, pytest.approx(0.01), pytest.approx(0.5))
+    assert C.sizeof(_hip.LevelCfg) == 80 and C.sizeof(_hip.LevelOut) == 23 * 8
+
+
+def test_gin_loader_syntax(tmp_path):
+    configs.clear_config()
+    f = tmp_path / "x.gin"
+    f.write_text("# comment\nConfig.exp_name = \\\n    'a#b'\nModel.num_levels = 2  # trailing\n"
+                 "Config.near = 0.\nNerfMLP.basis_shape = 'octahedron'\nConfig.unknown_field = 3\n")
+    configs.parse_config_files_and_bindings([str(f)], ["Config.batch_size = 77", "train/Config.far = 9."])
+    c = configs.Config()
+    assert (c.exp_name, c.near, c.batch_size, c.far) == ("a#b", 0.0, 77, 9.0)
+    assert configs.bindings_for("Model") == {"num_levels": 2}
+    assert "Model.num_levels = 2" in configs.config_str()
+    configs.clear_config()
+
+
+def test_model_surface_and_state_dict(cfg):
+    model = models.construct_model(utils.dummy_rays(), cfg)
+    assert isinstance(model.nerf_mlp, models.NerfMLP) and model.prop_mlp is model.nerf_mlp
+    sd = model.state_dict()
+    assert len(sd) == 92                                   # 46 tensors, aliased under prop_mlp
+    assert sum(p.numel() for p in model.parameters()) == layout.NUM_PARAMS
+    for spec in layout.PARAM_SPECS:
+        for pre in ("nerf_mlp.", "prop_mlp."):
+            assert tuple(sd[pre + spec.name + ".weight"].shape) == (spec.out_dim, spec.in_dim)
+            assert tuple(sd[pre + spec.name + ".bias"].shape) == (spec.out_dim,)
+    # reference init: U(+-1/sqrt(fan_in)), zero bias (models.py:38-47)
+    w = model.nerf_mlp.spatial_net[1].weight
+    assert float(w.abs().max()) <= 1 / 16 + 1e-6 and float(model.nerf_mlp.rgb.bias.abs().max()) == 0
+    assert (model.num_levels, model.num_prop_samples, model.num_nerf_samples, model.single_mlp) == (2, 128, 128, True)
+
+
+def test_flat_params_alias_and_roundtrip(cfg):
+    mlp = models.construct_model(None, cfg).nerf_mlp
+    blob = synthetic.make_params(3, 0.1)
+    mlp.load_flat_params(blob)
+    flat = mlp.flat_params()
+    assert np.array_equal(flat.numpy(), blob)
+    spec = layout.SPEC_BY_NAME["viewdir_mlp.5"]
+    assert np.array_equal(mlp.viewdir_mlp[5].weight.detach().numpy().reshape(-1), blob[spec.w_off:spec.w_off + 256 * 457])
+    with torch.no_grad():
+        mlp.rgb.bias.add_(1.0)                              # an optimiser-style in-place update
+    assert flat[layout.SPEC_BY_NAME["rgb"].b_off].item() == pytest.approx(blob[layout.SPEC_BY_NAME["rgb"].b_off] + 1.0)
+    sd = mlp.state_dict()
+    mlp2 = models.NerfMLP()
+    mlp2.load_state_dict(sd)
+    assert np.array_equal(mlp2.flat_params().numpy(), flat.numpy())
+
+
+def test_unsupported_configurations_raise(cfg):
+    with pytest.raises(ValueError, match="outside the fused Ref-NeRF family"):
+        models.MLP()                                        # reference defaults = mip-NeRF MLP
+    with pytest.raises(ValueError, match="Normals must be computed"):   # models.py:472-475
+        models.MLP(use_reflections=True, enable_pred_normals=False, disable_density_normals=True)
+    with pytest.raises(ValueError, match="Specular density is useless"):  # models.py:478-480
+        models.MLP(enable_pred_specular_density=True, use_diffuse_color=False)
+    with pytest.raises(ValueError, match="outside the fused"):
+        models.Model(config=cfg, dilation_bias=0.0025)
+
+
+def test_no_cpu_fallback(cfg):
+    """Without a GPU the product path must fail loudly, never fall back."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    model = models.construct_model(None, cfg).eval()
+    rays = utils.rays_from_dict(synthetic.blender_rays(4))
+    rays.to("cpu")
+    with pytest.raises(_hip.HipLibraryError, match="no CPU fallback"):
+        model(rays, 1.0, False)
+    with pytest.raises(_hip.HipLibraryError):
+        _hip.pack_weights(torch.zeros(layout.NUM_PARAMS))
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: the product may not import, link, load or include it."""
+    pat = re.compile(r"(from\s+oracle|import\s+oracle|librefnerf_oracle|#include\s*[\"<][^\n]*oracle)")
+    pkg = os.path.join(ROOT, "refnerf-pl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")) or fn == "Makefile":
+                assert not pat.search(open(os.path.join(dirpath, fn)).read()), fn
+
+
+def test_rays_container():
+    r = utils.rays_from_dict(synthetic.blender_rays(10))
+    assert r.shape == (10, 3) and r[2:5].origins.shape == (3, 3)
+    r.to("cpu")
+    assert isinstance(r.origins, torch.Tensor) and r.origins.dtype == torch.float32
+    assert r.reshape(2, 5, -1).radii.shape == (2, 5, 1)
+    d = utils.dummy_rays()
+    assert d.cam_idx.dtype == torch.int32 and d.origins.shape == (1, 3)
+
+
+def test_synthetic_ray_statistics():
+    b = synthetic.blender_rays(512, seed=1)
+    nd = np.linalg.norm(b["directions"], axis=-1)
+    assert 1.0 <= nd.min() and nd.max() < 1.12
+    np.testing.assert_allclose(b["radii"], 5.196e-4, rtol=2e-2)
+    np.testing.assert_allclose(np.linalg.norm(b["viewdirs"], axis=-1), 1.0, atol=1e-6)
+    l = synthetic.llff_rays(512, seed=1)
+    assert np.allclose(l["origins"][:, 2], -1.0) and np.allclose(l["directions"][:, 2], 2.0)
+    assert np.array_equal(synthetic.make_params(5, 0.1), synthetic.make_params(5, 0.1))
