@@ -140,9 +140,18 @@ def main():
         avg_ms = kern_ms / launches
         flop_per_launch = args.rays * args.samples * FLOP_PER_SAMPLE
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+        kernel = "rn::level_fwd_f32" if args.precision == "f32" else "rn::level_fwd_bf16"
+        traffic = None
+        try:   # PMC numbers cannot be collected inside this process: taken from the committed rocprofv3 passes
+            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
+            if args.rays == 4096 and args.samples == 128:
+                traffic = prof["bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
-                            "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": None,
-                            "kernel": "rn::level_fwd_f32", "avg_launch_ms": avg_ms, "launches": launches}
+                            "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic,
+                            "kernel": kernel, "avg_launch_ms": avg_ms, "launches": launches,
+                            "flop_per_launch": flop_per_launch}
     if rank == 0 and world == 1 and not args.no_image:
         # full-image render ms: 800x800 Blender view, 157 chunks of 4096 rays (models.render_image)
         from refnerf_pl_amd import models
