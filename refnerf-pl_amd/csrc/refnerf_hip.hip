@@ -22,20 +22,11 @@
 #include <vector>
 
 #include "refnerf_hip.h"
-#include "refnerf_device_math.h"
-#include "refnerf_layout.h"
+#include "refnerf_level_common.h"
+#include "refnerf_level_f32.h"
+#include "refnerf_level_bf16.h"
 
 namespace rn {
-
-typedef float v16f __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-constexpr int T_TILE = 128;  /* samples per pass: 4 waves x 32 */
-constexpr int NTHREADS = 256;
-constexpr int HD_ROWS = 12;
-constexpr int NPS = 20;      /* per-sample floats kept for compositing */
-/* per-sample slots in LDS PS[c][sample] */
-enum { PS_DENSITY = 0, PS_RGB = 1, PS_DIF = 4, PS_SPC = 7, PS_NPRED = 10, PS_TINT = 13, PS_ROUGH = 16, PS_NORMALS = 17 };
 
 /* ------------------------------------------------------------------ */
 /* weight packing                                                     */
@@ -109,550 +100,38 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
   }
 }
 
-/* ------------------------------------------------------------------ */
-/* fp32 MFMA GEMM op on one 32-sample block                           */
-/* ------------------------------------------------------------------ */
-
-typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-
-/* A fragments come through a buffer descriptor over the packed image: the
- * per-lane part of the address is one constant VGPR (lane*STRIDE*4), the
- * per-step part is an SGPR/immediate, so the 1000+ loads of an op cost no VALU
- * address arithmetic (flat global loads made hipcc precompute and spill
- * hundreds of 64-bit pointers). */
-template <int NOB, int STRIDE>
-__device__ __forceinline__ void load_a(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float (&a)[NOB]) {
-  if constexpr (STRIDE == 8) {
-    v4f x = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
-    a[0] = x[0];
-    if constexpr (NOB > 1) { a[1] = x[1]; a[2] = x[2]; a[3] = x[3]; }
-    if constexpr (NOB == 5) a[4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 16, soff, 0));
-    if constexpr (NOB == 8) {
-      v4f y = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, 0));
-      a[4] = y[0]; a[5] = y[1]; a[6] = y[2]; a[7] = y[3];
+/* bf16 image: one block per (op, ob) slice; see refnerf_layout.h. */
+__global__ void pack_weights_bf16(const float *__restrict__ P, char *__restrict__ out) {
+  const int op = blockIdx.y, ob = blockIdx.x;
+  const BfOp o = BFPACKED.op[op];
+  if (ob >= o.nob) return;
+  char *slice = out + ((size_t)o.off_kb + (size_t)ob * (o.ks + 1)) * 1024;
+  /* bias piece: fp32 [h][16], rest of the KB zero */
+  for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+    float v = 0.0f;
+    if (e < 32) {
+      int reg = e & 15, h = e >> 4;
+      v = canon_b(P, op, ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
     }
-  } else {
-    a[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    reinterpret_cast<float *>(slice)[e] = v;
   }
-}
-
-/* out[ob] = bias + W * in, W from the packed image `rs`.  a_off/b_off: float
- * offsets of the op inside the image (wave-uniform); `xl` = LDS X + h*T_TILE +
- * column (for LDS steps).  The A stream is software-pipelined PF steps ahead
- * through a register ring; sched_barrier pins "MFMAs of step s, then the loads
- * of step s+PF" so that hipcc cannot sink the loads back to their uses (it
- * otherwise emits load; s_waitcnt vmcnt(0); mfma).  lds_steps % PF == 0. */
-constexpr int PF = 3;
-template <int NOB, int STRIDE, bool HAS_REG>
-__device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
-                                        const v16f (&in)[8], v16f (&out)[NOB], const float *xl,
-                                        int lds_steps) {
-  constexpr int STEP_BYTES = 64 * STRIDE * 4;
-  const int voff = lane * STRIDE * 4;
-  int soff = a_off * 4;
-  float a[PF][NOB];
-#pragma unroll
-  for (int d = 0; d < PF; ++d) load_a<NOB, STRIDE>(rs, voff, soff + d * STEP_BYTES, a[d]);
-  soff += PF * STEP_BYTES;
-#pragma unroll
-  for (int ob = 0; ob < NOB; ++ob) {
-    v4f b[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      b[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, h * 64 + q * 16, b_off * 4 + ob * 128, 0));
-    out[ob] = (v16f){b[0][0], b[0][1], b[0][2], b[0][3], b[1][0], b[1][1], b[1][2], b[1][3],
-                     b[2][0], b[2][1], b[2][2], b[2][3], b[3][0], b[3][1], b[3][2], b[3][3]};
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (HAS_REG) {
-#pragma unroll
-    for (int step = 0; step < REG_STEPS; ++step) {
-      const float b = in[step >> 4][step & 15];
-#pragma unroll
-      for (int ob = 0; ob < NOB; ++ob)
-        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step % PF][ob], b, out[ob], 0, 0, 0);
-      load_a<NOB, STRIDE>(rs, voff, soff + step * STEP_BYTES, a[step % PF]);
-      __builtin_amdgcn_sched_barrier(0);
+  const int base = (o.ks_reg ? WIDTH : 0);     /* canonical column of the first non-register input */
+  for (int idx = threadIdx.x; idx < o.ks * 512; idx += blockDim.x) {
+    int e = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9;
+    int h = lane >> 5, row = ob * 32 + (lane & 31);
+    float v = 0.0f;
+    if (t < o.ks_reg + o.ks_bn) {
+      int tt = (t < o.ks_reg) ? t : t - o.ks_reg;
+      int r = 8 * (tt & 1) + e;
+      int feat = 32 * (tt >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+      v = canon_w(P, op, row, (t < o.ks_reg) ? feat : base + feat);
+    } else {
+      int kp = 16 * (t - o.ks_reg - o.ks_bn) + 8 * h + e;
+      if (op == 0 || op == 5) v = canon_w(P, op, row, base + ipe_col_of_kprime(kp));
+      else if (kp < IDE_DIM) v = canon_w(P, op, row, base + BNECK + kp);
+      else if (kp == IDE_DIM) v = canon_w(P, op, row, base + BNECK + IDE_DIM);
     }
-    soff += REG_STEPS * STEP_BYTES;
-  }
-  constexpr int P0 = HAS_REG ? (REG_STEPS % PF) : 0;
-  float bcur = xl[0];
-#pragma unroll 1
-  for (int s = 0; s < lds_steps; s += PF) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const float bnext = xl[2 * (s + u + 1) * T_TILE];
-#pragma unroll
-      for (int ob = 0; ob < NOB; ++ob)
-        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(P0 + u) % PF][ob], bcur, out[ob], 0, 0, 0);
-      load_a<NOB, STRIDE>(rs, voff, soff + u * STEP_BYTES, a[(P0 + u) % PF]);
-      bcur = bnext;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    soff += PF * STEP_BYTES;
-  }
-}
-
-__device__ __forceinline__ void relu_into(const v16f (&out)[8], v16f (&in)[8]) {
-#pragma unroll
-  for (int ob = 0; ob < 8; ++ob)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) in[ob][r] = fmaxf(out[ob][r], 0.0f);
-}
-
-/* ------------------------------------------------------------------ */
-/* level kernel                                                       */
-/* ------------------------------------------------------------------ */
-
-struct LevelArgs {
-  const float *packed;
-  refnerf_level_cfg cfg;
-  refnerf_rays rays;
-  int R;
-  int rpw;  /* rays per workgroup */
-  const float *sdist_in;
-  const float *weights_in;
-  refnerf_level_out out;
-};
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-/* inclusive scan of doubles across the wave */
-__device__ __forceinline__ double wave_scan_incl(double v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double t = __shfl_up(v, o, 64);
-    if (lane >= o) v += t;
-  }
-  return v;
-}
-
-/* stepfun.sample_intervals (stepfun.py:209-258) for one ray, executed by one
- * wave.  t_in[M+1], logits in LDS scratch `lg[M]`; writes sdist[N+1] to `sd`
- * (LDS) and optional bin indices.  Scratch: e[M] (aliases lg), cw[M+1], c[N].
- * The softmax sum and the float64 cumsum run sequentially on lane 0 so that the
- * CDF is bit-identical to the oracle / torch's accumulation order. */
-__device__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, float *c, int M, int N,
-                                      float smin, float smax, float *sd, int32_t *bin_idx_g, int lane) {
-  /* softmax: max is order-independent */
-  float mx = -INFINITY;
-  for (int i = lane; i < M; i += 64) mx = fmaxf(mx, lg[i]);
-  mx = wave_max(mx);
-  for (int i = lane; i < M; i += 64) lg[i] = rn_det_expf(lg[i] - mx);
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  float sum = 0.0f;
-  if (lane == 0) {
-    for (int i = 0; i < M; ++i) sum += lg[i];
-  }
-  sum = __shfl(sum, 0, 64);
-  for (int i = lane; i < M; i += 64) lg[i] = lg[i] / sum;
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {
-    cw[0] = 0.0f;
-    double acc = 0.0;
-    for (int i = 0; i < M - 1; ++i) { acc += (double)lg[i]; cw[i + 1] = fminf(1.0f, (float)acc); }
-    cw[M] = 1.0f;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  /* inverse CDF at the deterministic centres (math.py:88-111) */
-  for (int k = lane; k < N; k += 64) {
-    float u = linspace_u(k, N);
-    /* lo = max{j : u >= cw[j]}; cw is non-decreasing, cw[0]=0 <= u < 1=cw[M] */
-    int lo = 0, hi = M;  /* invariant: cw[lo] <= u, cw[hi] > u */
-    while (hi - lo > 1) {
-      int mid = (lo + hi) >> 1;
-      if (u >= cw[mid]) lo = mid; else hi = mid;
-    }
-    float xp0 = cw[lo], xp1 = cw[lo + 1], fp0 = t_in[lo], fp1 = t_in[lo + 1];
-    float q = (u - xp0) / (xp1 - xp0);
-    if (q != q) q = 0.0f;                       /* nan_to_num(., 0) */
-    float off = clip01(q);                      /* +-inf clip like +-FLT_MAX */
-    c[k] = fp0 + off * (fp1 - fp0);
-    if (bin_idx_g) bin_idx_g[k] = lo;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  for (int k = lane; k <= N; k += 64) {
-    float v;
-    if (k == 0) v = fmaxf(smin, 2.0f * c[0] - (c[1] + c[0]) / 2.0f);
-    else if (k == N) v = fminf(smax, 2.0f * c[N - 1] - (c[N - 1] + c[N - 2]) / 2.0f);
-    else v = (c[k] + c[k - 1]) / 2.0f;
-    sd[k] = v;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ void st3(float *base, size_t idx, float a, float b, float c) {
-  if (base) { base[idx * 3 + 0] = a; base[idx * 3 + 1] = b; base[idx * 3 + 2] = c; }
-}
-
-__global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const refnerf_level_cfg &cfg = A.cfg;
-  const int N = cfg.n_samples, M = cfg.n_in;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5, sl = lane & 31;
-  const int rpw = A.rpw;
-  const int ray0 = blockIdx.x * rpw;
-  const int n_tot = rpw * N;                 /* samples owned by this workgroup */
-
-  float *X = smem;                               /* [DIR_PAD][T_TILE]              */
-  float *HD = X + DIR_PAD * T_TILE;              /* [HD_ROWS][T_TILE]              */
-  float *TD = HD + HD_ROWS * T_TILE;             /* [rpw][N+1] metric distances    */
-  float *XP = TD + rpw * (N + 1);                /* [rpw][N+1] CDF knots for the percentiles */
-  float *PS = XP + rpw * (N + 1);                /* [NPS][n_tot]                   */
-
-  /* ---------------- P0: resample (one wave per ray) ---------------- */
-  {
-    float *scr = X + wave * (3 * 520 + 8);       /* per-wave scratch inside X */
-    float *t_in = scr, *lg = scr + 520, *cw = scr + 1040;
-    float *c = X + 4 * (3 * 520 + 8) + wave * 648;   /* sample centres, N <= 640 */
-    for (int rl = wave; rl < rpw; rl += 4) {
-      int ray = ray0 + rl;
-      if (ray >= A.R) break;
-      const float *tg = A.sdist_in + (size_t)ray * (M + 1);
-      const float *wg = A.weights_in + (size_t)ray * M;
-      for (int i = lane; i <= M; i += 64) t_in[i] = tg[i];
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      /* models.py:200-203 */
-      for (int i = lane; i < M; i += 64)
-        lg[i] = (t_in[i + 1] > t_in[i]) ? cfg.anneal * logf(wg[i] + cfg.resample_padding) : -INFINITY;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      float *sd = TD + rl * (N + 1);
-      sample_intervals_wave(t_in, lg, cw, c, M, N, cfg.s_near, cfg.s_far, sd,
-                            A.out.d_bin_idx ? A.out.d_bin_idx + (size_t)ray * N : nullptr, lane);
-      float nearv = A.rays.d_near[ray], farv = A.rays.d_far[ray];
-      for (int k = lane; k <= N; k += 64) {
-        float s = sd[k];
-        if (A.out.d_sdist) A.out.d_sdist[(size_t)ray * (N + 1) + k] = s;
-        sd[k] = s_to_t(s, nearv, farv);         /* models.py:218 */
-      }
-    }
-  }
-  __syncthreads();
-
-  /* ---------------- per-pass MLP over 32-sample blocks ---------------- */
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.packed, 0, PACKED.total * 4, 0x00020000);
-  const int col = wave * 32 + sl;                /* this lane's column in X / HD */
-  const float *xl = X + h * T_TILE + col;
-  v16f in[8], out[8];
-
-  for (int pass0 = 0; pass0 < n_tot; pass0 += T_TILE) {
-    const int g = pass0 + col;                   /* sample index inside the workgroup */
-    const int rl = g / N, si = g - rl * N;
-    const int ray = ray0 + rl;
-    const bool valid = (g < n_tot) && (ray < A.R);
-    const int rayc = valid ? ray : (A.R - 1);
-    float o[3], d[3], v[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      o[i] = A.rays.d_origins[(size_t)rayc * 3 + i];
-      d[i] = A.rays.d_directions[(size_t)rayc * 3 + i];
-      v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
-    }
-    /* P1: conical frustum -> lifted Gaussian -> IPE (half 0: sin, half 1: cos) */
-    {
-      float radius = A.rays.d_radii[rayc];
-      const float *td = TD + (valid ? rl : 0) * (N + 1);
-      float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
-      float lm[3], lv[3];
-      cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
-#pragma unroll 1
-      for (int j = 0; j < 16; ++j)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) X[(48 * h + j * 3 + b) * T_TILE + col] = ipe_feature(lm[b], lv[b], j, h);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    /* P2: spatial MLP (models.py:576-580) */
-    gemm_op<8, 8, false>(rs, PACKED.op[0].a_off, PACKED.op[0].b_off, lane, h, in, out, xl, PACKED.op[0].lds_steps);
-    relu_into(out, in);
-#pragma unroll 1
-    for (int op = 1; op < 8; ++op) {
-      gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
-      relu_into(out, in);
-    }
-    /* P3: heads (models.py:582,613,634-645): 4 bottleneck blocks + 1 scalar block */
-    {
-      v16f hd[5];
-      gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0);
-      __builtin_amdgcn_wave_barrier();          /* all IPE reads of this wave are done */
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) X[(blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * T_TILE + col] = hd[blk][r];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < HD_ROWS) HD[row * T_TILE + col] = hd[4][r];
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    /* P4: activations, reflection, IDE (models.py:611-686) */
-    float tint[3], raw_dif[3], npred[3], gp[3], density, rough;
-    {
-      float raw_density = HD[0 * T_TILE + col];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        gp[i] = HD[(1 + i) * T_TILE + col];
-        raw_dif[i] = HD[(5 + i) * T_TILE + col];
-        tint[i] = sigmoid_t(HD[(8 + i) * T_TILE + col]);
-      }
-      float raw_rough = HD[4 * T_TILE + col];
-      float n2 = fmaxf((gp[0] * gp[0] + gp[1] * gp[1]) + gp[2] * gp[2], EPS32);
-      float nrm = sqrtf(n2);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) npred[i] = -(gp[i] / nrm);
-      density = softplus_t(raw_density + cfg.density_bias);
-      rough = softplus_t(raw_rough + cfg.roughness_bias);
-      float w3[3] = {-v[0], -v[1], -v[2]};
-      float dot = (npred[0] * w3[0] + npred[1] * w3[1]) + npred[2] * w3[2];
-      float refd[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) refd[i] = (2.0f * dot) * npred[i] - w3[i];
-      float *xi = X + (BNECK + IDE_TERMS * h) * T_TILE + col;
-      ide_eval(refd[0], refd[1], refd[2], rough, h, [&](int q, float val) { xi[q * T_TILE] = val; });
-      if (h == 0) X[(BNECK + IDE_DIM) * T_TILE + col] = (npred[0] * v[0] + npred[1] * v[1]) + npred[2] * v[2];
-      else {
-#pragma unroll
-        for (int q = DIR_IN; q < DIR_PAD; ++q) X[q * T_TILE + col] = 0.0f;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    /* P5: directional MLP (models.py:690-694) + rgb (699-700) */
-    gemm_op<8, 8, false>(rs, PACKED.op[9].a_off, PACKED.op[9].b_off, lane, h, in, out, xl, PACKED.op[9].lds_steps);
-    relu_into(out, in);
-#pragma unroll 1
-    for (int op = 10; op < 17; ++op) {
-      gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
-      relu_into(out, in);
-    }
-    v16f rgbv[1];
-    gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0);
-    /* rows 0..2 live in half 0, regs 0..2; hand them to half 1 as well */
-    float raw_rgb[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(rgbv[0][i], sl, 64);
-
-    /* P6: colour head (models.py:699-729) */
-    if (valid && h == 0) {
-      float spec_lin[3], dif_lin[3], rgb[3], dif[3], spc[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        float sg = sigmoid_t(cfg.rgb_premultiplier * raw_rgb[i] + cfg.rgb_bias);
-        dif_lin[i] = sigmoid_t(raw_dif[i] - LOG3_F);
-        spec_lin[i] = tint[i] * sg;
-        rgb[i] = spec_lin[i] + dif_lin[i];
-      }
-      if (cfg.srgb_mapping) {
-        if (cfg.srgb_mapping_normalization) {
-          float norm = fmaxf(fmaxf(fmaxf(rgb[0], rgb[1]), rgb[2]), 1.0f);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] / norm;
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          rgb[i] = clip01(linear_to_srgb(rgb[i]));
-          dif[i] = clip01(linear_to_srgb(dif_lin[i]));
-          spc[i] = clip01(linear_to_srgb(spec_lin[i]));
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { dif[i] = dif_lin[i]; spc[i] = spec_lin[i]; }
-      }
-      const float pad_scale = (float)(1.0 + 2.0 * (double)cfg.rgb_padding);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] * pad_scale - cfg.rgb_padding;
-      PS[PS_DENSITY * n_tot + g] = density;
-      PS[PS_ROUGH * n_tot + g] = rough;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        PS[(PS_RGB + i) * n_tot + g] = rgb[i];
-        PS[(PS_DIF + i) * n_tot + g] = dif[i];
-        PS[(PS_SPC + i) * n_tot + g] = spc[i];
-        PS[(PS_NPRED + i) * n_tot + g] = npred[i];
-        PS[(PS_TINT + i) * n_tot + g] = tint[i];
-        PS[(PS_NORMALS + i) * n_tot + g] = 0.0f;
-      }
-      size_t gi = (size_t)ray * N + si;
-      if (A.out.d_density) A.out.d_density[gi] = density;
-      if (A.out.d_roughness) A.out.d_roughness[gi] = rough;
-      st3(A.out.d_rgb, gi, rgb[0], rgb[1], rgb[2]);
-      st3(A.out.d_diffuse, gi, dif[0], dif[1], dif[2]);
-      st3(A.out.d_specular, gi, spc[0], spc[1], spc[2]);
-      st3(A.out.d_normals_pred, gi, npred[0], npred[1], npred[2]);
-      st3(A.out.d_grad_pred, gi, gp[0], gp[1], gp[2]);
-      st3(A.out.d_tint, gi, tint[0], tint[1], tint[2]);
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();
-
-  /* ---------------- P7: alpha weights + compositing, one wave per ray ----------------
-   * render.py:132-149 and 152-254.  Each lane owns a contiguous chunk of
-   * samples so the exclusive float64 cumsum is a local prefix + one wave scan. */
-  for (int rl = wave; rl < rpw; rl += 4) {
-    const int ray = ray0 + rl;
-    if (ray >= A.R) break;
-    const float *td = TD + rl * (N + 1);
-    const int base = rl * N;
-    const int C = (N + 63) / 64;                 /* samples per lane */
-    const int i0 = lane * C;
-    float dx = A.rays.d_directions[(size_t)ray * 3], dy = A.rays.d_directions[(size_t)ray * 3 + 1], dz = A.rays.d_directions[(size_t)ray * 3 + 2];
-    const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
-    float *wbuf = PS + PS_DENSITY * n_tot + base;  /* density is overwritten by the weights */
-    /* pass 1: local sums of density*delta */
-    double local = 0.0;
-    for (int q = 0; q < C; ++q) {
-      int i = i0 + q;
-      if (i < N) {
-        float dd = wbuf[i] * ((td[i + 1] - td[i]) * norm);
-        if (cfg.opaque_background && i == N - 1) dd = INFINITY;
-        local += (double)dd;
-      }
-    }
-    double incl = wave_scan_incl(local, lane);
-    double cum = incl - local;                   /* exclusive prefix of this lane's chunk */
-    /* pass 2: weights + weighted sums */
-    float acc = 0, s_rgb[3] = {0, 0, 0}, s_dif[3] = {0, 0, 0}, s_spc[3] = {0, 0, 0}, s_np[3] = {0, 0, 0}, s_tn[3] = {0, 0, 0};
-    float s_nm[3] = {0, 0, 0};
-    float s_dist = 0, s_rgh = 0, s_logd = 0;
-    double wlocal = 0.0;
-    for (int q = 0; q < C; ++q) {
-      int i = i0 + q;
-      if (i < N) {
-        float dd = wbuf[i] * ((td[i + 1] - td[i]) * norm);
-        if (cfg.opaque_background && i == N - 1) dd = INFINITY;
-        float alpha = 1.0f - expf(-dd);
-        float trans = expf(-(float)cum);
-        float w = alpha * trans;
-        cum += (double)dd;
-        wbuf[i] = w;
-        wlocal += (double)w;
-        if (A.out.d_weights) A.out.d_weights[(size_t)ray * N + i] = w;
-        acc += w;
-        float tmid = 0.5f * (td[i] + td[i + 1]);
-        s_dist += w * tmid;
-        s_logd += w * logf(tmid);
-        s_rgh += w * PS[PS_ROUGH * n_tot + base + i];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          s_rgb[c] += w * PS[(PS_RGB + c) * n_tot + base + i];
-          s_dif[c] += w * PS[(PS_DIF + c) * n_tot + base + i];
-          s_spc[c] += w * PS[(PS_SPC + c) * n_tot + base + i];
-          s_np[c] += w * PS[(PS_NPRED + c) * n_tot + base + i];
-          s_tn[c] += w * PS[(PS_TINT + c) * n_tot + base + i];
-          s_nm[c] += w * PS[(PS_NORMALS + c) * n_tot + base + i];
-        }
-      }
-    }
-    acc = wave_sum(acc); s_dist = wave_sum(s_dist); s_logd = wave_sum(s_logd); s_rgh = wave_sum(s_rgh);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      s_rgb[c] = wave_sum(s_rgb[c]); s_dif[c] = wave_sum(s_dif[c]); s_spc[c] = wave_sum(s_spc[c]);
-      s_np[c] = wave_sum(s_np[c]); s_tn[c] = wave_sum(s_tn[c]); s_nm[c] = wave_sum(s_nm[c]);
-    }
-    const float bg_w = fmaxf(0.0f, 1.0f - acc);
-    float rgb[3], dif[3], spc[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      rgb[c] = s_rgb[c] + bg_w * cfg.bg_rgb; dif[c] = s_dif[c] + bg_w * cfg.bg_rgb; spc[c] = s_spc[c] + bg_w * cfg.bg_rgb;
-    }
-    const int mode = cfg.render_srgb_mode;
-    if (mode != REFNERF_SRGB_NONE) {              /* render.py:186-216 */
-      if (mode == REFNERF_SRGB_NORM_LINEAR || mode == REFNERF_SRGB_NORM_SRGB) {
-        float nr = fmaxf(fmaxf(fmaxf(rgb[0], rgb[1]), rgb[2]), 1.0f);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) rgb[c] = rgb[c] / nr;
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        if (mode == REFNERF_SRGB_SRGB || mode == REFNERF_SRGB_NORM_SRGB) {
-          rgb[c] = linear_to_srgb(rgb[c]); dif[c] = linear_to_srgb(dif[c]); spc[c] = linear_to_srgb(spc[c]);
-        }
-        rgb[c] = clip01(rgb[c]); dif[c] = clip01(dif[c]); spc[c] = clip01(spc[c]);
-      }
-    }
-    if (lane == 0) {
-      st3(A.out.d_r_rgb, ray, rgb[0], rgb[1], rgb[2]);
-      st3(A.out.d_r_diffuse, ray, dif[0], dif[1], dif[2]);
-      st3(A.out.d_r_specular, ray, spc[0], spc[1], spc[2]);
-      if (A.out.d_r_distance) A.out.d_r_distance[ray] = s_dist;
-      if (A.out.d_r_acc) A.out.d_r_acc[ray] = acc;
-      if (cfg.compute_extras) {
-        if (cfg.training) st3(A.out.d_r_normals, ray, s_nm[0], s_nm[1], s_nm[2]);
-        st3(A.out.d_r_normals_pred, ray, s_np[0], s_np[1], s_np[2]);
-        st3(A.out.d_r_tint, ray, s_tn[0], s_tn[1], s_tn[2]);
-        if (A.out.d_r_roughness) A.out.d_r_roughness[ray] = s_rgh;
-        if (A.out.d_r_distance_mean) {
-          float e = expf(s_logd / fmaxf(EPS32, acc));
-          if (e != e) e = INFINITY;
-          e = fminf(fmaxf(e, td[0]), td[N]);     /* +-inf -> clip (same as +-FLT_MAX then clip) */
-          A.out.d_r_distance_mean[ray] = e;
-        }
-      }
-    }
-    /* percentiles (stepfun.py:294-307, math.py:114-142) in float64 */
-    if (cfg.compute_extras && A.out.d_r_percentiles) {
-      /* knots xp[j], j = 0..N+1: xp[0]=0, xp[j]=min(1,float(cumsum w[0..j-1])), xp[N+1]=1.
-       * fp[j] = td[j] (j<=N), fp[N+1]=far. */
-      float *xp = XP + rl * (N + 1);
-      double wincl = wave_scan_incl(wlocal, lane);
-      double run = wincl - wlocal;
-      __builtin_amdgcn_wave_barrier();
-      for (int q = 0; q < C; ++q) {
-        int i = i0 + q;
-        if (i < N) { run += (double)wbuf[i]; xp[i + 1] = fminf(1.0f, (float)run); }
-      }
-      if (lane == 0) { xp[0] = 0.0f; }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      /* note xp[N] = min(1,cumsum of all N weights) is what integrate_weights
-       * produces for index N (weights_aug[:-1] = the N sample weights); xp[N+1] = 1. */
-      const float farv = A.rays.d_far[ray];
-      const float psf[3] = {5.0f / 100.0f, 50.0f / 100.0f, 95.0f / 100.0f};
-      const int nk = N + 2;
-      for (int p = 0; p < 3; ++p) {
-        double x = (double)psf[p];
-        int cnt = 0;
-        for (int j = lane; j < nk; j += 64) {
-          double xj = (j == nk - 1) ? 1.0 : (double)xp[j];
-          cnt += (x >= xj) ? 1 : 0;
-        }
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) cnt += __shfl_xor(cnt, o2, 64);
-        if (lane == 0) {
-          int idx = cnt - 1;
-          if (idx < 0) idx = 0;
-          if (idx > nk - 2) idx = nk - 2;
-          double x0 = (double)xp[idx], x1 = (idx + 1 == nk - 1) ? 1.0 : (double)xp[idx + 1];
-          double f0 = (double)td[idx], f1 = (idx + 1 == nk - 1) ? (double)farv : (double)td[idx + 1];
-          double m = (f1 - f0) / (x1 - x0);
-          double b = f0 - m * x0;
-          A.out.d_r_percentiles[(size_t)ray * 3 + p] = m * x + b;
-        }
-      }
-    }
+    reinterpret_cast<__bf16 *>(slice + 1024)[idx] = (__bf16)v;
   }
 }
 
@@ -671,8 +150,7 @@ __global__ __launch_bounds__(256) void sample_intervals_kernel(const float *t, c
   if (ray >= R) return;
   for (int i = lane; i <= M; i += 64) t_in[i] = t[(size_t)ray * (M + 1) + i];
   for (int i = lane; i < M; i += 64) lg[i] = logits[(size_t)ray * M + i];
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  wave_sync();
   sample_intervals_wave(t_in, lg, cw, c, M, N, smin, smax, sd, bin_idx ? bin_idx + (size_t)ray * N : nullptr, lane);
   for (int k = lane; k <= N; k += 64) sdist[(size_t)ray * (N + 1) + k] = sd[k];
 }
@@ -778,23 +256,32 @@ int refnerf_device_ok(void) {
 
 size_t refnerf_packed_weights_bytes(int precision) {
   if (precision == REFNERF_PREC_F32) return (size_t)rn::PACKED.total * sizeof(float);
+  if (precision == REFNERF_PREC_BF16) return ((size_t)rn::BFPACKED.total_kb + rn::BF_MAX_SLICE_KB) * 1024;
   return 0;
 }
 
 int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, void *stream) {
   if (!d_params || !d_packed) return fail(REFNERF_EINVAL, "refnerf_pack_weights: null pointer%s");
-  if (precision != REFNERF_PREC_F32) return fail(REFNERF_EUNSUPPORTED, "refnerf_pack_weights: precision mode not built%s");
-  dim3 grid(64, rn::NUM_OPS);
-  hipLaunchKernelGGL(rn::pack_weights_f32, grid, dim3(256), 0, (hipStream_t)stream, d_params, (float *)d_packed);
+  if (precision == REFNERF_PREC_F32) {
+    dim3 grid(64, rn::NUM_OPS);
+    hipLaunchKernelGGL(rn::pack_weights_f32, grid, dim3(256), 0, (hipStream_t)stream, d_params, (float *)d_packed);
+  } else if (precision == REFNERF_PREC_BF16) {
+    dim3 grid(8, rn::NUM_OPS);
+    hipLaunchKernelGGL(rn::pack_weights_bf16, grid, dim3(256), 0, (hipStream_t)stream, d_params, (char *)d_packed);
+  } else {
+    return fail(REFNERF_EINVAL, "refnerf_pack_weights: unknown precision%s");
+  }
   HIP_TRY(hipGetLastError());
   return REFNERF_OK;
 }
 
-static int rays_per_wg(int N) {
-  if (N % rn::T_TILE == 0) return 1;
-  if (rn::T_TILE % N == 0) return rn::T_TILE / N;
-  if ((2 * N) % rn::T_TILE == 0) return 2;
-  if ((4 * N) % rn::T_TILE == 0) return 4;
+static int rays_per_wg(int N, int tile) {
+  if (N % tile == 0) return 1;
+  if (tile % N == 0) return tile / N;
+  if (tile == rn::T_TILE) {
+    if ((2 * N) % tile == 0) return 2;
+    if ((4 * N) % tile == 0) return 4;
+  }
   return 1;
 }
 
@@ -809,22 +296,29 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
   /* render.py:126 */
   if (cfg->ray_shape != 0 && cfg->ray_shape != 1) return fail(REFNERF_EINVAL, "ray_shape must be 'cone' or 'cylinder'%s");
   if (cfg->n_in < 1 || cfg->n_in > 512) return fail(REFNERF_EINVAL, "n_in must be in [1,512]%s");
-  if (cfg->precision != REFNERF_PREC_F32) return fail(REFNERF_EUNSUPPORTED, "precision mode not built%s");
+  if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16)
+    return fail(REFNERF_EINVAL, "unknown precision mode%s");
   if (cfg->training) return fail(REFNERF_EUNSUPPORTED, "training-mode level (density-gradient normals) not built yet%s");
   if (!rays->d_origins || !rays->d_directions || !rays->d_viewdirs || !rays->d_radii || !rays->d_near || !rays->d_far)
     return fail(REFNERF_EINVAL, "refnerf_level_forward: null ray field%s");
   int rc = ensure_tables();
   if (rc) return rc;
   const int N = cfg->n_samples;
-  const int rpw = rays_per_wg(N);
+  const bool bf = cfg->precision == REFNERF_PREC_BF16;
+  const int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
   if (rpw * N > 640) return fail(REFNERF_EINVAL, "n_samples too large for the LDS budget (rays_per_wg*N must be <= 640)%s");
-  size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + 2 * rpw * (N + 1) + rn::NPS * rpw * N + 8);
+  const size_t per_ray = sizeof(float) * (size_t)(2 * rpw * (N + 1) + rn::NPS * rpw * N + 8);
+  size_t lds;
+  if (bf) lds = 2 * (size_t)rn::WBUF_BYTES + rn::BF_X_BYTES + sizeof(float) * rn::HD_ROWS * rn::BT + per_ray;
+  else lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE) + per_ray;
+  if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget of this precision mode%s");
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute((const void *)rn::level_fwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)rn::level_fwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   rn::LevelArgs a;
-  a.packed = (const float *)d_packed;
+  a.packed = d_packed;
   a.cfg = *cfg;
   a.rays = *rays;
   a.R = R;
@@ -844,7 +338,8 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
     }
     HIP_TRY(hipEventRecord(g_events[g_events_used].first, st));
   }
-  hipLaunchKernelGGL(rn::level_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
+  if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
+  else hipLaunchKernelGGL(rn::level_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());
   if (timed) {
     HIP_TRY(hipEventRecord(g_events[g_events_used].second, st));

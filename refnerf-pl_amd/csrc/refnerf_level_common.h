@@ -1,0 +1,384 @@
+/*
+ * refnerf_level_common.h -- phases shared by the fp32 and bf16 level kernels:
+ * P0 resample (one wave per ray), P4 per-sample head activations + reflection,
+ * P6 colour head + history stores, P7 per-ray alpha scan + compositing.
+ * Reference citations inline (file:line relative to the upstream repo root).
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "refnerf_hip.h"
+#include "refnerf_device_math.h"
+#include "refnerf_layout.h"
+
+namespace rn {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+constexpr int NTHREADS = 256;
+constexpr int HD_ROWS = 12;
+constexpr int NPS = 20;      /* per-sample floats kept in LDS for compositing */
+/* per-sample slots in LDS PS[c][sample] */
+enum { PS_DENSITY = 0, PS_RGB = 1, PS_DIF = 4, PS_SPC = 7, PS_NPRED = 10, PS_TINT = 13, PS_ROUGH = 16, PS_NORMALS = 17 };
+
+struct LevelArgs {
+  const void *packed;
+  refnerf_level_cfg cfg;
+  refnerf_rays rays;
+  int R;
+  int rpw;  /* rays per workgroup */
+  const float *sdist_in;
+  const float *weights_in;
+  refnerf_level_out out;
+};
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+/* inclusive scan of doubles across the wave */
+__device__ __forceinline__ double wave_scan_incl(double v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+/* stepfun.sample_intervals (stepfun.py:209-258) for one ray, executed by one
+ * wave.  t_in[M+1], logits in LDS scratch `lg[M]`; writes sdist[N+1] to `sd`
+ * (LDS) and optional bin indices.  Scratch: e[M] (aliases lg), cw[M+1], c[N].
+ * The softmax sum and the float64 cumsum run sequentially on lane 0 so that the
+ * CDF is bit-identical to the oracle / torch's accumulation order. */
+__device__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, float *c, int M, int N,
+                                      float smin, float smax, float *sd, int32_t *bin_idx_g, int lane) {
+  /* softmax: max is order-independent */
+  float mx = -INFINITY;
+  for (int i = lane; i < M; i += 64) mx = fmaxf(mx, lg[i]);
+  mx = wave_max(mx);
+  for (int i = lane; i < M; i += 64) lg[i] = rn_det_expf(lg[i] - mx);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float sum = 0.0f;
+  if (lane == 0) {
+    for (int i = 0; i < M; ++i) sum += lg[i];
+  }
+  sum = __shfl(sum, 0, 64);
+  for (int i = lane; i < M; i += 64) lg[i] = lg[i] / sum;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    cw[0] = 0.0f;
+    double acc = 0.0;
+    for (int i = 0; i < M - 1; ++i) { acc += (double)lg[i]; cw[i + 1] = fminf(1.0f, (float)acc); }
+    cw[M] = 1.0f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  /* inverse CDF at the deterministic centres (math.py:88-111) */
+  for (int k = lane; k < N; k += 64) {
+    float u = linspace_u(k, N);
+    /* lo = max{j : u >= cw[j]}; cw is non-decreasing, cw[0]=0 <= u < 1=cw[M] */
+    int lo = 0, hi = M;  /* invariant: cw[lo] <= u, cw[hi] > u */
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (u >= cw[mid]) lo = mid; else hi = mid;
+    }
+    float xp0 = cw[lo], xp1 = cw[lo + 1], fp0 = t_in[lo], fp1 = t_in[lo + 1];
+    float q = (u - xp0) / (xp1 - xp0);
+    if (q != q) q = 0.0f;                       /* nan_to_num(., 0) */
+    float off = clip01(q);                      /* +-inf clip like +-FLT_MAX */
+    c[k] = fp0 + off * (fp1 - fp0);
+    if (bin_idx_g) bin_idx_g[k] = lo;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int k = lane; k <= N; k += 64) {
+    float v;
+    if (k == 0) v = fmaxf(smin, 2.0f * c[0] - (c[1] + c[0]) / 2.0f);
+    else if (k == N) v = fminf(smax, 2.0f * c[N - 1] - (c[N - 1] + c[N - 2]) / 2.0f);
+    else v = (c[k] + c[k - 1]) / 2.0f;
+    sd[k] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void st3(float *base, size_t idx, float a, float b, float c) {
+  if (base) { base[idx * 3 + 0] = a; base[idx * 3 + 1] = b; base[idx * 3 + 2] = c; }
+}
+
+
+/* P0 (models.py:200-218): resample every ray of the workgroup, one wave per
+ * ray; writes metric distances tdist to TD[rl][N+1] (LDS) and sdist / bin
+ * indices to HBM.  `scratch` needs 4*(3*520+8) + 4*648 floats. */
+__device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratch, float *TD, int ray0, int wave, int lane) {
+  const refnerf_level_cfg &cfg = A.cfg;
+  const int N = cfg.n_samples, M = cfg.n_in, rpw = A.rpw;
+  float *scr = scratch + wave * (3 * 520 + 8);
+  float *t_in = scr, *lg = scr + 520, *cw = scr + 1040;
+  float *c = scratch + 4 * (3 * 520 + 8) + wave * 648;   /* sample centres, N <= 640 */
+  for (int rl = wave; rl < rpw; rl += 4) {
+    int ray = ray0 + rl;
+    if (ray >= A.R) break;
+    const float *tg = A.sdist_in + (size_t)ray * (M + 1);
+    const float *wg = A.weights_in + (size_t)ray * M;
+    for (int i = lane; i <= M; i += 64) t_in[i] = tg[i];
+    wave_sync();
+    /* models.py:200-203 */
+    for (int i = lane; i < M; i += 64)
+      lg[i] = (t_in[i + 1] > t_in[i]) ? cfg.anneal * logf(wg[i] + cfg.resample_padding) : -INFINITY;
+    wave_sync();
+    float *sd = TD + rl * (N + 1);
+    sample_intervals_wave(t_in, lg, cw, c, M, N, cfg.s_near, cfg.s_far, sd,
+                          A.out.d_bin_idx ? A.out.d_bin_idx + (size_t)ray * N : nullptr, lane);
+    float nearv = A.rays.d_near[ray], farv = A.rays.d_far[ray];
+    for (int k = lane; k <= N; k += 64) {
+      float s = sd[k];
+      if (A.out.d_sdist) A.out.d_sdist[(size_t)ray * (N + 1) + k] = s;
+      sd[k] = s_to_t(s, nearv, farv);         /* models.py:218 */
+    }
+  }
+}
+
+/* P4 (models.py:611-683): head activations, predicted normal, reflection. */
+struct SampleHeads {
+  float density, rough, dot;
+  float tint[3], raw_dif[3], npred[3], gp[3], refd[3];
+};
+__device__ __forceinline__ void sample_heads(const refnerf_level_cfg &cfg, float raw_density, const float gp[3],
+                                             float raw_rough, const float raw_dif[3], const float raw_tint[3],
+                                             const float v[3], SampleHeads &s) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { s.gp[i] = gp[i]; s.raw_dif[i] = raw_dif[i]; s.tint[i] = sigmoid_t(raw_tint[i]); }
+  float n2 = fmaxf((gp[0] * gp[0] + gp[1] * gp[1]) + gp[2] * gp[2], EPS32);
+  float nrm = sqrtf(n2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s.npred[i] = -(gp[i] / nrm);
+  s.density = softplus_t(raw_density + cfg.density_bias);
+  s.rough = softplus_t(raw_rough + cfg.roughness_bias);
+  float w3[3] = {-v[0], -v[1], -v[2]};
+  float dot = (s.npred[0] * w3[0] + s.npred[1] * w3[1]) + s.npred[2] * w3[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s.refd[i] = (2.0f * dot) * s.npred[i] - w3[i];
+  s.dot = (s.npred[0] * v[0] + s.npred[1] * v[1]) + s.npred[2] * v[2];
+}
+
+/* P6 (models.py:699-729): colour head; keeps what compositing needs in LDS
+ * PS[c][g] and stores the per-sample history. */
+__device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHeads &s, const float raw_rgb[3],
+                                             float *PS, int n_tot, int g, size_t gi) {
+  const refnerf_level_cfg &cfg = A.cfg;
+  float spec_lin[3], dif_lin[3], rgb[3], dif[3], spc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float sg = sigmoid_t(cfg.rgb_premultiplier * raw_rgb[i] + cfg.rgb_bias);
+    dif_lin[i] = sigmoid_t(s.raw_dif[i] - LOG3_F);
+    spec_lin[i] = s.tint[i] * sg;
+    rgb[i] = spec_lin[i] + dif_lin[i];
+  }
+  if (cfg.srgb_mapping) {
+    if (cfg.srgb_mapping_normalization) {
+      float norm = fmaxf(fmaxf(fmaxf(rgb[0], rgb[1]), rgb[2]), 1.0f);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] / norm;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      rgb[i] = clip01(linear_to_srgb(rgb[i]));
+      dif[i] = clip01(linear_to_srgb(dif_lin[i]));
+      spc[i] = clip01(linear_to_srgb(spec_lin[i]));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { dif[i] = dif_lin[i]; spc[i] = spec_lin[i]; }
+  }
+  const float pad_scale = (float)(1.0 + 2.0 * (double)cfg.rgb_padding);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] * pad_scale - cfg.rgb_padding;
+  PS[PS_DENSITY * n_tot + g] = s.density;
+  PS[PS_ROUGH * n_tot + g] = s.rough;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    PS[(PS_RGB + i) * n_tot + g] = rgb[i];
+    PS[(PS_DIF + i) * n_tot + g] = dif[i];
+    PS[(PS_SPC + i) * n_tot + g] = spc[i];
+    PS[(PS_NPRED + i) * n_tot + g] = s.npred[i];
+    PS[(PS_TINT + i) * n_tot + g] = s.tint[i];
+    PS[(PS_NORMALS + i) * n_tot + g] = 0.0f;
+  }
+  if (A.out.d_density) A.out.d_density[gi] = s.density;
+  if (A.out.d_roughness) A.out.d_roughness[gi] = s.rough;
+  st3(A.out.d_rgb, gi, rgb[0], rgb[1], rgb[2]);
+  st3(A.out.d_diffuse, gi, dif[0], dif[1], dif[2]);
+  st3(A.out.d_specular, gi, spc[0], spc[1], spc[2]);
+  st3(A.out.d_normals_pred, gi, s.npred[0], s.npred[1], s.npred[2]);
+  st3(A.out.d_grad_pred, gi, s.gp[0], s.gp[1], s.gp[2]);
+  st3(A.out.d_tint, gi, s.tint[0], s.tint[1], s.tint[2]);
+}
+
+/* P7: alpha weights + compositing, one wave per ray (render.py:132-149, 152-254). */
+__device__ __forceinline__ void composite_phase(const LevelArgs &A, const float *TD, float *XP, float *PS, int n_tot,
+                                                int ray0, int wave, int lane) {
+  const refnerf_level_cfg &cfg = A.cfg;
+  const int N = cfg.n_samples, rpw = A.rpw;
+  for (int rl = wave; rl < rpw; rl += 4) {
+    const int ray = ray0 + rl;
+    if (ray >= A.R) break;
+    const float *td = TD + rl * (N + 1);
+    const int base = rl * N;
+    const int C = (N + 63) / 64;                 /* samples per lane */
+    const int i0 = lane * C;
+    float dx = A.rays.d_directions[(size_t)ray * 3], dy = A.rays.d_directions[(size_t)ray * 3 + 1], dz = A.rays.d_directions[(size_t)ray * 3 + 2];
+    const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
+    float *wbuf = PS + PS_DENSITY * n_tot + base;  /* density is overwritten by the weights */
+    /* pass 1: local sums of density*delta */
+    double local = 0.0;
+    for (int q = 0; q < C; ++q) {
+      int i = i0 + q;
+      if (i < N) {
+        float dd = wbuf[i] * ((td[i + 1] - td[i]) * norm);
+        if (cfg.opaque_background && i == N - 1) dd = INFINITY;
+        local += (double)dd;
+      }
+    }
+    double incl = wave_scan_incl(local, lane);
+    double cum = incl - local;                   /* exclusive prefix of this lane's chunk */
+    /* pass 2: weights + weighted sums */
+    float acc = 0, s_rgb[3] = {0, 0, 0}, s_dif[3] = {0, 0, 0}, s_spc[3] = {0, 0, 0}, s_np[3] = {0, 0, 0}, s_tn[3] = {0, 0, 0};
+    float s_nm[3] = {0, 0, 0};
+    float s_dist = 0, s_rgh = 0, s_logd = 0;
+    double wlocal = 0.0;
+    for (int q = 0; q < C; ++q) {
+      int i = i0 + q;
+      if (i < N) {
+        float dd = wbuf[i] * ((td[i + 1] - td[i]) * norm);
+        if (cfg.opaque_background && i == N - 1) dd = INFINITY;
+        float alpha = 1.0f - expf(-dd);
+        float trans = expf(-(float)cum);
+        float w = alpha * trans;
+        cum += (double)dd;
+        wbuf[i] = w;
+        wlocal += (double)w;
+        if (A.out.d_weights) A.out.d_weights[(size_t)ray * N + i] = w;
+        acc += w;
+        float tmid = 0.5f * (td[i] + td[i + 1]);
+        s_dist += w * tmid;
+        s_logd += w * logf(tmid);
+        s_rgh += w * PS[PS_ROUGH * n_tot + base + i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          s_rgb[c] += w * PS[(PS_RGB + c) * n_tot + base + i];
+          s_dif[c] += w * PS[(PS_DIF + c) * n_tot + base + i];
+          s_spc[c] += w * PS[(PS_SPC + c) * n_tot + base + i];
+          s_np[c] += w * PS[(PS_NPRED + c) * n_tot + base + i];
+          s_tn[c] += w * PS[(PS_TINT + c) * n_tot + base + i];
+          s_nm[c] += w * PS[(PS_NORMALS + c) * n_tot + base + i];
+        }
+      }
+    }
+    acc = wave_sum(acc); s_dist = wave_sum(s_dist); s_logd = wave_sum(s_logd); s_rgh = wave_sum(s_rgh);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      s_rgb[c] = wave_sum(s_rgb[c]); s_dif[c] = wave_sum(s_dif[c]); s_spc[c] = wave_sum(s_spc[c]);
+      s_np[c] = wave_sum(s_np[c]); s_tn[c] = wave_sum(s_tn[c]); s_nm[c] = wave_sum(s_nm[c]);
+    }
+    const float bg_w = fmaxf(0.0f, 1.0f - acc);
+    float rgb[3], dif[3], spc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      rgb[c] = s_rgb[c] + bg_w * cfg.bg_rgb; dif[c] = s_dif[c] + bg_w * cfg.bg_rgb; spc[c] = s_spc[c] + bg_w * cfg.bg_rgb;
+    }
+    const int mode = cfg.render_srgb_mode;
+    if (mode != REFNERF_SRGB_NONE) {              /* render.py:186-216 */
+      if (mode == REFNERF_SRGB_NORM_LINEAR || mode == REFNERF_SRGB_NORM_SRGB) {
+        float nr = fmaxf(fmaxf(fmaxf(rgb[0], rgb[1]), rgb[2]), 1.0f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c] = rgb[c] / nr;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (mode == REFNERF_SRGB_SRGB || mode == REFNERF_SRGB_NORM_SRGB) {
+          rgb[c] = linear_to_srgb(rgb[c]); dif[c] = linear_to_srgb(dif[c]); spc[c] = linear_to_srgb(spc[c]);
+        }
+        rgb[c] = clip01(rgb[c]); dif[c] = clip01(dif[c]); spc[c] = clip01(spc[c]);
+      }
+    }
+    if (lane == 0) {
+      st3(A.out.d_r_rgb, ray, rgb[0], rgb[1], rgb[2]);
+      st3(A.out.d_r_diffuse, ray, dif[0], dif[1], dif[2]);
+      st3(A.out.d_r_specular, ray, spc[0], spc[1], spc[2]);
+      if (A.out.d_r_distance) A.out.d_r_distance[ray] = s_dist;
+      if (A.out.d_r_acc) A.out.d_r_acc[ray] = acc;
+      if (cfg.compute_extras) {
+        if (cfg.training) st3(A.out.d_r_normals, ray, s_nm[0], s_nm[1], s_nm[2]);
+        st3(A.out.d_r_normals_pred, ray, s_np[0], s_np[1], s_np[2]);
+        st3(A.out.d_r_tint, ray, s_tn[0], s_tn[1], s_tn[2]);
+        if (A.out.d_r_roughness) A.out.d_r_roughness[ray] = s_rgh;
+        if (A.out.d_r_distance_mean) {
+          float e = expf(s_logd / fmaxf(EPS32, acc));
+          if (e != e) e = INFINITY;
+          e = fminf(fmaxf(e, td[0]), td[N]);     /* +-inf -> clip (same as +-FLT_MAX then clip) */
+          A.out.d_r_distance_mean[ray] = e;
+        }
+      }
+    }
+    /* percentiles (stepfun.py:294-307, math.py:114-142) in float64 */
+    if (cfg.compute_extras && A.out.d_r_percentiles) {
+      /* knots xp[j], j = 0..N+1: xp[0]=0, xp[j]=min(1,float(cumsum w[0..j-1])), xp[N+1]=1.
+       * fp[j] = td[j] (j<=N), fp[N+1]=far. */
+      float *xp = XP + rl * (N + 1);
+      double wincl = wave_scan_incl(wlocal, lane);
+      double run = wincl - wlocal;
+      __builtin_amdgcn_wave_barrier();
+      for (int q = 0; q < C; ++q) {
+        int i = i0 + q;
+        if (i < N) { run += (double)wbuf[i]; xp[i + 1] = fminf(1.0f, (float)run); }
+      }
+      if (lane == 0) { xp[0] = 0.0f; }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      /* note xp[N] = min(1,cumsum of all N weights) is what integrate_weights
+       * produces for index N (weights_aug[:-1] = the N sample weights); xp[N+1] = 1. */
+      const float farv = A.rays.d_far[ray];
+      const float psf[3] = {5.0f / 100.0f, 50.0f / 100.0f, 95.0f / 100.0f};
+      const int nk = N + 2;
+      for (int p = 0; p < 3; ++p) {
+        double x = (double)psf[p];
+        int cnt = 0;
+        for (int j = lane; j < nk; j += 64) {
+          double xj = (j == nk - 1) ? 1.0 : (double)xp[j];
+          cnt += (x >= xj) ? 1 : 0;
+        }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) cnt += __shfl_xor(cnt, o2, 64);
+        if (lane == 0) {
+          int idx = cnt - 1;
+          if (idx < 0) idx = 0;
+          if (idx > nk - 2) idx = nk - 2;
+          double x0 = (double)xp[idx], x1 = (idx + 1 == nk - 1) ? 1.0 : (double)xp[idx + 1];
+          double f0 = (double)td[idx], f1 = (idx + 1 == nk - 1) ? (double)farv : (double)td[idx + 1];
+          double m = (f1 - f0) / (x1 - x0);
+          double b = f0 - m * x0;
+          A.out.d_r_percentiles[(size_t)ray * 3 + p] = m * x + b;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace rn

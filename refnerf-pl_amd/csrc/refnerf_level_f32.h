@@ -1,0 +1,230 @@
+/*
+ * refnerf_level_f32.h -- fp32-MFMA level kernel (the parity mode).
+ *
+ * workgroup = 4 waves = RPW whole rays; each wave owns 32-sample blocks.  The
+ * MLP runs transposed, D[out][sample] = W x X on v_mfma_f32_32x32x2_f32, so a
+ * layer's accumulator registers ARE the next layer's B operands: activations
+ * never leave the register file; only the encodings (IPE 96, dir-MLP input
+ * 204) sit in LDS.
+ */
+#pragma once
+#include "refnerf_level_common.h"
+
+namespace rn {
+
+constexpr int T_TILE = 128;  /* samples per pass: 4 waves x 32 */
+
+/* ------------------------------------------------------------------ */
+/* fp32 MFMA GEMM op on one 32-sample block                           */
+/* ------------------------------------------------------------------ */
+
+/* A fragments come through a buffer descriptor over the packed image: the
+ * per-lane part of the address is one constant VGPR (lane*STRIDE*4), the
+ * per-step part is an SGPR/immediate, so the 1000+ loads of an op cost no VALU
+ * address arithmetic (flat global loads made hipcc precompute and spill
+ * hundreds of 64-bit pointers). */
+template <int NOB, int STRIDE>
+__device__ __forceinline__ void load_a(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float (&a)[NOB]) {
+  if constexpr (STRIDE == 8) {
+    v4f x = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    a[0] = x[0];
+    if constexpr (NOB > 1) { a[1] = x[1]; a[2] = x[2]; a[3] = x[3]; }
+    if constexpr (NOB == 5) a[4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 16, soff, 0));
+    if constexpr (NOB == 8) {
+      v4f y = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, 0));
+      a[4] = y[0]; a[5] = y[1]; a[6] = y[2]; a[7] = y[3];
+    }
+  } else {
+    a[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+  }
+}
+
+/* out[ob] = bias + W * in, W from the packed image `rs`.  a_off/b_off: float
+ * offsets of the op inside the image (wave-uniform); `xl` = LDS X + h*T_TILE +
+ * column (for LDS steps).  The A stream is software-pipelined PF steps ahead
+ * through a register ring; sched_barrier pins "MFMAs of step s, then the loads
+ * of step s+PF" so that hipcc cannot sink the loads back to their uses (it
+ * otherwise emits load; s_waitcnt vmcnt(0); mfma).  lds_steps % PF == 0. */
+constexpr int PF = 3;
+template <int NOB, int STRIDE, bool HAS_REG>
+__device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
+                                        const v16f (&in)[8], v16f (&out)[NOB], const float *xl,
+                                        int lds_steps) {
+  constexpr int STEP_BYTES = 64 * STRIDE * 4;
+  const int voff = lane * STRIDE * 4;
+  int soff = a_off * 4;
+  float a[PF][NOB];
+#pragma unroll
+  for (int d = 0; d < PF; ++d) load_a<NOB, STRIDE>(rs, voff, soff + d * STEP_BYTES, a[d]);
+  soff += PF * STEP_BYTES;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+    v4f b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      b[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, h * 64 + q * 16, b_off * 4 + ob * 128, 0));
+    out[ob] = (v16f){b[0][0], b[0][1], b[0][2], b[0][3], b[1][0], b[1][1], b[1][2], b[1][3],
+                     b[2][0], b[2][1], b[2][2], b[2][3], b[3][0], b[3][1], b[3][2], b[3][3]};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (HAS_REG) {
+#pragma unroll
+    for (int step = 0; step < REG_STEPS; ++step) {
+      const float b = in[step >> 4][step & 15];
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob)
+        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step % PF][ob], b, out[ob], 0, 0, 0);
+      load_a<NOB, STRIDE>(rs, voff, soff + step * STEP_BYTES, a[step % PF]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    soff += REG_STEPS * STEP_BYTES;
+  }
+  constexpr int P0 = HAS_REG ? (REG_STEPS % PF) : 0;
+  float bcur = xl[0];
+#pragma unroll 1
+  for (int s = 0; s < lds_steps; s += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const float bnext = xl[2 * (s + u + 1) * T_TILE];
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob)
+        out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(P0 + u) % PF][ob], bcur, out[ob], 0, 0, 0);
+      load_a<NOB, STRIDE>(rs, voff, soff + u * STEP_BYTES, a[(P0 + u) % PF]);
+      bcur = bnext;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    soff += PF * STEP_BYTES;
+  }
+}
+
+__device__ __forceinline__ void relu_into(const v16f (&out)[8], v16f (&in)[8]) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) in[ob][r] = fmaxf(out[ob][r], 0.0f);
+}
+
+
+__global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const refnerf_level_cfg &cfg = A.cfg;
+  const int N = cfg.n_samples;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, sl = lane & 31;
+  const int rpw = A.rpw;
+  const int ray0 = blockIdx.x * rpw;
+  const int n_tot = rpw * N;                 /* samples owned by this workgroup */
+
+  float *X = smem;                               /* [DIR_PAD][T_TILE]              */
+  float *HD = X + DIR_PAD * T_TILE;              /* [HD_ROWS][T_TILE]              */
+  float *TD = HD + HD_ROWS * T_TILE;             /* [rpw][N+1] metric distances    */
+  float *XP = TD + rpw * (N + 1);                /* [rpw][N+1] CDF knots for the percentiles */
+  float *PS = XP + rpw * (N + 1);                /* [NPS][n_tot]                   */
+
+  resample_phase(A, X, TD, ray0, wave, lane);    /* P0 */
+  __syncthreads();
+
+  /* ---------------- per-pass MLP over 32-sample blocks ---------------- */
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.packed, 0, PACKED.total * 4, 0x00020000);
+  const int col = wave * 32 + sl;                /* this lane's column in X / HD */
+  const float *xl = X + h * T_TILE + col;
+  v16f in[8], out[8];
+
+  for (int pass0 = 0; pass0 < n_tot; pass0 += T_TILE) {
+    const int g = pass0 + col;                   /* sample index inside the workgroup */
+    const int rl = g / N, si = g - rl * N;
+    const int ray = ray0 + rl;
+    const bool valid = (g < n_tot) && (ray < A.R);
+    const int rayc = valid ? ray : (A.R - 1);
+    float o[3], d[3], v[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      o[i] = A.rays.d_origins[(size_t)rayc * 3 + i];
+      d[i] = A.rays.d_directions[(size_t)rayc * 3 + i];
+      v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
+    }
+    /* P1: conical frustum -> lifted Gaussian -> IPE (half 0: sin, half 1: cos) */
+    {
+      float radius = A.rays.d_radii[rayc];
+      const float *td = TD + (valid ? rl : 0) * (N + 1);
+      float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
+      float lm[3], lv[3];
+      cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
+#pragma unroll 1
+      for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) X[(48 * h + j * 3 + b) * T_TILE + col] = ipe_feature(lm[b], lv[b], j, h);
+    }
+    wave_sync();
+
+    /* P2: spatial MLP (models.py:576-580) */
+    gemm_op<8, 8, false>(rs, PACKED.op[0].a_off, PACKED.op[0].b_off, lane, h, in, out, xl, PACKED.op[0].lds_steps);
+    relu_into(out, in);
+#pragma unroll 1
+    for (int op = 1; op < 8; ++op) {
+      gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
+      relu_into(out, in);
+    }
+    /* P3: heads (models.py:582,613,634-645): 4 bottleneck blocks + 1 scalar block */
+    {
+      v16f hd[5];
+      gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0);
+      __builtin_amdgcn_wave_barrier();          /* all IPE reads of this wave are done */
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[(blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * T_TILE + col] = hd[blk][r];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < HD_ROWS) HD[row * T_TILE + col] = hd[4][r];
+      }
+    }
+    wave_sync();
+
+    /* P4: activations, reflection, IDE (models.py:611-686) */
+    SampleHeads sh;
+    {
+      float gp[3], raw_dif[3], raw_tint[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        gp[i] = HD[(1 + i) * T_TILE + col];
+        raw_dif[i] = HD[(5 + i) * T_TILE + col];
+        raw_tint[i] = HD[(8 + i) * T_TILE + col];
+      }
+      sample_heads(cfg, HD[0 * T_TILE + col], gp, HD[4 * T_TILE + col], raw_dif, raw_tint, v, sh);
+      float *xi = X + (BNECK + IDE_TERMS * h) * T_TILE + col;
+      ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { xi[q * T_TILE] = val; });
+      if (h == 0) X[(BNECK + IDE_DIM) * T_TILE + col] = sh.dot;
+      else {
+#pragma unroll
+        for (int q = DIR_IN; q < DIR_PAD; ++q) X[q * T_TILE + col] = 0.0f;
+      }
+    }
+    wave_sync();
+
+    /* P5: directional MLP (models.py:690-694) + rgb (699-700) */
+    gemm_op<8, 8, false>(rs, PACKED.op[9].a_off, PACKED.op[9].b_off, lane, h, in, out, xl, PACKED.op[9].lds_steps);
+    relu_into(out, in);
+#pragma unroll 1
+    for (int op = 10; op < 17; ++op) {
+      gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
+      relu_into(out, in);
+    }
+    v16f rgbv[1];
+    gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0);
+    /* rows 0..2 live in half 0, regs 0..2; hand them to half 1 as well */
+    float raw_rgb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(rgbv[0][i], sl, 64);
+
+    /* P6: colour head (models.py:699-729) */
+    if (valid && h == 0) colour_store(A, sh, raw_rgb, PS, n_tot, g, (size_t)ray * N + si);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+
+  composite_phase(A, TD, XP, PS, n_tot, ray0, wave, lane);   /* P7 */
+}
+
+}  // namespace rn
