@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -100,38 +101,44 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
   }
 }
 
-/* bf16 image: one block per (op, ob) slice; see refnerf_layout.h. */
+/* bf16 image: one block per (op, ob) slice, uniform 17 KB chunks in execution
+ * order; see refnerf_layout.h. */
 __global__ void pack_weights_bf16(const float *__restrict__ P, char *__restrict__ out) {
   const int op = blockIdx.y, ob = blockIdx.x;
   const BfOp o = BFPACKED.op[op];
   if (ob >= o.nob) return;
-  char *slice = out + ((size_t)o.off_kb + (size_t)ob * (o.ks + 1)) * 1024;
-  /* bias piece: fp32 [h][16], rest of the KB zero */
-  for (int e = threadIdx.x; e < 256; e += blockDim.x) {
-    float v = 0.0f;
-    if (e < 32) {
-      int reg = e & 15, h = e >> 4;
-      v = canon_b(P, op, ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+  const int base = (o.nchunk == 2) ? WIDTH : 0;     /* canonical column of the first non-register input */
+  for (int j = 0; j < o.nchunk; ++j) {
+    char *chunk = out + (size_t)(o.chunk0 + ob * o.nchunk + j) * BF_CHUNK_BYTES;
+    const int kind = o.kind[j];
+    /* bias piece: fp32 [h][16] (first chunk of the slice), rest of the KB zero */
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+      float v = 0.0f;
+      if (e < 32 && j == 0) {
+        int reg = e & 15, h = e >> 4;
+        v = canon_b(P, op, ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+      }
+      reinterpret_cast<float *>(chunk)[e] = v;
     }
-    reinterpret_cast<float *>(slice)[e] = v;
-  }
-  const int base = (o.ks_reg ? WIDTH : 0);     /* canonical column of the first non-register input */
-  for (int idx = threadIdx.x; idx < o.ks * 512; idx += blockDim.x) {
-    int e = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9;
-    int h = lane >> 5, row = ob * 32 + (lane & 31);
-    float v = 0.0f;
-    if (t < o.ks_reg + o.ks_bn) {
-      int tt = (t < o.ks_reg) ? t : t - o.ks_reg;
-      int r = 8 * (tt & 1) + e;
-      int feat = 32 * (tt >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
-      v = canon_w(P, op, row, (t < o.ks_reg) ? feat : base + feat);
-    } else {
-      int kp = 16 * (t - o.ks_reg - o.ks_bn) + 8 * h + e;
-      if (op == 0 || op == 5) v = canon_w(P, op, row, base + ipe_col_of_kprime(kp));
-      else if (kp < IDE_DIM) v = canon_w(P, op, row, base + BNECK + kp);
-      else if (kp == IDE_DIM) v = canon_w(P, op, row, base + BNECK + IDE_DIM);
+    for (int idx = threadIdx.x; idx < 16 * 512; idx += blockDim.x) {
+      int e = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9;
+      int h = lane >> 5, row = ob * 32 + (lane & 31);
+      float v = 0.0f;
+      const bool reg_step = (kind == BF_REG) || (kind == BF_BNLDS && t < 8);
+      if (reg_step) {
+        int r = 8 * (t & 1) + e;
+        int feat = 32 * (t >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+        v = canon_w(P, op, row, (kind == BF_REG) ? feat : base + feat);
+      } else if (kind == BF_LDS8) {
+        int kp = 16 * t + 8 * h + e;
+        if (t < BF_IPE_REAL_KS) v = canon_w(P, op, row, base + ipe_col_of_kprime(kp));
+      } else {
+        int kp = 16 * (t - 8) + 8 * h + e;
+        if (kp < IDE_DIM) v = canon_w(P, op, row, base + BNECK + kp);
+        else if (kp == IDE_DIM) v = canon_w(P, op, row, base + BNECK + IDE_DIM);
+      }
+      reinterpret_cast<__bf16 *>(chunk + 1024)[idx] = (__bf16)v;
     }
-    reinterpret_cast<__bf16 *>(slice + 1024)[idx] = (__bf16)v;
   }
 }
 
@@ -256,7 +263,7 @@ int refnerf_device_ok(void) {
 
 size_t refnerf_packed_weights_bytes(int precision) {
   if (precision == REFNERF_PREC_F32) return (size_t)rn::PACKED.total * sizeof(float);
-  if (precision == REFNERF_PREC_BF16) return ((size_t)rn::BFPACKED.total_kb + rn::BF_MAX_SLICE_KB) * 1024;
+  if (precision == REFNERF_PREC_BF16) return ((size_t)rn::BFPACKED.chunks_per_pass + 2) * rn::BF_CHUNK_BYTES;
   return 0;
 }
 
@@ -278,10 +285,8 @@ int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, v
 static int rays_per_wg(int N, int tile) {
   if (N % tile == 0) return 1;
   if (tile % N == 0) return tile / N;
-  if (tile == rn::T_TILE) {
-    if ((2 * N) % tile == 0) return 2;
-    if ((4 * N) % tile == 0) return 4;
-  }
+  if ((2 * N) % tile == 0) return 2;
+  if ((4 * N) % tile == 0) return 4;
   return 1;
 }
 
@@ -305,12 +310,19 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
   if (rc) return rc;
   const int N = cfg->n_samples;
   const bool bf = cfg->precision == REFNERF_PREC_BF16;
-  const int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
+  const int rpw = rays_per_wg(N, rn::T_TILE);
   if (rpw * N > 640) return fail(REFNERF_EINVAL, "n_samples too large for the LDS budget (rays_per_wg*N must be <= 640)%s");
   const size_t per_ray = sizeof(float) * (size_t)(2 * rpw * (N + 1) + rn::NPS * rpw * N + 8);
   size_t lds;
-  if (bf) lds = 2 * (size_t)rn::WBUF_BYTES + rn::BF_X_BYTES + sizeof(float) * rn::HD_ROWS * rn::BT + per_ray;
+  if (bf) lds = (size_t)rn::BF_RING_BYTES + rn::BF_X_BYTES + sizeof(float) * rn::HD_ROWS * rn::BT + per_ray;
   else lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE) + per_ray;
+  {
+    const int nw = rpw < 4 ? rpw : 4;
+    const size_t scratch = sizeof(float) * (size_t)nw * (3 * (cfg->n_in + 4) + N + 3);
+    if (scratch > (bf ? (size_t)rn::BF_X_BYTES : sizeof(float) * rn::DIR_PAD * rn::T_TILE))
+      return fail(REFNERF_EINVAL, "n_in / n_samples too large for the resampler scratch of this precision mode%s");
+  }
+  if (const char *padenv = getenv("REFNERF_LDS_PAD")) lds += (size_t)atoi(padenv);   /* debug: force 1 workgroup/CU */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget of this precision mode%s");
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {

@@ -96,47 +96,49 @@ constexpr Packed PACKED = make_packed();
 
 /* ---------------- bf16 MFMA operand image ----------------
  * Same 18 ops on v_mfma_f32_32x32x16_bf16 (K = 16 per step), two 32-sample
- * blocks per wave.  Weights travel HBM/L2 -> LDS once per workgroup as
- * "slices" = (op, output block ob): [1 KB bias piece][ks fragment pieces of
- * 1 KB], stored in EXECUTION ORDER so the LDS-DMA prefetcher just walks the
- * image.  Fragment piece (ob,t): lane l holds 8 bf16 = W[32*ob + (l&31)][kmap(t, l>>5, e)],
- * e = 0..7.  k-steps of a slice: ks_reg "register" steps (input = previous
- * layer's packed accumulators: kmap = 32*(t>>1) + (r&3) + 8*(r>>2) + 4*h with
- * r = 8*(t&1) + e), then ks_bn steps over the bottleneck (same map, kept in
- * registers for dir layers 0 and 5), then ks_lds steps over encodings staged
- * in LDS in k' order (k' = 16*t + 8*h + e; IPE k' = 6*j + 3*c + b; dir k' =
- * IDE index 0..71, 72 = n.v, 73..79 = 0).  Bias piece: fp32 [h][16] in
- * accumulator layout (first 128 B of the piece). */
-constexpr int BF_IPE_KS = 6;    /* 96 / 16 */
-constexpr int BF_DIR_KS = 5;    /* 80 / 16 */
-constexpr int BF_DIR_PAD = 80;
-constexpr int BF_BN_KS = 8;     /* 128 / 16 */
-constexpr int BF_REG_KS = 16;   /* 256 / 16 */
+ * blocks per wave.  Weights travel HBM/L2 -> LDS once per workgroup as uniform
+ * "chunks" of 17 KB = [1 KB bias piece][16 fragment pieces of 1 KB], stored in
+ * EXECUTION ORDER so the LDS-DMA prefetcher just walks the image.
+ * A slice = (op, 32-row output block ob) = 1 or 2 chunks:
+ *   REG   : 16 k-steps over the previous layer's packed accumulators
+ *   LDS8  : 8 k-steps over encodings staged in LDS (IPE: 6 real + 2 zero steps)
+ *   BNLDS : 8 k-steps over the bottleneck (kept in registers) + 8 k-steps over
+ *           the dir encodings in LDS (5 real + 3 zero steps)
+ * sp0: [LDS8]; sp5: [REG][LDS8]; vd0: [BNLDS]; vd5: [REG][BNLDS]; else [REG].
+ * Fragment piece t: lane l holds 8 bf16 = W[32*ob + (l&31)][kmap(t, l>>5, e)],
+ * e = 0..7.  Register steps: kmap = 32*(t>>1) + (r&3) + 8*(r>>2) + 4*h with
+ * r = 8*(t&1) + e (the accumulator layout of the producing MFMA); LDS steps:
+ * k' = 16*t + 8*h + e with IPE k' = 6*j + 3*c + b and dir k' = IDE index
+ * 0..71, 72 = n.v, rest zero.  Bias piece (first chunk of a slice): fp32
+ * [h][16] in accumulator layout. */
+constexpr int BF_CHUNK_KB = 17;
+constexpr int BF_CHUNK_BYTES = BF_CHUNK_KB * 1024;
+constexpr int BF_IPE_REAL_KS = 6;   /* 96 / 16 */
+constexpr int BF_DIR_REAL_KS = 5;   /* 80 / 16 */
+enum { BF_REG = 0, BF_LDS8 = 1, BF_BNLDS = 2 };
 
-struct BfOp { int nob; int ks_reg; int ks_bn; int ks_lds; int ks; int off_kb; };
-struct BfPacked { BfOp op[NUM_OPS]; int total_kb; int slices_per_pass; };
+struct BfOp { int nob; int nchunk; int kind[2]; int chunk0; };
+struct BfPacked { BfOp op[NUM_OPS]; int chunks_per_pass; };
 
 constexpr BfPacked make_bf_packed() {
   BfPacked P{};
-  int kb = 0, ns = 0;
+  int c = 0;
   for (int i = 0; i < NUM_OPS; ++i) {
     BfOp o{};
     o.nob = (i == OP_HEADS) ? 5 : (i == OP_RGB ? 1 : 8);
-    o.ks_reg = (i == 0 || i == 9) ? 0 : BF_REG_KS;
-    o.ks_bn = (i == 9 || i == 14) ? BF_BN_KS : 0;
-    o.ks_lds = (i == 0 || i == 5) ? BF_IPE_KS : ((i == 9 || i == 14) ? BF_DIR_KS : 0);
-    o.ks = o.ks_reg + o.ks_bn + o.ks_lds;
-    o.off_kb = kb;
-    kb += o.nob * (o.ks + 1);
-    ns += o.nob;
+    if (i == 0) { o.nchunk = 1; o.kind[0] = BF_LDS8; }
+    else if (i == 5) { o.nchunk = 2; o.kind[0] = BF_REG; o.kind[1] = BF_LDS8; }
+    else if (i == 9) { o.nchunk = 1; o.kind[0] = BF_BNLDS; }
+    else if (i == 14) { o.nchunk = 2; o.kind[0] = BF_REG; o.kind[1] = BF_BNLDS; }
+    else { o.nchunk = 1; o.kind[0] = BF_REG; }
+    o.chunk0 = c;
+    c += o.nob * o.nchunk;
     P.op[i] = o;
   }
-  P.total_kb = kb;
-  P.slices_per_pass = ns;
+  P.chunks_per_pass = c;
   return P;
 }
 constexpr BfPacked BFPACKED = make_bf_packed();
-constexpr int BF_MAX_SLICE_KB = 30;
 
 /* head rows inside op 8 (5 blocks of 32): 0..127 bottleneck, then */
 constexpr int HROW_DENSITY = 128, HROW_GRAD = 129, HROW_ROUGH = 132, HROW_DIFFUSE = 133, HROW_TINT = 136, HROWS = 139;

@@ -125,13 +125,13 @@ __device__ __forceinline__ void st3(float *base, size_t idx, float a, float b, f
 
 /* P0 (models.py:200-218): resample every ray of the workgroup, one wave per
  * ray; writes metric distances tdist to TD[rl][N+1] (LDS) and sdist / bin
- * indices to HBM.  `scratch` needs 4*(3*520+8) + 4*648 floats. */
+ * indices to HBM.  `scratch` needs min(rpw,4) * (3*(M+4) + N+3) floats. */
 __device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratch, float *TD, int ray0, int wave, int lane) {
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples, M = cfg.n_in, rpw = A.rpw;
-  float *scr = scratch + wave * (3 * 520 + 8);
-  float *t_in = scr, *lg = scr + 520, *cw = scr + 1040;
-  float *c = scratch + 4 * (3 * 520 + 8) + wave * 648;   /* sample centres, N <= 640 */
+  const int Mp = (M + 4) & ~3, Np = (N + 3) & ~3;      /* per-wave scratch: 3*Mp + Np floats */
+  float *scr = scratch + wave * (3 * Mp + Np);
+  float *t_in = scr, *lg = scr + Mp, *cw = scr + 2 * Mp, *c = scr + 3 * Mp;
   for (int rl = wave; rl < rpw; rl += 4) {
     int ray = ray0 + rl;
     if (ray >= A.R) break;
