@@ -18,6 +18,9 @@ constexpr float EPS32 = 1.1920928955078125e-07f; /* torch.finfo(float32).eps */
 constexpr float HALF_PI_F = 1.57079637050628662109375f;   /* fl32(0.5*pi) */
 constexpr float T100PI = 314.159271240234375f;            /* fl32(100*pi) */
 constexpr float LOG3_F = 1.09861228466033935546875f;      /* fl32(log 3)  */
+constexpr float LOG2E_F = 1.44269504088896341f;
+constexpr float LN2_F = 0.69314718055994531f;
+constexpr float INV_2PI_F = 0.15915494309189535f;
 
 /* IDE recurrence tables (see oracle rn_ide_stable_f32): c[17], a[17*17], b[17*17] */
 __constant__ float g_ide_c[17];
@@ -88,21 +91,54 @@ __device__ __forceinline__ float safe_arg(float x) {
 
 /* One IPE feature (coord.py:119-126): block 0 = sin, block 1 = "cos" =
  * sin(fl(x + pi/2)). */
+template <bool FAST = false>
 __device__ __forceinline__ float ipe_feature(float lm, float lv, int j, int cos_block) {
   float sc = __builtin_ldexpf(1.0f, j), sc2 = __builtin_ldexpf(1.0f, 2 * j);
+  if (FAST) {
+    /* sin is 2pi-periodic, so safe_sin's "mod 100pi" is the identity up to
+     * rounding: reduce in revolutions and use v_sin_f32 (input in revolutions) */
+    float r = (lm * sc) * INV_2PI_F;
+    if (cos_block) r = r + 0.25f;
+    r = r - floorf(r);
+    float e = __builtin_amdgcn_exp2f((-0.5f * LOG2E_F) * (lv * sc2));
+    return e * __builtin_amdgcn_sinf(r);
+  }
   float x = lm * sc;
   if (cos_block) x = x + HALF_PI_F;
   float e = expf(-0.5f * (lv * sc2));
   return e * sinf(safe_arg(x));
 }
 
-__device__ __forceinline__ float softplus_t(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
-__device__ __forceinline__ float sigmoid_t(float x) { return 1.0f / (1.0f + expf(-x)); }
+/* Transcendentals.  FAST = false: the accurate ocml routines in the reference's
+ * operation order (fp32 parity mode).  FAST = true (bf16 mode, whose MLP inputs
+ * are rounded to 8 bits anyway): hardware v_exp/v_log/v_rcp/v_sin. */
+template <bool FAST> __device__ __forceinline__ float m_exp(float x) {
+  if (FAST) return __builtin_amdgcn_exp2f(x * LOG2E_F);
+  return expf(x);
+}
+template <bool FAST> __device__ __forceinline__ float m_log(float x) {
+  if (FAST) return __builtin_amdgcn_logf(x) * LN2_F;
+  return logf(x);
+}
+template <bool FAST> __device__ __forceinline__ float m_div(float a, float b) {
+  if (FAST) return a * __builtin_amdgcn_rcpf(b);
+  return a / b;
+}
+template <bool FAST> __device__ __forceinline__ float softplus_m(float x) {
+  if (FAST) return x > 20.0f ? x : m_log<true>(1.0f + m_exp<true>(x));
+  return x > 20.0f ? x : log1pf(expf(x));
+}
+template <bool FAST> __device__ __forceinline__ float sigmoid_m(float x) { return m_div<FAST>(1.0f, 1.0f + m_exp<FAST>(-x)); }
+__device__ __forceinline__ float softplus_t(float x) { return softplus_m<false>(x); }
+__device__ __forceinline__ float sigmoid_t(float x) { return sigmoid_m<false>(x); }
 
 /* image.py:51-59 */
+template <bool FAST = false>
 __device__ __forceinline__ float linear_to_srgb(float x) {
   float srgb0 = (float)(323.0 / 25.0) * x;
-  float srgb1 = (211.0f * powf(fmaxf(EPS32, x), (float)(5.0 / 12.0)) - 11.0f) / 200.0f;
+  float pw = FAST ? __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(fmaxf(EPS32, x)) * (float)(5.0 / 12.0))
+                  : powf(fmaxf(EPS32, x), (float)(5.0 / 12.0));
+  float srgb1 = FAST ? (211.0f * pw - 11.0f) * (1.0f / 200.0f) : (211.0f * pw - 11.0f) / 200.0f;
   return (x <= 0.0031308f) ? srgb0 : srgb1;
 }
 
@@ -110,10 +146,10 @@ __device__ __forceinline__ float linear_to_srgb(float x) {
  * Legendre recurrence (same polynomials as the reference's Vandermonde form;
  * SURVEY.md H2).  part = 0: real parts (out[0..35]), 1: imaginary parts.
  * `emit(q, value)` receives term index q in the reference's (l,m) order. */
-template <typename Emit>
+template <bool FAST = false, typename Emit>
 __device__ __forceinline__ void ide_eval(float x, float y, float z, float kappa_inv, int part, Emit emit) {
-  float att1 = expf(-1.0f * kappa_inv), att2 = expf(-3.0f * kappa_inv), att4 = expf(-10.0f * kappa_inv);
-  float att8 = expf(-36.0f * kappa_inv), att16 = expf(-136.0f * kappa_inv);
+  float att1 = m_exp<FAST>(-1.0f * kappa_inv), att2 = m_exp<FAST>(-3.0f * kappa_inv), att4 = m_exp<FAST>(-10.0f * kappa_inv);
+  float att8 = m_exp<FAST>(-36.0f * kappa_inv), att16 = m_exp<FAST>(-136.0f * kappa_inv);
   float pr = 1.0f, pi = 0.0f;
 #pragma unroll 1
   for (int m = 0; m <= 16; ++m) {

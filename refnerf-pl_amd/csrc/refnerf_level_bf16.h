@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void level_fwd_bf16(const LevelArgs A)
         raw_dif[i] = HD[(5 + i) * BT + col];
         raw_tint[i] = HD[(8 + i) * BT + col];
       }
-      sample_heads(cfg, HD[0 * BT + col], gp, HD[4 * BT + col], raw_dif, raw_tint, v, sh);
+      sample_heads<true>(cfg, HD[0 * BT + col], gp, HD[4 * BT + col], raw_dif, raw_tint, v, sh);
     };
 
 #pragma unroll 1
@@ -253,13 +253,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void level_fwd_bf16(const LevelArgs A)
 #pragma unroll
           for (int b = 0; b < 3; ++b) {
             const int kp = 6 * j + 3 * h + b;
-            st_bf16(xs + (kp >> 3) * BT * 16 + (kp & 7) * 2, ipe_feature(lm[b], lv[b], j, h));
+            st_bf16(xs + (kp >> 3) * BT * 16 + (kp & 7) * 2, ipe_feature<true>(lm[b], lv[b], j, h));
           }
       } else {
         /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
         SampleHeads sh;
         load_heads(sh);
-        ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) {
+        ide_eval<true>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) {
           int kq = h * IDE_TERMS + q;
           st_bf16(xs + (kq >> 3) * BT * 16 + (kq & 7) * 2, val);
         });
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void level_fwd_bf16(const LevelArgs A)
         if (valid && h == 0) {                                                            /* P6 */
           SampleHeads sh;
           load_heads(sh);
-          colour_store(A, sh, raw_rgb, PS, n_tot, g, (size_t)ray * N + si);
+          colour_store<true>(A, sh, raw_rgb, PS, n_tot, g, (size_t)ray * N + si);
         }
       }
     }

@@ -160,17 +160,18 @@ struct SampleHeads {
   float density, rough, dot;
   float tint[3], raw_dif[3], npred[3], gp[3], refd[3];
 };
+template <bool FAST = false>
 __device__ __forceinline__ void sample_heads(const refnerf_level_cfg &cfg, float raw_density, const float gp[3],
                                              float raw_rough, const float raw_dif[3], const float raw_tint[3],
                                              const float v[3], SampleHeads &s) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { s.gp[i] = gp[i]; s.raw_dif[i] = raw_dif[i]; s.tint[i] = sigmoid_t(raw_tint[i]); }
+  for (int i = 0; i < 3; ++i) { s.gp[i] = gp[i]; s.raw_dif[i] = raw_dif[i]; s.tint[i] = sigmoid_m<FAST>(raw_tint[i]); }
   float n2 = fmaxf((gp[0] * gp[0] + gp[1] * gp[1]) + gp[2] * gp[2], EPS32);
   float nrm = sqrtf(n2);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) s.npred[i] = -(gp[i] / nrm);
-  s.density = softplus_t(raw_density + cfg.density_bias);
-  s.rough = softplus_t(raw_rough + cfg.roughness_bias);
+  for (int i = 0; i < 3; ++i) s.npred[i] = -m_div<FAST>(gp[i], nrm);
+  s.density = softplus_m<FAST>(raw_density + cfg.density_bias);
+  s.rough = softplus_m<FAST>(raw_rough + cfg.roughness_bias);
   float w3[3] = {-v[0], -v[1], -v[2]};
   float dot = (s.npred[0] * w3[0] + s.npred[1] * w3[1]) + s.npred[2] * w3[2];
 #pragma unroll
@@ -180,14 +181,15 @@ __device__ __forceinline__ void sample_heads(const refnerf_level_cfg &cfg, float
 
 /* P6 (models.py:699-729): colour head; keeps what compositing needs in LDS
  * PS[c][g] and stores the per-sample history. */
+template <bool FAST = false>
 __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHeads &s, const float raw_rgb[3],
                                              float *PS, int n_tot, int g, size_t gi) {
   const refnerf_level_cfg &cfg = A.cfg;
   float spec_lin[3], dif_lin[3], rgb[3], dif[3], spc[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    float sg = sigmoid_t(cfg.rgb_premultiplier * raw_rgb[i] + cfg.rgb_bias);
-    dif_lin[i] = sigmoid_t(s.raw_dif[i] - LOG3_F);
+    float sg = sigmoid_m<FAST>(cfg.rgb_premultiplier * raw_rgb[i] + cfg.rgb_bias);
+    dif_lin[i] = sigmoid_m<FAST>(s.raw_dif[i] - LOG3_F);
     spec_lin[i] = s.tint[i] * sg;
     rgb[i] = spec_lin[i] + dif_lin[i];
   }
@@ -195,13 +197,13 @@ __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHea
     if (cfg.srgb_mapping_normalization) {
       float norm = fmaxf(fmaxf(fmaxf(rgb[0], rgb[1]), rgb[2]), 1.0f);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] / norm;
+      for (int i = 0; i < 3; ++i) rgb[i] = m_div<FAST>(rgb[i], norm);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      rgb[i] = clip01(linear_to_srgb(rgb[i]));
-      dif[i] = clip01(linear_to_srgb(dif_lin[i]));
-      spc[i] = clip01(linear_to_srgb(spec_lin[i]));
+      rgb[i] = clip01(linear_to_srgb<FAST>(rgb[i]));
+      dif[i] = clip01(linear_to_srgb<FAST>(dif_lin[i]));
+      spc[i] = clip01(linear_to_srgb<FAST>(spec_lin[i]));
     }
   } else {
 #pragma unroll
