@@ -310,14 +310,15 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
   if (rc) return rc;
   const int N = cfg->n_samples;
   const bool bf = cfg->precision == REFNERF_PREC_BF16;
-  const int rpw = rays_per_wg(N, rn::T_TILE);
+  const int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
   if (rpw * N > 640) return fail(REFNERF_EINVAL, "n_samples too large for the LDS budget (rays_per_wg*N must be <= 640)%s");
   const size_t per_ray = sizeof(float) * (size_t)(2 * rpw * (N + 1) + rn::NPS * rpw * N + 8);
   size_t lds;
   if (bf) lds = (size_t)rn::BF_RING_BYTES + rn::BF_X_BYTES + sizeof(float) * rn::HD_ROWS * rn::BT + per_ray;
   else lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE) + per_ray;
   {
-    const int nw = rpw < 4 ? rpw : 4;
+    const int nwmax = bf ? rn::BF_NW : 4;
+    const int nw = rpw < nwmax ? rpw : nwmax;
     const size_t scratch = sizeof(float) * (size_t)nw * (3 * (cfg->n_in + 4) + N + 3);
     if (scratch > (bf ? (size_t)rn::BF_X_BYTES : sizeof(float) * rn::DIR_PAD * rn::T_TILE))
       return fail(REFNERF_EINVAL, "n_in / n_samples too large for the resampler scratch of this precision mode%s");
@@ -350,7 +351,7 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
     }
     HIP_TRY(hipEventRecord(g_events[g_events_used].first, st));
   }
-  if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
+  if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else hipLaunchKernelGGL(rn::level_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());
   if (timed) {

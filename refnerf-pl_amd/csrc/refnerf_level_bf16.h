@@ -2,10 +2,12 @@
  * refnerf_level_bf16.h -- bf16-MFMA level kernel (v_mfma_f32_32x32x16_bf16,
  * fp32 accumulate).
  *
- * workgroup = 4 waves x 32 samples (128 samples per pass), <= 256 registers per
- * lane and ~75 KB LDS so that TWO workgroups share a CU (2 waves/SIMD): while
- * one workgroup sits in a barrier / LDS-latency bubble or repacks its
- * accumulators on the VALU, the other one feeds the matrix pipe.
+ * workgroup = 8 waves x 32 samples = 256 samples per pass, ONE workgroup per CU,
+ * two waves per SIMD, <= 256 registers per lane (everything in arch VGPRs: hipcc
+ * copies MFMA A/B operands out of AGPRs instead of using them in place, which
+ * sank a 64-samples/wave variant).  256 samples per weight byte keep the
+ * weight stream at ~17 B/clk/CU at full MFMA rate (128 samples x 2 workgroups
+ * per CU measured LDS-DMA-bound at 40 % MFMA busy).
  * Per layer a wave computes D[256 out][32 samples] = W x X, A = W fragments,
  * B = activations:
  *   * activations stay in REGISTERS as packed bf16 B fragments (R0/R1 ping-pong,
@@ -13,9 +15,12 @@
  *     layout the next layer's B layout (k permutation folded into the weight
  *     image at pack time);
  *   * weights stream HBM/L2 -> LDS once per workgroup by LDS-DMA
- *     (global_load_lds_dwordx4) in uniform 17 KB chunks, double-buffered, one
- *     __syncthreads per chunk; all four waves read the same fragments
- *     (ds_read_b128, conflict-free lane-linear image, 4-step register ring);
+ *     (global_load_lds_dwordx4) in uniform 17 KB chunks through a 3-slot ring;
+ *     ONE barrier per chunk, placed MID-chunk: it certifies chunk c+1 (DMA'd a
+ *     whole chunk-time earlier) and frees the slot of chunk c-1 for the DMA of
+ *     c+2, so the A-fragment ring (ds_read_b128, 4 steps ahead) runs straight
+ *     across chunk/slice/layer boundaries; while one wave of a SIMD repacks
+ *     its accumulators the other one feeds the matrix pipe;
  *   * encodings (IPE, IDE) are staged in LDS as bf16 [k/8][sample][8] so a B
  *     fragment is one ds_read_b128; the bottleneck stays in registers across
  *     the directional MLP (used by its layers 0 and 5).
@@ -33,9 +38,11 @@ typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef unsigned v4uu __attribute__((ext_vector_type(4)));
 typedef short v2s __attribute__((ext_vector_type(2)));
 
-constexpr int BT = 128;                               /* samples per pass: 4 waves x 32 */
-constexpr int BF_RING_BYTES = 2 * BF_CHUNK_BYTES;     /* 34 KB */
-constexpr int BF_X_BYTES = (IPE_DIM / 8) * BT * 16;   /* 12 k-groups x 128 x 16 B = 24 KB */
+constexpr int BT = 256;                               /* samples per pass: 8 waves x 32 */
+constexpr int BF_NW = 8;                              /* waves per workgroup */
+constexpr int BF_NTHREADS = 64 * BF_NW;
+constexpr int BF_RING_BYTES = 3 * BF_CHUNK_BYTES;     /* 51 KB */
+constexpr int BF_X_BYTES = (IPE_DIM / 8) * BT * 16;   /* 12 k-groups x 256 x 16 B = 48 KB */
 constexpr int AF = 4;                                 /* A-fragment ring depth (k-steps ahead) */
 
 typedef __attribute__((address_space(1))) const void *gptr_t;
@@ -43,23 +50,23 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 
 struct Pipe {
   const char *img;   /* packed bf16 image (global) */
-  char *wbuf;        /* LDS ring base (2 slots) */
+  char *wbuf;        /* LDS ring base (3 slots) */
   const char *xp;    /* LDS encodings, pre-offset to this lane's B fragment (sample n, half h) */
-  int cur;           /* slot holding the chunk about to be consumed */
+  int cur_off, nxt_off, fil_off;   /* ring slots: being consumed / landed next / free */
   int dma_chunk;     /* next chunk (index in the image) to DMA */
   int dma_left;      /* chunks still to be DMA'd by this workgroup */
   int lane, wave, h;
 };
 
-/* LDS-DMA of one 17 KB chunk into ring slot `slot`: 17 pieces of 1 KB, waves
- * take pieces round-robin (lane-linear 16 B per lane). */
-__device__ __forceinline__ void issue_chunk(Pipe &p, int slot) {
+/* LDS-DMA of one 17 KB chunk into the ring slot at `slot_off`: 17 pieces of
+ * 1 KB, the 8 waves take pieces round-robin (lane-linear 16 B per lane). */
+__device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off) {
   if (p.dma_left <= 0) return;
-  char *dst = p.wbuf + slot * BF_CHUNK_BYTES;
+  char *dst = p.wbuf + slot_off;
   const char *src = p.img + (size_t)p.dma_chunk * BF_CHUNK_BYTES + p.lane * 16;
 #pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    int piece = p.wave + 4 * q;
+  for (int q = 0; q < 3; ++q) {
+    int piece = p.wave + BF_NW * q;
     if (piece < BF_CHUNK_KB)
       __builtin_amdgcn_global_load_lds((gptr_t)(src + piece * 1024), (lptr_t)(dst + piece * 1024), 16, 0, 0);
   }
@@ -118,19 +125,16 @@ __device__ __forceinline__ v8bf lds_b(const Pipe &p, int kl) {
 
 /* One chunk.  KIND: BF_REG (16 steps over `in`), BF_LDS8 (8 steps over LDS,
  * REAL_L real), BF_BNLDS (8 over `bn` + 8 over LDS, REAL_L real).
- * FIRST: the chunk opens a slice (accumulator starts from the bias piece). */
+ * FIRST: the chunk opens a slice (accumulator starts from the bias piece).
+ * `a` is the A-fragment ring; on entry it holds fragments 0..AF-1 of this chunk,
+ * on exit those of the next one. */
 template <int KIND, int REAL_L, bool FIRST>
-__device__ __forceinline__ void bf_chunk(Pipe &p, const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
+__device__ __forceinline__ void bf_chunk(Pipe &p, v8bf (&a)[AF], const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
   constexpr int KS = (KIND == BF_LDS8) ? 8 : 16;
   constexpr int L0 = (KIND == BF_BNLDS) ? 8 : 0;      /* first LDS step (for the LDS kinds) */
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* my DMA pieces of this chunk */
-  __syncthreads();   /* the chunk has landed for every wave; the other slot is free */
-  issue_chunk(p, p.cur ^ 1);
-  const char *w = p.wbuf + p.cur * BF_CHUNK_BYTES;
-  const char *wf = w + 1024 + p.lane * 16;
-  v8bf a[AF];
-#pragma unroll
-  for (int d = 0; d < AF; ++d) a[d] = lds_frag(wf + d * 1024);
+  const char *w = p.wbuf + p.cur_off;
+  const char *cur = w + 1024 + p.lane * 16;
+  const char *nxt = p.wbuf + p.nxt_off + 1024 + p.lane * 16;
   v8bf xr[2];
   if (KIND == BF_LDS8) { xr[0] = lds_b<REAL_L>(p, 0); xr[1] = lds_b<REAL_L>(p, 1); }
   if (FIRST) acc = bias16(w, p.h);
@@ -143,35 +147,45 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, const v4uu (&in)[16], const v4
     else if (KIND == BF_REG) b = __builtin_bit_cast(v8bf, in[k]);
     else b = __builtin_bit_cast(v8bf, bn[k & 7]);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k % AF], b, acc, 0, 0, 0);
-    if (k + AF < KS) a[k % AF] = lds_frag(wf + (k + AF) * 1024);
+    /* A ring: fragment k+AF of this chunk, or the head of the next chunk (landed: k >= KS/2) */
+    a[k % AF] = (k + AF < KS) ? lds_frag(cur + (k + AF) * 1024) : lds_frag(nxt + (k + AF - KS) * 1024);
     if (KIND != BF_REG) {
       const int kl2 = k + 2 - L0;                       /* LDS step to fetch now */
       if (kl2 >= 0 && kl2 < 8 && !(KIND == BF_LDS8 && kl2 < 2)) xr[kl2 & 1] = lds_b<REAL_L>(p, kl2);
     }
+    if (k == KS / 2 - 1) {
+      /* mid-chunk rendezvous: chunk c+1 is complete for every wave, chunk c-1's slot is free */
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      issue_chunk(p, p.fil_off);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
-  p.cur ^= 1;
+  const int t = p.cur_off;
+  p.cur_off = p.nxt_off;
+  p.nxt_off = p.fil_off;
+  p.fil_off = t;
 }
 
 /* One slice (32 output rows): first chunk of kind KIND0 plus, for the skip
  * layers, a run-time selected second chunk (1: IPE from LDS, 2: bottleneck +
  * dir encodings). */
 template <int KIND0, int REAL0>
-__device__ __forceinline__ void bf_slice(Pipe &p, int second, const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
-  bf_chunk<KIND0, REAL0, true>(p, in, bn, acc);
+__device__ __forceinline__ void bf_slice(Pipe &p, v8bf (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
+  bf_chunk<KIND0, REAL0, true>(p, a, in, bn, acc);
   if constexpr (KIND0 == BF_REG) {
-    if (second == 1) bf_chunk<BF_LDS8, BF_IPE_REAL_KS, false>(p, in, bn, acc);
-    else if (second == 2) bf_chunk<BF_BNLDS, BF_DIR_REAL_KS, false>(p, in, bn, acc);
+    if (second == 1) bf_chunk<BF_LDS8, BF_IPE_REAL_KS, false>(p, a, in, bn, acc);
+    else if (second == 2) bf_chunk<BF_BNLDS, BF_DIR_REAL_KS, false>(p, a, in, bn, acc);
   }
 }
 
 /* One 256-wide layer: 8 slices, ReLU, repack as next-layer B fragments. */
 template <int KIND0, int REAL0>
-__device__ __forceinline__ void bf_layer(Pipe &p, int second, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16]) {
+__device__ __forceinline__ void bf_layer(Pipe &p, v8bf (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16]) {
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) {
     v16f acc;
-    bf_slice<KIND0, REAL0>(p, second, in, bn, acc);
+    bf_slice<KIND0, REAL0>(p, a, second, in, bn, acc);
     pack_acc<true>(acc, out[2 * ob], out[2 * ob + 1]);
     __builtin_amdgcn_sched_barrier(0);     /* pack now: do not keep the fp32 tile alive */
   }
@@ -179,7 +193,7 @@ __device__ __forceinline__ void bf_layer(Pipe &p, int second, const v4uu (&in)[1
 
 __device__ __forceinline__ void st_bf16(char *q, float v) { *reinterpret_cast<__bf16 *>(q) = (__bf16)v; }
 
-__global__ __launch_bounds__(NTHREADS, 2) void level_fwd_bf16(const LevelArgs A) {
+__global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples;
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void level_fwd_bf16(const LevelArgs A)
   const int n_tot = rpw * N;
   const int n_pass = (n_tot + BT - 1) / BT;
 
-  char *WB = reinterpret_cast<char *>(smem);                 /* 2 x 17 KB chunk ring     */
+  char *WB = reinterpret_cast<char *>(smem);                 /* 3 x 17 KB chunk ring     */
   char *Xb = WB + BF_RING_BYTES;                             /* BF_X_BYTES: encodings    */
   float *HD = reinterpret_cast<float *>(Xb + BF_X_BYTES);    /* [HD_ROWS][BT]            */
   float *TD = HD + HD_ROWS * BT;                             /* [rpw][N+1]               */
@@ -204,16 +218,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void level_fwd_bf16(const LevelArgs A)
   p.img = reinterpret_cast<const char *>(A.packed);
   p.wbuf = WB;
   p.xp = Xb + (h * BT + col) * 16;
-  p.cur = 0;
+  p.cur_off = 0; p.nxt_off = BF_CHUNK_BYTES; p.fil_off = 2 * BF_CHUNK_BYTES;
   p.dma_chunk = 0;
   p.dma_left = n_pass * BFPACKED.chunks_per_pass;
   p.lane = lane; p.wave = wave; p.h = h;
-  issue_chunk(p, 0);                                         /* overlaps with the resampler */
+  issue_chunk(p, p.cur_off);                                 /* overlaps with the resampler */
+  issue_chunk(p, p.nxt_off);
 
-  resample_phase(A, reinterpret_cast<float *>(Xb), TD, ray0, wave, lane);   /* P0 */
-  __syncthreads();
+  resample_phase<BF_NW>(A, reinterpret_cast<float *>(Xb), TD, ray0, wave, lane);   /* P0 */
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                           /* chunks 0 and 1 have landed */
 
   v4uu R0[16], R1[16], bn[8];
+  v8bf ar[AF];
+#pragma unroll
+  for (int d = 0; d < AF; ++d) ar[d] = lds_frag(WB + 1024 + lane * 16 + d * 1024);
 
   for (int pass0 = 0; pass0 < n_tot; pass0 += BT) {
     const int g = pass0 + col;
@@ -274,21 +293,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void level_fwd_bf16(const LevelArgs A)
       wave_sync();
 
       /* layer 0 of the trunk: inputs from LDS (+ bottleneck registers for the dir MLP) -> R0 */
-      if (phase == 0) bf_layer<BF_LDS8, BF_IPE_REAL_KS>(p, 0, R0, bn, R0);
-      else bf_layer<BF_BNLDS, BF_DIR_REAL_KS>(p, 0, R0, bn, R0);
+      if (phase == 0) bf_layer<BF_LDS8, BF_IPE_REAL_KS>(p, ar, 0, R0, bn, R0);
+      else bf_layer<BF_BNLDS, BF_DIR_REAL_KS>(p, ar, 0, R0, bn, R0);
       /* layers 1..7: A (R0->R1), B (R1->R0); the third A carries the skip input */
 #pragma unroll 1
       for (int it = 0; it < 4; ++it) {
         const int second = (it == 2) ? (phase ? 2 : 1) : 0;
-        bf_layer<BF_REG, 0>(p, second, R0, bn, R1);
-        if (it < 3) bf_layer<BF_REG, 0>(p, 0, R1, bn, R0);
+        bf_layer<BF_REG, 0>(p, ar, second, R0, bn, R1);
+        if (it < 3) bf_layer<BF_REG, 0>(p, ar, 0, R1, bn, R0);
       }
       if (phase == 0) {
         /* P3: heads: 4 bottleneck blocks stay in registers, the scalar block goes to LDS HD */
 #pragma unroll
         for (int ob = 0; ob < 5; ++ob) {
           v16f acc;
-          bf_slice<BF_REG, 0>(p, 0, R1, bn, acc);
+          bf_slice<BF_REG, 0>(p, ar, 0, R1, bn, acc);
           if (ob < 4) pack_acc<false>(acc, bn[2 * ob], bn[2 * ob + 1]);
           else {
 #pragma unroll
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void level_fwd_bf16(const LevelArgs A)
       } else {
         /* rgb: one slice */
         v16f acc;
-        bf_slice<BF_REG, 0>(p, 0, R1, bn, acc);
+        bf_slice<BF_REG, 0>(p, ar, 0, R1, bn, acc);
         float raw_rgb[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n, 64);
@@ -318,7 +337,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void level_fwd_bf16(const LevelArgs A)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  composite_phase(A, TD, XP, PS, n_tot, ray0, wave, lane);   /* P7 */
+  composite_phase<BF_NW>(A, TD, XP, PS, n_tot, ray0, wave, lane);   /* P7 */
 }
 
 /* ---------------- bf16 weight image ---------------- */

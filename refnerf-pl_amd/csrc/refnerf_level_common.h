@@ -126,13 +126,14 @@ __device__ __forceinline__ void st3(float *base, size_t idx, float a, float b, f
 /* P0 (models.py:200-218): resample every ray of the workgroup, one wave per
  * ray; writes metric distances tdist to TD[rl][N+1] (LDS) and sdist / bin
  * indices to HBM.  `scratch` needs min(rpw,4) * (3*(M+4) + N+3) floats. */
+template <int NW = 4>
 __device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratch, float *TD, int ray0, int wave, int lane) {
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples, M = cfg.n_in, rpw = A.rpw;
   const int Mp = (M + 4) & ~3, Np = (N + 3) & ~3;      /* per-wave scratch: 3*Mp + Np floats */
   float *scr = scratch + wave * (3 * Mp + Np);
   float *t_in = scr, *lg = scr + Mp, *cw = scr + 2 * Mp, *c = scr + 3 * Mp;
-  for (int rl = wave; rl < rpw; rl += 4) {
+  for (int rl = wave; rl < rpw; rl += NW) {
     int ray = ray0 + rl;
     if (ray >= A.R) break;
     const float *tg = A.sdist_in + (size_t)ray * (M + 1);
@@ -234,11 +235,12 @@ __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHea
 }
 
 /* P7: alpha weights + compositing, one wave per ray (render.py:132-149, 152-254). */
+template <int NW = 4>
 __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float *TD, float *XP, float *PS, int n_tot,
                                                 int ray0, int wave, int lane) {
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples, rpw = A.rpw;
-  for (int rl = wave; rl < rpw; rl += 4) {
+  for (int rl = wave; rl < rpw; rl += NW) {
     const int ray = ray0 + rl;
     if (ray >= A.R) break;
     const float *td = TD + rl * (N + 1);
