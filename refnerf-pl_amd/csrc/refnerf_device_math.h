@@ -11,6 +11,7 @@
 
 #include "refnerf_detmath.h"
 #include "refnerf_layout.h"
+#include "refnerf_ide_tables.h"
 
 namespace rn {
 
@@ -22,10 +23,6 @@ constexpr float LOG2E_F = 1.44269504088896341f;
 constexpr float LN2_F = 0.69314718055994531f;
 constexpr float INV_2PI_F = 0.15915494309189535f;
 
-/* IDE recurrence tables (see oracle rn_ide_stable_f32): c[17], a[17*17], b[17*17] */
-__constant__ float g_ide_c[17];
-__constant__ float g_ide_a[17 * 17];
-__constant__ float g_ide_b[17 * 17];
 
 __device__ __forceinline__ float clip01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
@@ -151,27 +148,21 @@ __device__ __forceinline__ void ide_eval(float x, float y, float z, float kappa_
   float att1 = m_exp<FAST>(-1.0f * kappa_inv), att2 = m_exp<FAST>(-3.0f * kappa_inv), att4 = m_exp<FAST>(-10.0f * kappa_inv);
   float att8 = m_exp<FAST>(-36.0f * kappa_inv), att16 = m_exp<FAST>(-136.0f * kappa_inv);
   float pr = 1.0f, pi = 0.0f;
-#pragma unroll 1
+#pragma unroll
   for (int m = 0; m <= 16; ++m) {
     if (m > 0) { float nr = pr * x - pi * y; float ni = pr * y + pi * x; pr = nr; pi = ni; }
     const float pw = part ? pi : pr;
-    const float cm = g_ide_c[m];
-    float tm2 = 0.0f, tm1 = cm;
-    /* l == m term */
-    if (m == 1) emit(0 + m, pw * (cm * att1));
-    if (m == 2) emit(2 + m, pw * (cm * att2));
-    if (m == 4) emit(5 + m, pw * (cm * att4));
-    if (m == 8) emit(10 + m, pw * (cm * att8));
-    if (m == 16) emit(19 + m, pw * (cm * att16));
-#pragma unroll 1
-    for (int l = m + 1; l <= 16; ++l) {
-      float tl = g_ide_a[m * 17 + l] * (z * tm1 - g_ide_b[m * 17 + l] * tm2);
-      tm2 = tm1; tm1 = tl;
-      if ((l & (l - 1)) == 0) {                 /* l in {1,2,4,8,16} */
-        float att = (l == 1) ? att1 : (l == 2) ? att2 : (l == 4) ? att4 : (l == 8) ? att8 : att16;
-        int base = (l == 1) ? 0 : (l == 2) ? 2 : (l == 4) ? 5 : (l == 8) ? 10 : 19;
-        emit(base + m, pw * (tl * att));
-      }
+    float tm2 = 0.0f, tm1 = IDE_C[m];
+#pragma unroll
+    for (int l = m; l <= 16; ++l) {
+      float tl;
+      if (l == m) tl = IDE_C[m];
+      else { tl = IDE_A[m][l] * (z * tm1 - IDE_B[m][l] * tm2); tm2 = tm1; tm1 = tl; }
+      if (l == 1) emit(0 + m, pw * (tl * att1));
+      if (l == 2) emit(2 + m, pw * (tl * att2));
+      if (l == 4) emit(5 + m, pw * (tl * att4));
+      if (l == 8) emit(10 + m, pw * (tl * att8));
+      if (l == 16) emit(19 + m, pw * (tl * att16));
     }
   }
 }

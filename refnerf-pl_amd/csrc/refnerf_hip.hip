@@ -199,40 +199,14 @@ int fail(int code, const char *fmt, const char *detail = "") {
     if (e_ != hipSuccess) return fail(REFNERF_EHIP, #expr ": %s", hipGetErrorString(e_)); \
   } while (0)
 
-std::once_flag g_tab_once;
-int g_tab_status = 0;
+int ensure_tables() { return 0; }   /* IDE tables are compile-time literals now */
+
 /* kernel timing: event pairs recorded on the launch stream, resolved lazily in
  * refnerf_get_timing() so the timed region is not serialised by event syncs */
 bool g_timing = false;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
 size_t g_events_used = 0;
 
-double fact(int n) { double r = 1; for (int i = 2; i <= n; ++i) r *= i; return r; }
-
-void upload_tables() {
-  float c[17], a[17 * 17], b[17 * 17];
-  for (int m = 0; m <= 16; ++m) {
-    double df = 1;
-    for (int i = 1; i <= m; ++i) df *= (2 * i - 1);
-    double cm = ((m & 1) ? -1.0 : 1.0) * std::sqrt((2.0 * m + 1.0) / (4.0 * M_PI * fact(2 * m))) * df;
-    c[m] = (float)cm;
-    for (int l = 0; l <= 16; ++l) {
-      a[m * 17 + l] = 0; b[m * 17 + l] = 0;
-      if (l > m) {
-        a[m * 17 + l] = (float)std::sqrt((4.0 * l * l - 1.0) / ((double)l * l - (double)m * m));
-        if (l > m + 1) b[m * 17 + l] = (float)std::sqrt((((double)l - 1) * (l - 1) - (double)m * m) / (4.0 * (l - 1.0) * (l - 1.0) - 1.0));
-      }
-    }
-  }
-  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(rn::g_ide_c), c, sizeof(c));
-  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(rn::g_ide_a), a, sizeof(a));
-  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(rn::g_ide_b), b, sizeof(b));
-  g_tab_status = (e == hipSuccess) ? 0 : REFNERF_EHIP;
-}
-int ensure_tables() {
-  std::call_once(g_tab_once, upload_tables);
-  return g_tab_status ? fail(REFNERF_EHIP, "uploading IDE tables failed%s") : 0;
-}
 }  // namespace
 
 extern "C" {
@@ -339,6 +313,12 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
   a.sdist_in = d_sdist_in;
   a.weights_in = d_weights_in;
   a.out = *out;
+  a.prof = nullptr;
+  if (getenv("REFNERF_PROF")) {
+    static long long *d_prof = nullptr;
+    if (!d_prof) { HIP_TRY(hipMalloc(&d_prof, 8 * 32 * sizeof(long long))); }
+    a.prof = d_prof;
+  }
   int grid = (R + rpw - 1) / rpw;
   hipStream_t st = (hipStream_t)stream;
   const bool timed = g_timing && g_events_used < 65536;
@@ -357,6 +337,16 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
   if (timed) {
     HIP_TRY(hipEventRecord(g_events[g_events_used].second, st));
     g_events_used += 1;
+  }
+  if (a.prof) {   /* debug aid (REFNERF_PROF=1): per-phase cycle stamps of workgroup 0 */
+    long long hbuf[8 * 32];
+    HIP_TRY(hipMemcpy(hbuf, a.prof, sizeof(hbuf), hipMemcpyDeviceToHost));
+    const int nw = bf ? 8 : 4;
+    for (int w = 0; w < nw; ++w) {
+      fprintf(stderr, "[prof] wave %d:", w);
+      for (int sl = 1; sl <= 16; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
+      fprintf(stderr, "\n");
+    }
   }
   return REFNERF_OK;
 }

@@ -222,12 +222,15 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   p.dma_chunk = 0;
   p.dma_left = n_pass * BFPACKED.chunks_per_pass;
   p.lane = lane; p.wave = wave; p.h = h;
+  RN_STAMP(A, 0);
   issue_chunk(p, p.cur_off);                                 /* overlaps with the resampler */
   issue_chunk(p, p.nxt_off);
 
   resample_phase<BF_NW>(A, reinterpret_cast<float *>(Xb), TD, ray0, wave, lane);   /* P0 */
+  RN_STAMP(A, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                           /* chunks 0 and 1 have landed */
+  RN_STAMP(A, 2);
 
   v4uu R0[16], R1[16], bn[8];
   v8bf ar[AF];
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
     for (int phase = 0; phase < 2; ++phase) {
       char *xs = Xb + col * 16;
       if (phase == 0) {
-        /* P1: conical frustum -> lifted Gaussian -> IPE, k' = 6j + 3c + b; half h computes block c = h */
+        /* P1: conical frustum -> lifted Gaussian -> IPE (half h computes block h: sin / cos) */
         float o[3], d[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { o[i] = A.rays.d_origins[(size_t)rayc * 3 + i]; d[i] = A.rays.d_directions[(size_t)rayc * 3 + i]; }
@@ -267,13 +270,17 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
         float lm[3], lv[3];
         cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
-#pragma unroll 1
-        for (int j = 0; j < 16; ++j)
+        /* k' = canonical IPE index: half h owns block h (sin / cos) = k' 48h .. 48h+47 = 6 k-groups */
 #pragma unroll
-          for (int b = 0; b < 3; ++b) {
-            const int kp = 6 * j + 3 * h + b;
-            st_bf16(xs + (kp >> 3) * BT * 16 + (kp & 7) * 2, ipe_feature<true>(lm[b], lv[b], j, h));
+        for (int q = 0; q < 6; ++q) {
+          v8bf pk;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int kk = q * 8 + e;                    /* 3j + b inside the block */
+            pk[e] = (__bf16)ipe_feature<true>(lm[kk % 3], lv[kk % 3], kk / 3, h);
           }
+          *reinterpret_cast<v8bf *>(xs + (6 * h + q) * BT * 16) = pk;
+        }
       } else {
         /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
         SampleHeads sh;
@@ -291,10 +298,12 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         }
       }
       wave_sync();
+      RN_STAMP(A, 3 + phase * 8);
 
       /* layer 0 of the trunk: inputs from LDS (+ bottleneck registers for the dir MLP) -> R0 */
       if (phase == 0) bf_layer<BF_LDS8, BF_IPE_REAL_KS>(p, ar, 0, R0, bn, R0);
       else bf_layer<BF_BNLDS, BF_DIR_REAL_KS>(p, ar, 0, R0, bn, R0);
+      RN_STAMP(A, 4 + phase * 8);
       /* layers 1..7: A (R0->R1), B (R1->R0); the third A carries the skip input */
 #pragma unroll 1
       for (int it = 0; it < 4; ++it) {
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         bf_layer<BF_REG, 0>(p, ar, second, R0, bn, R1);
         if (it < 3) bf_layer<BF_REG, 0>(p, ar, 0, R1, bn, R0);
       }
+      RN_STAMP(A, 5 + phase * 8);
       if (phase == 0) {
         /* P3: heads: 4 bottleneck blocks stay in registers, the scalar block goes to LDS HD */
 #pragma unroll
@@ -318,6 +328,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
           }
         }
         wave_sync();
+        RN_STAMP(A, 6);
       } else {
         /* rgb: one slice */
         v16f acc;
@@ -330,20 +341,20 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
           load_heads(sh);
           colour_store<true>(A, sh, raw_rgb, PS, n_tot, g, (size_t)ray * N + si);
         }
+        RN_STAMP(A, 14);
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  RN_STAMP(A, 15);
 
   composite_phase<BF_NW>(A, TD, XP, PS, n_tot, ray0, wave, lane);   /* P7 */
+  RN_STAMP(A, 16);
 }
 
 /* ---------------- bf16 weight image ---------------- */
-__device__ __forceinline__ int ipe_col_of_kprime(int kp) {        /* k' = 6j + 3c + b */
-  int j = kp / 6, cb = kp % 6;
-  return (cb / 3) * 48 + j * 3 + (cb % 3);
-}
+__device__ __forceinline__ int ipe_col_of_kprime(int kp) { return kp; }   /* LDS order = canonical IPE order */
 
 }  // namespace rn

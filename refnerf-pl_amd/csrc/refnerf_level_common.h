@@ -32,7 +32,10 @@ struct LevelArgs {
   const float *sdist_in;
   const float *weights_in;
   refnerf_level_out out;
+  long long *prof;   /* debug: per-phase cycle stamps of workgroup 0 (REFNERF_PROF=1), else NULL */
 };
+
+#define RN_STAMP(A, slot) do { if ((A).prof && blockIdx.x == 0 && (threadIdx.x & 63) == 0) (A).prof[(threadIdx.x >> 6) * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
