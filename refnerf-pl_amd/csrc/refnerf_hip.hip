@@ -134,8 +134,10 @@ __global__ void pack_weights_bf16(const float *__restrict__ P, char *__restrict_
         if (t < BF_IPE_REAL_KS) v = canon_w(P, op, row, base + ipe_col_of_kprime(kp));
       } else {
         int kp = 16 * (t - 8) + 8 * h + e;
-        if (kp < IDE_DIM) v = canon_w(P, op, row, base + BNECK + kp);
-        else if (kp == IDE_DIM) v = canon_w(P, op, row, base + BNECK + IDE_DIM);
+        /* dir k': [Re x36 | n.v | 0 0 0 | Im x36 | 0 0 0 0] */
+        if (kp < IDE_TERMS) v = canon_w(P, op, row, base + BNECK + kp);
+        else if (kp == IDE_TERMS) v = canon_w(P, op, row, base + BNECK + IDE_DIM);
+        else if (kp >= 40 && kp < 40 + IDE_TERMS) v = canon_w(P, op, row, base + BNECK + IDE_TERMS + (kp - 40));
       }
       reinterpret_cast<__bf16 *>(chunk + 1024)[idx] = (__bf16)v;
     }
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void sample_intervals_kernel(const float *t, c
   for (int i = lane; i <= M; i += 64) t_in[i] = t[(size_t)ray * (M + 1) + i];
   for (int i = lane; i < M; i += 64) lg[i] = logits[(size_t)ray * M + i];
   wave_sync();
-  sample_intervals_wave(t_in, lg, cw, c, M, N, smin, smax, sd, bin_idx ? bin_idx + (size_t)ray * N : nullptr, lane);
+  sample_intervals_wave<true>(t_in, lg, cw, c, M, N, smin, smax, sd, bin_idx ? bin_idx + (size_t)ray * N : nullptr, lane);
   for (int k = lane; k <= N; k += 64) sdist[(size_t)ray * (N + 1) + k] = sd[k];
 }
 

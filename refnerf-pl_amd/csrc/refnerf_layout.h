@@ -108,8 +108,8 @@ constexpr Packed PACKED = make_packed();
  * Fragment piece t: lane l holds 8 bf16 = W[32*ob + (l&31)][kmap(t, l>>5, e)],
  * e = 0..7.  Register steps: kmap = 32*(t>>1) + (r&3) + 8*(r>>2) + 4*h with
  * r = 8*(t&1) + e (the accumulator layout of the producing MFMA); LDS steps:
- * k' = 16*t + 8*h + e with IPE k' = canonical feature index and dir k' = IDE index
- * 0..71, 72 = n.v, rest zero.  Bias piece (first chunk of a slice): fp32
+ * k' = 16*t + 8*h + e with IPE k' = canonical feature index and dir k' =
+ * [Re(IDE) x36 | n.v | 0 0 0 | Im(IDE) x36 | 0 0 0 0].  Bias piece (first chunk of a slice): fp32
  * [h][16] in accumulator layout. */
 constexpr int BF_CHUNK_KB = 17;
 constexpr int BF_CHUNK_BYTES = BF_CHUNK_KB * 1024;

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   issue_chunk(p, p.cur_off);                                 /* overlaps with the resampler */
   issue_chunk(p, p.nxt_off);
 
-  resample_phase<BF_NW>(A, reinterpret_cast<float *>(Xb), TD, ray0, wave, lane);   /* P0 */
+  resample_phase<BF_NW, false>(A, reinterpret_cast<float *>(Xb), TD, ray0, wave, lane);   /* P0 */
   RN_STAMP(A, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                           /* chunks 0 and 1 have landed */
@@ -259,6 +259,14 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
 
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {
+      /* tell the register allocator that the activation registers are dead across the
+       * VALU phases (it cannot see through the rolled phase loop and would spill them) */
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { R0[e] = (v4uu){0, 0, 0, 0}; R1[e] = (v4uu){0, 0, 0, 0}; }
+      if (phase == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bn[e] = (v4uu){0, 0, 0, 0};
+      }
       char *xs = Xb + col * 16;
       if (phase == 0) {
         /* P1: conical frustum -> lifted Gaussian -> IPE (half h computes block h: sin / cos) */
@@ -285,16 +293,18 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
         SampleHeads sh;
         load_heads(sh);
-        ide_eval<true>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) {
-          int kq = h * IDE_TERMS + q;
-          st_bf16(xs + (kq >> 3) * BT * 16 + (kq & 7) * 2, val);
-        });
-        if (h == 0) {
-          v8bf tail;
-          tail[0] = (__bf16)sh.dot;
+        /* dir k' layout: [Re x36 | n.v | 0 0 0 | Im x36 | 0 0 0 0] = 2 x 5 k-groups; half h packs its 5 */
+        float ide[40];
 #pragma unroll
-          for (int e = 1; e < 8; ++e) tail[e] = (__bf16)0.0f;
-          *reinterpret_cast<v8bf *>(xs + 9 * BT * 16) = tail;
+        for (int q = 36; q < 40; ++q) ide[q] = 0.0f;
+        ide_eval<true>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { ide[q] = val; });
+        if (h == 0) ide[36] = sh.dot;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          v8bf pk;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pk[e] = (__bf16)ide[q * 8 + e];
+          *reinterpret_cast<v8bf *>(xs + (5 * h + q) * BT * 16) = pk;
         }
       }
       wave_sync();
@@ -339,8 +349,10 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         if (valid && h == 0) {                                                            /* P6 */
           SampleHeads sh;
           load_heads(sh);
-          colour_store<true>(A, sh, raw_rgb, PS, n_tot, g, (size_t)ray * N + si);
+          colour_store<true>(A, sh, raw_rgb, PS, n_tot, g);
         }
+        wave_sync();
+        history_flush(A, PS, n_tot, pass0 + wave * 32, (size_t)ray0 * N + pass0 + wave * 32, lane);
         RN_STAMP(A, 14);
       }
     }
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   __syncthreads();
   RN_STAMP(A, 15);
 
-  composite_phase<BF_NW>(A, TD, XP, PS, n_tot, ray0, wave, lane);   /* P7 */
+  composite_phase<BF_NW, true>(A, TD, XP, PS, n_tot, ray0, wave, lane);   /* P7 */
   RN_STAMP(A, 16);
 }
 

@@ -19,9 +19,9 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 constexpr int NTHREADS = 256;
 constexpr int HD_ROWS = 12;
-constexpr int NPS = 20;      /* per-sample floats kept in LDS for compositing */
-/* per-sample slots in LDS PS[c][sample] */
-enum { PS_DENSITY = 0, PS_RGB = 1, PS_DIF = 4, PS_SPC = 7, PS_NPRED = 10, PS_TINT = 13, PS_ROUGH = 16, PS_NORMALS = 17 };
+constexpr int NPS = 23;      /* per-sample floats kept in LDS for compositing / the history flush */
+/* per-sample slots in LDS: PS[sample][slot], odd stride NPS = conflict-free per-sample access */
+enum { PS_DENSITY = 0, PS_RGB = 1, PS_DIF = 4, PS_SPC = 7, PS_NPRED = 10, PS_TINT = 13, PS_ROUGH = 16, PS_NORMALS = 17, PS_GP = 20 };
 
 struct LevelArgs {
   const void *packed;
@@ -67,6 +67,7 @@ __device__ __forceinline__ double wave_scan_incl(double v, int lane) {
  * (LDS) and optional bin indices.  Scratch: e[M] (aliases lg), cw[M+1], c[N].
  * The softmax sum and the float64 cumsum run sequentially on lane 0 so that the
  * CDF is bit-identical to the oracle / torch's accumulation order. */
+template <bool EXACT = true>
 __device__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, float *c, int M, int N,
                                       float smin, float smax, float *sd, int32_t *bin_idx_g, int lane) {
   /* softmax: max is order-independent */
@@ -77,18 +78,34 @@ __device__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, f
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
   float sum = 0.0f;
-  if (lane == 0) {
-    for (int i = 0; i < M; ++i) sum += lg[i];
+  if (EXACT) {
+    if (lane == 0) {
+      for (int i = 0; i < M; ++i) sum += lg[i];
+    }
+    sum = __shfl(sum, 0, 64);
+  } else {
+    for (int i = lane; i < M; i += 64) sum += lg[i];
+    sum = wave_sum(sum);
   }
-  sum = __shfl(sum, 0, 64);
   for (int i = lane; i < M; i += 64) lg[i] = lg[i] / sum;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {
-    cw[0] = 0.0f;
-    double acc = 0.0;
-    for (int i = 0; i < M - 1; ++i) { acc += (double)lg[i]; cw[i + 1] = fminf(1.0f, (float)acc); }
-    cw[M] = 1.0f;
+  if (EXACT) {
+    if (lane == 0) {
+      cw[0] = 0.0f;
+      double acc = 0.0;
+      for (int i = 0; i < M - 1; ++i) { acc += (double)lg[i]; cw[i + 1] = fminf(1.0f, (float)acc); }
+      cw[M] = 1.0f;
+    }
+  } else {
+    /* wave-parallel prefix sum (float64 partials, chunk per lane): same CDF up to
+     * the summation order, not bit-identical to the sequential one */
+    const int Cn = (M + 63) / 64, i0 = lane * Cn;
+    double loc = 0.0;
+    for (int q = 0; q < Cn; ++q) if (i0 + q < M - 1) loc += (double)lg[i0 + q];
+    double run = wave_scan_incl(loc, lane) - loc;
+    for (int q = 0; q < Cn; ++q) if (i0 + q < M - 1) { run += (double)lg[i0 + q]; cw[i0 + q + 1] = fminf(1.0f, (float)run); }
+    if (lane == 0) { cw[0] = 0.0f; cw[M] = 1.0f; }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -129,7 +146,7 @@ __device__ __forceinline__ void st3(float *base, size_t idx, float a, float b, f
 /* P0 (models.py:200-218): resample every ray of the workgroup, one wave per
  * ray; writes metric distances tdist to TD[rl][N+1] (LDS) and sdist / bin
  * indices to HBM.  `scratch` needs min(rpw,4) * (3*(M+4) + N+3) floats. */
-template <int NW = 4>
+template <int NW = 4, bool EXACT = true>
 __device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratch, float *TD, int ray0, int wave, int lane) {
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples, M = cfg.n_in, rpw = A.rpw;
@@ -148,7 +165,7 @@ __device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratc
       lg[i] = (t_in[i + 1] > t_in[i]) ? cfg.anneal * logf(wg[i] + cfg.resample_padding) : -INFINITY;
     wave_sync();
     float *sd = TD + rl * (N + 1);
-    sample_intervals_wave(t_in, lg, cw, c, M, N, cfg.s_near, cfg.s_far, sd,
+    sample_intervals_wave<EXACT>(t_in, lg, cw, c, M, N, cfg.s_near, cfg.s_far, sd,
                           A.out.d_bin_idx ? A.out.d_bin_idx + (size_t)ray * N : nullptr, lane);
     float nearv = A.rays.d_near[ray], farv = A.rays.d_far[ray];
     for (int k = lane; k <= N; k += 64) {
@@ -184,10 +201,10 @@ __device__ __forceinline__ void sample_heads(const refnerf_level_cfg &cfg, float
 }
 
 /* P6 (models.py:699-729): colour head; keeps what compositing needs in LDS
- * PS[c][g] and stores the per-sample history. */
+ * PS[c][g] (the history is flushed from there by history_flush). */
 template <bool FAST = false>
 __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHeads &s, const float raw_rgb[3],
-                                             float *PS, int n_tot, int g, size_t gi) {
+                                             float *PS, int n_tot, int g) {
   const refnerf_level_cfg &cfg = A.cfg;
   float spec_lin[3], dif_lin[3], rgb[3], dif[3], spc[3];
 #pragma unroll
@@ -216,29 +233,50 @@ __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHea
   const float pad_scale = (float)(1.0 + 2.0 * (double)cfg.rgb_padding);
 #pragma unroll
   for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] * pad_scale - cfg.rgb_padding;
-  PS[PS_DENSITY * n_tot + g] = s.density;
-  PS[PS_ROUGH * n_tot + g] = s.rough;
+  PS[g * NPS + PS_DENSITY] = s.density;
+  PS[g * NPS + PS_ROUGH] = s.rough;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    PS[(PS_RGB + i) * n_tot + g] = rgb[i];
-    PS[(PS_DIF + i) * n_tot + g] = dif[i];
-    PS[(PS_SPC + i) * n_tot + g] = spc[i];
-    PS[(PS_NPRED + i) * n_tot + g] = s.npred[i];
-    PS[(PS_TINT + i) * n_tot + g] = s.tint[i];
-    PS[(PS_NORMALS + i) * n_tot + g] = 0.0f;
+    PS[g * NPS + PS_RGB + i] = rgb[i];
+    PS[g * NPS + PS_DIF + i] = dif[i];
+    PS[g * NPS + PS_SPC + i] = spc[i];
+    PS[g * NPS + PS_NPRED + i] = s.npred[i];
+    PS[g * NPS + PS_TINT + i] = s.tint[i];
+    PS[g * NPS + PS_NORMALS + i] = 0.0f;
+    PS[g * NPS + PS_GP + i] = s.gp[i];
   }
-  if (A.out.d_density) A.out.d_density[gi] = s.density;
-  if (A.out.d_roughness) A.out.d_roughness[gi] = s.rough;
-  st3(A.out.d_rgb, gi, rgb[0], rgb[1], rgb[2]);
-  st3(A.out.d_diffuse, gi, dif[0], dif[1], dif[2]);
-  st3(A.out.d_specular, gi, spc[0], spc[1], spc[2]);
-  st3(A.out.d_normals_pred, gi, s.npred[0], s.npred[1], s.npred[2]);
-  st3(A.out.d_grad_pred, gi, s.gp[0], s.gp[1], s.gp[2]);
-  st3(A.out.d_tint, gi, s.tint[0], s.tint[1], s.tint[2]);
+}
+
+/* Per-sample history (models.py:731-750) of one wave's 32-sample block, written
+ * from LDS PS with fully coalesced stores: for the [R,N,3] tensors lane L writes
+ * flat element 3*sample + channel = L, L+64.  gw0 = first sample (workgroup
+ * index) of the block, gs0 = its global sample index ray*N + i. */
+__device__ __forceinline__ void history_flush(const LevelArgs &A, const float *PS, int n_tot, int gw0, size_t gs0, int lane) {
+  const size_t total = (size_t)A.R * A.cfg.n_samples;
+  auto vec3 = [&](float *dst, int slot) {
+    if (!dst) return;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int f = lane + 64 * it;
+      const int smp = f / 3, c = f - 3 * smp;
+      if (f < 96 && gw0 + smp < n_tot && gs0 + smp < total) dst[gs0 * 3 + f] = PS[(gw0 + smp) * NPS + slot + c];
+    }
+  };
+  auto scal = [&](float *dst, int slot) {
+    if (dst && lane < 32 && gw0 + lane < n_tot && gs0 + lane < total) dst[gs0 + lane] = PS[(gw0 + lane) * NPS + slot];
+  };
+  scal(A.out.d_density, PS_DENSITY);
+  scal(A.out.d_roughness, PS_ROUGH);
+  vec3(A.out.d_rgb, PS_RGB);
+  vec3(A.out.d_diffuse, PS_DIF);
+  vec3(A.out.d_specular, PS_SPC);
+  vec3(A.out.d_normals_pred, PS_NPRED);
+  vec3(A.out.d_grad_pred, PS_GP);
+  vec3(A.out.d_tint, PS_TINT);
 }
 
 /* P7: alpha weights + compositing, one wave per ray (render.py:132-149, 152-254). */
-template <int NW = 4>
+template <int NW = 4, bool FAST = false>
 __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float *TD, float *XP, float *PS, int n_tot,
                                                 int ray0, int wave, int lane) {
   const refnerf_level_cfg &cfg = A.cfg;
@@ -252,13 +290,13 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
     const int i0 = lane * C;
     float dx = A.rays.d_directions[(size_t)ray * 3], dy = A.rays.d_directions[(size_t)ray * 3 + 1], dz = A.rays.d_directions[(size_t)ray * 3 + 2];
     const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
-    float *wbuf = PS + PS_DENSITY * n_tot + base;  /* density is overwritten by the weights */
+    float *wbuf = PS + base * NPS + PS_DENSITY;    /* density (stride NPS) is overwritten by the weights */
     /* pass 1: local sums of density*delta */
     double local = 0.0;
     for (int q = 0; q < C; ++q) {
       int i = i0 + q;
       if (i < N) {
-        float dd = wbuf[i] * ((td[i + 1] - td[i]) * norm);
+        float dd = wbuf[i * NPS] * ((td[i + 1] - td[i]) * norm);
         if (cfg.opaque_background && i == N - 1) dd = INFINITY;
         local += (double)dd;
       }
@@ -273,28 +311,28 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
     for (int q = 0; q < C; ++q) {
       int i = i0 + q;
       if (i < N) {
-        float dd = wbuf[i] * ((td[i + 1] - td[i]) * norm);
+        float dd = wbuf[i * NPS] * ((td[i + 1] - td[i]) * norm);
         if (cfg.opaque_background && i == N - 1) dd = INFINITY;
-        float alpha = 1.0f - expf(-dd);
-        float trans = expf(-(float)cum);
+        float alpha = 1.0f - m_exp<FAST>(-dd);
+        float trans = m_exp<FAST>(-(float)cum);
         float w = alpha * trans;
         cum += (double)dd;
-        wbuf[i] = w;
+        wbuf[i * NPS] = w;
         wlocal += (double)w;
         if (A.out.d_weights) A.out.d_weights[(size_t)ray * N + i] = w;
         acc += w;
         float tmid = 0.5f * (td[i] + td[i + 1]);
         s_dist += w * tmid;
-        s_logd += w * logf(tmid);
-        s_rgh += w * PS[PS_ROUGH * n_tot + base + i];
+        s_logd += w * m_log<FAST>(tmid);
+        s_rgh += w * PS[(base + i) * NPS + PS_ROUGH];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          s_rgb[c] += w * PS[(PS_RGB + c) * n_tot + base + i];
-          s_dif[c] += w * PS[(PS_DIF + c) * n_tot + base + i];
-          s_spc[c] += w * PS[(PS_SPC + c) * n_tot + base + i];
-          s_np[c] += w * PS[(PS_NPRED + c) * n_tot + base + i];
-          s_tn[c] += w * PS[(PS_TINT + c) * n_tot + base + i];
-          s_nm[c] += w * PS[(PS_NORMALS + c) * n_tot + base + i];
+          s_rgb[c] += w * PS[(base + i) * NPS + PS_RGB + c];
+          s_dif[c] += w * PS[(base + i) * NPS + PS_DIF + c];
+          s_spc[c] += w * PS[(base + i) * NPS + PS_SPC + c];
+          s_np[c] += w * PS[(base + i) * NPS + PS_NPRED + c];
+          s_tn[c] += w * PS[(base + i) * NPS + PS_TINT + c];
+          s_nm[c] += w * PS[(base + i) * NPS + PS_NORMALS + c];
         }
       }
     }
@@ -354,7 +392,7 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
       __builtin_amdgcn_wave_barrier();
       for (int q = 0; q < C; ++q) {
         int i = i0 + q;
-        if (i < N) { run += (double)wbuf[i]; xp[i + 1] = fminf(1.0f, (float)run); }
+        if (i < N) { run += (double)wbuf[i * NPS]; xp[i + 1] = fminf(1.0f, (float)run); }
       }
       if (lane == 0) { xp[0] = 0.0f; }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

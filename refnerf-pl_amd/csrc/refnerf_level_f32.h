@@ -219,7 +219,9 @@ __global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) {
     for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(rgbv[0][i], sl, 64);
 
     /* P6: colour head (models.py:699-729) */
-    if (valid && h == 0) colour_store(A, sh, raw_rgb, PS, n_tot, g, (size_t)ray * N + si);
+    if (valid && h == 0) colour_store(A, sh, raw_rgb, PS, n_tot, g);
+    wave_sync();
+    history_flush(A, PS, n_tot, pass0 + wave * 32, (size_t)ray0 * N + pass0 + wave * 32, lane);
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
