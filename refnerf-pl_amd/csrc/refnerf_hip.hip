@@ -347,7 +347,7 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
     for (int w = 0; w < nw; ++w) {
       fprintf(stderr, "[prof] wave %d:", w);
       for (int sl = 1; sl <= 16; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
-      fprintf(stderr, "\n");
+      fprintf(stderr, "  | dma-wait %lld barrier-wait %lld\n", hbuf[w * 32 + 20], hbuf[w * 32 + 21]);
     }
   }
   return REFNERF_OK;

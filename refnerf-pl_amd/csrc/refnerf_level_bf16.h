@@ -49,29 +49,31 @@ typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 struct Pipe {
-  const char *img;   /* packed bf16 image (global) */
+  const char *src;   /* this lane's DMA source inside the image: advances one chunk per rendezvous */
+  const char *src_end;   /* end of one pass worth of chunks (wrap point) for this lane */
   char *wbuf;        /* LDS ring base (3 slots) */
   const char *xp;    /* LDS encodings, pre-offset to this lane's B fragment (sample n, half h) */
   int cur_off, nxt_off, fil_off;   /* ring slots: being consumed / landed next / free */
-  int dma_chunk;     /* next chunk (index in the image) to DMA */
   int dma_left;      /* chunks still to be DMA'd by this workgroup */
   int lane, wave, h;
+  long long t_vm, t_bar;   /* debug (REFNERF_PROF): cycles spent in the DMA wait / in the barrier */
 };
 
-/* LDS-DMA of one 17 KB chunk into the ring slot at `slot_off`: 17 pieces of
- * 1 KB, the 8 waves take pieces round-robin (lane-linear 16 B per lane). */
+/* LDS-DMA of one 17 KB chunk into the ring slot at `slot_off`.  Wave w moves the
+ * adjacent pieces 3w..3w+2 (waves 0-4; wave 5 moves 15,16): one address and the
+ * instruction's immediate offset cover both the global and the LDS side. */
 __device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off) {
-  if (p.dma_left <= 0) return;
-  char *dst = p.wbuf + slot_off;
-  const char *src = p.img + (size_t)p.dma_chunk * BF_CHUNK_BYTES + p.lane * 16;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    int piece = p.wave + BF_NW * q;
-    if (piece < BF_CHUNK_KB)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + piece * 1024), (lptr_t)(dst + piece * 1024), 16, 0, 0);
+  if (p.dma_left > 0) {
+    if (p.wave < 6) {
+      lptr_t dst = (lptr_t)(p.wbuf + slot_off + p.wave * 3072);
+      __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 1024, 0);
+      if (p.wave < 5) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 2048, 0);
+    }
+    p.src += BF_CHUNK_BYTES;
+    if (p.src == p.src_end) p.src -= (size_t)BFPACKED.chunks_per_pass * BF_CHUNK_BYTES;
+    p.dma_left -= 1;
   }
-  p.dma_chunk = (p.dma_chunk + 1 == BFPACKED.chunks_per_pass) ? 0 : p.dma_chunk + 1;
-  p.dma_left -= 1;
 }
 
 __device__ __forceinline__ v8bf lds_frag(const char *q) { return *reinterpret_cast<const v8bf *>(q); }
@@ -155,8 +157,18 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, v8bf (&a)[AF], const v4uu (&in
     }
     if (k == KS / 2 - 1) {
       /* mid-chunk rendezvous: chunk c+1 is complete for every wave, chunk c-1's slot is free */
+#ifdef REFNERF_PROF_WAITS
+      long long t0 = (long long)__builtin_readcyclecounter();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      long long t1 = (long long)__builtin_readcyclecounter();
+      __syncthreads();
+      long long t2 = (long long)__builtin_readcyclecounter();
+      p.t_vm += t1 - t0;
+      p.t_bar += t2 - t1;
+#else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+#endif
       issue_chunk(p, p.fil_off);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -179,14 +191,25 @@ __device__ __forceinline__ void bf_slice(Pipe &p, v8bf (&a)[AF], int second, con
   }
 }
 
-/* One 256-wide layer: 8 slices, ReLU, repack as next-layer B fragments. */
+/* One 256-wide layer: 8 slices, ReLU, repack as next-layer B fragments.
+ * The slice loop is ROLLED (one slice body per layer instance instead of eight:
+ * the fully unrolled kernel was 80 KB of straight-line code cycling through a
+ * 64 KB instruction cache, i.e. fetch-bound).  A rolled loop cannot index the
+ * destination registers dynamically, so `out` works as a shift register: the
+ * new fragments enter at [14],[15] and everything moves down two places; after
+ * the 8 slices fragment pair ob sits at [2ob],[2ob+1]. */
 template <int KIND0, int REAL0>
 __device__ __forceinline__ void bf_layer(Pipe &p, v8bf (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16]) {
-#pragma unroll
+#pragma unroll 1
   for (int ob = 0; ob < 8; ++ob) {
     v16f acc;
     bf_slice<KIND0, REAL0>(p, a, second, in, bn, acc);
-    pack_acc<true>(acc, out[2 * ob], out[2 * ob + 1]);
+    v4uu f0, f1;
+    pack_acc<true>(acc, f0, f1);
+#pragma unroll
+    for (int e = 0; e < 14; ++e) out[e] = out[e + 2];
+    out[14] = f0;
+    out[15] = f1;
     __builtin_amdgcn_sched_barrier(0);     /* pack now: do not keep the fp32 tile alive */
   }
 }
@@ -215,13 +238,14 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   const int col = wave * 32 + n;                             /* this lane's sample column */
 
   Pipe p;
-  p.img = reinterpret_cast<const char *>(A.packed);
+  p.src = reinterpret_cast<const char *>(A.packed) + wave * 3072 + lane * 16;
+  p.src_end = p.src + (size_t)BFPACKED.chunks_per_pass * BF_CHUNK_BYTES;
   p.wbuf = WB;
   p.xp = Xb + (h * BT + col) * 16;
   p.cur_off = 0; p.nxt_off = BF_CHUNK_BYTES; p.fil_off = 2 * BF_CHUNK_BYTES;
-  p.dma_chunk = 0;
   p.dma_left = n_pass * BFPACKED.chunks_per_pass;
   p.lane = lane; p.wave = wave; p.h = h;
+  p.t_vm = 0; p.t_bar = 0;
   RN_STAMP(A, 0);
   issue_chunk(p, p.cur_off);                                 /* overlaps with the resampler */
   issue_chunk(p, p.nxt_off);
@@ -238,7 +262,11 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   for (int d = 0; d < AF; ++d) ar[d] = lds_frag(WB + 1024 + lane * 16 + d * 1024);
 
   for (int pass0 = 0; pass0 < n_tot; pass0 += BT) {
-    const int g = pass0 + col;
+    /* opaque copies: keep hipcc from hoisting ~100 registers of per-lane address
+     * arithmetic out of the pass loop (it then spills them to scratch) */
+    int lane_v = lane, col_v = col;
+    asm volatile("" : "+v"(lane_v), "+v"(col_v));
+    const int g = pass0 + col_v;
     const int rl = g / N, si = g - rl * N;
     const int ray = ray0 + rl;
     const bool valid = (g < n_tot) && (ray < A.R);
@@ -352,7 +380,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
           colour_store<true>(A, sh, raw_rgb, PS, n_tot, g);
         }
         wave_sync();
-        history_flush(A, PS, n_tot, pass0 + wave * 32, (size_t)ray0 * N + pass0 + wave * 32, lane);
+        history_flush(A, PS, n_tot, pass0 + wave * 32, (size_t)ray0 * N + pass0 + wave * 32, lane_v);
         RN_STAMP(A, 14);
       }
     }
@@ -361,6 +389,9 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   RN_STAMP(A, 15);
+#ifdef REFNERF_PROF_WAITS
+  if (A.prof && blockIdx.x == 0 && lane == 0) { A.prof[wave * 32 + 20] = p.t_vm; A.prof[wave * 32 + 21] = p.t_bar; }
+#endif
 
   composite_phase<BF_NW, true>(A, TD, XP, PS, n_tot, ray0, wave, lane);   /* P7 */
   RN_STAMP(A, 16);
