@@ -261,9 +261,10 @@ int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, v
 static int rays_per_wg(int N, int tile) {
   if (N % tile == 0) return 1;
   if (tile % N == 0) return tile / N;
-  if ((2 * N) % tile == 0) return 2;
-  if ((4 * N) % tile == 0) return 4;
-  return 1;
+  /* otherwise whole passes only if a small multiple fits the per-sample LDS budget */
+  if ((2 * N) % tile == 0 && 2 * N <= 512) return 2;
+  if ((4 * N) % tile == 0 && 4 * N <= 512) return 4;
+  return 1;   /* last pass partially filled */
 }
 
 int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays,

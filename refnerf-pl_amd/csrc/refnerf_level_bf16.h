@@ -256,6 +256,9 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   __syncthreads();                                           /* chunks 0 and 1 have landed */
   RN_STAMP(A, 2);
 
+  /* static priority for the younger wave of each SIMD (waves 4-7): age-based
+   * arbitration otherwise lets waves 0-3 run ahead and idle at every rendezvous */
+  if (wave >= BF_NW / 2) __builtin_amdgcn_s_setprio(1);
   v4uu R0[16], R1[16], bn[8];
   v8bf ar[AF];
 #pragma unroll
