@@ -107,21 +107,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    _hip.set_timing(True)          # HIP events on the kernel's own stream, inside the library
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    kern_ms, launches = _hip.get_timing()
-    _hip.set_timing(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(n_steps, n_warm):
+        """n_warm untimed steps, then exactly n_steps bracketed by barrier + synchronize on
+        both sides; returns (elapsed s [max over ranks], kernel ms total, launches, last output)."""
+        for _ in range(n_warm):
+            step()
+        sync()
+        _hip.set_timing(True)      # HIP event pairs on the kernel's own stream, inside the library
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            out = step()
+        sync()
+        el = time.perf_counter() - t0
+        kern_ms, launches = _hip.get_timing()
+        _hip.set_timing(False)
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, kern_ms, launches, out
+
+    def roofline(prec, kern_ms, launches):
+        avg_ms = kern_ms / launches
+        flop_per_launch = args.rays * args.samples * FLOP_PER_SAMPLE
+        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+        kernel = "rn::level_fwd_f32" if prec == "f32" else "rn::level_fwd_bf16"
+        traffic = None
+        try:   # PMC numbers cannot be collected inside this process: taken from the committed rocprofv3 passes
+            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
+            if args.rays == 4096 and args.samples == 128:
+                traffic = prof["bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
+        return {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                "frac": achieved / PEAK_TFLOPS[prec], "traffic": traffic, "kernel": kernel,
+                "avg_launch_ms": avg_ms, "launches": launches, "flop_per_launch": flop_per_launch}
+
+    elapsed, kern_ms, launches, out = timed(args.steps, args.warmup)
     rgb = out[0][-1]["rgb"]
     assert torch.isfinite(rgb).all()
 
@@ -137,21 +159,19 @@ def main():
                    "rays_per_gpu": args.rays, "parallelism": f"ray-tile dp{world}"},
     }
     if launches:
-        avg_ms = kern_ms / launches
-        flop_per_launch = args.rays * args.samples * FLOP_PER_SAMPLE
-        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
-        kernel = "rn::level_fwd_f32" if args.precision == "f32" else "rn::level_fwd_bf16"
-        traffic = None
-        try:   # PMC numbers cannot be collected inside this process: taken from the committed rocprofv3 passes
-            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
-            if args.rays == 4096 and args.samples == 128:
-                traffic = prof["bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
-                            "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic,
-                            "kernel": kernel, "avg_launch_ms": avg_ms, "launches": launches,
-                            "flop_per_launch": flop_per_launch}
+        line["roofline"] = roofline(args.precision, kern_ms, launches)
+    if rank == 0 and world == 1:
+        # the other arithmetic mode on the same batch (f32 = exact-fp32 MFMA, the strict parity mode)
+        other = "f32" if args.precision == "bf16" else "bf16"
+        cfg.hip_precision = other
+        n2 = max(3, args.steps // 2)
+        el2, k2, l2, out2 = timed(n2, 1)
+        line[other + "_mode"] = {"value": samples_per_step * n2 / el2, "unit": "ray-samples/s",
+                                 "ms_per_step": 1e3 * el2 / n2, "dtype": other, "roofline": roofline(other, k2, l2)}
+        line["mode_agreement"] = {"rgb_linf_bf16_vs_f32": float((out[0][-1]["rgb"] - out2[0][-1]["rgb"]).abs().max()),
+                                  "note": "rendered RGB of the two modes on this batch; parity of each mode vs the "
+                                          "reference's golden vectors is asserted in tests/test_hip_parity.py"}
+        cfg.hip_precision = args.precision
     if rank == 0 and world == 1 and not args.no_image:
         # full-image render ms: 800x800 Blender view, 157 chunks of 4096 rays (models.render_image)
         from refnerf_pl_amd import models

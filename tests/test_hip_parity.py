@@ -229,9 +229,9 @@ def test_full_size_properties(hip):
 @pytest.mark.parametrize("name", EVAL_CASES)
 def test_bf16_mode_tolerance(hip, name):
     """bf16 MFMA mode (bf16 weights/activations, fp32 accumulate, hardware
-    transcendentals): its own, looser, documented tolerance against the reference
-    golden vectors -- rendered RGB L-inf <= 2e-3 (measured <= 1e-4 on these
-    fixtures), per-sample colour 1e-3, >= 99% identical CDF bin indices."""
+    transcendentals) against the reference golden vectors: rendered RGB L-inf
+    <= 1e-4 (the north-star bar; measured 1e-5 .. 9e-5 on these fixtures, and
+    deterministic), per-sample colour 2e-3, >= 99% identical CDF bin indices."""
     g = load_golden(name)
     P = params_from_golden(g)
     rays = rays_from_golden(g)
@@ -239,7 +239,7 @@ def test_bf16_mode_tolerance(hip, name):
     outs = run_hip_model(hip, P, rays, kw, lv, precision=1)
     f32 = run_hip_model(hip, P, rays, kw, lv, precision=0)
     for L, res in enumerate(outs):
-        assert np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max() <= 2e-3
+        assert np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max() <= 1e-4
         assert np.abs(res["rgb"] - g[f"L{L}_h_rgb"].reshape(res["rgb"].shape)).max() <= 2e-3
         np.testing.assert_allclose(res["weights"], g[f"L{L}_h_weights"], rtol=0, atol=1e-3)
         np.testing.assert_allclose(res["r_acc"], g[f"L{L}_r_acc"], rtol=0, atol=2e-3)
@@ -265,7 +265,7 @@ def test_bf16_full_size_properties(hip):
         bg = np.maximum(0, 1 - a[L]["r_acc"])[:, None]
         np.testing.assert_allclose(a[L]["r_rgb"], (w[..., None] * a[L]["rgb"]).sum(1) + bg, rtol=0, atol=2e-5)
         # against the fp32 parity mode at the full BASELINE size
-        assert np.abs(a[L]["r_rgb"] - ref[L]["r_rgb"]).max() <= 2e-3
+        assert np.abs(a[L]["r_rgb"] - ref[L]["r_rgb"]).max() <= 1e-4
     for R, n0, n1 in ((3, 64, 64), (5, 192, 256), (2, 33, 2)):
         rr = synthetic.blender_rays(R, seed=R, center_frac=0.3)
         x = run_hip_model(hip, P, rr, {}, dict(num_prop_samples=n0, num_nerf_samples=n1), precision=1)
