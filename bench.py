@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--samples", type=int, default=128)
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--precision", default="bf16", choices=["f32", "bf16"],
+                    help="arithmetic of the MLP contractions for the headline value; the other mode is reported alongside")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-image", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
