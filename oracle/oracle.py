@@ -275,3 +275,51 @@ def model_forward(params, rays: dict, num_levels=2, num_prop_samples=128, num_ne
         outs.append(res)
         sdist, weights = res["sdist"], res["weights"]
     return outs
+
+
+class LossCfg(C.Structure):
+    _fields_ = [("data_mult", C.c_float), ("orientation_mult", C.c_float), ("normal_mult", C.c_float)]
+
+
+def model_train(params, rays: dict, gt_rgb, num_levels=2, num_prop_samples=128, num_nerf_samples=128,
+                data_mults=(0.1, 1.0), orientation_mults=(0.01, 0.1), normal_mults=(3e-5, 3e-4),
+                n_threads=0, **cfg_kw):
+    """Forward + data/orientation/predicted-normal losses + backward of Model.__call__
+    in training mode.  *_mults = (coarse, fine) multipliers (blender_refnerf.gin:9-16).
+    Returns (losses dict, grads blob float32, per-level dicts with sdist/weights/r_rgb)."""
+    lib().rn_level_train.restype = C.c_int
+    p, pp = _f(params)
+    rs, keep = _rays_struct(rays)
+    R = keep["origins"].shape[0]
+    gt, gtp = _f(np.asarray(gt_rgb)[..., :3].reshape(R, 3))
+    lm, lmp = _f(np.asarray(rays["lossmult"]).reshape(R))
+    grads = np.zeros(p.shape[0], np.float32)
+    sdist = np.tile(np.array([[cfg_kw.get("s_near", 0.0), cfg_kw.get("s_far", 1.0)]], np.float32), (R, 1))
+    weights = np.ones((R, 1), np.float32)
+    losses = {"data": 0.0, "orientation": 0.0, "normal": 0.0}
+    levels = []
+    for lvl in range(num_levels):
+        fine = lvl == num_levels - 1
+        n = num_nerf_samples if fine else num_prop_samples
+        cfg = default_cfg(n_samples=n, n_in=weights.shape[1], training=1, **cfg_kw)
+        lc = LossCfg(data_mults[1] if fine else data_mults[0], orientation_mults[1] if fine else orientation_mults[0],
+                     normal_mults[1] if fine else normal_mults[0])
+        out = LevelOut()
+        res = {"sdist": np.zeros((R, n + 1), np.float32), "weights": np.zeros((R, n), np.float32),
+               "r_rgb": np.zeros((R, 3), np.float32)}
+        for k, a in res.items():
+            setattr(out, k, a.ctypes.data_as(_FP))
+        loss3 = (C.c_double * 3)()
+        sd_in, sdp = _f(sdist)
+        w_in, wp = _f(weights)
+        rc = lib().rn_level_train(pp, C.byref(cfg), C.byref(rs), C.c_int(R), sdp, wp, gtp, lmp, C.byref(lc), C.byref(out),
+                                  grads.ctypes.data_as(_FP), loss3, C.c_int(n_threads))
+        if rc != 0:
+            raise ValueError(f"rn_level_train failed with code {rc}")
+        losses["data"] += loss3[0]
+        losses["orientation"] += loss3[1]
+        losses["normal"] += loss3[2]
+        levels.append(res)
+        sdist, weights = res["sdist"], res["weights"]
+    losses["total"] = losses["data"] + losses["orientation"] + losses["normal"]
+    return losses, grads, levels

@@ -731,3 +731,359 @@ int rn_level_forward(const float *params, const rn_level_cfg *cfg, const rn_rays
   model_free(&model);
   return 0;
 }
+
+/* ================================================================== */
+/* training: per-sample forward cache + backward       */
+/* ================================================================== */
+
+typedef struct rn_cache {
+  float ipe[RN_IPE_DIM];
+  float sp_act[RN_DEPTH][RN_WIDTH];           /* post-ReLU */
+  float raw_density, raw_rough, gp[3], raw_diff[3], raw_tint[3];
+  float din[RN_DIR_IN];
+  float vd_act[RN_DEPTH][RN_WIDTH];
+  float raw_rgb[3];
+  float refdir[3], rough, npred[3], nrm2, tint[3];
+} rn_cache;
+
+static float softplus_grad(float x) { return x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x)); }
+
+/* gradient of rn_ide_stable_f32 w.r.t. xyz and kappa_inv given g_out[72] */
+static void ide_stable_grad(const float *xyz, float kappa_inv, const float *g_out, float *g_xyz, float *g_kappa) {
+  if (!g_ide_init) { rn_ide_tables(g_ide_c, &g_ide_a[0][0], &g_ide_b[0][0]); g_ide_init = 1; }
+  float x = xyz[0], y = xyz[1], z = xyz[2];
+  float pr[17], pi[17], gpr[17], gpi[17];
+  pr[0] = 1.0f; pi[0] = 0.0f;
+  for (int m = 1; m <= 16; ++m) { pr[m] = pr[m - 1] * x - pi[m - 1] * y; pi[m] = pr[m - 1] * y + pi[m - 1] * x; }
+  for (int m = 0; m <= 16; ++m) gpr[m] = gpi[m] = 0.0f;
+  float gz = 0.0f, gk = 0.0f;
+  for (int m = 0; m <= 16; ++m) {
+    float tm2 = 0.0f, tm1 = g_ide_c[m], dm2 = 0.0f, dm1 = 0.0f;
+    for (int l = m; l <= 16; ++l) {
+      float tl, dl;
+      if (l == m) { tl = g_ide_c[m]; dl = 0.0f; }
+      else {
+        float a = g_ide_a[m][l], b = g_ide_b[m][l];
+        tl = a * (z * tm1 - b * tm2);
+        dl = a * (tm1 + z * dm1 - b * dm2);
+        tm2 = tm1; tm1 = tl; dm2 = dm1; dm1 = dl;
+      }
+      if (l >= 1 && (l & (l - 1)) == 0) {
+        int idx = ide_term_index(l, m);
+        float sigma = (float)(0.5 * l * (l + 1));
+        float att = expf(-sigma * kappa_inv);
+        float gre = g_out[idx], gim = g_out[RN_IDE_TERMS + idx];
+        float s = tl * att;
+        float gs = gre * pr[m] + gim * pi[m];
+        gpr[m] += gre * s; gpi[m] += gim * s;
+        gz += gs * att * dl;
+        gk += gs * tl * (-sigma * att);
+      }
+    }
+  }
+  float gx = 0.0f, gy = 0.0f;
+  for (int m = 1; m <= 16; ++m) {
+    gx += (float)m * (gpr[m] * pr[m - 1] + gpi[m] * pi[m - 1]);
+    gy += (float)m * (-gpr[m] * pi[m - 1] + gpi[m] * pr[m - 1]);
+  }
+  g_xyz[0] = gx; g_xyz[1] = gy; g_xyz[2] = gz;
+  *g_kappa = gk;
+}
+
+static float srgb_grad(float u) { /* d linear_to_srgb / du (image.py:51-59) */
+  if (u <= 0.0031308f) return (float)(323.0 / 25.0);
+  if (!(u > EPS32)) return 0.0f;
+  return (211.0f / 200.0f) * (float)(5.0 / 12.0) * powf(u, (float)(5.0 / 12.0) - 1.0f);
+}
+
+/* forward of one sample with everything the backward needs */
+static void mlp_forward_cached(const rn_model *M, const rn_level_cfg *cfg, const float *lmean, const float *lvar,
+                               const float *v, rn_cache *c, rn_sample_out *out) {
+  const rn_param_offsets *L = &M->L;
+  const float *P = M->P, *T = M->T;
+  float x[RN_WIDTH + RN_DIR_IN], y[RN_WIDTH];
+  rn_ipe(lmean, lvar, c->ipe);
+  memcpy(x, c->ipe, sizeof(c->ipe));
+  for (int i = 0; i < RN_DEPTH; ++i) {
+    dense_block(T + L->sp_w[i], P + L->sp_b[i], x, 0, L->sp_in[i], RN_WIDTH, y, RN_WIDTH, 1, 1);
+    memcpy(c->sp_act[i], y, sizeof(y));
+    memcpy(x, y, sizeof(y));
+    if (i % RN_SKIP == 0 && i > 0) memcpy(x + RN_WIDTH, c->ipe, sizeof(c->ipe));
+  }
+  float bneck[RN_BNECK];
+  dense_block(T + L->bneck_w, P + L->bneck_b, x, 0, RN_WIDTH, RN_BNECK, bneck, RN_BNECK, 1, 0);
+  dense_block(P + L->density_w, P + L->density_b, x, 0, RN_WIDTH, 1, &c->raw_density, 1, 1, 0);
+  dense_block(T + L->gradpred_w, P + L->gradpred_b, x, 0, RN_WIDTH, 3, c->gp, 3, 1, 0);
+  dense_block(T + L->diffuse_w, P + L->diffuse_b, x, 0, RN_WIDTH, 3, c->raw_diff, 3, 1, 0);
+  dense_block(T + L->tint_w, P + L->tint_b, x, 0, RN_WIDTH, 3, c->raw_tint, 3, 1, 0);
+  dense_block(P + L->rough_w, P + L->rough_b, x, 0, RN_WIDTH, 1, &c->raw_rough, 1, 1, 0);
+  c->nrm2 = (c->gp[0] * c->gp[0] + c->gp[1] * c->gp[1]) + c->gp[2] * c->gp[2];
+  float nrm = sqrtf(fmaxf(c->nrm2, EPS32));
+  for (int i = 0; i < 3; ++i) { c->npred[i] = -(c->gp[i] / nrm); c->tint[i] = sigmoid_t(c->raw_tint[i]); }
+  c->rough = softplus_t(c->raw_rough + cfg->roughness_bias);
+  float w[3] = {-v[0], -v[1], -v[2]};
+  float dot = (c->npred[0] * w[0] + c->npred[1] * w[1]) + c->npred[2] * w[2];
+  for (int i = 0; i < 3; ++i) c->refdir[i] = (2.0f * dot) * c->npred[i] - w[i];
+  memcpy(c->din, bneck, sizeof(bneck));
+  rn_ide_stable_f32(c->refdir, c->rough, c->din + RN_BNECK);
+  c->din[RN_DIR_IN - 1] = (c->npred[0] * v[0] + c->npred[1] * v[1]) + c->npred[2] * v[2];
+  memcpy(x, c->din, sizeof(c->din));
+  for (int i = 0; i < RN_DEPTH; ++i) {
+    dense_block(T + L->vd_w[i], P + L->vd_b[i], x, 0, L->vd_in[i], RN_WIDTH, y, RN_WIDTH, 1, 1);
+    memcpy(c->vd_act[i], y, sizeof(y));
+    memcpy(x, y, sizeof(y));
+    if (i % RN_SKIP == 0 && i > 0) memcpy(x + RN_WIDTH, c->din, sizeof(c->din));
+  }
+  dense_block(T + L->rgb_w, P + L->rgb_b, x, 0, RN_WIDTH, 3, c->raw_rgb, 3, 1, 0);
+  (void)out;
+}
+
+/* acc[o][k] += d[o] * x[k], bias grad, and gin[k] = sum_o W[o][k] d[o] */
+static void dense_backward(const float *W, int in, int out, const float *d, const float *xin, float *gW, float *gb, float *gin) {
+  if (gin) for (int k = 0; k < in; ++k) gin[k] = 0.0f;
+  for (int o = 0; o < out; ++o) {
+    float dv = d[o];
+    if (dv == 0.0f) continue;
+    const float *w = W + (size_t)o * in;
+    float *gw = gW + (size_t)o * in;
+    for (int k = 0; k < in; ++k) gw[k] += dv * xin[k];
+    gb[o] += dv;
+    if (gin) for (int k = 0; k < in; ++k) gin[k] += w[k] * dv;
+  }
+}
+
+/* backward of one sample: upstream grads w.r.t. density, sample rgb, n_pred */
+static void mlp_backward(const rn_model *M, const rn_level_cfg *cfg, const rn_cache *c, const float *v,
+                         float g_density, const float *g_rgb_out, const float *g_npred_loss, float *G) {
+  const rn_param_offsets *L = &M->L;
+  const float *P = M->P;
+  const float LOG3 = 1.0986122886681098f;
+  /* ---- colour head (models.py:699-729) ---- */
+  float sg[3], dl[3], spec[3], col[3];
+  for (int i = 0; i < 3; ++i) {
+    sg[i] = sigmoid_t(cfg->rgb_premultiplier * c->raw_rgb[i] + cfg->rgb_bias);
+    dl[i] = sigmoid_t(c->raw_diff[i] - LOG3);
+    spec[i] = c->tint[i] * sg[i];
+    col[i] = spec[i] + dl[i];
+  }
+  float pad_scale = (float)(1.0 + 2.0 * (double)cfg->rgb_padding);
+  float g_col[3];
+  for (int i = 0; i < 3; ++i) g_col[i] = g_rgb_out[i] * pad_scale;
+  if (cfg->srgb_mapping) {
+    float u[3], norm = 1.0f, mxc = fmaxf(fmaxf(col[0], col[1]), col[2]);
+    if (cfg->srgb_mapping_normalization) norm = fmaxf(mxc, 1.0f);
+    float g_u[3];
+    for (int i = 0; i < 3; ++i) {
+      u[i] = col[i] / norm;
+      float yv = rn_linear_to_srgb(u[i]);
+      float pass = (yv >= 0.0f && yv <= 1.0f) ? 1.0f : 0.0f;   /* torch.clip backward */
+      g_u[i] = g_col[i] * pass * srgb_grad(u[i]);
+    }
+    float g_norm = 0.0f;
+    for (int i = 0; i < 3; ++i) { g_col[i] = g_u[i] / norm; g_norm += -g_u[i] * col[i] / (norm * norm); }
+    if (cfg->srgb_mapping_normalization) {
+      float gm = (mxc > 1.0f) ? g_norm : (mxc == 1.0f ? 0.5f * g_norm : 0.0f);   /* torch.maximum */
+      if (gm != 0.0f) {
+        int cnt = 0;
+        for (int i = 0; i < 3; ++i) cnt += (col[i] == mxc);
+        for (int i = 0; i < 3; ++i) if (col[i] == mxc) g_col[i] += gm / (float)cnt;     /* amax: ties share */
+      }
+    }
+  }
+  float g_tint[3], g_raw_rgb[3], g_raw_diff[3];
+  for (int i = 0; i < 3; ++i) {
+    g_tint[i] = g_col[i] * sg[i];
+    g_raw_rgb[i] = (g_col[i] * c->tint[i]) * sg[i] * (1.0f - sg[i]) * cfg->rgb_premultiplier;
+    g_raw_diff[i] = g_col[i] * dl[i] * (1.0f - dl[i]);
+  }
+  /* ---- directional MLP ---- */
+  float d[RN_WIDTH + RN_DIR_IN], gin[RN_WIDTH + RN_DIR_IN], g_din[RN_DIR_IN];
+  float xin[RN_WIDTH + RN_DIR_IN];
+  memset(g_din, 0, sizeof(g_din));
+  dense_backward(P + L->rgb_w, RN_WIDTH, 3, g_raw_rgb, c->vd_act[RN_DEPTH - 1], G + L->rgb_w, G + L->rgb_b, gin);
+  for (int i = RN_DEPTH - 1; i >= 0; --i) {
+    for (int o = 0; o < RN_WIDTH; ++o) d[o] = (c->vd_act[i][o] > 0.0f) ? gin[o] : 0.0f;
+    int in = L->vd_in[i];
+    if (i == 0) memcpy(xin, c->din, sizeof(c->din));
+    else { memcpy(xin, c->vd_act[i - 1], sizeof(float) * RN_WIDTH); if (in > RN_WIDTH) memcpy(xin + RN_WIDTH, c->din, sizeof(c->din)); }
+    dense_backward(P + L->vd_w[i], in, RN_WIDTH, d, xin, G + L->vd_w[i], G + L->vd_b[i], gin);
+    if (i == 0) { for (int k = 0; k < RN_DIR_IN; ++k) g_din[k] += gin[k]; }
+    else if (in > RN_WIDTH) { for (int k = 0; k < RN_DIR_IN; ++k) g_din[k] += gin[RN_WIDTH + k]; }
+  }
+  /* ---- encodings / reflection (models.py:657-686) ---- */
+  float g_ref[3], g_rough, g_np[3];
+  ide_stable_grad(c->refdir, c->rough, g_din + RN_BNECK, g_ref, &g_rough);
+  float g_dot = g_din[RN_DIR_IN - 1];
+  float w[3] = {-v[0], -v[1], -v[2]};
+  float ndw = (c->npred[0] * w[0] + c->npred[1] * w[1]) + c->npred[2] * w[2];
+  float grn = (g_ref[0] * c->npred[0] + g_ref[1] * c->npred[1]) + g_ref[2] * c->npred[2];
+  for (int i = 0; i < 3; ++i) g_np[i] = g_npred_loss[i] + 2.0f * (grn * w[i] + ndw * g_ref[i]) + g_dot * v[i];
+  /* n_pred = -g/sqrt(max(|g|^2, eps)) (ref_utils.py:40-42) */
+  float s = fmaxf(c->nrm2, EPS32), rs = sqrtf(s);
+  float g_gp[3];
+  {
+    float gdotg = (c->gp[0] * g_np[0] + c->gp[1] * g_np[1]) + c->gp[2] * g_np[2];
+    float live = (c->nrm2 > EPS32) ? 1.0f : (c->nrm2 == EPS32 ? 0.5f : 0.0f);
+    for (int i = 0; i < 3; ++i) g_gp[i] = -(g_np[i] / rs - live * c->gp[i] * gdotg / (s * rs));
+  }
+  float g_raw_rough = g_rough * softplus_grad(c->raw_rough + cfg->roughness_bias);
+  float g_raw_tint[3];
+  for (int i = 0; i < 3; ++i) g_raw_tint[i] = g_tint[i] * c->tint[i] * (1.0f - c->tint[i]);
+  float g_raw_density = g_density * softplus_grad(c->raw_density + cfg->density_bias);
+  /* ---- heads ---- */
+  const float *x7 = c->sp_act[RN_DEPTH - 1];
+  float gx[RN_WIDTH], tmp[RN_WIDTH + RN_IPE_DIM];
+  memset(gx, 0, sizeof(gx));
+#define HEADB(woff, boff, outn, dvec) do { dense_backward(P + (woff), RN_WIDTH, (outn), (dvec), x7, G + (woff), G + (boff), tmp); for (int k_ = 0; k_ < RN_WIDTH; ++k_) gx[k_] += tmp[k_]; } while (0)
+  HEADB(L->density_w, L->density_b, 1, &g_raw_density);
+  HEADB(L->gradpred_w, L->gradpred_b, 3, g_gp);
+  HEADB(L->rough_w, L->rough_b, 1, &g_raw_rough);
+  HEADB(L->diffuse_w, L->diffuse_b, 3, g_raw_diff);
+  HEADB(L->tint_w, L->tint_b, 3, g_raw_tint);
+  HEADB(L->bneck_w, L->bneck_b, RN_BNECK, g_din);
+#undef HEADB
+  /* ---- spatial MLP ---- */
+  memcpy(gin, gx, sizeof(gx));
+  for (int i = RN_DEPTH - 1; i >= 0; --i) {
+    for (int o = 0; o < RN_WIDTH; ++o) d[o] = (c->sp_act[i][o] > 0.0f) ? gin[o] : 0.0f;
+    int in = L->sp_in[i];
+    if (i == 0) memcpy(xin, c->ipe, sizeof(c->ipe));
+    else { memcpy(xin, c->sp_act[i - 1], sizeof(float) * RN_WIDTH); if (in > RN_WIDTH) memcpy(xin + RN_WIDTH, c->ipe, sizeof(c->ipe)); }
+    dense_backward(P + L->sp_w[i], in, RN_WIDTH, d, xin, G + L->sp_w[i], G + L->sp_b[i], (i > 0) ? gin : NULL);
+  }
+}
+
+int rn_level_train(const float *params, const rn_level_cfg *cfg_in, const rn_rays *rays, int R,
+                   const float *sdist_in, const float *weights_in, const float *gt_rgb,
+                   const float *lossmult, const rn_loss_cfg *lc, rn_level_out *out,
+                   float *grads, double *loss3, int n_threads) {
+  rn_level_cfg cfgv = *cfg_in;
+  cfgv.training = 1;
+  const rn_level_cfg *cfg = &cfgv;
+  const int N = cfg->n_samples, M = cfg->n_in;
+  if (N <= 1) return -1;
+  rn_model model;
+  model_init(&model, params);
+  double denom = 0.0;
+  for (int r = 0; r < R; ++r) denom += 3.0 * (double)lossmult[r];
+  double l_data = 0.0, l_or = 0.0, l_nm = 0.0;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel reduction(+ : l_data, l_or, l_nm)
+  {
+    float *G = (float *)calloc((size_t)model.L.total, sizeof(float));
+    rn_cache *cache = (rn_cache *)malloc(sizeof(rn_cache) * (size_t)N);
+    rn_sample_out *so = (rn_sample_out *)malloc(sizeof(rn_sample_out) * (size_t)N);
+    float *buf = (float *)malloc(sizeof(float) * (size_t)(M + 5 * (N + 1)));
+    float *logits = buf, *sd = buf + M, *td = sd + (N + 1), *dens = td + (N + 1), *wts = dens + (N + 1), *gw = wts + (N + 1);
+    int32_t *bidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
+#pragma omp for schedule(dynamic, 1)
+    for (int r = 0; r < R; ++r) {
+      const float *o = rays->origins + 3 * r, *d = rays->directions + 3 * r, *v = rays->viewdirs + 3 * r;
+      float nearv = rays->near[r], farv = rays->far[r], radius = rays->radii[r];
+      rn_resample_logits(sdist_in + (size_t)r * (M + 1), weights_in + (size_t)r * M, M, cfg->anneal, cfg->resample_padding, logits);
+      rn_sample_intervals(sdist_in + (size_t)r * (M + 1), logits, M, N, cfg->s_near, cfg->s_far, sd, bidx);
+      for (int i = 0; i <= N; ++i) td[i] = rn_s_to_t(sd[i], nearv, farv);
+      for (int i = 0; i < N; ++i) {
+        float lm[3], lv[3];
+        rn_cast_sample(o, d, radius, td[i], td[i + 1], cfg->ray_shape, lm, lv, NULL);
+        mlp_block(&model, cfg, lm, lv, v, 1, &so[i]);              /* outputs incl. density normals */
+        mlp_forward_cached(&model, cfg, lm, lv, v, &cache[i], NULL);
+        dens[i] = so[i].density;
+      }
+      rn_alpha_weights(dens, td, d, N, cfg->opaque_background, wts);
+      if (out) {
+        if (out->sdist) memcpy(out->sdist + (size_t)r * (N + 1), sd, sizeof(float) * (N + 1));
+        if (out->weights) memcpy(out->weights + (size_t)r * N, wts, sizeof(float) * N);
+      }
+      /* ---- forward render + losses ---- */
+      float acc = 0.0f, rgb[3] = {0, 0, 0};
+      for (int i = 0; i < N; ++i) { acc += wts[i]; for (int c = 0; c < 3; ++c) rgb[c] += wts[i] * so[i].rgb[c]; }
+      float bg_w = fmaxf(0.0f, 1.0f - acc);
+      float pre[3];
+      for (int c = 0; c < 3; ++c) { rgb[c] += bg_w * cfg->bg_rgb; pre[c] = rgb[c]; }
+      float dif_[3] = {0, 0, 0}, spc_[3] = {0, 0, 0};
+      render_map(cfg->render_srgb_mode, rgb, dif_, spc_);
+      if (out && out->r_rgb) memcpy(out->r_rgb + 3 * (size_t)r, rgb, 12);
+      float g_rgb[3];
+      for (int c = 0; c < 3; ++c) {
+        float res = rgb[c] - gt_rgb[3 * r + c];
+        l_data += (double)lc->data_mult * (double)lossmult[r] * (double)res * (double)res / denom;
+        g_rgb[c] = (float)((double)lc->data_mult * 2.0 * (double)lossmult[r] * (double)res / denom);
+      }
+      /* back through the render-time mapping (render.py:186-216) */
+      {
+        int mode = cfg->render_srgb_mode;
+        if (mode != RN_SRGB_NONE) {
+          float norm = 1.0f, mxc = fmaxf(fmaxf(pre[0], pre[1]), pre[2]);
+          int normed = (mode == RN_SRGB_NORM_LINEAR || mode == RN_SRGB_NORM_SRGB);
+          if (normed) norm = fmaxf(mxc, 1.0f);
+          float gu[3], gnorm = 0.0f;
+          for (int c = 0; c < 3; ++c) {
+            float u = pre[c] / norm;
+            float yv = (mode == RN_SRGB_SRGB || mode == RN_SRGB_NORM_SRGB) ? rn_linear_to_srgb(u) : u;
+            float pass = (yv >= 0.0f && yv <= 1.0f) ? 1.0f : 0.0f;
+            float dy = (mode == RN_SRGB_SRGB || mode == RN_SRGB_NORM_SRGB) ? srgb_grad(u) : 1.0f;
+            gu[c] = g_rgb[c] * pass * dy;
+          }
+          for (int c = 0; c < 3; ++c) { g_rgb[c] = gu[c] / norm; gnorm += -gu[c] * pre[c] / (norm * norm); }
+          if (normed) {
+            float gm = (mxc > 1.0f) ? gnorm : (mxc == 1.0f ? 0.5f * gnorm : 0.0f);
+            if (gm != 0.0f) {
+              int cnt = 0;
+              for (int c = 0; c < 3; ++c) cnt += (pre[c] == mxc);
+              for (int c = 0; c < 3; ++c) if (pre[c] == mxc) g_rgb[c] += gm / (float)cnt;
+            }
+          }
+        }
+      }
+      /* per-sample upstream gradients */
+      float gsum = (g_rgb[0] + g_rgb[1] + g_rgb[2]) * cfg->bg_rgb;
+      for (int i = 0; i < N; ++i) {
+        float ndv = -((so[i].normals_pred[0] * v[0] + so[i].normals_pred[1] * v[1]) + so[i].normals_pred[2] * v[2]);
+        float mn = fminf(0.0f, ndv);
+        float nn = (so[i].normals[0] * so[i].normals_pred[0] + so[i].normals[1] * so[i].normals_pred[1]) + so[i].normals[2] * so[i].normals_pred[2];
+        l_or += (double)lc->orientation_mult * (double)(wts[i] * mn * mn) / (double)R;
+        l_nm += (double)lc->normal_mult * (double)(wts[i] * (1.0f - nn)) / (double)R;
+        float g = (g_rgb[0] * so[i].rgb[0] + g_rgb[1] * so[i].rgb[1]) + g_rgb[2] * so[i].rgb[2];
+        if (acc < 1.0f) g -= gsum;                      /* bg_w = max(0, 1 - acc) */
+        g += lc->orientation_mult * (mn * mn) / (float)R + lc->normal_mult * (1.0f - nn) / (float)R;
+        gw[i] = g;
+      }
+      /* weights -> density (render.py:132-149): w_i = (1-e^{-dd_i}) e^{-c_i} */
+      float norm_d = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+      double suffix = 0.0;                               /* sum_{j>i} g_w_j w_j */
+      {
+        double cum_all = 0.0;
+        for (int i = 0; i < N; ++i) cum_all += (double)(dens[i] * ((td[i + 1] - td[i]) * norm_d));
+        double cum = cum_all;
+        for (int i = N - 1; i >= 0; --i) {
+          float delta = (td[i + 1] - td[i]) * norm_d;
+          float dd = dens[i] * delta;
+          cum -= (double)dd;                             /* c_i */
+          float e_dd = expf(-dd), tr = expf(-(float)cum);
+          float g_dd = gw[i] * e_dd * tr - (float)suffix;
+          suffix += (double)(gw[i] * wts[i]);
+          float g_density = g_dd * delta;
+          float g_rgb_s[3], g_np[3];
+          float ndv = -((so[i].normals_pred[0] * v[0] + so[i].normals_pred[1] * v[1]) + so[i].normals_pred[2] * v[2]);
+          float mn = fminf(0.0f, ndv);
+          for (int c = 0; c < 3; ++c) {
+            g_rgb_s[c] = wts[i] * g_rgb[c];
+            g_np[c] = lc->orientation_mult / (float)R * wts[i] * 2.0f * mn * (-v[c])
+                      + lc->normal_mult / (float)R * wts[i] * (-so[i].normals[c]);
+          }
+          if (cfg->opaque_background && i == N - 1) g_density = 0.0f;
+          mlp_backward(&model, cfg, &cache[i], v, g_density, g_rgb_s, g_np, G);
+        }
+      }
+    }
+#pragma omp critical
+    { for (int k = 0; k < model.L.total; ++k) grads[k] += G[k]; }
+    free(G); free(cache); free(so); free(buf); free(bidx);
+  }
+  model_free(&model);
+  if (loss3) { loss3[0] = l_data; loss3[1] = l_or; loss3[2] = l_nm; }
+  return 0;
+}

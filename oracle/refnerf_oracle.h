@@ -170,6 +170,23 @@ int rn_level_forward(const float *params, const rn_level_cfg *cfg,
                      const rn_rays *rays, int R, const float *sdist_in,
                      const float *weights_in, rn_level_out *out, int n_threads);
 
+/* ---- training step of one level (forward + the three Ref-NeRF losses +
+ * backward), SURVEY.md A8/A10 ----
+ * Losses (train_utils.py): data = mult * sum(lossmult*(rgb-gt)^2)/sum(lossmult)
+ * (:33-88, mse), orientation = mult * mean_R sum_N w*min(0, n_pred.(-v))^2
+ * (:165-183), predicted-normal = mult * mean_R sum_N w*(1 - n.n_pred), n
+ * detached (:186-204).  The caller passes the level's multipliers (coarse or
+ * fine).  `grads` (canonical blob layout) is ACCUMULATED into; loss3 receives
+ * {data, orientation, predicted-normal} already multiplied. */
+typedef struct rn_loss_cfg {
+  float data_mult, orientation_mult, normal_mult;
+} rn_loss_cfg;
+
+int rn_level_train(const float *params, const rn_level_cfg *cfg, const rn_rays *rays, int R,
+                   const float *sdist_in, const float *weights_in, const float *gt_rgb /*[R,3]*/,
+                   const float *lossmult /*[R]*/, const rn_loss_cfg *lc, rn_level_out *out,
+                   float *grads, double *loss3, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,3 +152,29 @@ def test_model_end_to_end(name):
             # gradient is tiny: gate the bulk tightly, the tail loosely.
             assert np.median(err) < 1e-4 and np.mean(err < 1e-3) > 0.97, (np.median(err), np.mean(err < 1e-3))
             np.testing.assert_allclose(res["r_normals"], g[f"L{L}_r_normals"], rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("name", ["model_blender_sharp_train", "model_llff_linear_train"])
+def test_training_step_losses_and_gradients(name):
+    """rn_level_train (forward + data / orientation / predicted-normal losses +
+    backward) against the reference's autograd: loss values and
+    the parameter gradients (every 97th element + per-tensor L2 norms)."""
+    from refnerf_pl_amd import layout
+    g = load_golden(name)
+    P = params_from_golden(g)
+    kw, lv = cfg_from_bindings(g["bindings"])
+    losses, grads, _ = O.model_train(P, rays_from_golden(g), g["gt_rgb"], **lv, **kw)
+    assert losses["data"] == pytest.approx(float(g["loss_data"]), rel=2e-6)
+    assert losses["orientation"] == pytest.approx(float(g["loss_orientation"]), rel=2e-4)
+    assert losses["normal"] == pytest.approx(float(g["loss_normal"]), rel=2e-4)
+    assert losses["total"] == pytest.approx(float(g["loss_total"]), rel=2e-6)
+    ref = g["grads_sub"]
+    mine = grads[::97]
+    assert np.linalg.norm(mine - ref) / np.linalg.norm(ref) < 1e-4
+    np.testing.assert_allclose(mine, ref, rtol=0, atol=1e-6 * max(1.0, np.abs(ref).max() / 1e-3))
+    norms = g["grads_tensor_l2"]
+    for i, s in enumerate(layout.PARAM_SPECS):      # all 46 tensors receive their gradient (A10)
+        n = s.out_dim * s.in_dim
+        assert np.linalg.norm(grads[s.w_off:s.w_off + n]) == pytest.approx(norms[i, 0], rel=2e-3), s.name
+        assert np.linalg.norm(grads[s.b_off:s.b_off + s.out_dim]) == pytest.approx(norms[i, 1], rel=2e-3), s.name
+        assert norms[i, 0] > 0
