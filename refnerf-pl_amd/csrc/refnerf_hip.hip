@@ -71,32 +71,54 @@ __device__ float canon_b(const float *P, int op, int row) {
 
 __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict__ out) {
   int op = blockIdx.y;
-  const Op o = PACKED.op[op];
-  int n_a = (o.reg_steps + o.lds_steps) * 64 * o.stride;
-  int n_b = o.nob * 32;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_a + n_b; e += gridDim.x * blockDim.x) {
-    if (e < n_a) {
-      int ob = e % o.stride, lane = (e / o.stride) % 64, step = e / (o.stride * 64);
-      int h = lane >> 5, row = ob * 32 + (lane & 31);
-      float v = 0.0f;
-      if (ob < o.nob) {
-        if (step < o.reg_steps) {
-          int kb = step >> 4, r = step & 15;
-          int k = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
-          v = canon_w(P, op, row, k);
-        } else {
-          int kl = 2 * (step - o.reg_steps) + h;
-          int k = (o.reg_steps ? WIDTH : 0) + kl;
-          int valid_k = (op == 0 || op == 5) ? IPE_DIM : DIR_IN;
-          v = (kl < valid_k) ? canon_w(P, op, row, k) : 0.0f;
+  if (op < NUM_OPS) {
+    const Op o = PACKED.op[op];
+    int n_a = (o.reg_steps + o.lds_steps) * 64 * o.stride;
+    int n_b = o.nob * 32;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_a + n_b; e += gridDim.x * blockDim.x) {
+      if (e < n_a) {
+        int ob = e % o.stride, lane = (e / o.stride) % 64, step = e / (o.stride * 64);
+        int h = lane >> 5, row = ob * 32 + (lane & 31);
+        float v = 0.0f;
+        if (ob < o.nob) {
+          if (step < o.reg_steps) {
+            int kb = step >> 4, r = step & 15;
+            int k = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+            v = canon_w(P, op, row, k);
+          } else {
+            int kl = 2 * (step - o.reg_steps) + h;
+            int k = (o.reg_steps ? WIDTH : 0) + kl;
+            int valid_k = (op == 0 || op == 5) ? IPE_DIM : DIR_IN;
+            v = (kl < valid_k) ? canon_w(P, op, row, k) : 0.0f;
+          }
         }
+        out[o.a_off + e] = v;
+      } else {
+        int b = e - n_a;
+        int reg = b & 15, h = (b >> 4) & 1, ob = b >> 5;
+        int row = ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        out[o.b_off + b] = canon_b(P, op, row);
       }
-      out[o.a_off + e] = v;
-    } else {
-      int b = e - n_a;
+    }
+  } else if (op < NUM_OPS + NUM_TOPS) {
+    /* transposed spatial layers: A[step][lane][ob] = W[o = kidx(step,h)][in_row] */
+    const int t = op - NUM_OPS;
+    const Op o = PACKED.top[t];
+    const int layer = (t < 7) ? t + 1 : (t == TOP_SP5_IPE ? 5 : 0);
+    const int col0 = (t == TOP_SP5_IPE) ? WIDTH : 0;   /* canonical input column of row 0 */
+    int n_a = o.reg_steps * 64 * o.stride;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_a; e += gridDim.x * blockDim.x) {
+      int ob = e % o.stride, lane = (e / o.stride) % 64, step = e / (o.stride * 64);
+      int h = lane >> 5, in_row = ob * 32 + (lane & 31);
+      int kb = step >> 4, r = step & 15;
+      int oo = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;   /* output feature feeding this k slot */
+      out[o.a_off + e] = (ob < o.nob) ? canon_w(P, layer, oo, col0 + in_row) : 0.0f;
+    }
+  } else {
+    /* WD: raw_density.weight in accumulator layout [ob][h][16] */
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < 8 * 32; b += gridDim.x * blockDim.x) {
       int reg = b & 15, h = (b >> 4) & 1, ob = b >> 5;
-      int row = ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      out[o.b_off + b] = canon_b(P, op, row);
+      out[PACKED.wd_off + b] = P[CANON.density_w + ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
     }
   }
 }
@@ -246,7 +268,7 @@ size_t refnerf_packed_weights_bytes(int precision) {
 int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, void *stream) {
   if (!d_params || !d_packed) return fail(REFNERF_EINVAL, "refnerf_pack_weights: null pointer%s");
   if (precision == REFNERF_PREC_F32) {
-    dim3 grid(64, rn::NUM_OPS);
+    dim3 grid(64, rn::NUM_OPS + rn::NUM_TOPS + 1);
     hipLaunchKernelGGL(rn::pack_weights_f32, grid, dim3(256), 0, (hipStream_t)stream, d_params, (float *)d_packed);
   } else if (precision == REFNERF_PREC_BF16) {
     dim3 grid(8, rn::NUM_OPS);
@@ -280,7 +302,8 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
   if (cfg->n_in < 1 || cfg->n_in > 512) return fail(REFNERF_EINVAL, "n_in must be in [1,512]%s");
   if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16)
     return fail(REFNERF_EINVAL, "unknown precision mode%s");
-  if (cfg->training) return fail(REFNERF_EUNSUPPORTED, "training-mode level (density-gradient normals) not built yet%s");
+  if (cfg->training && cfg->precision != REFNERF_PREC_F32)
+    return fail(REFNERF_EUNSUPPORTED, "training-mode level (density-gradient normals) runs in the f32 precision mode only%s");
   if (!rays->d_origins || !rays->d_directions || !rays->d_viewdirs || !rays->d_radii || !rays->d_near || !rays->d_far)
     return fail(REFNERF_EINVAL, "refnerf_level_forward: null ray field%s");
   int rc = ensure_tables();
@@ -305,6 +328,7 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute((const void *)rn::level_fwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)rn::level_fwd_train_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)rn::level_fwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   rn::LevelArgs a;
@@ -335,6 +359,7 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
     HIP_TRY(hipEventRecord(g_events[g_events_used].first, st));
   }
   if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  else if (cfg->training) hipLaunchKernelGGL(rn::level_fwd_train_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else hipLaunchKernelGGL(rn::level_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());
   if (timed) {

@@ -69,8 +69,19 @@ constexpr int OP_HEADS = 8;
 constexpr int OP_RGB = 17;
 constexpr int REG_STEPS = 128;   /* 256 inputs / 2 */
 
+/* Transposed ("backward-data") ops, same operand format with A = W^T:
+ * D[in_row][sample] = sum_o W[o][in_row] * delta[o][sample]; K = the layer's 256
+ * outputs (all register steps), rows = the layer's inputs in blocks of 32.
+ *   TOP_SP(i), i = 1..7 : spatial layer i, rows 0..255 (8 blocks)
+ *   TOP_SP5_IPE / TOP_SP0: the 96 IPE inputs of layers 5 / 0 (3 blocks)
+ * (used by the density-gradient normals VJP of the training forward and by
+ * the backward kernel).  No bias: accumulators start at zero.
+ * WD: raw_density.weight[256] in accumulator layout (the VJP seed). */
+constexpr int NUM_TOPS = 9;
+constexpr int TOP_SP5_IPE = 7, TOP_SP0 = 8;    /* TOP index i-1 = spatial layer i main part, i = 1..7 */
+
 struct Op { int nob; int stride; int reg_steps; int lds_k; int lds_steps; int a_off; int b_off; };
-struct Packed { Op op[NUM_OPS]; int total; };
+struct Packed { Op op[NUM_OPS]; Op top[NUM_TOPS]; int wd_off; int total; };
 
 constexpr Packed make_packed() {
   Packed P{};
@@ -88,11 +99,20 @@ constexpr Packed make_packed() {
     p = (p + 3) & ~3;
     P.op[i] = o;
   }
+  for (int i = 0; i < NUM_TOPS; ++i) {
+    Op o{};
+    o.nob = (i < 7) ? 8 : 3;
+    o.stride = (i < 7) ? 8 : 4;
+    o.reg_steps = REG_STEPS;
+    o.a_off = p; p += o.reg_steps * 64 * o.stride;
+    o.b_off = -1;
+    P.top[i] = o;
+  }
+  P.wd_off = p; p += 8 * 32;
   P.total = p + 4 * 64 * 8;   /* tail pad: the A prefetch runs PF steps past an op */
   return P;
 }
 constexpr Packed PACKED = make_packed();
-
 
 /* ---------------- bf16 MFMA operand image ----------------
  * Same 18 ops on v_mfma_f32_32x32x16_bf16 (K = 16 per step), two 32-sample

@@ -180,6 +180,7 @@ __device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratc
 struct SampleHeads {
   float density, rough, dot;
   float tint[3], raw_dif[3], npred[3], gp[3], refd[3];
+  float normals[3] = {0.0f, 0.0f, 0.0f};   /* density-gradient normals (training forward) */
 };
 template <bool FAST = false>
 __device__ __forceinline__ void sample_heads(const refnerf_level_cfg &cfg, float raw_density, const float gp[3],
@@ -242,7 +243,7 @@ __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHea
     PS[g * NPS + PS_SPC + i] = spc[i];
     PS[g * NPS + PS_NPRED + i] = s.npred[i];
     PS[g * NPS + PS_TINT + i] = s.tint[i];
-    PS[g * NPS + PS_NORMALS + i] = 0.0f;
+    PS[g * NPS + PS_NORMALS + i] = s.normals[i];
     PS[g * NPS + PS_GP + i] = s.gp[i];
   }
 }
@@ -273,6 +274,7 @@ __device__ __forceinline__ void history_flush(const LevelArgs &A, const float *P
   vec3(A.out.d_normals_pred, PS_NPRED);
   vec3(A.out.d_grad_pred, PS_GP);
   vec3(A.out.d_tint, PS_TINT);
+  if (A.cfg.training) vec3(A.out.d_normals, PS_NORMALS);
 }
 
 /* P7: alpha weights + compositing, one wave per ray (render.py:132-149, 152-254). */

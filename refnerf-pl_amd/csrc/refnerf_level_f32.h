@@ -34,8 +34,26 @@ __device__ __forceinline__ void load_a(__amdgpu_buffer_rsrc_t rs, int voff, int 
       v4f y = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, 0));
       a[4] = y[0]; a[5] = y[1]; a[6] = y[2]; a[7] = y[3];
     }
+  } else if constexpr (STRIDE == 4) {
+    v4f x = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+#pragma unroll
+    for (int i = 0; i < NOB; ++i) a[i] = x[i];
   } else {
     a[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+  }
+}
+
+/* A vector stored in accumulator layout [ob][h][16] (bias images, WD). */
+template <int NOB>
+__device__ __forceinline__ void load_acc(__amdgpu_buffer_rsrc_t rs, int off, int h, v16f (&out)[NOB]) {
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+    v4f b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      b[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, h * 64 + q * 16, off * 4 + ob * 128, 0));
+    out[ob] = (v16f){b[0][0], b[0][1], b[0][2], b[0][3], b[1][0], b[1][1], b[1][2], b[1][3],
+                     b[2][0], b[2][1], b[2][2], b[2][3], b[3][0], b[3][1], b[3][2], b[3][3]};
   }
 }
 
@@ -46,7 +64,7 @@ __device__ __forceinline__ void load_a(__amdgpu_buffer_rsrc_t rs, int voff, int 
  * of step s+PF" so that hipcc cannot sink the loads back to their uses (it
  * otherwise emits load; s_waitcnt vmcnt(0); mfma).  lds_steps % PF == 0. */
 constexpr int PF = 3;
-template <int NOB, int STRIDE, bool HAS_REG>
+template <int NOB, int STRIDE, bool HAS_REG, bool BIAS = true>
 __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
                                         const v16f (&in)[8], v16f (&out)[NOB], const float *xl,
                                         int lds_steps) {
@@ -57,14 +75,12 @@ __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, in
 #pragma unroll
   for (int d = 0; d < PF; ++d) load_a<NOB, STRIDE>(rs, voff, soff + d * STEP_BYTES, a[d]);
   soff += PF * STEP_BYTES;
+  if constexpr (BIAS) load_acc<NOB>(rs, b_off, h, out);
+  else {
 #pragma unroll
-  for (int ob = 0; ob < NOB; ++ob) {
-    v4f b[4];
+    for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      b[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, h * 64 + q * 16, b_off * 4 + ob * 128, 0));
-    out[ob] = (v16f){b[0][0], b[0][1], b[0][2], b[0][3], b[1][0], b[1][1], b[1][2], b[1][3],
-                     b[2][0], b[2][1], b[2][2], b[2][3], b[3][0], b[3][1], b[3][2], b[3][3]};
+      for (int r = 0; r < 16; ++r) out[ob][r] = 0.0f;
   }
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (HAS_REG) {
@@ -104,8 +120,84 @@ __device__ __forceinline__ void relu_into(const v16f (&out)[8], v16f (&in)[8]) {
     for (int r = 0; r < 16; ++r) in[ob][r] = fmaxf(out[ob][r], 0.0f);
 }
 
+/* ReLU that also records the sign pattern: bit (16*(ob&1) + r) of mk[ob>>1]. */
+__device__ __forceinline__ void relu_mask_into(const v16f (&out)[8], v16f (&in)[8], unsigned (&mk)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) mk[q] = 0u;
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool p = out[ob][r] > 0.0f;          /* relu'(0) = 0, as torch */
+      in[ob][r] = p ? out[ob][r] : 0.0f;
+      mk[ob >> 1] |= p ? (1u << (16 * (ob & 1) + r)) : 0u;
+    }
+}
+/* in = out where the recorded ReLU was active, else 0 (delta through a ReLU). */
+__device__ __forceinline__ void masked_into(const v16f (&out)[8], v16f (&in)[8], const unsigned (&mk)[4]) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) in[ob][r] = ((mk[ob >> 1] >> (16 * (ob & 1) + r)) & 1u) ? out[ob][r] : 0.0f;
+}
 
-__global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) {
+/* Contribution of this lane's 48 IPE-gradient rows to d(raw_density)/d(lifted
+ * mean) (coord.py:119-126 differentiated: d/dx [e*sin(r(x*2^j))] = e*cos(r)*2^j,
+ * the variance path is detached with the rest of the sample geometry). */
+__device__ __forceinline__ void ipe_vjp_accum(const v16f (&gi)[3], const float lm[3], const float lv[3], int h, float gl[3]) {
+#pragma unroll
+  for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int cb = k >= 48, kk = cb ? k - 48 : k;
+      const int j = kk / 3, b = kk - 3 * j;
+      const float m = (b == 0) ? lm[0] : (b == 1 ? lm[1] : lm[2]);
+      const float vv = (b == 0) ? lv[0] : (b == 1 ? lv[1] : lv[2]);
+      const float sc = __builtin_ldexpf(1.0f, j), sc2 = __builtin_ldexpf(1.0f, 2 * j);
+      float x = m * sc;
+      if (cb) x = x + HALF_PI_F;
+      const float e = expf(-0.5f * (vv * sc2));
+      const float t = ((gi[blk][r] * e) * cosf(safe_arg(x))) * sc;
+      if (b == 0) gl[0] += t; else if (b == 1) gl[1] += t; else gl[2] += t;
+    }
+}
+
+/* Density-gradient normals (models.py:603-609): VJP of raw_density through the
+ * spatial MLP (transposed packed ops, recorded ReLU masks) and the IPE, then
+ * -normalize.  `in`/`out` are scratch; M[l] = mask of layer l (consumed). */
+__device__ __forceinline__ void density_normals(__amdgpu_buffer_rsrc_t rs, int lane, int h, v16f (&in)[8], v16f (&out)[8],
+                                                unsigned (&M)[8][4], const float lm[3], const float lv[3],
+                                                const float *xl, float nrm_out[3]) {
+  load_acc<8>(rs, PACKED.wd_off, h, out);
+  masked_into(out, in, M[7]);
+  float gl[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+  for (int i = 7; i >= 0; --i) {
+    if (i == 5 || i == 0) {
+      v16f gi[3];
+      gemm_op<3, 4, true, false>(rs, PACKED.top[i == 5 ? TOP_SP5_IPE : TOP_SP0].a_off, 0, lane, h, in, gi, xl, 0);
+      ipe_vjp_accum(gi, lm, lv, h, gl);
+    }
+    if (i > 0) {
+      gemm_op<8, 8, true, false>(rs, PACKED.top[i - 1].a_off, 0, lane, h, in, out, xl, 0);
+#pragma unroll
+      for (int l = 7; l > 0; --l)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[l][q] = M[l - 1][q];
+      masked_into(out, in, M[7]);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 3; ++b) gl[b] += __shfl_xor(gl[b], 32, 64);
+  const float gx[3] = {-gl[2], -gl[1], -gl[0]};            /* basis^T (octahedron/1: lifted = (-z,-y,-x)) */
+  const float ng = sqrtf(fmaxf((gx[0] * gx[0] + gx[1] * gx[1]) + gx[2] * gx[2], EPS32));
+#pragma unroll
+  for (int b = 0; b < 3; ++b) nrm_out[b] = -(gx[b] / ng);
+}
+
+template <bool TRAIN>
+__device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples;
@@ -144,11 +236,11 @@ __global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) {
       v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
     }
     /* P1: conical frustum -> lifted Gaussian -> IPE (half 0: sin, half 1: cos) */
+    float lm[3], lv[3];
     {
       float radius = A.rays.d_radii[rayc];
       const float *td = TD + (valid ? rl : 0) * (N + 1);
       float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
-      float lm[3], lv[3];
       cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
 #pragma unroll 1
       for (int j = 0; j < 16; ++j)
@@ -158,12 +250,19 @@ __global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) {
     wave_sync();
 
     /* P2: spatial MLP (models.py:576-580) */
+    unsigned M[TRAIN ? 8 : 1][4];                /* ReLU masks of the spatial layers (training) */
     gemm_op<8, 8, false>(rs, PACKED.op[0].a_off, PACKED.op[0].b_off, lane, h, in, out, xl, PACKED.op[0].lds_steps);
-    relu_into(out, in);
+    if constexpr (TRAIN) relu_mask_into(out, in, M[7]); else relu_into(out, in);
 #pragma unroll 1
     for (int op = 1; op < 8; ++op) {
       gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
-      relu_into(out, in);
+      if constexpr (TRAIN) {
+#pragma unroll
+        for (int l = 0; l < 7; ++l)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) M[l][q] = M[l + 1][q];
+        relu_mask_into(out, in, M[7]);
+      } else relu_into(out, in);
     }
     /* P3: heads (models.py:582,613,634-645): 4 bottleneck blocks + 1 scalar block */
     {
@@ -182,8 +281,10 @@ __global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) {
     }
     wave_sync();
 
-    /* P4: activations, reflection, IDE (models.py:611-686) */
     SampleHeads sh;
+    if constexpr (TRAIN) density_normals(rs, lane, h, in, out, M, lm, lv, xl, sh.normals);
+
+    /* P4: activations, reflection, IDE (models.py:611-686) */
     {
       float gp[3], raw_dif[3], raw_tint[3];
 #pragma unroll
@@ -228,5 +329,9 @@ __global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) {
 
   composite_phase(A, TD, XP, PS, n_tot, ray0, wave, lane);   /* P7 */
 }
+
+__global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false>(A); }
+/* training forward: + density-gradient normals (models.py:603-609) */
+__global__ __launch_bounds__(NTHREADS) void level_fwd_train_f32(const LevelArgs A) { level_fwd_f32_body<true>(A); }
 
 }  // namespace rn

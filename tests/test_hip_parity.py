@@ -138,6 +138,33 @@ def test_level_forward_vs_oracle_and_reference(hip, O, name):
         np.testing.assert_allclose(res["r_percentiles"], pc, rtol=0, atol=2e-5)
 
 
+TRAIN_CASES = ["model_blender_sharp_train", "model_llff_linear_train"]
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_training_forward_density_normals(hip, O, name):
+    """Training-mode level forward: density-gradient normals (models.py:603-609)
+    through the transposed-weight VJP; everything else as in eval."""
+    g = load_golden(name)
+    P = params_from_golden(g)
+    rays = rays_from_golden(g)
+    kw, lv = cfg_from_bindings(g["bindings"])
+    ref = O.model_forward(P, rays, training=1, **lv, **kw)
+    outs = run_hip_model(hip, P, rays, dict(kw, training=1), lv)
+    for L, (res, orc) in enumerate(zip(outs, ref)):
+        assert np.mean(res["bin_idx"] == orc["bin_idx"]) == 1.0
+        for k in HIST_KEYS:
+            tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 5e-6)
+            np.testing.assert_allclose(res[k], orc[k].reshape(res[k].shape), rtol=0, atol=tol, err_msg=f"L{L} {k}")
+        assert np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max() <= 1e-4
+        for refn, bulk, tail in ((orc["normals"], 2e-5, 0.99), (g[f"L{L}_h_normals"], 1e-4, 0.97)):
+            err = np.abs(res["normals"] - refn.reshape(res["normals"].shape)).max(-1)
+            # ill-conditioned where the density gradient is tiny: bulk tight, tail loose
+            assert np.median(err) < bulk and np.mean(err < 1e-3) > tail, (L, np.median(err), np.mean(err < 1e-3))
+        np.testing.assert_allclose(res["r_normals"], g[f"L{L}_r_normals"], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(res["r_normals"], orc["r_normals"], rtol=0, atol=5e-4)
+
+
 def test_model_api_matches_reference_contract(hip):
     """Model.__call__ through the host mirror: keys, shapes, dtypes and values."""
     from refnerf_pl_amd import configs, models, utils
