@@ -128,6 +128,39 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg,
                           const float *d_sdist_in, const float *d_weights_in,
                           const refnerf_level_out *out, void *stream);
 
+/* ---- training (the autograd graph of the same level) ----
+ * With cfg->training = 1 (f32 precision mode) refnerf_level_forward also emits
+ * the density-gradient normals (models.py:603-609).  refnerf_level_backward is
+ * what `loss.backward()` runs for one level in the reference
+ * (internal/nerf_system.py training_step -> autograd through models.py:162-306):
+ * given the level's saved forward outputs and dL/d(outputs) for the outputs the
+ * reference's losses read (train_utils.py:33-204: rendering rgb, history
+ * weights, history normals_pred; the density-gradient normals, sdist and the
+ * resampling inputs are detached there as well), it ACCUMULATES dL/d(params)
+ * into d_param_grads (canonical blob, REFNERF_NUM_PARAMS floats).
+ * The MLP forward is recomputed inside; d_workspace holds the per-sample layer
+ * inputs / output gradients the weight-gradient GEMM contracts. */
+typedef struct refnerf_level_saved {
+  const float *d_sdist;     /* [R,N+1] refnerf_level_out.d_sdist   */
+  const float *d_density;   /* [R,N]                               */
+  const float *d_rgb;       /* [R,N,3]                             */
+  const float *d_weights;   /* [R,N]                               */
+} refnerf_level_saved;
+
+typedef struct refnerf_level_grads {
+  const float *d_g_r_rgb;         /* [R,3]   dL/d renderings['rgb']                  */
+  const float *d_g_weights;       /* [R,N]   dL/d ray_history['weights'], or NULL    */
+  const float *d_g_normals_pred;  /* [R,N,3] dL/d ray_history['normals_pred'], or NULL */
+} refnerf_level_grads;
+
+size_t refnerf_backward_workspace_bytes(int32_t R, int32_t n_samples);
+
+int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg,
+                           const refnerf_rays *rays, int32_t R,
+                           const refnerf_level_saved *saved, const refnerf_level_grads *grads,
+                           float *d_param_grads, void *d_workspace, size_t workspace_bytes,
+                           void *stream);
+
 /* Stage entry points (same device code as the fused kernel; used by the
  * parity tests and for drop-in use of the individual reference functions). */
 

@@ -18,6 +18,7 @@ PREC_F32, PREC_BF16 = 0, 1
 SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 4}
 
 _FP = C.c_void_p
+NUM_PARAMS = 1110158   # REFNERF_NUM_PARAMS
 
 
 class LevelCfg(C.Structure):
@@ -41,6 +42,14 @@ OUT_FIELDS = ("d_sdist", "d_bin_idx", "d_density", "d_rgb", "d_normals", "d_norm
 
 class LevelOut(C.Structure):
     _fields_ = [(n, _FP) for n in OUT_FIELDS]
+
+
+class LevelSaved(C.Structure):
+    _fields_ = [(n, _FP) for n in ("d_sdist", "d_density", "d_rgb", "d_weights")]
+
+
+class LevelGrads(C.Structure):
+    _fields_ = [(n, _FP) for n in ("d_g_r_rgb", "d_g_weights", "d_g_normals_pred")]
 
 
 class HipLibraryError(RuntimeError):
@@ -72,6 +81,10 @@ def lib():
         L.refnerf_pack_weights.argtypes = [_FP, _FP, C.c_int, _FP]
         L.refnerf_level_forward.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
                                             _FP, _FP, C.POINTER(LevelOut), _FP]
+        L.refnerf_backward_workspace_bytes.restype = C.c_size_t
+        L.refnerf_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.refnerf_level_backward.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
+                                             C.POINTER(LevelSaved), C.POINTER(LevelGrads), _FP, _FP, C.c_size_t, _FP]
         L.refnerf_sample_intervals.argtypes = [_FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                                _FP, _FP, _FP]
         L.refnerf_integrated_pos_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
@@ -182,6 +195,53 @@ def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, histo
     w = weights_in.to(torch.float32).contiguous()
     check(lib().refnerf_level_forward(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out), stream_ptr()))
     return res
+
+
+_workspace = {}
+
+
+def backward_workspace(R: int, n_samples: int, device) -> torch.Tensor:
+    """Cached byte workspace for refnerf_level_backward (grown on demand, one per device)."""
+    need = lib().refnerf_backward_workspace_bytes(R, n_samples)
+    ws = _workspace.get(device)
+    if ws is None or ws.numel() < need:
+        _workspace[device] = None
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _workspace[device] = ws
+    return ws
+
+
+def level_backward(packed, cfg: LevelCfg, rays: dict, saved: dict, g_r_rgb, g_weights, g_normals_pred,
+                   param_grads: torch.Tensor):
+    """Backward of one level: accumulates dL/d(params) into `param_grads`
+    (canonical blob).  saved: dict with sdist, density, rgb, weights of the
+    training forward; g_*: upstream gradients (g_weights / g_normals_pred may
+    be None)."""
+    require_device()
+    R = rays["origins"].shape[0]
+    N = cfg.n_samples
+    rs = RaysStruct()
+    keep = []
+    for name in ("origins", "directions", "viewdirs", "radii", "near", "far"):
+        t = rays[name].to(torch.float32).contiguous()
+        keep.append(t)
+        setattr(rs, "d_" + name, t.data_ptr())
+    sv = LevelSaved()
+    for name in ("sdist", "density", "rgb", "weights"):
+        t = saved[name].to(torch.float32).contiguous()
+        keep.append(t)
+        setattr(sv, "d_" + name, t.data_ptr())
+    gr = LevelGrads()
+    for name, t in (("d_g_r_rgb", g_r_rgb), ("d_g_weights", g_weights), ("d_g_normals_pred", g_normals_pred)):
+        if t is not None:
+            t = t.to(torch.float32).contiguous()
+            keep.append(t)
+            setattr(gr, name, t.data_ptr())
+    assert param_grads.dtype == torch.float32 and param_grads.is_contiguous() and param_grads.numel() == NUM_PARAMS
+    ws = backward_workspace(R, N, param_grads.device)
+    check(lib().refnerf_level_backward(ptr(packed), C.byref(cfg), C.byref(rs), R, C.byref(sv), C.byref(gr),
+                                       ptr(param_grads), ptr(ws), ws.numel(), stream_ptr()))
+    return param_grads
 
 
 def sample_intervals(t, logits, n, smin=0.0, smax=1.0):

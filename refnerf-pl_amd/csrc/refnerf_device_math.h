@@ -167,4 +167,88 @@ __device__ __forceinline__ void ide_eval(float x, float y, float z, float kappa_
   }
 }
 
+/* ---- derivatives used by the backward kernel ---- */
+__device__ __forceinline__ float softplus_grad(float x) { return x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x)); }
+/* d linear_to_srgb / du (image.py:51-59) */
+__device__ __forceinline__ float srgb_grad(float u) {
+  if (u <= 0.0031308f) return (float)(323.0 / 25.0);
+  if (!(u > EPS32)) return 0.0f;
+  return (211.0f / 200.0f) * (float)(5.0 / 12.0) * powf(u, (float)(5.0 / 12.0) - 1.0f);
+}
+
+/* Backward of a 3-channel "optionally normalise by max(max_c, 1), optionally
+ * sRGB-encode, clip to [0,1]" map (models.py:712-723 and render.py:186-216),
+ * with torch's subgradient conventions (clip passes on the closed interval,
+ * maximum splits ties 1/2, amax shares among ties).  pre[]: inputs of the map;
+ * g[]: upstream gradient in, gradient w.r.t. pre out. */
+__device__ __forceinline__ void colour_map_backward(const float pre[3], bool normed, bool srgb, float g[3]) {
+  float norm = 1.0f;
+  const float mxc = fmaxf(fmaxf(pre[0], pre[1]), pre[2]);
+  if (normed) norm = fmaxf(mxc, 1.0f);
+  float gu[3], gnorm = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float u = pre[c] / norm;
+    float yv = srgb ? linear_to_srgb(u) : u;
+    float pass = (yv >= 0.0f && yv <= 1.0f) ? 1.0f : 0.0f;
+    float dy = srgb ? srgb_grad(u) : 1.0f;
+    gu[c] = g[c] * pass * dy;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { g[c] = gu[c] / norm; gnorm += -gu[c] * pre[c] / (norm * norm); }
+  if (normed) {
+    float gm = (mxc > 1.0f) ? gnorm : (mxc == 1.0f ? 0.5f * gnorm : 0.0f);
+    if (gm != 0.0f) {
+      int cnt = 0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) cnt += (pre[c] == mxc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) if (pre[c] == mxc) g[c] += gm / (float)cnt;
+    }
+  }
+}
+
+/* Gradient of ide_eval (stable form) w.r.t. (x,y,z) and kappa_inv.
+ * g(q) = upstream gradient of output q (0..35 real parts, 36..71 imaginary). */
+template <typename G>
+__device__ __forceinline__ void ide_grad(float x, float y, float z, float kappa_inv, G g, float (&gxyz)[3], float &gkappa) {
+  const float att1 = expf(-1.0f * kappa_inv), att2 = expf(-3.0f * kappa_inv), att4 = expf(-10.0f * kappa_inv);
+  const float att8 = expf(-36.0f * kappa_inv), att16 = expf(-136.0f * kappa_inv);
+  float pr = 1.0f, pi = 0.0f, prm1 = 0.0f, pim1 = 0.0f;
+  float gx = 0.0f, gy = 0.0f, gz = 0.0f, gk = 0.0f;
+#pragma unroll
+  for (int m = 0; m <= 16; ++m) {
+    if (m > 0) { prm1 = pr; pim1 = pi; pr = prm1 * x - pim1 * y; pi = prm1 * y + pim1 * x; }
+    float gpr = 0.0f, gpi = 0.0f;
+    float tm2 = 0.0f, tm1 = IDE_C[m], dm2 = 0.0f, dm1 = 0.0f;
+#pragma unroll
+    for (int l = m; l <= 16; ++l) {
+      float tl, dl;
+      if (l == m) { tl = IDE_C[m]; dl = 0.0f; }
+      else {
+        tl = IDE_A[m][l] * (z * tm1 - IDE_B[m][l] * tm2);
+        dl = IDE_A[m][l] * (tm1 + z * dm1 - IDE_B[m][l] * dm2);
+        tm2 = tm1; tm1 = tl; dm2 = dm1; dm1 = dl;
+      }
+      if (l == 1 || l == 2 || l == 4 || l == 8 || l == 16) {
+        const int idx = (l == 1 ? 0 : l == 2 ? 2 : l == 4 ? 5 : l == 8 ? 10 : 19) + m;
+        const float sigma = (float)(0.5 * l * (l + 1));
+        const float att = (l == 1 ? att1 : l == 2 ? att2 : l == 4 ? att4 : l == 8 ? att8 : att16);
+        const float gre = g(idx), gim = g(IDE_TERMS + idx);
+        const float s = tl * att;
+        const float gs = gre * pr + gim * pi;
+        gpr += gre * s; gpi += gim * s;
+        gz += gs * att * dl;
+        gk += gs * tl * (-sigma * att);
+      }
+    }
+    if (m > 0) {
+      gx += (float)m * (gpr * prm1 + gpi * pim1);
+      gy += (float)m * (-gpr * pim1 + gpi * prm1);
+    }
+  }
+  gxyz[0] = gx; gxyz[1] = gy; gxyz[2] = gz;
+  gkappa = gk;
+}
+
 }  // namespace rn

@@ -26,6 +26,8 @@
 #include "refnerf_level_common.h"
 #include "refnerf_level_f32.h"
 #include "refnerf_level_bf16.h"
+#include "refnerf_level_bwd_f32.h"
+#include "refnerf_wgrad.h"
 
 namespace rn {
 
@@ -101,24 +103,34 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
       }
     }
   } else if (op < NUM_OPS + NUM_TOPS) {
-    /* transposed spatial layers: A[step][lane][ob] = W[o = kidx(step,h)][in_row] */
+    /* transposed ops: A[step][lane][ob] = W[o = k slot][in_row] (see refnerf_layout.h) */
     const int t = op - NUM_OPS;
     const Op o = PACKED.top[t];
-    const int layer = (t < 7) ? t + 1 : (t == TOP_SP5_IPE ? 5 : 0);
-    const int col0 = (t == TOP_SP5_IPE) ? WIDTH : 0;   /* canonical input column of row 0 */
-    int n_a = o.reg_steps * 64 * o.stride;
+    const TopSrc src = PACKED.top_src[t];
+    int n_a = (o.reg_steps + o.lds_steps) * 64 * o.stride;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_a; e += gridDim.x * blockDim.x) {
       int ob = e % o.stride, lane = (e / o.stride) % 64, step = e / (o.stride * 64);
       int h = lane >> 5, in_row = ob * 32 + (lane & 31);
-      int kb = step >> 4, r = step & 15;
-      int oo = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;   /* output feature feeding this k slot */
-      out[o.a_off + e] = (ob < o.nob) ? canon_w(P, layer, oo, col0 + in_row) : 0.0f;
+      float v = 0.0f;
+      if (ob < o.nob) {
+        if (t == TOP_HEADS) {
+          int hr = 2 * step + h;                               /* head row feeding this k slot */
+          v = (hr < HROWS) ? canon_w(P, OP_HEADS, hr, in_row) : 0.0f;
+        } else {
+          int kb = step >> 4, r = step & 15;
+          int oo = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;   /* output feature feeding this k slot */
+          v = canon_w(P, src.fwd_op, oo, src.col0 + in_row);
+        }
+      }
+      out[o.a_off + e] = v;
     }
   } else {
-    /* WD: raw_density.weight in accumulator layout [ob][h][16] */
-    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < 8 * 32; b += gridDim.x * blockDim.x) {
-      int reg = b & 15, h = (b >> 4) & 1, ob = b >> 5;
-      out[PACKED.wd_off + b] = P[CANON.density_w + ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
+    /* WD / WRGB: raw_density.weight and rgb_layer.weight rows in accumulator layout [ob][h][16] */
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < 4 * 8 * 32; b += gridDim.x * blockDim.x) {
+      int reg = b & 15, h = (b >> 4) & 1, ob = (b >> 5) & 7, which = b >> 8;
+      int k = ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (which == 0) out[PACKED.wd_off + (b & 255)] = P[CANON.density_w + k];
+      else out[PACKED.wrgb_off + (which - 1) * 256 + (b & 255)] = P[CANON.rgb_w + (which - 1) * WIDTH + k];
     }
   }
 }
@@ -376,6 +388,81 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
       fprintf(stderr, "  | dma-wait %lld barrier-wait %lld\n", hbuf[w * 32 + 20], hbuf[w * 32 + 21]);
     }
   }
+  return REFNERF_OK;
+}
+
+namespace {
+struct BwdPlan { long long S, pitch; int slices, k_per_slice; size_t act_off, delta_off, part_off, total; };
+BwdPlan bwd_plan(int R, int N) {
+  BwdPlan p;
+  p.S = (long long)R * N;
+  p.pitch = (p.S + 127) / 128 * 128;
+  long long sl = (p.S + 2047) / 2048;
+  p.slices = (int)(sl < 1 ? 1 : (sl > 32 ? 32 : sl));
+  long long per = (p.S + p.slices - 1) / p.slices;
+  p.k_per_slice = (int)((per + rn::WG_KT - 1) / rn::WG_KT * rn::WG_KT);
+  p.act_off = 0;
+  p.delta_off = p.act_off + sizeof(float) * (size_t)rn::ACT_ROWS * p.pitch;
+  p.part_off = p.delta_off + sizeof(float) * (size_t)rn::DEL_ROWS * p.pitch;
+  p.total = p.part_off + sizeof(float) * (size_t)p.slices * rn::NUM_PARAMS;
+  return p;
+}
+}  // namespace
+
+size_t refnerf_backward_workspace_bytes(int32_t R, int32_t n_samples) {
+  if (R <= 0 || n_samples <= 1) return 0;
+  return bwd_plan(R, n_samples).total;
+}
+
+int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays, int32_t R,
+                           const refnerf_level_saved *saved, const refnerf_level_grads *grads, float *d_param_grads,
+                           void *d_workspace, size_t workspace_bytes, void *stream) {
+  if (!d_packed || !cfg || !rays || !saved || !grads || !d_param_grads || !d_workspace)
+    return fail(REFNERF_EINVAL, "refnerf_level_backward: null pointer%s");
+  if (R <= 0) return fail(REFNERF_EINVAL, "refnerf_level_backward: R must be positive%s");
+  if (cfg->n_samples <= 1) return fail(REFNERF_EINVAL, "num_samples must be > 1%s");
+  if (cfg->ray_shape != 0 && cfg->ray_shape != 1) return fail(REFNERF_EINVAL, "ray_shape must be 'cone' or 'cylinder'%s");
+  if (cfg->precision != REFNERF_PREC_F32)
+    return fail(REFNERF_EUNSUPPORTED, "refnerf_level_backward runs in the f32 precision mode only%s");
+  if (!saved->d_sdist || !saved->d_density || !saved->d_rgb || !saved->d_weights || !grads->d_g_r_rgb)
+    return fail(REFNERF_EINVAL, "refnerf_level_backward: null saved tensor / rendering gradient%s");
+  if (!rays->d_origins || !rays->d_directions || !rays->d_viewdirs || !rays->d_radii || !rays->d_near || !rays->d_far)
+    return fail(REFNERF_EINVAL, "refnerf_level_backward: null ray field%s");
+  int rc = ensure_tables();
+  if (rc) return rc;
+  const int N = cfg->n_samples;
+  const BwdPlan plan = bwd_plan(R, N);
+  if (workspace_bytes < plan.total) return fail(REFNERF_EINVAL, "refnerf_level_backward: workspace too small (see refnerf_backward_workspace_bytes)%s");
+  const int rpw = rays_per_wg(N, rn::T_TILE);
+  const size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + rpw * (N + 1) + rn::NGS * rpw * N + 8);
+  if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget%s");
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
+    (void)hipFuncSetAttribute((const void *)rn::level_bwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  char *ws = (char *)d_workspace;
+  rn::BwdArgs a;
+  a.packed = d_packed;
+  a.cfg = *cfg;
+  a.rays = *rays;
+  a.R = R;
+  a.rpw = rpw;
+  a.sdist = saved->d_sdist; a.density = saved->d_density; a.rgb = saved->d_rgb; a.weights = saved->d_weights;
+  a.g_r_rgb = grads->d_g_r_rgb; a.g_weights = grads->d_g_weights; a.g_npred = grads->d_g_normals_pred;
+  a.act = (float *)(ws + plan.act_off);
+  a.delta = (float *)(ws + plan.delta_off);
+  a.pitch = plan.pitch;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rn::level_bwd_f32, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
+  HIP_TRY(hipGetLastError());
+  rn::WgradArgs w;
+  w.act = a.act; w.delta = a.delta; w.pitch = plan.pitch; w.S = plan.S; w.k_per_slice = plan.k_per_slice;
+  w.part = (float *)(ws + plan.part_off);
+  const int slices = (int)((plan.S + plan.k_per_slice - 1) / plan.k_per_slice);
+  hipLaunchKernelGGL(rn::wgrad_kernel, dim3(rn::WJOBS.tiles, slices), dim3(256), 0, st, w);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(rn::wgrad_reduce, dim3(1024), dim3(256), 0, st, w.part, slices, d_param_grads);
+  HIP_TRY(hipGetLastError());
   return REFNERF_OK;
 }
 

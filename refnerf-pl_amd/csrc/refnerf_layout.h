@@ -72,16 +72,24 @@ constexpr int REG_STEPS = 128;   /* 256 inputs / 2 */
 /* Transposed ("backward-data") ops, same operand format with A = W^T:
  * D[in_row][sample] = sum_o W[o][in_row] * delta[o][sample]; K = the layer's 256
  * outputs (all register steps), rows = the layer's inputs in blocks of 32.
- *   TOP_SP(i), i = 1..7 : spatial layer i, rows 0..255 (8 blocks)
- *   TOP_SP5_IPE / TOP_SP0: the 96 IPE inputs of layers 5 / 0 (3 blocks)
- * (used by the density-gradient normals VJP of the training forward and by
- * the backward kernel).  No bias: accumulators start at zero.
- * WD: raw_density.weight[256] in accumulator layout (the VJP seed). */
-constexpr int NUM_TOPS = 9;
-constexpr int TOP_SP5_IPE = 7, TOP_SP0 = 8;    /* TOP index i-1 = spatial layer i main part, i = 1..7 */
+ *   TOP_SP(i)  i = 1..7 : spatial layer i, input rows 0..255        (8 blocks)
+ *   TOP_SP5_IPE / TOP_SP0: the 96 IPE inputs of layers 5 / 0        (3 blocks)
+ *   TOP_VD(i)  i = 1..7 : directional layer i, input rows 0..255    (8 blocks)
+ *   TOP_VD5_DIN / TOP_VD0: the 201 dir-encoding inputs of layers 5/0 (7 blocks, rows >= 201 zero)
+ *   TOP_HEADS : the 139 head rows transposed, K = head rows read from LDS
+ *               (72 LDS steps, rows >= 139 zero), output rows = the 256 features
+ * (used by the density-gradient normals VJP of the training forward and by the
+ * backward kernel).  No bias: accumulators start at zero.
+ * WD / WRGB: raw_density.weight[256] and rgb_layer.weight[3][256] in
+ * accumulator layout (seeds of the two backward chains). */
+constexpr int NUM_TOPS = 19;
+constexpr int TOP_SP5_IPE = 7, TOP_SP0 = 8, TOP_VD1 = 9, TOP_VD5_DIN = 16, TOP_VD0 = 17, TOP_HEADS = 18;
+constexpr int HEADS_T_STEPS = 72;           /* 144 padded head rows / 2 */
+constexpr int DIN_BLOCKS = 7;               /* 201 dir inputs -> 224 rows */
 
 struct Op { int nob; int stride; int reg_steps; int lds_k; int lds_steps; int a_off; int b_off; };
-struct Packed { Op op[NUM_OPS]; Op top[NUM_TOPS]; int wd_off; int total; };
+struct TopSrc { int fwd_op; int col0; };    /* forward op whose weight is transposed, first input column */
+struct Packed { Op op[NUM_OPS]; Op top[NUM_TOPS]; TopSrc top_src[NUM_TOPS]; int wd_off; int wrgb_off; int total; };
 
 constexpr Packed make_packed() {
   Packed P{};
@@ -101,18 +109,46 @@ constexpr Packed make_packed() {
   }
   for (int i = 0; i < NUM_TOPS; ++i) {
     Op o{};
-    o.nob = (i < 7) ? 8 : 3;
-    o.stride = (i < 7) ? 8 : 4;
-    o.reg_steps = REG_STEPS;
-    o.a_off = p; p += o.reg_steps * 64 * o.stride;
+    TopSrc t{};
+    if (i < 7) { o.nob = 8; t.fwd_op = i + 1; t.col0 = 0; }
+    else if (i == TOP_SP5_IPE) { o.nob = 3; t.fwd_op = 5; t.col0 = WIDTH; }
+    else if (i == TOP_SP0) { o.nob = 3; t.fwd_op = 0; t.col0 = 0; }
+    else if (i < TOP_VD5_DIN) { o.nob = 8; t.fwd_op = 9 + (i - TOP_VD1 + 1); t.col0 = 0; }
+    else if (i == TOP_VD5_DIN) { o.nob = DIN_BLOCKS; t.fwd_op = 14; t.col0 = WIDTH; }
+    else if (i == TOP_VD0) { o.nob = DIN_BLOCKS; t.fwd_op = 9; t.col0 = 0; }
+    else { o.nob = 8; t.fwd_op = OP_HEADS; t.col0 = 0; }
+    o.stride = (o.nob == 3) ? 4 : 8;
+    o.reg_steps = (i == TOP_HEADS) ? 0 : REG_STEPS;
+    o.lds_steps = (i == TOP_HEADS) ? HEADS_T_STEPS : 0;
+    o.lds_k = 2 * o.lds_steps;
+    o.a_off = p; p += (o.reg_steps + o.lds_steps) * 64 * o.stride;
     o.b_off = -1;
     P.top[i] = o;
+    P.top_src[i] = t;
   }
   P.wd_off = p; p += 8 * 32;
+  P.wrgb_off = p; p += 3 * 8 * 32;
   P.total = p + 4 * 64 * 8;   /* tail pad: the A prefetch runs PF steps past an op */
   return P;
 }
 constexpr Packed PACKED = make_packed();
+
+/* ---------------- backward workspace (weight-gradient operands) ----------------
+ * The backward kernel writes, for every sample s, the input of every linear
+ * layer (ACT) and the gradient w.r.t. its pre-activation output (DELTA) as
+ * [feature row][sample] fp32 matrices with row pitch `pitch` floats; the
+ * weight-gradient kernel then forms dW[o][k] = sum_s DELTA[o][s] * ACT[k][s].
+ * Row maps (all row counts multiples of 4): */
+constexpr int ACT_IPE = 0;                         /* 96: IPE features                     */
+constexpr int ACT_SP = ACT_IPE + IPE_DIM;          /* 8 x 256: spatial activations x0..x7  */
+constexpr int ACT_DIN = ACT_SP + 8 * WIDTH;        /* 204: [bottleneck | IDE | n.v | 0 0 0] */
+constexpr int ACT_VD = ACT_DIN + DIR_PAD;          /* 8 x 256: directional activations     */
+constexpr int ACT_ROWS = ACT_VD + 8 * WIDTH;       /* 4396 */
+constexpr int DEL_SP = 0;                          /* 8 x 256: spatial layer deltas         */
+constexpr int DEL_HEADS = DEL_SP + 8 * WIDTH;      /* 144: head rows (HROW_* order), 139 used */
+constexpr int DEL_VD = DEL_HEADS + 144;            /* 8 x 256: directional layer deltas     */
+constexpr int DEL_RGB = DEL_VD + 8 * WIDTH;        /* 4: rgb layer (3 used)                 */
+constexpr int DEL_ROWS = DEL_RGB + 4;              /* 4244 */
 
 /* ---------------- bf16 MFMA operand image ----------------
  * Same 18 ops on v_mfma_f32_32x32x16_bf16 (K = 16 per step), two 32-sample

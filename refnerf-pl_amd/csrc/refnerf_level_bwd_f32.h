@@ -1,0 +1,411 @@
+/*
+ * refnerf_level_bwd_f32.h -- backward of one level (fp32 MFMA).
+ *
+ * Same decomposition as the forward kernel (workgroup = 4 waves = RPW whole
+ * rays, 32-sample blocks per wave, transposed GEMMs with activations in the
+ * accumulator registers).  Nothing but the per-sample history that the
+ * training forward already wrote is read back: the MLP forward is recomputed
+ * here (recording the ReLU sign masks in registers), then the gradient runs
+ *   rendering -> alpha weights -> density / sample rgb / predicted normals
+ *   -> colour head -> directional MLP -> IDE / reflection -> heads -> spatial MLP
+ * through the transposed packed weights (refnerf_layout.h: TOP_*).
+ *
+ * Weight gradients are NOT accumulated here: every layer's input (ACT) and
+ * pre-activation gradient (DELTA) is streamed to HBM as [feature][sample]
+ * matrices and refnerf_wgrad.h contracts them over the sample axis.
+ *
+ * Restates the autograd of internal/models.py:533-750 + render.py:132-216
+ * (SURVEY.md A10); oracle: rn_level_train / mlp_backward.
+ */
+#pragma once
+#include "refnerf_level_f32.h"
+
+namespace rn {
+
+struct BwdArgs {
+  const void *packed;
+  refnerf_level_cfg cfg;
+  refnerf_rays rays;
+  int R;
+  int rpw;
+  const float *sdist;       /* [R,N+1] this level's sample edges (forward output) */
+  const float *density;     /* [R,N]   forward history                            */
+  const float *rgb;         /* [R,N,3]                                            */
+  const float *weights;     /* [R,N]                                              */
+  const float *g_r_rgb;     /* [R,3]   dL/d rendering rgb (after the render map)  */
+  const float *g_weights;   /* [R,N]   dL/d history weights, or NULL              */
+  const float *g_npred;     /* [R,N,3] dL/d history normals_pred, or NULL         */
+  float *act, *delta;       /* workspace matrices, row pitch `pitch` floats       */
+  long long pitch;
+};
+
+constexpr int NGS = 7;      /* per-sample upstream gradients in LDS: density, rgb[3], n_pred[3] */
+
+/* rows [row0 + 32*blk + row(r,h)] of a [rows][pitch] matrix, column gs: 128 B
+ * contiguous per (row, half-wave).  Uniform 64-bit row base + 32-bit lane offset. */
+template <int NB>
+__device__ __forceinline__ void store_rows(float *base, long long pitch, int row0, size_t gs, int h, bool valid, const v16f *x) {
+  char *ub = reinterpret_cast<char *>(base + (long long)row0 * pitch);
+  const unsigned voff = (unsigned)(((long long)(4 * h) * pitch + (long long)gs) * 4);
+  if (valid) {
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        *reinterpret_cast<float *>(ub + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch * 4 + voff) = x[blk][r];
+  }
+}
+__device__ __forceinline__ void store_row1(float *base, long long pitch, int row, size_t gs, float v) {
+  base[(long long)row * pitch + (long long)gs] = v;
+}
+
+/* Per-ray part of the backward (one wave per ray): rendering gradient through
+ * the render-time colour map (render.py:186-216), compositing (152-176) and
+ * the alpha weights (132-149) down to per-sample gradients in GS. */
+__device__ __forceinline__ void bwd_prologue(const BwdArgs &A, float *TD, float *GS, int ray0, int wave, int lane) {
+  const refnerf_level_cfg &cfg = A.cfg;
+  const int N = cfg.n_samples, rpw = A.rpw;
+  for (int rl = wave; rl < rpw; rl += 4) {
+    const int ray = ray0 + rl;
+    if (ray >= A.R) break;
+    float *td = TD + rl * (N + 1);
+    const float nearv = A.rays.d_near[ray], farv = A.rays.d_far[ray];
+    for (int k = lane; k <= N; k += 64) td[k] = s_to_t(A.sdist[(size_t)ray * (N + 1) + k], nearv, farv);
+    wave_sync();
+    const float dx = A.rays.d_directions[(size_t)ray * 3], dy = A.rays.d_directions[(size_t)ray * 3 + 1],
+                dz = A.rays.d_directions[(size_t)ray * 3 + 2];
+    const float norm_d = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float *wg = A.weights + (size_t)ray * N, *dg = A.density + (size_t)ray * N, *cg = A.rgb + (size_t)ray * N * 3;
+    const int C = (N + 63) / 64, i0 = lane * C;
+    float acc = 0.0f, s_rgb[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = i0; i < i0 + C && i < N; ++i) {
+      const float w = wg[i];
+      acc += w;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s_rgb[c] += w * cg[i * 3 + c];
+    }
+    acc = wave_sum(acc);
+    float pre[3], g_rgb[3];
+    const float bg_w = fmaxf(0.0f, 1.0f - acc);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { pre[c] = wave_sum(s_rgb[c]) + bg_w * cfg.bg_rgb; g_rgb[c] = A.g_r_rgb[(size_t)ray * 3 + c]; }
+    const int mode = cfg.render_srgb_mode;
+    if (mode != REFNERF_SRGB_NONE)
+      colour_map_backward(pre, mode == REFNERF_SRGB_NORM_LINEAR || mode == REFNERF_SRGB_NORM_SRGB,
+                          mode == REFNERF_SRGB_SRGB || mode == REFNERF_SRGB_NORM_SRGB, g_rgb);
+    const float gsum = (g_rgb[0] + g_rgb[1] + g_rgb[2]) * cfg.bg_rgb;
+    /* dL/dw_i and the two running sums of the weight backward */
+    double l_dd = 0.0, l_gw = 0.0;
+    for (int i = i0; i < i0 + C && i < N; ++i) {
+      float g = (g_rgb[0] * cg[i * 3] + g_rgb[1] * cg[i * 3 + 1]) + g_rgb[2] * cg[i * 3 + 2];
+      if (acc < 1.0f) g -= gsum;                              /* bg weight = max(0, 1 - acc) */
+      if (A.g_weights) g += A.g_weights[(size_t)ray * N + i];
+      l_dd += (double)(dg[i] * ((td[i + 1] - td[i]) * norm_d));
+      l_gw += (double)(g * wg[i]);
+    }
+    const double incl_dd = wave_scan_incl(l_dd, lane), incl_gw = wave_scan_incl(l_gw, lane);
+    const double tot_gw = __shfl(incl_gw, 63, 64);
+    double cum = incl_dd - l_dd;                              /* optical depth in front of sample i */
+    double run_gw = incl_gw - l_gw;
+    for (int i = i0; i < i0 + C && i < N; ++i) {
+      const float w = wg[i];
+      float g = (g_rgb[0] * cg[i * 3] + g_rgb[1] * cg[i * 3 + 1]) + g_rgb[2] * cg[i * 3 + 2];
+      if (acc < 1.0f) g -= gsum;
+      if (A.g_weights) g += A.g_weights[(size_t)ray * N + i];
+      const float delta = (td[i + 1] - td[i]) * norm_d;
+      const float dd = dg[i] * delta;
+      run_gw += (double)(g * w);
+      const double suffix = tot_gw - run_gw;                  /* sum_{j>i} g_j w_j */
+      /* w_i = (1 - e^{-dd_i}) e^{-cum_i} */
+      const float g_dd = g * expf(-dd) * expf(-(float)cum) - (float)suffix;
+      cum += (double)dd;
+      float g_density = g_dd * delta;
+      if (cfg.opaque_background && i == N - 1) g_density = 0.0f;
+      float *gs = GS + (size_t)(rl * N + i) * NGS;
+      gs[0] = g_density;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gs[1 + c] = w * g_rgb[c];
+        gs[4 + c] = A.g_npred ? A.g_npred[((size_t)ray * N + i) * 3 + c] : 0.0f;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ v16f load_acc_blk(__amdgpu_buffer_rsrc_t rs, int off, int h, int ob) {
+  v4f b[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    b[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, h * 64 + q * 16, off * 4 + ob * 128, 0));
+  return (v16f){b[0][0], b[0][1], b[0][2], b[0][3], b[1][0], b[1][1], b[1][2], b[1][3],
+                b[2][0], b[2][1], b[2][2], b[2][3], b[3][0], b[3][1], b[3][2], b[3][3]};
+}
+
+__device__ __forceinline__ void shift_masks_down(unsigned (&M)[8][4]) {
+#pragma unroll
+  for (int l = 0; l < 7; ++l)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) M[l][q] = M[l + 1][q];
+}
+__device__ __forceinline__ void shift_masks_up(unsigned (&M)[8][4]) {
+#pragma unroll
+  for (int l = 7; l > 0; --l)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) M[l][q] = M[l - 1][q];
+}
+
+__global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const refnerf_level_cfg &cfg = A.cfg;
+  const int N = cfg.n_samples;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, sl = lane & 31;
+  const int rpw = A.rpw;
+  const int ray0 = blockIdx.x * rpw;
+  const int n_tot = rpw * N;
+  const long long pitch = A.pitch;
+
+  float *X = smem;                               /* [DIR_PAD][T_TILE] */
+  float *HD = X + DIR_PAD * T_TILE;              /* [HD_ROWS][T_TILE] */
+  float *TD = HD + HD_ROWS * T_TILE;             /* [rpw][N+1]        */
+  float *GS = TD + rpw * (N + 1);                /* [n_tot][NGS]      */
+
+  bwd_prologue(A, TD, GS, ray0, wave, lane);
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.packed, 0, PACKED.total * 4, 0x00020000);
+  const int col = wave * 32 + sl;
+  const float *xl = X + h * T_TILE + col;
+  v16f in[8], out[8];
+
+  for (int pass0 = 0; pass0 < n_tot; pass0 += T_TILE) {
+    const int g = pass0 + col;
+    const int rl = g / N, si = g - rl * N;
+    const int ray = ray0 + rl;
+    const bool valid = (g < n_tot) && (ray < A.R);
+    const int rayc = valid ? ray : (A.R - 1);
+    const size_t gs = valid ? (size_t)ray * N + si : 0;
+    float o[3], d[3], v[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      o[i] = A.rays.d_origins[(size_t)rayc * 3 + i];
+      d[i] = A.rays.d_directions[(size_t)rayc * 3 + i];
+      v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
+    }
+    /* ================= forward recompute ================= */
+    {
+      float radius = A.rays.d_radii[rayc];
+      const float *td = TD + (valid ? rl : 0) * (N + 1);
+      float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
+      float lm[3], lv[3];
+      cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
+#pragma unroll 1
+      for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const float f = ipe_feature(lm[b], lv[b], j, h);
+          X[(48 * h + j * 3 + b) * T_TILE + col] = f;
+          if (valid) store_row1(A.act, pitch, ACT_IPE + 48 * h + j * 3 + b, gs, f);
+        }
+    }
+    wave_sync();
+
+    unsigned M[8][4], VM[8][4];                  /* ReLU masks: spatial / directional layers */
+    gemm_op<8, 8, false>(rs, PACKED.op[0].a_off, PACKED.op[0].b_off, lane, h, in, out, xl, PACKED.op[0].lds_steps);
+    relu_mask_into(out, in, M[7]);
+    store_rows<8>(A.act, pitch, ACT_SP, gs, h, valid, in);
+#pragma unroll 1
+    for (int op = 1; op < 8; ++op) {
+      gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
+      shift_masks_down(M);
+      relu_mask_into(out, in, M[7]);
+      store_rows<8>(A.act, pitch, ACT_SP + op * WIDTH, gs, h, valid, in);
+    }
+    {
+      v16f hd[5];
+      gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[(blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * T_TILE + col] = hd[blk][r];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < HD_ROWS) HD[row * T_TILE + col] = hd[4][r];
+      }
+      store_rows<4>(A.act, pitch, ACT_DIN, gs, h, valid, hd);
+    }
+    wave_sync();
+
+    SampleHeads sh;
+    float raw_density, raw_rough, raw_tint[3];
+    {
+      float gp[3], raw_dif[3];
+      raw_density = HD[0 * T_TILE + col];
+      raw_rough = HD[4 * T_TILE + col];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        gp[i] = HD[(1 + i) * T_TILE + col];
+        raw_dif[i] = HD[(5 + i) * T_TILE + col];
+        raw_tint[i] = HD[(8 + i) * T_TILE + col];
+      }
+      sample_heads(cfg, raw_density, gp, raw_rough, raw_dif, raw_tint, v, sh);
+      float *xi = X + (BNECK + IDE_TERMS * h) * T_TILE + col;
+      ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) {
+        xi[q * T_TILE] = val;
+        if (valid) store_row1(A.act, pitch, ACT_DIN + BNECK + IDE_TERMS * h + q, gs, val);
+      });
+      if (h == 0) {
+        X[(BNECK + IDE_DIM) * T_TILE + col] = sh.dot;
+        if (valid) store_row1(A.act, pitch, ACT_DIN + BNECK + IDE_DIM, gs, sh.dot);
+      } else {
+#pragma unroll
+        for (int q = DIR_IN; q < DIR_PAD; ++q) X[q * T_TILE + col] = 0.0f;
+      }
+    }
+    wave_sync();
+
+    gemm_op<8, 8, false>(rs, PACKED.op[9].a_off, PACKED.op[9].b_off, lane, h, in, out, xl, PACKED.op[9].lds_steps);
+    relu_mask_into(out, in, VM[7]);
+    store_rows<8>(A.act, pitch, ACT_VD, gs, h, valid, in);
+#pragma unroll 1
+    for (int op = 10; op < 17; ++op) {
+      gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
+      shift_masks_down(VM);
+      relu_mask_into(out, in, VM[7]);
+      store_rows<8>(A.act, pitch, ACT_VD + (op - 9) * WIDTH, gs, h, valid, in);
+    }
+    float raw_rgb[3];
+    {
+      v16f rgbv[1];
+      gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(rgbv[0][i], sl, 64);
+    }
+
+    /* ================= backward ================= */
+    float gsv[NGS];
+#pragma unroll
+    for (int i = 0; i < NGS; ++i) gsv[i] = valid ? GS[(size_t)g * NGS + i] : 0.0f;
+    /* ---- colour head (models.py:699-729) ---- */
+    float g_tint[3], g_raw_rgb[3], g_raw_diff[3];
+    {
+      float sg[3], dl[3], colr[3], g_col[3];
+      const float pad_scale = (float)(1.0 + 2.0 * (double)cfg.rgb_padding);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        sg[i] = sigmoid_t(cfg.rgb_premultiplier * raw_rgb[i] + cfg.rgb_bias);
+        dl[i] = sigmoid_t(sh.raw_dif[i] - LOG3_F);
+        colr[i] = sh.tint[i] * sg[i] + dl[i];
+        g_col[i] = gsv[1 + i] * pad_scale;
+      }
+      if (cfg.srgb_mapping) colour_map_backward(colr, cfg.srgb_mapping_normalization != 0, true, g_col);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        g_tint[i] = g_col[i] * sg[i];
+        g_raw_rgb[i] = (g_col[i] * sh.tint[i]) * sg[i] * (1.0f - sg[i]) * cfg.rgb_premultiplier;
+        g_raw_diff[i] = g_col[i] * dl[i] * (1.0f - dl[i]);
+      }
+    }
+    if (valid && h == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) store_row1(A.delta, pitch, DEL_RGB + i, gs, g_raw_rgb[i]);
+    }
+    /* ---- seed of the directional chain: W_rgb^T g_raw_rgb through the last ReLU ---- */
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) {
+      const v16f w0 = load_acc_blk(rs, PACKED.wrgb_off, h, ob), w1 = load_acc_blk(rs, PACKED.wrgb_off + 256, h, ob),
+                 w2 = load_acc_blk(rs, PACKED.wrgb_off + 512, h, ob);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[ob][r] = (w0[r] * g_raw_rgb[0] + w1[r] * g_raw_rgb[1]) + w2[r] * g_raw_rgb[2];
+    }
+    masked_into(out, in, VM[7]);
+    /* ---- directional MLP, layers 7..0 ---- */
+    v16f(&gd)[DIN_BLOCKS] = reinterpret_cast<v16f(&)[DIN_BLOCKS]>(out);   /* gradient w.r.t. the 201 dir inputs */
+#pragma unroll 1
+    for (int i = 7; i >= 0; --i) {
+      store_rows<8>(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid, in);
+      if (i == 5 || i == 0) {
+        gemm_op<DIN_BLOCKS, 8, true, false>(rs, PACKED.top[i == 5 ? TOP_VD5_DIN : TOP_VD0].a_off, 0, lane, h, in, gd, xl, 0);
+        /* layer 5 (skip connection) parks its share in LDS; layer 0 adds it back */
+#pragma unroll
+        for (int blk = 0; blk < DIN_BLOCKS; ++blk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (blk < 6 || row < DIR_PAD) {
+              float *px = X + row * T_TILE + col;
+              if (i == 0) gd[blk][r] += *px;
+              *px = gd[blk][r];
+            }
+          }
+      }
+      if (i > 0) {
+        gemm_op<8, 8, true, false>(rs, PACKED.top[TOP_VD1 + i - 1].a_off, 0, lane, h, in, out, xl, 0);
+        shift_masks_up(VM);
+        masked_into(out, in, VM[7]);
+      }
+    }
+    /* X rows 0..127: dL/d bottleneck (= head rows 0..127), rows 128..200: dL/d (IDE, n.v) */
+    store_rows<4>(A.delta, pitch, DEL_HEADS, gs, h, valid, gd);
+    wave_sync();
+    /* ---- IDE, reflection, predicted normal, head activations (models.py:611-686) ---- */
+    {
+      float g_ref[3], g_rough;
+      ide_grad(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, [&](int q) { return X[(BNECK + q) * T_TILE + col]; }, g_ref, g_rough);
+      const float g_dot = X[(BNECK + IDE_DIM) * T_TILE + col];
+      const float w3[3] = {-v[0], -v[1], -v[2]};
+      const float ndw = (sh.npred[0] * w3[0] + sh.npred[1] * w3[1]) + sh.npred[2] * w3[2];
+      const float grn = (g_ref[0] * sh.npred[0] + g_ref[1] * sh.npred[1]) + g_ref[2] * sh.npred[2];
+      float g_np[3], g_gp[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) g_np[i] = gsv[4 + i] + 2.0f * (grn * w3[i] + ndw * g_ref[i]) + g_dot * v[i];
+      /* n_pred = -g / sqrt(max(|g|^2, eps)) (ref_utils.py:40-42) */
+      const float nrm2 = (sh.gp[0] * sh.gp[0] + sh.gp[1] * sh.gp[1]) + sh.gp[2] * sh.gp[2];
+      const float s = fmaxf(nrm2, EPS32), rsq = sqrtf(s);
+      const float gdotg = (sh.gp[0] * g_np[0] + sh.gp[1] * g_np[1]) + sh.gp[2] * g_np[2];
+      const float live = (nrm2 > EPS32) ? 1.0f : (nrm2 == EPS32 ? 0.5f : 0.0f);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) g_gp[i] = -(g_np[i] / rsq - live * sh.gp[i] * gdotg / (s * rsq));
+      const float g_raw_rough = g_rough * softplus_grad(raw_rough + cfg.roughness_bias);
+      const float g_raw_density = gsv[0] * softplus_grad(raw_density + cfg.density_bias);
+      float hrow[11];
+      hrow[0] = g_raw_density;
+      hrow[4] = g_raw_rough;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        hrow[1 + i] = g_gp[i];
+        hrow[5 + i] = g_raw_diff[i];
+        hrow[8 + i] = g_tint[i] * sh.tint[i] * (1.0f - sh.tint[i]);
+      }
+      wave_sync();                               /* both half-waves have read the IDE gradients */
+      if (h == 0) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+          X[(HROW_DENSITY + i) * T_TILE + col] = hrow[i];
+          if (valid) store_row1(A.delta, pitch, DEL_HEADS + HROW_DENSITY + i, gs, hrow[i]);
+        }
+      } else {
+#pragma unroll
+        for (int q = HROWS; q < 2 * HEADS_T_STEPS + 2; ++q) X[q * T_TILE + col] = 0.0f;
+      }
+    }
+    wave_sync();
+    /* ---- heads^T, then the spatial MLP, layers 7..0 ---- */
+    gemm_op<8, 8, false, false>(rs, PACKED.top[TOP_HEADS].a_off, 0, lane, h, in, out, xl, HEADS_T_STEPS);
+    masked_into(out, in, M[7]);
+#pragma unroll 1
+    for (int i = 7; i >= 0; --i) {
+      store_rows<8>(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid, in);
+      if (i > 0) {
+        gemm_op<8, 8, true, false>(rs, PACKED.top[i - 1].a_off, 0, lane, h, in, out, xl, 0);
+        shift_masks_up(M);
+        masked_into(out, in, M[7]);
+      }
+    }
+    wave_sync();
+  }
+}
+
+}  // namespace rn

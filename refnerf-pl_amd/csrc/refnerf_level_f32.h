@@ -30,9 +30,10 @@ __device__ __forceinline__ void load_a(__amdgpu_buffer_rsrc_t rs, int voff, int 
     a[0] = x[0];
     if constexpr (NOB > 1) { a[1] = x[1]; a[2] = x[2]; a[3] = x[3]; }
     if constexpr (NOB == 5) a[4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 16, soff, 0));
-    if constexpr (NOB == 8) {
+    if constexpr (NOB > 5) {
       v4f y = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, 0));
-      a[4] = y[0]; a[5] = y[1]; a[6] = y[2]; a[7] = y[3];
+#pragma unroll
+      for (int i = 4; i < NOB; ++i) a[i] = y[i - 4];
     }
   } else if constexpr (STRIDE == 4) {
     v4f x = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));

@@ -1,0 +1,176 @@
+/*
+ * refnerf_wgrad.h -- weight/bias gradients of one level from the backward
+ * workspace: dW[o][k] = sum_s DELTA[o][s] * ACT[k][s], db[o] = sum_s DELTA[o][s]
+ * (the contraction PyTorch autograd performs for every nn.Linear of
+ * internal/models.py:497-531).
+ *
+ * One fp32-MFMA GEMM over all 18 layers: a constexpr job table maps (DELTA row
+ * range, ACT row range) to the canonical gradient blob; a workgroup owns one
+ * 128x128 output tile and one slice of the sample axis (split-K), accumulates
+ * it on v_mfma_f32_32x32x2_f32 from LDS-staged 128x32 operand tiles, and
+ * writes its partial tile to PART[slice].  wgrad_reduce then adds the slices
+ * in fixed order into the gradient blob: bit-reproducible, no atomics.
+ */
+#pragma once
+#include "refnerf_level_common.h"
+
+namespace rn {
+
+struct WJob { int d_row, n_out, a_row, n_in, w_off, ld, b_off, tiles_n, tile0; };
+constexpr int WG_TM = 128, WG_TN = 128, WG_KT = 32, WG_LDK = 36;
+constexpr int MAX_WJOBS = 32;
+struct WJobs { WJob job[MAX_WJOBS]; int n; int tiles; };
+
+constexpr WJobs make_wjobs() {
+  WJobs J{};
+  int n = 0, t = 0;
+  auto add = [&](int d_row, int n_out, int a_row, int n_in, int w_off, int ld, int b_off) {
+    WJob j{};
+    j.d_row = d_row; j.n_out = n_out; j.a_row = a_row; j.n_in = n_in; j.w_off = w_off; j.ld = ld; j.b_off = b_off;
+    j.tiles_n = (n_in + WG_TN - 1) / WG_TN;
+    j.tile0 = t;
+    t += ((n_out + WG_TM - 1) / WG_TM) * j.tiles_n;
+    J.job[n++] = j;
+  };
+  for (int i = 0; i < DEPTH; ++i) {            /* spatial MLP (models.py:576-580) */
+    const int dr = DEL_SP + i * WIDTH, ld = CANON.sp_in[i];
+    if (i == 0) add(dr, WIDTH, ACT_IPE, IPE_DIM, CANON.sp_w[0], ld, CANON.sp_b[0]);
+    else {
+      add(dr, WIDTH, ACT_SP + (i - 1) * WIDTH, WIDTH, CANON.sp_w[i], ld, CANON.sp_b[i]);
+      if (i == 5) add(dr, WIDTH, ACT_IPE, IPE_DIM, CANON.sp_w[i] + WIDTH, ld, -1);
+    }
+  }
+  const int x7 = ACT_SP + 7 * WIDTH;             /* heads (models.py:582,613,634-645) */
+  add(DEL_HEADS, BNECK, x7, WIDTH, CANON.bneck_w, WIDTH, CANON.bneck_b);
+  add(DEL_HEADS + HROW_DENSITY, 1, x7, WIDTH, CANON.density_w, WIDTH, CANON.density_b);
+  add(DEL_HEADS + HROW_GRAD, 3, x7, WIDTH, CANON.gradpred_w, WIDTH, CANON.gradpred_b);
+  add(DEL_HEADS + HROW_ROUGH, 1, x7, WIDTH, CANON.rough_w, WIDTH, CANON.rough_b);
+  add(DEL_HEADS + HROW_DIFFUSE, 3, x7, WIDTH, CANON.diffuse_w, WIDTH, CANON.diffuse_b);
+  add(DEL_HEADS + HROW_TINT, 3, x7, WIDTH, CANON.tint_w, WIDTH, CANON.tint_b);
+  for (int i = 0; i < DEPTH; ++i) {            /* directional MLP (models.py:690-694) */
+    const int dr = DEL_VD + i * WIDTH, ld = CANON.vd_in[i];
+    if (i == 0) add(dr, WIDTH, ACT_DIN, DIR_IN, CANON.vd_w[0], ld, CANON.vd_b[0]);
+    else {
+      add(dr, WIDTH, ACT_VD + (i - 1) * WIDTH, WIDTH, CANON.vd_w[i], ld, CANON.vd_b[i]);
+      if (i == 5) add(dr, WIDTH, ACT_DIN, DIR_IN, CANON.vd_w[i] + WIDTH, ld, -1);
+    }
+  }
+  add(DEL_RGB, 3, ACT_VD + 7 * WIDTH, WIDTH, CANON.rgb_w, WIDTH, CANON.rgb_b);   /* models.py:699 */
+  J.n = n; J.tiles = t;
+  return J;
+}
+constexpr WJobs WJOBS = make_wjobs();
+
+struct WgradArgs {
+  const float *act, *delta;
+  long long pitch;
+  long long S;            /* valid samples (columns) */
+  int k_per_slice;        /* samples per split-K slice, multiple of WG_KT */
+  float *part;            /* [slices][NUM_PARAMS] */
+};
+
+/* grid = (WJOBS.tiles, slices), 256 threads: waves 2x2 over the 128x128 tile. */
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
+  __shared__ __attribute__((aligned(16))) float Ds[WG_TM * WG_LDK];
+  __shared__ __attribute__((aligned(16))) float As[WG_TN * WG_LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, sl = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  int ji = 0;
+#pragma unroll 1
+  for (int j = 1; j < WJOBS.n; ++j) if ((int)blockIdx.x >= WJOBS.job[j].tile0) ji = j;
+  const WJob J = WJOBS.job[ji];
+  const int tl = blockIdx.x - J.tile0;
+  const int tm = tl / J.tiles_n, tn = tl - tm * J.tiles_n;
+  const long long k_begin = (long long)blockIdx.y * A.k_per_slice;
+  long long k_end = k_begin + A.k_per_slice;
+  if (k_end > A.S) k_end = A.S;
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+  const int lrow = tid >> 3, lc4 = (tid & 7) * 4;     /* loader: rows lrow + 32p, 4 samples at lc4 */
+  for (long long k0 = k_begin; k0 < k_end; k0 += WG_KT) {
+    v4f dv[4], av[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = lrow + 32 * p;
+      const long long k = k0 + lc4;
+      const int orow = tm * WG_TM + row, irow = tn * WG_TN + row;
+      v4f x = {0.0f, 0.0f, 0.0f, 0.0f}, y = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (orow < J.n_out && k < k_end) {
+        x = *reinterpret_cast<const v4f *>(A.delta + (long long)(J.d_row + orow) * A.pitch + k);
+#pragma unroll
+        for (int e = 1; e < 4; ++e) if (k + e >= k_end) x[e] = 0.0f;
+      }
+      if (irow < J.n_in && k < k_end) {
+        y = *reinterpret_cast<const v4f *>(A.act + (long long)(J.a_row + irow) * A.pitch + k);
+#pragma unroll
+        for (int e = 1; e < 4; ++e) if (k + e >= k_end) y[e] = 0.0f;
+      }
+      dv[p] = x; av[p] = y;
+    }
+    __syncthreads();                                   /* previous tile fully consumed */
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<v4f *>(Ds + (lrow + 32 * p) * WG_LDK + lc4) = dv[p];
+      *reinterpret_cast<v4f *>(As + (lrow + 32 * p) * WG_LDK + lc4) = av[p];
+      bsum[p] += (dv[p][0] + dv[p][1]) + (dv[p][2] + dv[p][3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < WG_KT / 8; ++kk) {
+      v4f a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const v4f *>(Ds + (wm * 64 + i * 32 + sl) * WG_LDK + kk * 8 + 4 * h);
+        b[i] = *reinterpret_cast<const v4f *>(As + (wn * 64 + i * 32 + sl) * WG_LDK + kk * 8 + 4 * h);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+    }
+  }
+  float *part = A.part + (size_t)blockIdx.y * NUM_PARAMS;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int colk = tn * WG_TN + wn * 64 + j * 32 + sl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = tm * WG_TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (orow < J.n_out && colk < J.n_in) part[J.w_off + (size_t)orow * J.ld + colk] = acc[i][j][r];
+      }
+    }
+  if (tn == 0 && J.b_off >= 0) {
+    /* bias gradient: the 8 loader threads of a row hold its partial sums */
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float s = bsum[p];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      const int orow = tm * WG_TM + lrow + 32 * p;
+      if ((tid & 7) == 0 && orow < J.n_out) part[J.b_off + orow] = s;
+    }
+  }
+}
+
+/* grads[i] += sum over slices (fixed order) of PART[slice][i] */
+__global__ void wgrad_reduce(const float *__restrict__ part, int slices, float *__restrict__ grads) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NUM_PARAMS; i += gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int c = 0; c < slices; ++c) s += part[(size_t)c * NUM_PARAMS + i];
+    grads[i] += s;
+  }
+}
+
+}  // namespace rn

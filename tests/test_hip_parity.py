@@ -165,6 +165,70 @@ def test_training_forward_density_normals(hip, O, name):
         np.testing.assert_allclose(res["r_normals"], orc["r_normals"], rtol=0, atol=5e-4)
 
 
+def _hip_train_step(hip, P, rays, gt_rgb, lossmult, kw, lv, mults):
+    """Training forward + torch losses on the level outputs + HIP backward."""
+    packed = hip.pack_weights(torch.tensor(P, device=DEV), precision=0)
+    r = dev_rays(rays)
+    R = rays["origins"].shape[0]
+    sdist = torch.tensor([[0.0, 1.0]], device=DEV).repeat(R, 1)
+    weights = torch.ones((R, 1), device=DEV)
+    gt = torch.tensor(np.asarray(gt_rgb, np.float32)[..., :3].reshape(R, 3), device=DEV)
+    lm = torch.tensor(np.asarray(lossmult, np.float32).reshape(R, 1), device=DEV).expand(R, 3)
+    grads = torch.zeros(hip.NUM_PARAMS, device=DEV)
+    nl = lv.get("num_levels", 2)
+    losses = {"data": 0.0, "orientation": 0.0, "normal": 0.0}
+    for L in range(nl):
+        fine = L == nl - 1
+        n = lv.get("num_nerf_samples", 128) if fine else lv.get("num_prop_samples", 128)
+        cfg = hip.default_cfg(n_samples=n, n_in=weights.shape[1], precision=0, training=1, **kw)
+        res = hip.level_forward(packed, cfg, r, sdist, weights)
+        rgb = res["r_rgb"].clone().requires_grad_(True)
+        w = res["weights"].clone().requires_grad_(True)
+        npred = res["normals_pred"].clone().requires_grad_(True)
+        dm, om, nm = (mults[0][fine], mults[1][fine], mults[2][fine])
+        l_data = dm * (lm * (rgb - gt) ** 2).sum() / lm.sum()                      # train_utils.py:33-88
+        ndv = (npred * (-r["viewdirs"])[:, None, :]).sum(-1)
+        l_or = om * (w * torch.clamp(ndv, max=0.0) ** 2).sum(-1).mean()            # :165-183
+        l_nm = nm * (w * (1.0 - (res["normals"] * npred).sum(-1))).sum(-1).mean()  # :186-204
+        (l_data + l_or + l_nm).backward()
+        hip.level_backward(packed, cfg, r, res, rgb.grad, w.grad, npred.grad, grads)
+        losses["data"] += float(l_data.detach()); losses["orientation"] += float(l_or.detach()); losses["normal"] += float(l_nm.detach())
+        sdist, weights = res["sdist"], res["weights"]
+    torch.cuda.synchronize()
+    return losses, grads.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_training_step_gradients(hip, O, name):
+    """HIP backward (recompute + transposed chains + split-K weight-gradient
+    GEMM) against the oracle's backward and the reference's autograd gradients."""
+    from refnerf_pl_amd import layout
+    g = load_golden(name)
+    P = params_from_golden(g)
+    rays = rays_from_golden(g)
+    kw, lv = cfg_from_bindings(g["bindings"])
+    mults = ((0.1, 1.0), (0.01, 0.1), (3e-5, 3e-4))
+    losses, grads = _hip_train_step(hip, P, rays, g["gt_rgb"], rays["lossmult"], kw, lv, mults)
+    o_losses, o_grads, _ = O.model_train(P, rays, g["gt_rgb"], **lv, **kw)
+    for k in ("data", "orientation", "normal"):
+        assert losses[k] == pytest.approx(o_losses[k], rel=2e-4), k
+    assert losses["data"] == pytest.approx(float(g["loss_data"]), rel=1e-5)
+    rel = np.linalg.norm(grads - o_grads) / np.linalg.norm(o_grads)
+    assert rel < 2e-4, rel      # fp32 summation order over the sample axis differs (split-K MFMA vs sequential)
+    ref = g["grads_sub"]
+    assert np.linalg.norm(grads[::97] - ref) / np.linalg.norm(ref) < 2e-4
+    norms = g["grads_tensor_l2"]
+    for i, s in enumerate(layout.PARAM_SPECS):       # all 46 tensors receive their gradient
+        nw = s.out_dim * s.in_dim
+        assert np.linalg.norm(grads[s.w_off:s.w_off + nw]) == pytest.approx(norms[i, 0], rel=2e-3), s.name
+        assert np.linalg.norm(grads[s.b_off:s.b_off + s.out_dim]) == pytest.approx(norms[i, 1], rel=2e-3), s.name
+        ow, ob = o_grads[s.w_off:s.w_off + nw], o_grads[s.b_off:s.b_off + s.out_dim]
+        # per tensor: round-off level (~6e-7) except where a pre-activation within 1 ulp of 0 takes the
+        # other side of the ReLU than in the oracle's summation order (isolated flips, <= ~2e-3 of a tensor)
+        assert np.linalg.norm(grads[s.w_off:s.w_off + nw] - ow) <= 5e-3 * np.linalg.norm(ow) + 1e-12, s.name
+        assert np.linalg.norm(grads[s.b_off:s.b_off + s.out_dim] - ob) <= 5e-3 * np.linalg.norm(ob) + 1e-12, s.name
+
+
 def test_model_api_matches_reference_contract(hip):
     """Model.__call__ through the host mirror: keys, shapes, dtypes and values."""
     from refnerf_pl_amd import configs, models, utils
