@@ -1,0 +1,114 @@
+"""Multi-GPU use of the hot path: one process per GPU, rays sharded, no
+data-path collective; the only exchange is the gradient all-reduce of the
+4.44 MB parameter blob after backward (what Lightning DDP does for the
+reference, nerf_system.py / train.py: `strategy='ddp'`).
+
+`torch.distributed` backend "nccl" is RCCL on ROCm (xGMI between the 8 GPUs of
+a node); "gloo" is used by the CPU tests.  The blob is reduced with ONE
+collective: per-link ring time for 4.44 MB is ~50 us, so bucketing or overlap
+with backward has nothing to win at this size.
+"""
+import os
+from dataclasses import fields
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import utils
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT (torchrun).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(n: int, rank: int, world: int) -> tuple:
+    """Contiguous, balanced [begin, end) of `n` items for `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(n, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def shard_rays(rays: utils.Rays, rank: int, world: int) -> utils.Rays:
+    """This rank's contiguous slice of a flat [R, ...] ray bundle."""
+    b, e = shard_bounds(rays.origins.shape[0], rank, world)
+    return utils.Rays(*[getattr(rays, f.name)[b:e] for f in fields(rays)])
+
+
+def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = True) -> None:
+    """Sum (or average) the .grad of every parameter over the group with one
+    all-reduce of the flattened blob.  Parameters without a gradient contribute zeros."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    params = [p for p in module.parameters() if p.requires_grad]
+    if not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Make every rank start from rank `src`'s parameters (DDP does this at wrap time)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for p in module.parameters():
+            dist.broadcast(p.data, src=src, group=group)
+
+
+def render_image_sharded(render_fn, rays: utils.Rays, config, group=None):
+    """models.render_image with the image's rays split across the ranks of
+    `group`: every rank renders its contiguous slice of pixels in chunks and the
+    per-pixel outputs are all-gathered.  Returns the [H, W, ...] tensors of the
+    last level (the `ray_*` visualisation bundles stay local and are dropped)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    height, width = rays.origins.shape[:2]
+    n = height * width
+    flat = rays.reshape(n, -1)
+    mine = shard_rays(flat, rank, world)
+    chunks = []
+    for i0 in range(0, mine.origins.shape[0], config.render_chunk_size):
+        part = utils.Rays(*[getattr(mine, f.name)[i0:i0 + config.render_chunk_size] for f in fields(mine)])
+        renderings, _ = render_fn(part)
+        chunks.append({k: utils.recursive_detach(v) for k, v in renderings[-1].items() if not k.startswith("ray_")})
+    local = utils.merge_chunks(chunks) if chunks else {}
+    if world == 1:
+        return {k: v.reshape((height, width) + v.shape[1:]) for k, v in local.items()}
+    sizes = [shard_bounds(n, r, world) for r in range(world)]
+    biggest = max(e - b for b, e in sizes)
+    out = {}
+    for k in sorted(local):
+        v = local[k]
+        pad = torch.zeros((biggest,) + v.shape[1:], dtype=v.dtype, device=v.device)
+        pad[:v.shape[0]] = v
+        gathered = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(gathered, pad, group=group)
+        full = torch.cat([g[:e - b] for g, (b, e) in zip(gathered, sizes)], dim=0)
+        out[k] = full.reshape((height, width) + full.shape[1:])
+    return out

@@ -171,6 +171,13 @@ class MLP(nn.Module):
             flat.copy_(torch.as_tensor(blob, dtype=torch.float32).to(flat.device))
         self._packed_key = None
 
+    def ordered_parameters(self):
+        """[w0, b0, w1, b1, ...] in canonical (state_dict) order."""
+        out = []
+        for _, lin in self._named_linears():
+            out += [lin.weight, lin.bias]
+        return out
+
     def _param_version(self):
         return tuple(p._version for p in self.parameters())
 
@@ -187,6 +194,46 @@ class MLP(nn.Module):
         raise _hip.HipLibraryError(
             "MLP.__call__ on caller-supplied Gaussians is not a separate entry point of the fused "
             "path: the MLP runs inside refnerf_level_forward (Model.__call__).")
+
+
+# outputs of one training level, in the order _LevelFunction returns them; the
+# first three are what the reference's losses differentiate (train_utils.py:33-204)
+_DIFF_KEYS = ("r_rgb", "weights", "normals_pred")
+
+
+class _LevelFunction(torch.autograd.Function):
+    """One level of Model.__call__ in training mode as a single autograd node:
+    forward = refnerf_level_forward(training=1), backward = refnerf_level_backward
+    (what autograd replays through models.py:162-306 in the reference)."""
+
+    @staticmethod
+    def forward(ctx, mlp, cfg, rays, holder, sdist_in, weights_in, *params):
+        packed = mlp.packed_weights(cfg.precision)
+        res = _hip.level_forward(packed, cfg, rays, sdist_in, weights_in, history=True)
+        ctx.mlp, ctx.cfg, ctx.rays, ctx.packed = mlp, cfg, rays, packed
+        ctx.packed_key = mlp._packed_key
+        ctx.saved = {k: res[k] for k in ("sdist", "density", "rgb", "weights")}
+        keys = _DIFF_KEYS + tuple(k for k in res if k not in _DIFF_KEYS)
+        holder["keys"] = keys                      # autograd Functions return tuples: tell the caller the names
+        outs = tuple(res[k] for k in keys)
+        ctx.mark_non_differentiable(*outs[len(_DIFF_KEYS):])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_weights, g_npred, *unused):
+        mlp = ctx.mlp
+        if mlp._packed_key != ctx.packed_key:
+            raise _hip.HipLibraryError("parameters changed between the training forward and backward of a level")
+        grads = torch.zeros(layout.NUM_PARAMS, dtype=torch.float32, device=ctx.saved["sdist"].device)
+        if g_rgb is None:
+            g_rgb = torch.zeros_like(ctx.saved["sdist"][:, :3])
+        _hip.level_backward(ctx.packed, ctx.cfg, ctx.rays, ctx.saved, g_rgb, g_weights, g_npred, grads)
+        out = []
+        for spec in layout.PARAM_SPECS:            # same order as MLP.ordered_parameters()
+            n = spec.out_dim * spec.in_dim
+            out.append(grads[spec.w_off:spec.w_off + n].view(spec.out_dim, spec.in_dim))
+            out.append(grads[spec.b_off:spec.b_off + spec.out_dim])
+        return (None, None, None, None, None, None) + tuple(out)
 
 
 @configs.configurable
@@ -274,7 +321,7 @@ class Model(nn.Module):
             compute_extras=int(bool(compute_extras)), srgb_mapping=int(mlp.srgb_mapping),
             srgb_mapping_normalization=int(mlp.srgb_mapping_normalization), render_srgb_mode=mode,
             opaque_background=int(self.opaque_background), ray_shape=0 if self.ray_shape == 'cone' else 1,
-            precision=_PREC[prec], anneal=float(anneal), resample_padding=float(self.resample_padding),
+            precision=_PREC["f32"] if self.training else _PREC[prec], anneal=float(anneal), resample_padding=float(self.resample_padding),
             s_near=float(self.init_s_near), s_far=float(self.init_s_far), density_bias=float(mlp.density_bias),
             roughness_bias=float(mlp.roughness_bias), rgb_premultiplier=float(mlp.rgb_premultiplier),
             rgb_bias=float(mlp.rgb_bias), rgb_padding=float(mlp.rgb_padding), bg_rgb=float(bg))
@@ -299,9 +346,6 @@ class Model(nn.Module):
         sdist = torch.cat([torch.full((R, 1), float(self.init_s_near), device=dev),
                            torch.full((R, 1), float(self.init_s_far), device=dev)], dim=-1)
         weights = torch.ones((R, 1), device=dev)
-        if self.training:
-            raise _hip.HipLibraryError("training-mode forward/backward is not built yet in this round")
-
         renderings, ray_history = [], []
         for i_level in range(self.num_levels):
             is_prop = i_level < (self.num_levels - 1)
@@ -310,7 +354,15 @@ class Model(nn.Module):
                 raise ValueError(f'num_samples must be > 1, is {num_samples}.')   # stepfun.py:234-235
             mlp = self.prop_mlp if is_prop else self.nerf_mlp
             cfg = self._level_cfg(mlp, num_samples, weights.shape[-1], train_frac, compute_extras)
-            res = _hip.level_forward(mlp.packed_weights(cfg.precision), cfg, r, sdist, weights, history=True)
+            if self.training and torch.is_grad_enabled():
+                # one autograd node per level; sdist / resampling inputs are detached (models.py:205-216)
+                mlp.flat_params()
+                holder = {}
+                outs = _LevelFunction.apply(mlp, cfg, r, holder, sdist.detach(), weights.detach(),
+                                            *mlp.ordered_parameters())
+                res = dict(zip(holder["keys"], outs))
+            else:
+                res = _hip.level_forward(mlp.packed_weights(cfg.precision), cfg, r, sdist, weights, history=True)
             sdist, weights = res["sdist"], res["weights"]
 
             def rs(x, *tail):

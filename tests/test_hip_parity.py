@@ -267,6 +267,54 @@ def test_model_api_matches_reference_contract(hip):
     np.testing.assert_allclose(rendering["rgb"].reshape(-1, 3).cpu().numpy(), g["L1_r_rgb"], rtol=0, atol=2e-5)
 
 
+def test_model_training_step_autograd(hip):
+    """Model.__call__ in training mode + the reference-shaped losses + loss.backward():
+    the 46 nn.Parameters receive the reference's gradients (golden autograd vectors)."""
+    import os
+    from refnerf_pl_amd import configs, layout, models, train_utils, utils
+    g = load_golden("model_blender_sharp_train")
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")], [])
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
+    model.nerf_mlp.load_flat_params(params_from_golden(g))
+    rd = rays_from_golden(g)
+    rays = utils.rays_from_dict(rd, DEV)
+    batch = utils.Batch(rays=rays, rgb=np.asarray(g["gt_rgb"], np.float32))
+    renderings, history = model(rays, 1.0, False)
+    assert history[0]["normals"] is not None and "normals" not in renderings[0]     # compute_extras=False
+    total, terms, stats = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+    assert float(terms["data"].detach()) == pytest.approx(float(g["loss_data"]), rel=1e-5)
+    assert float(terms["orientation"].detach()) == pytest.approx(float(g["loss_orientation"]), rel=2e-4)
+    assert float(terms["predicted_normals"].detach()) == pytest.approx(float(g["loss_normal"]), rel=2e-4)
+    assert float(total.detach()) == pytest.approx(float(g["loss_total"]), rel=1e-5)
+    assert stats["mses"].shape == (2,)
+    total.backward()
+    flat = torch.zeros(layout.NUM_PARAMS)
+    for spec, lin in model.nerf_mlp._named_linears():
+        assert lin.weight.grad is not None and lin.bias.grad is not None, spec.name
+        flat[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = lin.weight.grad.reshape(-1).cpu()
+        flat[spec.b_off:spec.b_off + spec.out_dim] = lin.bias.grad.cpu()
+    grads = flat.numpy()
+    ref = g["grads_sub"]
+    assert np.linalg.norm(grads[::97] - ref) / np.linalg.norm(ref) < 2e-4
+    norms = g["grads_tensor_l2"]
+    for i, s in enumerate(layout.PARAM_SPECS):
+        nw = s.out_dim * s.in_dim
+        assert np.linalg.norm(grads[s.w_off:s.w_off + nw]) == pytest.approx(norms[i, 0], rel=2e-3), s.name
+    # an optimiser step invalidates the packed weight image; the next forward repacks and changes
+    before = renderings[1]["rgb"].detach().clone()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    opt.step()
+    r2, _ = model(rays, 1.0, False)
+    assert (r2[1]["rgb"].detach() - before).abs().max() > 0
+    # eval mode under no_grad still takes the inference kernel and yields no normals
+    model.eval()
+    with torch.no_grad():
+        _, h3 = model(rays, 1.0, False)
+    assert h3[0]["normals"] is None
+
+
 def test_edge_shapes_and_errors(hip, O):
     """Ragged / edge sizes: R not a multiple of the workgroup tile, N in {2, 33,
     64, 192, 256}, a single ray; and the reference's error cases."""
