@@ -39,6 +39,7 @@ def parse():
                     help="arithmetic of the MLP contractions for the headline value; the other mode is reported alongside")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-image", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -77,6 +78,44 @@ def cpu_baseline(blob, args, target_seconds):
     dt = time.time() - t0
     return {"value": n_rays * args.samples * 2 / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
             "sample": f"{n_rays} of {args.rays} rays x {args.samples} samples x 2 levels, eval forward, fp32, {dt:.1f} s"}
+
+
+def train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync):
+    """Secondary figure: one full training step (training forward with density-gradient
+    normals, the three Ref-NeRF losses, HIP backward + weight-gradient GEMM, gradient
+    all-reduce over the ranks, Adam step) on the same batch; fp32 MFMA (the only
+    training arithmetic built so far)."""
+    from refnerf_pl_amd import distributed, synthetic, train_utils, utils
+    model.train()
+    gt = synthetic.target_rgb(args.rays, seed=7 + rank)
+    batch = utils.Batch(rays=rays, rgb=gt)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        renderings, history = model(rays, 1.0, False)
+        total, terms, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+        total.backward()
+        distributed.allreduce_gradients(model)
+        opt.step()
+        return total
+
+    n = max(2, args.steps // 3)
+    step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = step()
+    sync()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    model.eval()
+    assert torch.isfinite(loss.detach()).all()
+    return {"value": world * args.rays * args.samples * 2 * n / el, "unit": "ray-samples/s (fwd+bwd+Adam)",
+            "ms_per_step": 1e3 * el / n, "steps": n, "dtype": "f32", "loss": float(loss.detach())}
 
 
 def main():
@@ -184,6 +223,8 @@ def main():
         torch.cuda.synchronize()
         line["full_image_render_ms"] = 1e3 * (time.perf_counter() - t0)
         assert rendering["rgb"].shape == (800, 800, 3)
+    if not args.no_train:
+        line["train_step"] = train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(blob, args, args.cpu_seconds)
     if rank == 0:

@@ -146,7 +146,7 @@ def pack_weights(params: torch.Tensor, packed: torch.Tensor = None, precision=PR
     nbytes = packed_weights_bytes(precision)
     if nbytes == 0:
         raise HipLibraryError("precision mode not built")
-    if packed is None:
+    if packed is None or packed.numel() * packed.element_size() != nbytes or packed.device != params.device:
         packed = torch.empty(nbytes // 4, dtype=torch.float32, device=params.device)
     check(lib().refnerf_pack_weights(ptr(params), ptr(packed), precision, stream_ptr()))
     return packed

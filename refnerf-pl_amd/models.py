@@ -182,13 +182,18 @@ class MLP(nn.Module):
         return tuple(p._version for p in self.parameters())
 
     def packed_weights(self, precision: int) -> torch.Tensor:
+        """MFMA operand image of the current parameters for a precision mode
+        (one cached buffer per mode, re-packed in place when the parameters changed)."""
         flat = self.flat_params()
         key = (precision, flat.data_ptr(), self._param_version(), flat._version)
-        if self._packed is None or self._packed_key != key:
-            self._packed = _hip.pack_weights(flat, None if self._packed is None or
-                                             self._packed.device != flat.device else self._packed, precision)
-            self._packed_key = key
-        return self._packed
+        if self._packed is None:
+            self._packed = {}
+        buf, have = self._packed.get(precision, (None, None))
+        if have != key or self._packed_key is None:
+            buf = _hip.pack_weights(flat, buf, precision)
+            self._packed[precision] = (buf, key)
+        self._packed_key = key
+        return buf
 
     def __call__(self, gaussians, viewdirs=None, imageplane=None):
         raise _hip.HipLibraryError(
