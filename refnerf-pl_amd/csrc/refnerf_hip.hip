@@ -322,12 +322,18 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
   if (rc) return rc;
   const int N = cfg->n_samples;
   const bool bf = cfg->precision == REFNERF_PREC_BF16;
-  const int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
+  int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
+  auto lds_bytes = [&](int rays) -> size_t {
+    const int np = bf ? rn::NPS_EVAL : rn::NPS_TRAIN, tile = bf ? rn::BT : rn::T_TILE;
+    const size_t per_wg = sizeof(float) * (size_t)(2 * rays * (N + 1) + np * rays * N + 3 * tile + 8);
+    if (bf) return (size_t)rn::BF_RING_BYTES + rn::BF_X_BYTES + sizeof(float) * rn::HD_ROWS * rn::BT + per_wg;
+    return sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE) + per_wg;
+  };
+  /* bf16: the per-ray phases (resample, compositing) occupy one wave per ray, so take as many rays per
+   * workgroup as the LDS holds (up to one per wave): the other waves idle for a shorter share of the pass */
+  if (bf) while (2 * rpw <= rn::BF_NW && 2 * rpw * N <= 640 && lds_bytes(2 * rpw) <= 160 * 1024) rpw *= 2;
   if (rpw * N > 640) return fail(REFNERF_EINVAL, "n_samples too large for the LDS budget (rays_per_wg*N must be <= 640)%s");
-  const size_t per_ray = sizeof(float) * (size_t)(2 * rpw * (N + 1) + rn::NPS * rpw * N + 8);
-  size_t lds;
-  if (bf) lds = (size_t)rn::BF_RING_BYTES + rn::BF_X_BYTES + sizeof(float) * rn::HD_ROWS * rn::BT + per_ray;
-  else lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE) + per_ray;
+  size_t lds = lds_bytes(rpw);
   {
     const int nwmax = bf ? rn::BF_NW : 4;
     const int nw = rpw < nwmax ? rpw : nwmax;
@@ -384,7 +390,7 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
     const int nw = bf ? 8 : 4;
     for (int w = 0; w < nw; ++w) {
       fprintf(stderr, "[prof] wave %d:", w);
-      for (int sl = 1; sl <= 16; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
+      for (int sl = 1; sl <= 24; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
       fprintf(stderr, "  | dma-wait %lld barrier-wait %lld\n", hbuf[w * 32 + 20], hbuf[w * 32 + 21]);
     }
   }

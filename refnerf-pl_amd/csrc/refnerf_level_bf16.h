@@ -61,7 +61,9 @@ struct Pipe {
 
 /* LDS-DMA of one 17 KB chunk into the ring slot at `slot_off`.  Wave w moves the
  * adjacent pieces 3w..3w+2 (waves 0-4; wave 5 moves 15,16): one address and the
- * instruction's immediate offset cover both the global and the LDS side. */
+ * instruction's immediate offset cover both the global and the LDS side.
+ * (Measured alternatives: all pieces issued by the prioritised waves 4-7, or
+ * 2 pieces per wave with 16 KB chunks -- both slower in the full kernel.) */
 __device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off) {
   if (p.dma_left > 0) {
     if (p.wave < 6) {
@@ -232,7 +234,8 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   float *HD = reinterpret_cast<float *>(Xb + BF_X_BYTES);    /* [HD_ROWS][BT]            */
   float *TD = HD + HD_ROWS * BT;                             /* [rpw][N+1]               */
   float *XP = TD + rpw * (N + 1);                            /* [rpw][N+1]               */
-  float *PS = XP + rpw * (N + 1);                            /* [NPS][n_tot]             */
+  float *PS = XP + rpw * (N + 1);                            /* [n_tot][NPS_EVAL]        */
+  float *PX = PS + n_tot * NPS_EVAL;                         /* [BT][3] grad_pred of the pass */
 
   const int h = lane >> 5, n = lane & 31;
   const int col = wave * 32 + n;                             /* this lane's sample column */
@@ -264,6 +267,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
 #pragma unroll
   for (int d = 0; d < AF; ++d) ar[d] = lds_frag(WB + 1024 + lane * 16 + d * 1024);
 
+  RN_STAMP(A, 24);
   for (int pass0 = 0; pass0 < n_tot; pass0 += BT) {
     /* opaque copies: keep hipcc from hoisting ~100 registers of per-lane address
      * arithmetic out of the pass loop (it then spills them to scratch) */
@@ -299,8 +303,10 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         for (int e = 0; e < 8; ++e) bn[e] = (v4uu){0, 0, 0, 0};
       }
       char *xs = Xb + col * 16;
+      RN_STAMP(A, 19);
       if (phase == 0) {
         /* P1: conical frustum -> lifted Gaussian -> IPE (half h computes block h: sin / cos) */
+        RN_STAMP(A, 22);
         float o[3], d[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { o[i] = A.rays.d_origins[(size_t)rayc * 3 + i]; d[i] = A.rays.d_directions[(size_t)rayc * 3 + i]; }
@@ -308,18 +314,26 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         const float *td = TD + (valid ? rl : 0) * (N + 1);
         float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
         float lm[3], lv[3];
+        { float sacc = (o[0] + d[0]) + radius + t0 + t1; asm volatile("" : "+v"(sacc)); }
+        RN_STAMP(A, 23);
         cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
-        /* k' = canonical IPE index: half h owns block h (sin / cos) = k' 48h .. 48h+47 = 6 k-groups */
+        /* k' = canonical IPE index: half h owns block h (sin / cos) = k' 48h .. 48h+47 = 6 k-groups;
+         * rolled over two halves of 24 features (8 degrees x 3 axes): the (axis, degree) pattern repeats */
+        RN_STAMP(A, 17);
+#pragma unroll 1
+        for (int qq = 0; qq < 2; ++qq) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          v8bf pk;
+          for (int q = 0; q < 3; ++q) {
+            v8bf pk;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int kk = q * 8 + e;                    /* 3j + b inside the block */
-            pk[e] = (__bf16)ipe_feature<true>(lm[kk % 3], lv[kk % 3], kk / 3, h);
+            for (int e = 0; e < 8; ++e) {
+              const int kk = q * 8 + e;                  /* 3 * (j - 8qq) + b */
+              pk[e] = (__bf16)ipe_feature<true>(lm[kk % 3], lv[kk % 3], 8 * qq + kk / 3, h);
+            }
+            *reinterpret_cast<v8bf *>(xs + (6 * h + 3 * qq + q) * BT * 16) = pk;
           }
-          *reinterpret_cast<v8bf *>(xs + (6 * h + q) * BT * 16) = pk;
         }
+        RN_STAMP(A, 18);
       } else {
         /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
         SampleHeads sh;
@@ -377,13 +391,17 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         float raw_rgb[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n, 64);
+        /* opaque copies taken HERE: the per-lane output addresses of P6 must not be computed at
+         * the top of the pass and carried (spilled) across both MLP phases */
+        int lane_w = lane, g_w = g, pass_w = pass0;
+        asm volatile("" : "+v"(lane_w), "+v"(g_w), "+s"(pass_w));
         if (valid && h == 0) {                                                            /* P6 */
           SampleHeads sh;
           load_heads(sh);
-          colour_store<true>(A, sh, raw_rgb, PS, n_tot, g);
+          colour_store<true, NPS_EVAL>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
         }
         wave_sync();
-        history_flush(A, PS, n_tot, pass0 + wave * 32, (size_t)ray0 * N + pass0 + wave * 32, lane_v);
+        history_flush<NPS_EVAL>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);
         RN_STAMP(A, 14);
       }
     }
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   if (A.prof && blockIdx.x == 0 && lane == 0) { A.prof[wave * 32 + 20] = p.t_vm; A.prof[wave * 32 + 21] = p.t_bar; }
 #endif
 
-  composite_phase<BF_NW, true>(A, TD, XP, PS, n_tot, ray0, wave, lane);   /* P7 */
+  composite_phase<BF_NW, true, NPS_EVAL>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB));   /* P7 */
   RN_STAMP(A, 16);
 }
 

@@ -19,9 +19,12 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 constexpr int NTHREADS = 256;
 constexpr int HD_ROWS = 12;
-constexpr int NPS = 23;      /* per-sample floats kept in LDS for compositing / the history flush */
-/* per-sample slots in LDS: PS[sample][slot], odd stride NPS = conflict-free per-sample access */
-enum { PS_DENSITY = 0, PS_RGB = 1, PS_DIF = 4, PS_SPC = 7, PS_NPRED = 10, PS_TINT = 13, PS_ROUGH = 16, PS_NORMALS = 17, PS_GP = 20 };
+/* Per-sample floats kept in LDS until the rays of the workgroup are composited:
+ * PS[sample][slot] with an odd stride NP (conflict-free per-sample access).
+ * NP = NPS_EVAL (17 slots) or NPS_TRAIN (+ the density-gradient normals).  What only
+ * the per-sample history needs (grad_pred) lives in a per-pass tile PX[column][3]. */
+constexpr int NPS_EVAL = 17, NPS_TRAIN = 21;
+enum { PS_DENSITY = 0, PS_RGB = 1, PS_DIF = 4, PS_SPC = 7, PS_NPRED = 10, PS_TINT = 13, PS_ROUGH = 16, PS_NORMALS = 17 };
 
 struct LevelArgs {
   const void *packed;
@@ -35,7 +38,7 @@ struct LevelArgs {
   long long *prof;   /* debug: per-phase cycle stamps of workgroup 0 (REFNERF_PROF=1), else NULL */
 };
 
-#define RN_STAMP(A, slot) do { if ((A).prof && blockIdx.x == 0 && (threadIdx.x & 63) == 0) (A).prof[(threadIdx.x >> 6) * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define RN_STAMP(A, slot) do { asm volatile("; RNMARK " #slot); if ((A).prof && blockIdx.x == 0 && (threadIdx.x & 63) == 0) (A).prof[(threadIdx.x >> 6) * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -52,6 +55,29 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+/* Sum K per-lane values over the wave through an LDS transpose: lane k adds
+ * the 64 partials of value k (65-float pitch: conflict-free both ways), then
+ * every total is broadcast.  ~K/6 of the instructions (and time) of K butterfly
+ * reductions.  `scr` = 65*K floats of wave-private LDS. */
+constexpr int WSUM_PITCH = 65;
+template <int K>
+__device__ __forceinline__ void wave_sum_many(float (&v)[K], float *scr, int lane) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) scr[k * WSUM_PITCH + lane] = v[k];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float s = 0.0f;
+  if (lane < K) {
+    const float *col = scr + lane * WSUM_PITCH;
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < 64; j += 4) s += (col[j] + col[j + 1]) + (col[j + 2] + col[j + 3]);
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = __shfl(s, k, 64);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 /* inclusive scan of doubles across the wave */
 __device__ __forceinline__ double wave_scan_incl(double v, int lane) {
 #pragma unroll
@@ -72,21 +98,26 @@ __device__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, f
                                       float smin, float smax, float *sd, int32_t *bin_idx_g, int lane) {
   /* softmax: max is order-independent */
   float mx = -INFINITY;
+  #pragma clang loop unroll(disable)
   for (int i = lane; i < M; i += 64) mx = fmaxf(mx, lg[i]);
   mx = wave_max(mx);
+  #pragma clang loop unroll(disable)
   for (int i = lane; i < M; i += 64) lg[i] = rn_det_expf(lg[i] - mx);
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
   float sum = 0.0f;
   if (EXACT) {
     if (lane == 0) {
+      #pragma clang loop unroll(disable)
       for (int i = 0; i < M; ++i) sum += lg[i];
     }
     sum = __shfl(sum, 0, 64);
   } else {
+    #pragma clang loop unroll(disable)
     for (int i = lane; i < M; i += 64) sum += lg[i];
     sum = wave_sum(sum);
   }
+  #pragma clang loop unroll(disable)
   for (int i = lane; i < M; i += 64) lg[i] = lg[i] / sum;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -94,6 +125,7 @@ __device__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, f
     if (lane == 0) {
       cw[0] = 0.0f;
       double acc = 0.0;
+      #pragma clang loop unroll(disable)
       for (int i = 0; i < M - 1; ++i) { acc += (double)lg[i]; cw[i + 1] = fminf(1.0f, (float)acc); }
       cw[M] = 1.0f;
     }
@@ -102,18 +134,22 @@ __device__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, f
      * the summation order, not bit-identical to the sequential one */
     const int Cn = (M + 63) / 64, i0 = lane * Cn;
     double loc = 0.0;
+    #pragma clang loop unroll(disable)
     for (int q = 0; q < Cn; ++q) if (i0 + q < M - 1) loc += (double)lg[i0 + q];
     double run = wave_scan_incl(loc, lane) - loc;
+    #pragma clang loop unroll(disable)
     for (int q = 0; q < Cn; ++q) if (i0 + q < M - 1) { run += (double)lg[i0 + q]; cw[i0 + q + 1] = fminf(1.0f, (float)run); }
     if (lane == 0) { cw[0] = 0.0f; cw[M] = 1.0f; }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
   /* inverse CDF at the deterministic centres (math.py:88-111) */
+  #pragma clang loop unroll(disable)
   for (int k = lane; k < N; k += 64) {
     float u = linspace_u(k, N);
     /* lo = max{j : u >= cw[j]}; cw is non-decreasing, cw[0]=0 <= u < 1=cw[M] */
     int lo = 0, hi = M;  /* invariant: cw[lo] <= u, cw[hi] > u */
+    #pragma clang loop unroll(disable)
     while (hi - lo > 1) {
       int mid = (lo + hi) >> 1;
       if (u >= cw[mid]) lo = mid; else hi = mid;
@@ -127,6 +163,7 @@ __device__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, f
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  #pragma clang loop unroll(disable)
   for (int k = lane; k <= N; k += 64) {
     float v;
     if (k == 0) v = fmaxf(smin, 2.0f * c[0] - (c[1] + c[0]) / 2.0f);
@@ -153,14 +190,17 @@ __device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratc
   const int Mp = (M + 4) & ~3, Np = (N + 3) & ~3;      /* per-wave scratch: 3*Mp + Np floats */
   float *scr = scratch + wave * (3 * Mp + Np);
   float *t_in = scr, *lg = scr + Mp, *cw = scr + 2 * Mp, *c = scr + 3 * Mp;
+  #pragma clang loop unroll(disable)
   for (int rl = wave; rl < rpw; rl += NW) {
     int ray = ray0 + rl;
     if (ray >= A.R) break;
     const float *tg = A.sdist_in + (size_t)ray * (M + 1);
     const float *wg = A.weights_in + (size_t)ray * M;
+    #pragma clang loop unroll(disable)
     for (int i = lane; i <= M; i += 64) t_in[i] = tg[i];
     wave_sync();
     /* models.py:200-203 */
+    #pragma clang loop unroll(disable)
     for (int i = lane; i < M; i += 64)
       lg[i] = (t_in[i + 1] > t_in[i]) ? cfg.anneal * logf(wg[i] + cfg.resample_padding) : -INFINITY;
     wave_sync();
@@ -168,6 +208,7 @@ __device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratc
     sample_intervals_wave<EXACT>(t_in, lg, cw, c, M, N, cfg.s_near, cfg.s_far, sd,
                           A.out.d_bin_idx ? A.out.d_bin_idx + (size_t)ray * N : nullptr, lane);
     float nearv = A.rays.d_near[ray], farv = A.rays.d_far[ray];
+    #pragma clang loop unroll(disable)
     for (int k = lane; k <= N; k += 64) {
       float s = sd[k];
       if (A.out.d_sdist) A.out.d_sdist[(size_t)ray * (N + 1) + k] = s;
@@ -203,9 +244,9 @@ __device__ __forceinline__ void sample_heads(const refnerf_level_cfg &cfg, float
 
 /* P6 (models.py:699-729): colour head; keeps what compositing needs in LDS
  * PS[c][g] (the history is flushed from there by history_flush). */
-template <bool FAST = false>
+template <bool FAST = false, int NP = NPS_TRAIN>
 __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHeads &s, const float raw_rgb[3],
-                                             float *PS, int n_tot, int g) {
+                                             float *PS, float *PX, int n_tot, int g, int gcol) {
   const refnerf_level_cfg &cfg = A.cfg;
   float spec_lin[3], dif_lin[3], rgb[3], dif[3], spc[3];
 #pragma unroll
@@ -234,17 +275,17 @@ __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHea
   const float pad_scale = (float)(1.0 + 2.0 * (double)cfg.rgb_padding);
 #pragma unroll
   for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] * pad_scale - cfg.rgb_padding;
-  PS[g * NPS + PS_DENSITY] = s.density;
-  PS[g * NPS + PS_ROUGH] = s.rough;
+  PS[g * NP + PS_DENSITY] = s.density;
+  PS[g * NP + PS_ROUGH] = s.rough;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    PS[g * NPS + PS_RGB + i] = rgb[i];
-    PS[g * NPS + PS_DIF + i] = dif[i];
-    PS[g * NPS + PS_SPC + i] = spc[i];
-    PS[g * NPS + PS_NPRED + i] = s.npred[i];
-    PS[g * NPS + PS_TINT + i] = s.tint[i];
-    PS[g * NPS + PS_NORMALS + i] = s.normals[i];
-    PS[g * NPS + PS_GP + i] = s.gp[i];
+    PS[g * NP + PS_RGB + i] = rgb[i];
+    PS[g * NP + PS_DIF + i] = dif[i];
+    PS[g * NP + PS_SPC + i] = spc[i];
+    PS[g * NP + PS_NPRED + i] = s.npred[i];
+    PS[g * NP + PS_TINT + i] = s.tint[i];
+    if (NP > PS_NORMALS) PS[g * NP + PS_NORMALS + i] = s.normals[i];
+    PX[gcol * 3 + i] = s.gp[i];
   }
 }
 
@@ -252,7 +293,9 @@ __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHea
  * from LDS PS with fully coalesced stores: for the [R,N,3] tensors lane L writes
  * flat element 3*sample + channel = L, L+64.  gw0 = first sample (workgroup
  * index) of the block, gs0 = its global sample index ray*N + i. */
-__device__ __forceinline__ void history_flush(const LevelArgs &A, const float *PS, int n_tot, int gw0, size_t gs0, int lane) {
+template <int NP = NPS_TRAIN>
+__device__ __forceinline__ void history_flush(const LevelArgs &A, const float *PS, const float *PX, int n_tot, int gw0, int gcol0,
+                                              size_t gs0, int lane) {
   const size_t total = (size_t)A.R * A.cfg.n_samples;
   auto vec3 = [&](float *dst, int slot) {
     if (!dst) return;
@@ -260,11 +303,11 @@ __device__ __forceinline__ void history_flush(const LevelArgs &A, const float *P
     for (int it = 0; it < 2; ++it) {
       const int f = lane + 64 * it;
       const int smp = f / 3, c = f - 3 * smp;
-      if (f < 96 && gw0 + smp < n_tot && gs0 + smp < total) dst[gs0 * 3 + f] = PS[(gw0 + smp) * NPS + slot + c];
+      if (f < 96 && gw0 + smp < n_tot && gs0 + smp < total) dst[gs0 * 3 + f] = PS[(gw0 + smp) * NP + slot + c];
     }
   };
   auto scal = [&](float *dst, int slot) {
-    if (dst && lane < 32 && gw0 + lane < n_tot && gs0 + lane < total) dst[gs0 + lane] = PS[(gw0 + lane) * NPS + slot];
+    if (dst && lane < 32 && gw0 + lane < n_tot && gs0 + lane < total) dst[gs0 + lane] = PS[(gw0 + lane) * NP + slot];
   };
   scal(A.out.d_density, PS_DENSITY);
   scal(A.out.d_roughness, PS_ROUGH);
@@ -272,17 +315,25 @@ __device__ __forceinline__ void history_flush(const LevelArgs &A, const float *P
   vec3(A.out.d_diffuse, PS_DIF);
   vec3(A.out.d_specular, PS_SPC);
   vec3(A.out.d_normals_pred, PS_NPRED);
-  vec3(A.out.d_grad_pred, PS_GP);
+  if (A.out.d_grad_pred) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int f = lane + 64 * it;
+      const int smp = f / 3;
+      if (f < 96 && gw0 + smp < n_tot && gs0 + smp < total) A.out.d_grad_pred[gs0 * 3 + f] = PX[gcol0 * 3 + f];
+    }
+  }
   vec3(A.out.d_tint, PS_TINT);
-  if (A.cfg.training) vec3(A.out.d_normals, PS_NORMALS);
+  if (NP > PS_NORMALS && A.cfg.training) vec3(A.out.d_normals, PS_NORMALS);
 }
 
 /* P7: alpha weights + compositing, one wave per ray (render.py:132-149, 152-254). */
-template <int NW = 4, bool FAST = false>
+template <int NW = 4, bool FAST = false, int NP = NPS_TRAIN>
 __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float *TD, float *XP, float *PS, int n_tot,
-                                                int ray0, int wave, int lane) {
+                                                int ray0, int wave, int lane, float *wscr) {
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples, rpw = A.rpw;
+  #pragma clang loop unroll(disable)
   for (int rl = wave; rl < rpw; rl += NW) {
     const int ray = ray0 + rl;
     if (ray >= A.R) break;
@@ -292,13 +343,14 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
     const int i0 = lane * C;
     float dx = A.rays.d_directions[(size_t)ray * 3], dy = A.rays.d_directions[(size_t)ray * 3 + 1], dz = A.rays.d_directions[(size_t)ray * 3 + 2];
     const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
-    float *wbuf = PS + base * NPS + PS_DENSITY;    /* density (stride NPS) is overwritten by the weights */
+    float *wbuf = PS + base * NP + PS_DENSITY;    /* density (stride NPS) is overwritten by the weights */
     /* pass 1: local sums of density*delta */
     double local = 0.0;
+    #pragma clang loop unroll(disable)
     for (int q = 0; q < C; ++q) {
       int i = i0 + q;
       if (i < N) {
-        float dd = wbuf[i * NPS] * ((td[i + 1] - td[i]) * norm);
+        float dd = wbuf[i * NP] * ((td[i + 1] - td[i]) * norm);
         if (cfg.opaque_background && i == N - 1) dd = INFINITY;
         local += (double)dd;
       }
@@ -310,39 +362,46 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
     float s_nm[3] = {0, 0, 0};
     float s_dist = 0, s_rgh = 0, s_logd = 0;
     double wlocal = 0.0;
+    #pragma clang loop unroll(disable)
     for (int q = 0; q < C; ++q) {
       int i = i0 + q;
       if (i < N) {
-        float dd = wbuf[i * NPS] * ((td[i + 1] - td[i]) * norm);
+        float dd = wbuf[i * NP] * ((td[i + 1] - td[i]) * norm);
         if (cfg.opaque_background && i == N - 1) dd = INFINITY;
         float alpha = 1.0f - m_exp<FAST>(-dd);
         float trans = m_exp<FAST>(-(float)cum);
         float w = alpha * trans;
         cum += (double)dd;
-        wbuf[i * NPS] = w;
+        wbuf[i * NP] = w;
         wlocal += (double)w;
         if (A.out.d_weights) A.out.d_weights[(size_t)ray * N + i] = w;
         acc += w;
         float tmid = 0.5f * (td[i] + td[i + 1]);
         s_dist += w * tmid;
         s_logd += w * m_log<FAST>(tmid);
-        s_rgh += w * PS[(base + i) * NPS + PS_ROUGH];
+        s_rgh += w * PS[(base + i) * NP + PS_ROUGH];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          s_rgb[c] += w * PS[(base + i) * NPS + PS_RGB + c];
-          s_dif[c] += w * PS[(base + i) * NPS + PS_DIF + c];
-          s_spc[c] += w * PS[(base + i) * NPS + PS_SPC + c];
-          s_np[c] += w * PS[(base + i) * NPS + PS_NPRED + c];
-          s_tn[c] += w * PS[(base + i) * NPS + PS_TINT + c];
-          s_nm[c] += w * PS[(base + i) * NPS + PS_NORMALS + c];
+          s_rgb[c] += w * PS[(base + i) * NP + PS_RGB + c];
+          s_dif[c] += w * PS[(base + i) * NP + PS_DIF + c];
+          s_spc[c] += w * PS[(base + i) * NP + PS_SPC + c];
+          s_np[c] += w * PS[(base + i) * NP + PS_NPRED + c];
+          s_tn[c] += w * PS[(base + i) * NP + PS_TINT + c];
+          if (NP > PS_NORMALS) s_nm[c] += w * PS[(base + i) * NP + PS_NORMALS + c];
         }
       }
     }
-    acc = wave_sum(acc); s_dist = wave_sum(s_dist); s_logd = wave_sum(s_logd); s_rgh = wave_sum(s_rgh);
+    {
+      float red[22] = {acc, s_dist, s_logd, s_rgh, s_rgb[0], s_rgb[1], s_rgb[2], s_dif[0], s_dif[1], s_dif[2],
+                       s_spc[0], s_spc[1], s_spc[2], s_np[0], s_np[1], s_np[2], s_tn[0], s_tn[1], s_tn[2],
+                       s_nm[0], s_nm[1], s_nm[2]};
+      wave_sum_many<22>(red, wscr + wave * (22 * WSUM_PITCH), lane);
+      acc = red[0]; s_dist = red[1]; s_logd = red[2]; s_rgh = red[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      s_rgb[c] = wave_sum(s_rgb[c]); s_dif[c] = wave_sum(s_dif[c]); s_spc[c] = wave_sum(s_spc[c]);
-      s_np[c] = wave_sum(s_np[c]); s_tn[c] = wave_sum(s_tn[c]); s_nm[c] = wave_sum(s_nm[c]);
+      for (int c = 0; c < 3; ++c) {
+        s_rgb[c] = red[4 + c]; s_dif[c] = red[7 + c]; s_spc[c] = red[10 + c];
+        s_np[c] = red[13 + c]; s_tn[c] = red[16 + c]; s_nm[c] = red[19 + c];
+      }
     }
     const float bg_w = fmaxf(0.0f, 1.0f - acc);
     float rgb[3], dif[3], spc[3];
@@ -360,7 +419,7 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         if (mode == REFNERF_SRGB_SRGB || mode == REFNERF_SRGB_NORM_SRGB) {
-          rgb[c] = linear_to_srgb(rgb[c]); dif[c] = linear_to_srgb(dif[c]); spc[c] = linear_to_srgb(spc[c]);
+          rgb[c] = linear_to_srgb<FAST>(rgb[c]); dif[c] = linear_to_srgb<FAST>(dif[c]); spc[c] = linear_to_srgb<FAST>(spc[c]);
         }
         rgb[c] = clip01(rgb[c]); dif[c] = clip01(dif[c]); spc[c] = clip01(spc[c]);
       }
@@ -392,9 +451,10 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
       double wincl = wave_scan_incl(wlocal, lane);
       double run = wincl - wlocal;
       __builtin_amdgcn_wave_barrier();
+      #pragma clang loop unroll(disable)
       for (int q = 0; q < C; ++q) {
         int i = i0 + q;
-        if (i < N) { run += (double)wbuf[i * NPS]; xp[i + 1] = fminf(1.0f, (float)run); }
+        if (i < N) { run += (double)wbuf[i * NP]; xp[i + 1] = fminf(1.0f, (float)run); }
       }
       if (lane == 0) { xp[0] = 0.0f; }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -404,9 +464,11 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
       const float farv = A.rays.d_far[ray];
       const float psf[3] = {5.0f / 100.0f, 50.0f / 100.0f, 95.0f / 100.0f};
       const int nk = N + 2;
+      #pragma clang loop unroll(disable)
       for (int p = 0; p < 3; ++p) {
         double x = (double)psf[p];
         int cnt = 0;
+        #pragma clang loop unroll(disable)
         for (int j = lane; j < nk; j += 64) {
           double xj = (j == nk - 1) ? 1.0 : (double)xp[j];
           cnt += (x >= xj) ? 1 : 0;

@@ -212,7 +212,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   float *HD = X + DIR_PAD * T_TILE;              /* [HD_ROWS][T_TILE]              */
   float *TD = HD + HD_ROWS * T_TILE;             /* [rpw][N+1] metric distances    */
   float *XP = TD + rpw * (N + 1);                /* [rpw][N+1] CDF knots for the percentiles */
-  float *PS = XP + rpw * (N + 1);                /* [NPS][n_tot]                   */
+  float *PS = XP + rpw * (N + 1);                /* [n_tot][NPS_TRAIN]             */
+  float *PX = PS + n_tot * NPS_TRAIN;            /* [T_TILE][3] grad_pred of the pass */
 
   resample_phase(A, X, TD, ray0, wave, lane);    /* P0 */
   __syncthreads();
@@ -321,14 +322,14 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(rgbv[0][i], sl, 64);
 
     /* P6: colour head (models.py:699-729) */
-    if (valid && h == 0) colour_store(A, sh, raw_rgb, PS, n_tot, g);
+    if (valid && h == 0) colour_store(A, sh, raw_rgb, PS, PX, n_tot, g, col);
     wave_sync();
-    history_flush(A, PS, n_tot, pass0 + wave * 32, (size_t)ray0 * N + pass0 + wave * 32, lane);
+    history_flush(A, PS, PX, n_tot, pass0 + wave * 32, wave * 32, (size_t)ray0 * N + pass0 + wave * 32, lane);
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
 
-  composite_phase(A, TD, XP, PS, n_tot, ray0, wave, lane);   /* P7 */
+  composite_phase(A, TD, XP, PS, n_tot, ray0, wave, lane, X);   /* P7 */
 }
 
 __global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false>(A); }
