@@ -390,7 +390,7 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
     const int nw = bf ? 8 : 4;
     for (int w = 0; w < nw; ++w) {
       fprintf(stderr, "[prof] wave %d:", w);
-      for (int sl = 1; sl <= 24; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
+      for (int sl = 1; sl <= 18; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
       fprintf(stderr, "  | dma-wait %lld barrier-wait %lld\n", hbuf[w * 32 + 20], hbuf[w * 32 + 21]);
     }
   }

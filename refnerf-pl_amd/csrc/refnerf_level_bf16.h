@@ -267,7 +267,6 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
 #pragma unroll
   for (int d = 0; d < AF; ++d) ar[d] = lds_frag(WB + 1024 + lane * 16 + d * 1024);
 
-  RN_STAMP(A, 24);
   for (int pass0 = 0; pass0 < n_tot; pass0 += BT) {
     /* opaque copies: keep hipcc from hoisting ~100 registers of per-lane address
      * arithmetic out of the pass loop (it then spills them to scratch) */
@@ -303,10 +302,8 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         for (int e = 0; e < 8; ++e) bn[e] = (v4uu){0, 0, 0, 0};
       }
       char *xs = Xb + col * 16;
-      RN_STAMP(A, 19);
       if (phase == 0) {
         /* P1: conical frustum -> lifted Gaussian -> IPE (half h computes block h: sin / cos) */
-        RN_STAMP(A, 22);
         float o[3], d[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { o[i] = A.rays.d_origins[(size_t)rayc * 3 + i]; d[i] = A.rays.d_directions[(size_t)rayc * 3 + i]; }
@@ -314,8 +311,6 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         const float *td = TD + (valid ? rl : 0) * (N + 1);
         float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
         float lm[3], lv[3];
-        { float sacc = (o[0] + d[0]) + radius + t0 + t1; asm volatile("" : "+v"(sacc)); }
-        RN_STAMP(A, 23);
         cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
         /* k' = canonical IPE index: half h owns block h (sin / cos) = k' 48h .. 48h+47 = 6 k-groups;
          * rolled over two halves of 24 features (8 degrees x 3 axes): the (axis, degree) pattern repeats */

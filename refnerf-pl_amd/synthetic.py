@@ -140,15 +140,19 @@ def blender_rays(n_rays: int, seed: int = 1, full_image: bool = False,
     return _bundle(*_pixels_to_rays(px, py, focal, width, height, c2w), near=2.0, far=6.0)
 
 
-def llff_rays(n_rays: int, seed: int = 1, width: int = 1008, height: int = 756) -> dict:
+def llff_rays(n_rays: int, seed: int = 1, width: int = 1008, height: int = 756, full_image: bool = False) -> dict:
     """LLFF-style forward-facing rays in NDC (near 0 / far 1)."""
     focal = 815.0
     u = hash_uniform(seed, 7, 3)
     c2w = np.zeros((3, 4))
     c2w[:3, :3] = np.eye(3)
     c2w[:3, 3] = (u - 0.5) * np.array([0.6, 0.4, 0.2])
-    px = np.floor(hash_uniform(seed, 1, n_rays) * width).astype(np.int64)
-    py = np.floor(hash_uniform(seed, 2, n_rays) * height).astype(np.int64)
+    if full_image:
+        yy, xx = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+        px, py = xx.reshape(-1), yy.reshape(-1)
+    else:
+        px = np.floor(hash_uniform(seed, 1, n_rays) * width).astype(np.int64)
+        py = np.floor(hash_uniform(seed, 2, n_rays) * height).astype(np.int64)
     return _bundle(*_pixels_to_rays(px, py, focal, width, height, c2w, ndc_near=1.0), near=0.0, far=1.0)
 
 

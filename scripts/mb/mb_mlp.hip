@@ -49,10 +49,26 @@ __global__ __launch_bounds__(512) void mlp_loop(const char *img, float *out, lon
 #endif
   const char *src_end = src + (size_t)136 * CHUNK;
   int left = NCH;
+#ifdef ROT
+  const int rot = (blockIdx.x * 5) % 17;
+  const char *srcb = img + lane * 16;
+  const char *srcb_end = srcb + (size_t)136 * CHUNK;
+#endif
   auto issue = [&](int slot) {
     if (left > 0) {
 #ifndef NODMA
-#if defined(DMAHI)
+#if defined(ROT)
+      // piece order rotated per workgroup: at any instant different CUs pull different L2 lines
+      if (wave < 6) {
+        const int np = (wave < 5) ? 3 : 2;
+        for (int q = 0; q < np; ++q) {
+          int piece = (wave * 3 + q + rot) % 17;
+          __builtin_amdgcn_global_load_lds((gptr_t)(srcb + piece * 1024), (lptr_t)(WB + slot + piece * 1024), 16, 0, 0);
+        }
+      }
+      srcb += CHUNK;
+      if (srcb == srcb_end) srcb -= (size_t)136 * CHUNK;
+#elif defined(DMAHI)
       // all 17 pieces issued by the prioritized waves 4-7 (4,4,4,5): they idle at the rendezvous anyway
       if (wave >= 4) {
         lptr_t dst = (lptr_t)(WB + slot + (wave - 4) * 4096);
@@ -89,6 +105,30 @@ __global__ __launch_bounds__(512) void mlp_loop(const char *img, float *out, lon
       left -= 1;
     }
   };
+#ifdef VLOAD
+  // weight stream through VGPRs: wave w owns pieces 2w, 2w+1 (+ piece 16 for wave 0)
+  v4u st0 = {0}, st1 = {0}, st2 = {0};
+  const char *vsrc = img + wave * 2048 + lane * 16;
+  const char *vsrc_end = vsrc + (size_t)136 * CHUNK;
+  int vleft = NCH - 2, wslot = fil;
+  auto vload = [&]() {
+    if (vleft > 0) {
+      st0 = *reinterpret_cast<const v4u *>(vsrc);
+      st1 = *reinterpret_cast<const v4u *>(vsrc + 1024);
+      if (wave == 0) st2 = *reinterpret_cast<const v4u *>(vsrc + 16384);
+      vsrc += CHUNK; if (vsrc == vsrc_end) vsrc -= (size_t)136 * CHUNK;
+    }
+  };
+  auto vwrite = [&](int slot) {
+    if (vleft > 0) {
+      char *d = WB + slot + wave * 2048 + lane * 16;
+      *reinterpret_cast<v4u *>(d) = st0;
+      *reinterpret_cast<v4u *>(d + 1024) = st1;
+      if (wave == 0) *reinterpret_cast<v4u *>(d + 16384) = st2;
+      vleft -= 1;
+    }
+  };
+#endif
   issue(cur); issue(nxt);
 #ifdef BAR2
   issue(fil);
@@ -140,6 +180,15 @@ __global__ __launch_bounds__(512) void mlp_loop(const char *img, float *out, lon
       }
       if (k == 7 && (c & 1) == 1) issue(fil2);
 #else
+#ifdef VLOAD
+      if (k == 7) {
+        // pieces loaded one rendezvous ago go to the slot freed one rendezvous ago, then the next loads start
+        if (c > 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); vwrite(wslot); }
+        __syncthreads();
+        wslot = fil;
+        vload();
+      }
+#else
       if (k == 7) {
 #ifndef NOBAR
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -151,6 +200,7 @@ __global__ __launch_bounds__(512) void mlp_loop(const char *img, float *out, lon
         issue(fil);
 #endif
       }
+#endif
 #endif
 #ifdef STAG
       if (k == 11 && wave >= 4) issue(fil);
