@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of scripts/profile_gpu.sh (gpurun_out/prof_<tag>/) into the small
+per-round summaries committed under profiles/<round>/:
+  kernel_stats.csv        -- rocprofv3 --kernel-trace --stats table of the rn:: kernels
+  pmc_<kernel>.csv        -- per-dispatch mean/min/max of every counter collected (separate --pmc passes)
+and refresh profiles/traffic.json (HBM-side bytes per launch, gfx950 FETCH_SIZE x2 correction).
+usage: summarize_prof.py gpurun_out/prof_r01b profiles/r01"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+KERNELS = {"level_fwd_bf16": "rn::level_fwd_bf16", "level_fwd_f32": "rn::level_fwd_f32",
+           "level_fwd_train_f32": "rn::level_fwd_train_f32", "level_bwd_f32": "rn::level_bwd_f32",
+           "wgrad_kernel": "rn::wgrad_kernel"}
+
+rows = list(csv.reader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
+with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-image\n")
+    w.writerow(rows[0])
+    for r in rows[1:]:
+        if r and r[0].startswith("rn::"):
+            w.writerow(r)
+
+stats = defaultdict(lambda: defaultdict(list))
+meta = {}
+for path in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].split("(")[0]
+        for short, full in KERNELS.items():
+            if name == full:
+                stats[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta[short] = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"])
+for short, counters in stats.items():
+    with open(os.path.join(dst, f"pmc_{short}.csv"), "w") as f:
+        g = meta[short]
+        f.write(f"# rocprofv3 --pmc passes (separate runs) of: python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-image\n")
+        f.write(f"# kernel {KERNELS[short]}, grid {g[0]}, wg {g[1]}, VGPR {g[2]}, AGPR {g[3]}, SGPR {g[4]}, scratch {g[5]}\n")
+        f.write("counter,dispatches,mean_per_dispatch,min,max\n")
+        for c in sorted(counters):
+            v = counters[c]
+            f.write(f"{c},{len(v)},{sum(v) / len(v):.1f},{min(v):.1f},{max(v):.1f}\n")
+
+tj = os.path.join(os.path.dirname(dst.rstrip("/")), "traffic.json")
+traffic = json.load(open(tj)) if os.path.exists(tj) else {}
+for short, counters in stats.items():
+    if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        fs = sum(counters["FETCH_SIZE"]) / len(counters["FETCH_SIZE"])
+        ws = sum(counters["WRITE_SIZE"]) / len(counters["WRITE_SIZE"])
+        e = traffic.get(KERNELS[short], {})
+        e.update({"round": os.path.basename(dst.rstrip("/")), "workload": "4096 rays x 128 samples, one level per launch",
+                  "FETCH_SIZE_KB": round(fs, 1), "WRITE_SIZE_KB": round(ws, 1),
+                  "bytes_per_launch": int((2 * fs + ws) * 1024)})
+        traffic[KERNELS[short]] = e
+json.dump(traffic, open(tj, "w"), indent=2)
+print("wrote", sorted(os.listdir(dst)))
