@@ -351,8 +351,9 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
       int i = i0 + q;
       if (i < N) {
         float dd = wbuf[i * NP] * ((td[i + 1] - td[i]) * norm);
-        if (cfg.opaque_background && i == N - 1) dd = INFINITY;
-        local += (double)dd;
+        /* opaque background (render.py:139-143): the last interval's optical depth is +inf; nothing lies
+         * behind it, so it stays out of the prefix sums (inf - inf would poison the exclusive scan) */
+        if (!(cfg.opaque_background && i == N - 1)) local += (double)dd;
       }
     }
     double incl = wave_scan_incl(local, lane);

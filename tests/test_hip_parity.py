@@ -267,6 +267,63 @@ def test_model_api_matches_reference_contract(hip):
     np.testing.assert_allclose(rendering["rgb"].reshape(-1, 3).cpu().numpy(), g["L1_r_rgb"], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("R,nprop,nfine,extra", [(5, 64, 96, {}), (3, 33, 40, {"opaque_background": 1}),
+                                                 (9, 128, 64, {"srgb_mapping": 0, "render_srgb_mode": 2})])
+def test_training_step_ragged_shapes(hip, O, R, nprop, nfine, extra):
+    """Backward at ragged sizes (R not a multiple of the workgroup tile, N not a
+    multiple of 32, partially filled passes), opaque background and the
+    render-time norm_linear colour map, against the oracle."""
+    from refnerf_pl_amd import synthetic
+    P = synthetic.make_params(seed=3, bias_scale=0.05, sharpen=8.0)
+    rays = synthetic.blender_rays(R, seed=11, center_frac=0.5)
+    rays["lossmult"] = (0.5 + synthetic.hash_uniform(5, 9, R)).astype(np.float32).reshape(R, 1)
+    gt = synthetic.target_rgb(R, seed=4)
+    kw = dict(extra)
+    if "render_srgb_mode" in kw:
+        kw["render_srgb_mode"] = int(kw["render_srgb_mode"])
+    lv = dict(num_levels=2, num_prop_samples=nprop, num_nerf_samples=nfine)
+    mults = ((0.1, 1.0), (0.01, 0.1), (3e-5, 3e-4))
+    losses, grads = _hip_train_step(hip, P, rays, gt, rays["lossmult"], kw, lv, mults)
+    o_losses, o_grads, _ = O.model_train(P, rays, gt, **lv, **kw)
+    for k in ("data", "orientation", "normal"):
+        assert losses[k] == pytest.approx(o_losses[k], rel=5e-4, abs=1e-9), k
+    rel = np.linalg.norm(grads - o_grads) / np.linalg.norm(o_grads)
+    assert np.isfinite(grads).all() and rel < 5e-4, rel
+
+
+def test_backward_is_linear_in_the_upstream_gradients(hip):
+    """Size-independent property at a larger batch: the parameter gradient is linear in
+    (dL/d rgb, dL/d weights, dL/d n_pred), accumulates across calls, and a zero seed gives zero."""
+    from refnerf_pl_amd import synthetic
+    R, N = 320, 128
+    P = synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0)
+    packed = hip.pack_weights(torch.tensor(P, device=DEV), precision=0)
+    r = dev_rays(synthetic.blender_rays(R, seed=2, center_frac=0.5))
+    sd = torch.tensor([[0.0, 1.0]], device=DEV).repeat(R, 1)
+    w = torch.ones((R, 1), device=DEV)
+    cfg = hip.default_cfg(n_samples=N, n_in=1, precision=0, training=1)
+    res = hip.level_forward(packed, cfg, r, sd, w)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    ga = [torch.randn((R, 3), generator=g).to(DEV) * 1e-3, torch.randn((R, N), generator=g).to(DEV) * 1e-3,
+          torch.randn((R, N, 3), generator=g).to(DEV) * 1e-3]
+    gb = [torch.randn((R, 3), generator=g).to(DEV) * 1e-3, None, None]
+
+    def run(seeds, acc=None):
+        out = torch.zeros(hip.NUM_PARAMS, device=DEV) if acc is None else acc
+        hip.level_backward(packed, cfg, r, res, seeds[0], seeds[1], seeds[2], out)
+        return out
+    A, B = run(ga), run(gb)
+    AB = run([ga[0] * 2.0 + gb[0] * -3.0, ga[1] * 2.0, ga[2] * 2.0])
+    ref = 2.0 * A - 3.0 * B
+    assert float((AB - ref).norm() / ref.norm()) < 2e-5
+    acc = run(gb, acc=A.clone())                                   # accumulation into an existing blob
+    assert float((acc - (A + B)).norm() / (A + B).norm()) < 1e-6
+    Z = run([torch.zeros((R, 3), device=DEV), None, None])
+    assert float(Z.abs().max()) == 0.0
+    A2 = run(ga)                                                   # bit-reproducible (no atomics)
+    assert torch.equal(A, A2)
+
+
 def test_model_training_step_autograd(hip):
     """Model.__call__ in training mode + the reference-shaped losses + loss.backward():
     the 46 nn.Parameters receive the reference's gradients (golden autograd vectors)."""
@@ -336,6 +393,24 @@ def test_edge_shapes_and_errors(hip, O):
         hip.level_forward(packed, hip.default_cfg(n_samples=1), r, sd, w)
     with pytest.raises(ValueError, match="ray_shape"):
         hip.level_forward(packed, hip.default_cfg(ray_shape=3), r, sd, w)
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_opaque_background(hip, O, precision):
+    """Model.opaque_background (render.py:139-143): last interval alpha = 1, acc = 1, no NaN."""
+    from refnerf_pl_amd import synthetic
+    P = synthetic.make_params(seed=3, bias_scale=0.05, sharpen=8.0)
+    rays = synthetic.blender_rays(7, seed=11, center_frac=0.5)
+    kw, lv = dict(opaque_background=1), dict(num_levels=2, num_prop_samples=33, num_nerf_samples=64)
+    ref = O.model_forward(P, rays, **lv, **kw)
+    outs = run_hip_model(hip, P, rays, kw, lv, precision=precision)
+    tol = 1e-5 if precision == 0 else 1e-3
+    for res, orc in zip(outs, ref):
+        for k in ("weights", "r_rgb", "r_acc", "r_distance"):
+            assert np.isfinite(res[k]).all(), k
+            if precision == 0 or k != "weights":
+                np.testing.assert_allclose(res[k], orc[k].reshape(res[k].shape), rtol=0, atol=tol, err_msg=k)
+        np.testing.assert_allclose(res["r_acc"], 1.0, rtol=0, atol=1e-5)
 
 
 def test_full_size_properties(hip):
