@@ -96,7 +96,7 @@ __device__ __forceinline__ float ipe_feature(float lm, float lv, int j, int cos_
      * rounding: reduce in revolutions and use v_sin_f32 (input in revolutions) */
     float r = (lm * sc) * INV_2PI_F;
     if (cos_block) r = r + 0.25f;
-    r = r - floorf(r);
+    r = __builtin_amdgcn_fractf(r);
     float e = __builtin_amdgcn_exp2f((-0.5f * LOG2E_F) * (lv * sc2));
     return e * __builtin_amdgcn_sinf(r);
   }

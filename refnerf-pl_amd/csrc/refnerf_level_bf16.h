@@ -236,6 +236,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   float *XP = TD + rpw * (N + 1);                            /* [rpw][N+1]               */
   float *PS = XP + rpw * (N + 1);                            /* [n_tot][NPS_EVAL]        */
   float *PX = PS + n_tot * NPS_EVAL;                         /* [BT][3] grad_pred of the pass */
+  float *NRM = PX + 3 * BT;                                  /* [rpw] |direction| per ray */
 
   const int h = lane >> 5, n = lane & 31;
   const int col = wave * 32 + n;                             /* this lane's sample column */
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   issue_chunk(p, p.cur_off);                                 /* overlaps with the resampler */
   issue_chunk(p, p.nxt_off);
 
-  resample_phase<BF_NW, false>(A, reinterpret_cast<float *>(Xb), TD, ray0, wave, lane);   /* P0 */
+  resample_phase<BF_NW, false>(A, reinterpret_cast<float *>(Xb), TD, NRM, ray0, wave, lane);   /* P0 */
   RN_STAMP(A, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                           /* chunks 0 and 1 have landed */
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   if (A.prof && blockIdx.x == 0 && lane == 0) { A.prof[wave * 32 + 20] = p.t_vm; A.prof[wave * 32 + 21] = p.t_bar; }
 #endif
 
-  composite_phase<BF_NW, true, NPS_EVAL>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB));   /* P7 */
+  composite_phase<BF_NW, true, NPS_EVAL>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB), NRM);   /* P7 */
   RN_STAMP(A, 16);
 }
 

@@ -184,7 +184,7 @@ __device__ __forceinline__ void st3(float *base, size_t idx, float a, float b, f
  * ray; writes metric distances tdist to TD[rl][N+1] (LDS) and sdist / bin
  * indices to HBM.  `scratch` needs min(rpw,4) * (3*(M+4) + N+3) floats. */
 template <int NW = 4, bool EXACT = true>
-__device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratch, float *TD, int ray0, int wave, int lane) {
+__device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratch, float *TD, float *NRM, int ray0, int wave, int lane) {
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples, M = cfg.n_in, rpw = A.rpw;
   const int Mp = (M + 4) & ~3, Np = (N + 3) & ~3;      /* per-wave scratch: 3*Mp + Np floats */
@@ -208,6 +208,11 @@ __device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratc
     sample_intervals_wave<EXACT>(t_in, lg, cw, c, M, N, cfg.s_near, cfg.s_far, sd,
                           A.out.d_bin_idx ? A.out.d_bin_idx + (size_t)ray * N : nullptr, lane);
     float nearv = A.rays.d_near[ray], farv = A.rays.d_far[ray];
+    /* |d| for the compositing phase (NRM[rpw] in LDS): P7 would otherwise start with a global-load round trip */
+    if (!EXACT && lane == 0) {                 /* bf16 kernel only: the fp32 kernels keep their proven code path */
+      float dx = A.rays.d_directions[(size_t)ray * 3], dy = A.rays.d_directions[(size_t)ray * 3 + 1], dz = A.rays.d_directions[(size_t)ray * 3 + 2];
+      NRM[rl] = sqrtf((dx * dx + dy * dy) + dz * dz);
+    }
     #pragma clang loop unroll(disable)
     for (int k = lane; k <= N; k += 64) {
       float s = sd[k];
@@ -330,7 +335,7 @@ __device__ __forceinline__ void history_flush(const LevelArgs &A, const float *P
 /* P7: alpha weights + compositing, one wave per ray (render.py:132-149, 152-254). */
 template <int NW = 4, bool FAST = false, int NP = NPS_TRAIN>
 __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float *TD, float *XP, float *PS, int n_tot,
-                                                int ray0, int wave, int lane, float *wscr) {
+                                                int ray0, int wave, int lane, float *wscr, const float *NRM) {
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples, rpw = A.rpw;
   #pragma clang loop unroll(disable)
@@ -341,9 +346,13 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
     const int base = rl * N;
     const int C = (N + 63) / 64;                 /* samples per lane */
     const int i0 = lane * C;
-    float dx = A.rays.d_directions[(size_t)ray * 3], dy = A.rays.d_directions[(size_t)ray * 3 + 1], dz = A.rays.d_directions[(size_t)ray * 3 + 2];
-    const float norm = sqrtf((dx * dx + dy * dy) + dz * dz);
-    float *wbuf = PS + base * NP + PS_DENSITY;    /* density (stride NPS) is overwritten by the weights */
+    float norm;
+    if (FAST) norm = NRM[rl];                     /* |d|, parked by the resample phase */
+    else {
+      float dx = A.rays.d_directions[(size_t)ray * 3], dy = A.rays.d_directions[(size_t)ray * 3 + 1], dz = A.rays.d_directions[(size_t)ray * 3 + 2];
+      norm = sqrtf((dx * dx + dy * dy) + dz * dz);
+    }
+    float *wbuf = PS + base * NP + PS_DENSITY;    /* density (stride NP) is overwritten by the weights */
     /* pass 1: local sums of density*delta */
     double local = 0.0;
     #pragma clang loop unroll(disable)
@@ -463,28 +472,53 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
       /* note xp[N] = min(1,cumsum of all N weights) is what integrate_weights
        * produces for index N (weights_aug[:-1] = the N sample weights); xp[N+1] = 1. */
       const float farv = A.rays.d_far[ray];
-      const float psf[3] = {5.0f / 100.0f, 50.0f / 100.0f, 95.0f / 100.0f};
+      const double psd[3] = {(double)(5.0f / 100.0f), (double)(50.0f / 100.0f), (double)(95.0f / 100.0f)};
       const int nk = N + 2;
-      #pragma clang loop unroll(disable)
-      for (int p = 0; p < 3; ++p) {
-        double x = (double)psf[p];
-        int cnt = 0;
+      if (FAST) {
+        /* searchsorted for the three percentiles at once: wave ballots instead of shuffle reductions,
+         * then lane p interpolates percentile p */
+        int cnt[3] = {0, 0, 0};
         #pragma clang loop unroll(disable)
-        for (int j = lane; j < nk; j += 64) {
-          double xj = (j == nk - 1) ? 1.0 : (double)xp[j];
-          cnt += (x >= xj) ? 1 : 0;
-        }
+        for (int j0 = 0; j0 < nk; j0 += 64) {
+          const int j = j0 + lane;
+          const bool in = j < nk;
+          const double xj = (!in || j == nk - 1) ? 1.0 : (double)xp[j];
 #pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) cnt += __shfl_xor(cnt, o2, 64);
-        if (lane == 0) {
-          int idx = cnt - 1;
+          for (int p = 0; p < 3; ++p) cnt[p] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in && psd[p] >= xj));
+        }
+        if (lane < 3) {
+          const double x = lane == 0 ? psd[0] : (lane == 1 ? psd[1] : psd[2]);
+          int idx = (lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : cnt[2])) - 1;
           if (idx < 0) idx = 0;
           if (idx > nk - 2) idx = nk - 2;
           double x0 = (double)xp[idx], x1 = (idx + 1 == nk - 1) ? 1.0 : (double)xp[idx + 1];
           double f0 = (double)td[idx], f1 = (idx + 1 == nk - 1) ? (double)farv : (double)td[idx + 1];
           double m = (f1 - f0) / (x1 - x0);
           double b = f0 - m * x0;
-          A.out.d_r_percentiles[(size_t)ray * 3 + p] = m * x + b;
+          A.out.d_r_percentiles[(size_t)ray * 3 + lane] = m * x + b;
+        }
+      } else {
+        #pragma clang loop unroll(disable)
+        for (int p = 0; p < 3; ++p) {
+          double x = psd[p];
+          int cnt = 0;
+          #pragma clang loop unroll(disable)
+          for (int j = lane; j < nk; j += 64) {
+            double xj = (j == nk - 1) ? 1.0 : (double)xp[j];
+            cnt += (x >= xj) ? 1 : 0;
+          }
+#pragma unroll
+          for (int o2 = 32; o2 > 0; o2 >>= 1) cnt += __shfl_xor(cnt, o2, 64);
+          if (lane == 0) {
+            int idx = cnt - 1;
+            if (idx < 0) idx = 0;
+            if (idx > nk - 2) idx = nk - 2;
+            double x0 = (double)xp[idx], x1 = (idx + 1 == nk - 1) ? 1.0 : (double)xp[idx + 1];
+            double f0 = (double)td[idx], f1 = (idx + 1 == nk - 1) ? (double)farv : (double)td[idx + 1];
+            double m = (f1 - f0) / (x1 - x0);
+            double b = f0 - m * x0;
+            A.out.d_r_percentiles[(size_t)ray * 3 + p] = m * x + b;
+          }
         }
       }
     }

@@ -214,8 +214,9 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   float *XP = TD + rpw * (N + 1);                /* [rpw][N+1] CDF knots for the percentiles */
   float *PS = XP + rpw * (N + 1);                /* [n_tot][NPS_TRAIN]             */
   float *PX = PS + n_tot * NPS_TRAIN;            /* [T_TILE][3] grad_pred of the pass */
+  float *NRM = PX + 3 * T_TILE;                  /* [rpw] |direction| per ray      */
 
-  resample_phase(A, X, TD, ray0, wave, lane);    /* P0 */
+  resample_phase(A, X, TD, NRM, ray0, wave, lane);    /* P0 */
   __syncthreads();
 
   /* ---------------- per-pass MLP over 32-sample blocks ---------------- */
@@ -329,7 +330,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   }
   __syncthreads();
 
-  composite_phase(A, TD, XP, PS, n_tot, ray0, wave, lane, X);   /* P7 */
+  composite_phase(A, TD, XP, PS, n_tot, ray0, wave, lane, X, NRM);   /* P7 */
 }
 
 __global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false>(A); }
