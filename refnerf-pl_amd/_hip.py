@@ -85,6 +85,8 @@ def lib():
         L.refnerf_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.refnerf_level_backward.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
                                              C.POINTER(LevelSaved), C.POINTER(LevelGrads), _FP, _FP, C.c_size_t, _FP]
+        L.refnerf_mlp_forward.argtypes = [_FP, C.POINTER(LevelCfg), _FP, _FP, C.c_int32, _FP, C.c_int32, C.c_int32,
+                                          C.POINTER(LevelOut), _FP]
         L.refnerf_sample_intervals.argtypes = [_FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                                _FP, _FP, _FP]
         L.refnerf_integrated_pos_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
@@ -194,6 +196,28 @@ def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, histo
     sd = sdist_in.to(torch.float32).contiguous()
     w = weights_in.to(torch.float32).contiguous()
     check(lib().refnerf_level_forward(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out), stream_ptr()))
+    return res
+
+
+def mlp_forward(packed, cfg: LevelCfg, means, covs, viewdirs):
+    """MLP.__call__ on caller-supplied Gaussians: means [R,N,3], covs [R,N,3,3] or [R,N,3], viewdirs [R,3]
+    (device tensors) -> dict of per-sample tensors (the reference's `ray_results`)."""
+    require_device()
+    R, N = means.shape[0], means.shape[1]
+    f32 = dict(dtype=torch.float32, device=means.device)
+    m = means.to(torch.float32).contiguous()
+    c = covs.to(torch.float32).contiguous()
+    v = viewdirs.to(torch.float32).contiguous()
+    full = 1 if c.dim() == 4 else 0
+    res = {k: torch.empty((R, N, 3), **f32) for k in ("rgb", "normals_pred", "grad_pred", "tint", "diffuse", "specular")}
+    res["density"] = torch.empty((R, N), **f32)
+    res["roughness"] = torch.empty((R, N), **f32)
+    if cfg.training:
+        res["normals"] = torch.empty((R, N, 3), **f32)
+    out = LevelOut()
+    for k, t in res.items():
+        setattr(out, "d_" + k, t.data_ptr())
+    check(lib().refnerf_mlp_forward(ptr(packed), C.byref(cfg), ptr(m), ptr(c), full, ptr(v), R, N, C.byref(out), stream_ptr()))
     return res
 
 

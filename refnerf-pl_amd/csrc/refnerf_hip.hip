@@ -359,6 +359,7 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
   a.weights_in = d_weights_in;
   a.out = *out;
   a.prof = nullptr;
+  a.g_means = nullptr; a.g_covs = nullptr; a.cov_full = 0;
   if (getenv("REFNERF_PROF")) {
     static long long *d_prof = nullptr;
     if (!d_prof) { HIP_TRY(hipMalloc(&d_prof, 8 * 32 * sizeof(long long))); }
@@ -394,6 +395,45 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
       fprintf(stderr, "  | dma-wait %lld barrier-wait %lld\n", hbuf[w * 32 + 20], hbuf[w * 32 + 21]);
     }
   }
+  return REFNERF_OK;
+}
+
+int refnerf_mlp_forward(const void *d_packed, const refnerf_level_cfg *cfg, const float *d_means, const float *d_covs,
+                        int32_t cov_is_full, const float *d_viewdirs, int32_t R, int32_t N, const refnerf_level_out *out,
+                        void *stream) {
+  if (!d_packed || !cfg || !d_means || !d_covs || !d_viewdirs || !out)
+    return fail(REFNERF_EINVAL, "refnerf_mlp_forward: null pointer%s");
+  if (R <= 0 || N <= 0) return fail(REFNERF_EINVAL, "refnerf_mlp_forward: R and N must be positive%s");
+  if (cfg->precision != REFNERF_PREC_F32)
+    return fail(REFNERF_EUNSUPPORTED, "refnerf_mlp_forward runs in the f32 precision mode only%s");
+  int rc = ensure_tables();
+  if (rc) return rc;
+  int rpw = rays_per_wg(N, rn::T_TILE);
+  if (rpw * N > 640) return fail(REFNERF_EINVAL, "n too large for the LDS budget (rays_per_wg*N must be <= 640)%s");
+  const size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + 2 * rpw * (N + 1) +
+                                              rn::NPS_TRAIN * rpw * N + 3 * rn::T_TILE + 8);
+  if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n too large for the 160 KiB LDS budget%s");
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
+    (void)hipFuncSetAttribute((const void *)rn::mlp_fwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)rn::mlp_fwd_train_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  rn::LevelArgs a{};
+  a.packed = d_packed;
+  a.cfg = *cfg;
+  a.cfg.n_samples = N;
+  a.rays.d_viewdirs = d_viewdirs;
+  a.R = R;
+  a.rpw = rpw;
+  a.out = *out;
+  a.prof = nullptr;
+  a.g_means = d_means;
+  a.g_covs = d_covs;
+  a.cov_full = cov_is_full;
+  const int grid = (R + rpw - 1) / rpw;
+  if (cfg->training) hipLaunchKernelGGL(rn::mlp_fwd_train_f32, dim3(grid), dim3(rn::NTHREADS), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(rn::mlp_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
   return REFNERF_OK;
 }
 

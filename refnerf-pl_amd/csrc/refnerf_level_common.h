@@ -36,6 +36,10 @@ struct LevelArgs {
   const float *weights_in;
   refnerf_level_out out;
   long long *prof;   /* debug: per-phase cycle stamps of workgroup 0 (REFNERF_PROF=1), else NULL */
+  /* MLP stage entry (refnerf_mlp_forward): caller-supplied Gaussians instead of resample + cast */
+  const float *g_means;   /* [R,N,3] */
+  const float *g_covs;    /* [R,N,3,3] (cov_full) or [R,N,3] diagonal */
+  int cov_full;
 };
 
 #define RN_STAMP(A, slot) do { asm volatile("; RNMARK " #slot); if ((A).prof && blockIdx.x == 0 && (threadIdx.x & 63) == 0) (A).prof[(threadIdx.x >> 6) * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)

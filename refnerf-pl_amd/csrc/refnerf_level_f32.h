@@ -197,7 +197,9 @@ __device__ __forceinline__ void density_normals(__amdgpu_buffer_rsrc_t rs, int l
   for (int b = 0; b < 3; ++b) nrm_out[b] = -(gx[b] / ng);
 }
 
-template <bool TRAIN>
+/* STAGE: MLP.__call__ on caller-supplied Gaussians (no resampling, no compositing): the per-sample
+ * outputs of models.py:533-750 for means / covariances given per sample. */
+template <bool TRAIN, bool STAGE = false>
 __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const refnerf_level_cfg &cfg = A.cfg;
@@ -216,8 +218,10 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   float *PX = PS + n_tot * NPS_TRAIN;            /* [T_TILE][3] grad_pred of the pass */
   float *NRM = PX + 3 * T_TILE;                  /* [rpw] |direction| per ray      */
 
-  resample_phase(A, X, TD, NRM, ray0, wave, lane);    /* P0 */
-  __syncthreads();
+  if constexpr (!STAGE) {
+    resample_phase(A, X, TD, NRM, ray0, wave, lane);    /* P0 */
+    __syncthreads();
+  }
 
   /* ---------------- per-pass MLP over 32-sample blocks ---------------- */
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.packed, 0, PACKED.total * 4, 0x00020000);
@@ -231,20 +235,32 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     const int ray = ray0 + rl;
     const bool valid = (g < n_tot) && (ray < A.R);
     const int rayc = valid ? ray : (A.R - 1);
-    float o[3], d[3], v[3];
+    float o[3] = {0.0f, 0.0f, 0.0f}, d[3] = {0.0f, 0.0f, 0.0f}, v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      o[i] = A.rays.d_origins[(size_t)rayc * 3 + i];
-      d[i] = A.rays.d_directions[(size_t)rayc * 3 + i];
+      if constexpr (!STAGE) {
+        o[i] = A.rays.d_origins[(size_t)rayc * 3 + i];
+        d[i] = A.rays.d_directions[(size_t)rayc * 3 + i];
+      }
       v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
     }
     /* P1: conical frustum -> lifted Gaussian -> IPE (half 0: sin, half 1: cos) */
     float lm[3], lv[3];
     {
-      float radius = A.rays.d_radii[rayc];
-      const float *td = TD + (valid ? rl : 0) * (N + 1);
-      float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
-      cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
+      if constexpr (STAGE) {
+        /* coord.lift_and_diagonalize (coord.py:129-133) with the octahedron/1 basis:
+         * lifted mean = (-z,-y,-x), lifted var = (C_zz, C_yy, C_xx) */
+        const size_t sidx = valid ? (size_t)ray * N + si : 0;
+        const float *m = A.g_means + sidx * 3;
+        lm[0] = -m[2]; lm[1] = -m[1]; lm[2] = -m[0];
+        if (A.cov_full) { const float *c = A.g_covs + sidx * 9; lv[0] = c[8]; lv[1] = c[4]; lv[2] = c[0]; }
+        else { const float *c = A.g_covs + sidx * 3; lv[0] = c[2]; lv[1] = c[1]; lv[2] = c[0]; }
+      } else {
+        float radius = A.rays.d_radii[rayc];
+        const float *td = TD + (valid ? rl : 0) * (N + 1);
+        float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
+        cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
+      }
 #pragma unroll 1
       for (int j = 0; j < 16; ++j)
 #pragma unroll
@@ -330,11 +346,14 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   }
   __syncthreads();
 
-  composite_phase(A, TD, XP, PS, n_tot, ray0, wave, lane, X, NRM);   /* P7 */
+  if constexpr (!STAGE) composite_phase(A, TD, XP, PS, n_tot, ray0, wave, lane, X, NRM);   /* P7 */
 }
 
 __global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false>(A); }
 /* training forward: + density-gradient normals (models.py:603-609) */
 __global__ __launch_bounds__(NTHREADS) void level_fwd_train_f32(const LevelArgs A) { level_fwd_f32_body<true>(A); }
+/* MLP.__call__ stage entry (eval / training) */
+__global__ __launch_bounds__(NTHREADS) void mlp_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false, true>(A); }
+__global__ __launch_bounds__(NTHREADS) void mlp_fwd_train_f32(const LevelArgs A) { level_fwd_f32_body<true, true>(A); }
 
 }  // namespace rn

@@ -196,9 +196,49 @@ class MLP(nn.Module):
         return buf
 
     def __call__(self, gaussians, viewdirs=None, imageplane=None):
-        raise _hip.HipLibraryError(
-            "MLP.__call__ on caller-supplied Gaussians is not a separate entry point of the fused "
-            "path: the MLP runs inside refnerf_level_forward (Model.__call__).")
+        """Evaluate the MLP on caller-supplied Gaussians (models.py:533-750).
+
+        gaussians = (means [..., n, 3], covs [..., n, 3, 3] or [..., n, 3]), viewdirs [..., 3].
+        Returns the reference's `ray_results` dict: density [..., n]; rgb, normals (training
+        mode, else None), normals_pred, grad_pred, tint, diffuse, specular [..., n, 3];
+        roughness [..., n, 1].  One launch of the MLP stage kernel (refnerf_mlp_forward, the
+        fused level kernel without resampling / compositing; f32 arithmetic).  This entry is
+        forward-only: gradients flow through Model.__call__ (refnerf_level_backward)."""
+        del imageplane                                   # unused by the reference as well (models.py:536)
+        _hip.require_device()
+        means, covs = gaussians
+        if viewdirs is None:
+            raise ValueError("the fused Ref-NeRF MLP needs viewdirs (use_viewdirs / use_reflections)")
+        dev = self.spatial_net[0].weight.device
+        means = torch.as_tensor(means, dtype=torch.float32, device=dev)
+        covs = torch.as_tensor(covs, dtype=torch.float32, device=dev)
+        batch = tuple(means.shape[:-2])
+        n = means.shape[-2]
+        full = covs.dim() == means.dim() + 1
+        m = means.reshape(-1, n, 3)
+        c = covs.reshape(-1, n, 3, 3) if full else covs.reshape(-1, n, 3)
+        v = torch.as_tensor(viewdirs, dtype=torch.float32, device=dev).reshape(-1, 3)
+        if v.shape[0] != m.shape[0]:
+            raise ValueError("viewdirs must have one direction per ray of the Gaussians batch")
+        cfg = _hip.default_cfg(
+            n_samples=int(n), n_in=1, training=int(self.training), compute_extras=0,
+            srgb_mapping=int(self.srgb_mapping), srgb_mapping_normalization=int(self.srgb_mapping_normalization),
+            precision=_PREC["f32"], density_bias=float(self.density_bias), roughness_bias=float(self.roughness_bias),
+            rgb_premultiplier=float(self.rgb_premultiplier), rgb_bias=float(self.rgb_bias),
+            rgb_padding=float(self.rgb_padding))
+        res = _hip.mlp_forward(self.packed_weights(cfg.precision), cfg, m, c, v)
+
+        def rs(x, *tail):
+            return x.reshape(batch + (n,) + tuple(tail))
+        ray_results = dict(density=rs(res["density"]), rgb=rs(res["rgb"], 3))
+        ray_results["normals"] = rs(res["normals"], 3) if self.training else None
+        ray_results["normals_pred"] = rs(res["normals_pred"], 3)
+        ray_results["grad_pred"] = rs(res["grad_pred"], 3)
+        ray_results["tint"] = rs(res["tint"], 3)
+        ray_results["diffuse"] = rs(res["diffuse"], 3)
+        ray_results["specular"] = rs(res["specular"], 3)
+        ray_results["roughness"] = rs(res["roughness"], 1)
+        return ray_results
 
 
 # outputs of one training level, in the order _LevelFunction returns them; the

@@ -324,6 +324,44 @@ def test_backward_is_linear_in_the_upstream_gradients(hip):
     assert torch.equal(A, A2)
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("covform", ["full", "diag"])
+def test_mlp_call_stage_entry(hip, mode, covform):
+    """MLP.__call__(gaussians=(means, covs), viewdirs) -- the reference's per-sample entry
+    (models.py:533-750) -- against the vectors captured from the reference MLP."""
+    import os
+    from refnerf_pl_amd import configs, models, synthetic, utils
+    g = load_golden("mlp")
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")], [])
+    model = models.construct_model(utils.dummy_rays(), configs.Config()).to(DEV)
+    pk = g["param_kw"]
+    model.nerf_mlp.load_flat_params(synthetic.make_params(seed=int(pk[0]), bias_scale=float(pk[1]), sharpen=float(pk[2]),
+                                                          roughness_bias=float(pk[3])))
+    mlp = model.nerf_mlp.train() if mode == "train" else model.nerf_mlp.eval()
+    lm, lv = g["lmean"], g["lvar"]
+    means = np.stack([-lm[..., 2], -lm[..., 1], -lm[..., 0]], -1)           # un-lift: basis = [[0,0,-1],[0,-1,0],[-1,0,0]]
+    if covform == "full":
+        covs = np.zeros(lm.shape[:-1] + (3, 3), np.float32)
+        covs[..., 0, 0], covs[..., 1, 1], covs[..., 2, 2] = lv[..., 2], lv[..., 1], lv[..., 0]
+        covs[..., 0, 1] = covs[..., 1, 0] = 0.37 * lv[..., 0]              # off-diagonals do not reach the octahedron/1 lift
+    else:
+        covs = np.stack([lv[..., 2], lv[..., 1], lv[..., 0]], -1)
+    with torch.no_grad():
+        res = mlp((torch.tensor(means), torch.tensor(covs)), viewdirs=torch.tensor(g["viewdirs"]))
+    assert list(res.keys()) == ["density", "rgb", "normals", "normals_pred", "grad_pred", "tint", "diffuse", "specular", "roughness"]
+    for k, v in res.items():
+        if k == "normals" and mode == "eval":
+            assert v is None
+            continue
+        want = g[f"{mode}_{k}"]
+        assert tuple(v.shape) == want.shape, k
+        tol = 5e-6 if k in ("normals", "normals_pred") else 2e-6
+        np.testing.assert_allclose(v.cpu().numpy(), want, rtol=0, atol=tol, err_msg=k)
+    with pytest.raises(ValueError):
+        mlp((torch.tensor(means), torch.tensor(covs)), viewdirs=None)
+
+
 def test_model_training_step_autograd(hip):
     """Model.__call__ in training mode + the reference-shaped losses + loss.backward():
     the 46 nn.Parameters receive the reference's gradients (golden autograd vectors)."""
