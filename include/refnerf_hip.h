@@ -164,9 +164,9 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg,
 /* MLP.__call__ (internal/models.py:533-750) on caller-supplied Gaussians -- the
  * reference's per-sample entry point: d_means [R,N,3], d_covs [R,N,3,3]
  * (cov_is_full) or [R,N,3] (diagonal), d_viewdirs [R,3] -> the `ray_results`
- * dict as the per-sample fields of refnerf_level_out (density, rgb, normals
+ * dict as the per-sample fields of the refnerf_level_out struct: density, rgb, normals
  * when cfg->training, normals_pred, grad_pred, tint, diffuse, specular,
- * roughness; the other pointers are ignored).  Same device code as the fused
+ * roughness; the other pointers are ignored.  Same device code as the fused
  * level kernel without the resampling and compositing phases; f32 mode. */
 int refnerf_mlp_forward(const void *d_packed, const refnerf_level_cfg *cfg,
                         const float *d_means, const float *d_covs, int32_t cov_is_full,
