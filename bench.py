@@ -222,10 +222,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_image:
         # full-image render ms: 800x800 Blender view, 157 chunks of 4096 rays (models.render_image)
         from refnerf_pl_amd import models
-        img = utils.rays_from_dict({k: v.reshape(800, 800, -1) for k, v in synthetic.blender_rays(0, seed=1, full_image=True).items()}, dev)
+        # rays of the whole view are cast on the device (refnerf_pixels_to_rays), inside the timed region
+        from refnerf_pl_amd import camera_utils
+        c2w, focal = synthetic.blender_camera(seed=1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with torch.no_grad():
+            img = camera_utils.cast_pinhole_rays(c2w.astype(np.float32), 800, 800, focal, 2.0, 6.0, device=dev)
             rendering = models.render_image(lambda r: model(r, 1.0, True), img, cfg, verbose=False, device=dev)
         torch.cuda.synchronize()
         line["full_image_render_ms"] = 1e3 * (time.perf_counter() - t0)

@@ -173,6 +173,21 @@ int refnerf_mlp_forward(const void *d_packed, const refnerf_level_cfg *cfg,
                         const float *d_viewdirs, int32_t R, int32_t N,
                         const refnerf_level_out *out, void *stream);
 
+/* The step in front of the path, on the device: camera_utils.pixels_to_rays
+ * (internal/camera_utils.py:502-614) for perspective cameras without lens
+ * distortion, with the optional NDC conversion (:31-97, near = 1).
+ * d_pix_x / d_pix_y [n] int32; d_pixtocams [3,3] (or [n,3,3] when
+ * pixtocam_per_ray); d_camtoworlds [3,4] (or [n,3,4]); d_pixtocam_ndc [3,3] or
+ * NULL.  Outputs: origins / directions / viewdirs [n,3], radii [n],
+ * imageplane [n,2] (optional).  Saves the 64 B/ray host-to-device copy and the
+ * numpy ray casting of whole-image rendering. */
+int refnerf_pixels_to_rays(const int32_t *d_pix_x, const int32_t *d_pix_y,
+                           const float *d_pixtocams, int32_t pixtocam_per_ray,
+                           const float *d_camtoworlds, int32_t camtoworld_per_ray,
+                           const float *d_pixtocam_ndc, int32_t n,
+                           float *d_origins, float *d_directions, float *d_viewdirs,
+                           float *d_radii, float *d_imageplane, void *stream);
+
 /* Stage entry points (same device code as the fused kernel; used by the
  * parity tests and for drop-in use of the individual reference functions). */
 

@@ -85,6 +85,8 @@ def lib():
         L.refnerf_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.refnerf_level_backward.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
                                              C.POINTER(LevelSaved), C.POINTER(LevelGrads), _FP, _FP, C.c_size_t, _FP]
+        L.refnerf_pixels_to_rays.argtypes = [_FP, _FP, _FP, C.c_int32, _FP, C.c_int32, _FP, C.c_int32,
+                                             _FP, _FP, _FP, _FP, _FP, _FP]
         L.refnerf_mlp_forward.argtypes = [_FP, C.POINTER(LevelCfg), _FP, _FP, C.c_int32, _FP, C.c_int32, C.c_int32,
                                           C.POINTER(LevelOut), _FP]
         L.refnerf_sample_intervals.argtypes = [_FP, _FP, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
@@ -197,6 +199,26 @@ def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, histo
     w = weights_in.to(torch.float32).contiguous()
     check(lib().refnerf_level_forward(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out), stream_ptr()))
     return res
+
+
+def pixels_to_rays(pix_x, pix_y, pixtocams, camtoworlds, pixtocam_ndc=None):
+    """Device tensors in, device tensors out: (origins, directions, viewdirs [n,3], radii [n,1], imageplane [n,2])."""
+    require_device()
+    dev = pix_x.device
+    n = pix_x.numel()
+    px = pix_x.reshape(-1).to(torch.int32).contiguous()
+    py = pix_y.reshape(-1).to(torch.int32).contiguous()
+    p2c = pixtocams.to(torch.float32).contiguous()
+    c2w = camtoworlds.to(torch.float32)[..., :3, :4].contiguous()
+    ndc = None if pixtocam_ndc is None else pixtocam_ndc.to(torch.float32).contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    o, d, v = (torch.empty((n, 3), **f32) for _ in range(3))
+    r = torch.empty((n, 1), **f32)
+    ip = torch.empty((n, 2), **f32)
+    check(lib().refnerf_pixels_to_rays(ptr(px), ptr(py), ptr(p2c), int(p2c.dim() > 2), ptr(c2w), int(c2w.dim() > 2),
+                                       ptr(ndc) if ndc is not None else None, n, ptr(o), ptr(d), ptr(v), ptr(r), ptr(ip),
+                                       stream_ptr()))
+    return o, d, v, r, ip
 
 
 def mlp_forward(packed, cfg: LevelCfg, means, covs, viewdirs):

@@ -28,6 +28,7 @@
 #include "refnerf_level_bf16.h"
 #include "refnerf_level_bwd_f32.h"
 #include "refnerf_wgrad.h"
+#include "refnerf_rays.h"
 
 namespace rn {
 
@@ -395,6 +396,25 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
       fprintf(stderr, "  | dma-wait %lld barrier-wait %lld\n", hbuf[w * 32 + 20], hbuf[w * 32 + 21]);
     }
   }
+  return REFNERF_OK;
+}
+
+int refnerf_pixels_to_rays(const int32_t *d_pix_x, const int32_t *d_pix_y, const float *d_pixtocams, int32_t pixtocam_per_ray,
+                           const float *d_camtoworlds, int32_t camtoworld_per_ray, const float *d_pixtocam_ndc, int32_t n,
+                           float *d_origins, float *d_directions, float *d_viewdirs, float *d_radii, float *d_imageplane,
+                           void *stream) {
+  if (!d_pix_x || !d_pix_y || !d_pixtocams || !d_camtoworlds || !d_origins || !d_directions || !d_viewdirs || !d_radii)
+    return fail(REFNERF_EINVAL, "refnerf_pixels_to_rays: null pointer%s");
+  if (n <= 0) return fail(REFNERF_EINVAL, "refnerf_pixels_to_rays: n must be positive%s");
+  rn::RayGenArgs a;
+  a.pix_x = d_pix_x; a.pix_y = d_pix_y;
+  a.pixtocams = d_pixtocams; a.camtoworlds = d_camtoworlds; a.pixtocam_ndc = d_pixtocam_ndc;
+  a.p2c_stride = pixtocam_per_ray ? 9 : 0;
+  a.c2w_stride = camtoworld_per_ray ? 12 : 0;
+  a.n = n;
+  a.origins = d_origins; a.directions = d_directions; a.viewdirs = d_viewdirs; a.radii = d_radii; a.imageplane = d_imageplane;
+  hipLaunchKernelGGL(rn::pixels_to_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
   return REFNERF_OK;
 }
 

@@ -121,6 +121,16 @@ def _bundle(o, d, v, radii, imageplane, near, far):
                 cam_idx=np.zeros((n, 1), np.float32))
 
 
+def blender_camera(seed: int = 1, width: int = 800):
+    """(camtoworld [3,4] float64, focal) of the synthetic Blender-style view used by blender_rays."""
+    focal = 0.5 * 800 / math.tan(0.5 * 0.6911112070083618) * (width / 800.0)
+    rot = _rot(seed)
+    c2w = np.zeros((3, 4))
+    c2w[:3, :3] = rot
+    c2w[:3, 3] = rot @ np.array([0.0, 0.0, 4.0])
+    return c2w, focal
+
+
 def blender_rays(n_rays: int, seed: int = 1, full_image: bool = False,
                  width: int = 800, height: int = 800, center_frac: float = 1.0) -> dict:
     """Blender-style rays: pinhole, camera at distance 4 looking at the origin."""

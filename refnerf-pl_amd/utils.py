@@ -68,6 +68,17 @@ def rays_from_dict(d: dict, device=None) -> Rays:
 
 
 @dataclass
+class Pixels:
+    """utils.py:31-48: integer pixel coordinates + per-pixel metadata, any batch shape."""
+    pix_x_int: _Array
+    pix_y_int: _Array
+    lossmult: _Array
+    near: _Array
+    far: _Array
+    cam_idx: _Array
+
+
+@dataclass
 class Batch:
     """utils.py:110-118"""
     rays: Rays

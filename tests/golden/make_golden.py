@@ -275,7 +275,36 @@ def golden_models():
         save(name, **res)
 
 
+def golden_camera():
+    """camera_utils.pixels_to_rays (camera_utils.py:502-614): pinhole Blender-style camera and an
+    LLFF-style camera with the NDC conversion (camera_utils.py:31-97)."""
+    from internal import camera_utils
+    out = {}
+    rng = np.random.default_rng(21)
+    for tag, (w, h, focal, ndc) in dict(blender=(800, 800, 1111.111, False), llff=(1008, 756, 815.0, True)).items():
+        n = 96
+        px = rng.integers(0, w, n).astype(np.int32)
+        py = rng.integers(0, h, n).astype(np.int32)
+        px[:4] = [0, w - 1, 0, w - 1]
+        py[:4] = [0, 0, h - 1, h - 1]
+        intr = np.array([[focal, 0, w / 2.0], [0, focal, h / 2.0], [0, 0, 1.0]])
+        pixtocam = np.linalg.inv(intr).astype(np.float32)
+        c2w = np.zeros((3, 4), np.float32)
+        if ndc:
+            c2w[:3, :3] = np.eye(3)
+            c2w[:3, 3] = [0.11, -0.07, 0.03]
+        else:
+            c2w[:3, :3] = synthetic._rot(5).astype(np.float32)
+            c2w[:3, 3] = (synthetic._rot(5) @ np.array([0.0, 0.0, 4.0])).astype(np.float32)
+        res = camera_utils.pixels_to_rays(px, py, pixtocam, c2w, pixtocam_ndc=pixtocam if ndc else None, xnp=np)
+        out[tag + "_pix_x"], out[tag + "_pix_y"] = px, py
+        out[tag + "_pixtocam"], out[tag + "_camtoworld"] = pixtocam, c2w
+        for k, v in zip(("origins", "directions", "viewdirs", "radii", "imageplane"), res):
+            out[f"{tag}_{k}"] = np.asarray(v, np.float32)
+    save("camera", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera"]
     for w in which:
         globals()["golden_" + w]()

@@ -362,6 +362,38 @@ def test_mlp_call_stage_entry(hip, mode, covform):
         mlp((torch.tensor(means), torch.tensor(covs)), viewdirs=None)
 
 
+@pytest.mark.parametrize("tag", ["blender", "llff"])
+def test_device_ray_generation(hip, tag):
+    """camera_utils.pixels_to_rays on the device against the reference's output (pinhole + NDC),
+    per-pixel cameras, and cast_pinhole_rays against the numpy generator used for the fixtures."""
+    from refnerf_pl_amd import camera_utils, synthetic
+    g = load_golden("camera")
+    ndc = g[tag + "_pixtocam"] if tag == "llff" else None
+    res = camera_utils.pixels_to_rays(g[tag + "_pix_x"], g[tag + "_pix_y"], g[tag + "_pixtocam"], g[tag + "_camtoworld"],
+                                      pixtocam_ndc=ndc, device=torch.device(DEV))
+    keys = ("origins", "directions", "viewdirs", "radii", "imageplane")
+    for k, v in zip(keys, res):
+        want = g[f"{tag}_{k}"]
+        assert tuple(v.shape) == want.shape, k
+        np.testing.assert_allclose(v.cpu().numpy(), want, rtol=2e-6, atol=2e-7, err_msg=k)
+    n = g[tag + "_pix_x"].shape[0]
+    per = camera_utils.pixels_to_rays(g[tag + "_pix_x"], g[tag + "_pix_y"], np.tile(g[tag + "_pixtocam"], (n, 1, 1)),
+                                      np.tile(g[tag + "_camtoworld"], (n, 1, 1)), pixtocam_ndc=ndc, device=torch.device(DEV))
+    for a, b in zip(res, per):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        camera_utils.pixels_to_rays(g[tag + "_pix_x"], g[tag + "_pix_y"], g[tag + "_pixtocam"], g[tag + "_camtoworld"],
+                                    camtype=camera_utils.ProjectionType.FISHEYE, device=torch.device(DEV))
+    if tag == "blender":
+        rays = camera_utils.cast_pinhole_rays(g["blender_camtoworld"], 40, 56, 77.0, 2.0, 6.0, device=torch.device(DEV))
+        yy, xx = np.meshgrid(np.arange(40), np.arange(56), indexing="ij")
+        o, d, v, r, ip = synthetic._pixels_to_rays(xx.reshape(-1), yy.reshape(-1), 77.0, 56, 40, g["blender_camtoworld"].astype(np.float64))
+        assert tuple(rays.origins.shape) == (40, 56, 3) and tuple(rays.near.shape) == (40, 56, 1)
+        np.testing.assert_allclose(rays.directions.reshape(-1, 3).cpu().numpy(), d, rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(rays.radii.reshape(-1, 1).cpu().numpy(), r, rtol=2e-6, atol=1e-9)
+        assert float(rays.far.min()) == 6.0
+
+
 def test_model_training_step_autograd(hip):
     """Model.__call__ in training mode + the reference-shaped losses + loss.backward():
     the 46 nn.Parameters receive the reference's gradients (golden autograd vectors)."""

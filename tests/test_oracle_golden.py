@@ -178,3 +178,16 @@ def test_training_step_losses_and_gradients(name):
         assert np.linalg.norm(grads[s.w_off:s.w_off + n]) == pytest.approx(norms[i, 0], rel=2e-3), s.name
         assert np.linalg.norm(grads[s.b_off:s.b_off + s.out_dim]) == pytest.approx(norms[i, 1], rel=2e-3), s.name
         assert norms[i, 0] > 0
+
+
+@pytest.mark.parametrize("tag,spec", [("blender", (800, 800, 1111.111, None)), ("llff", (1008, 756, 815.0, 1.0))])
+def test_ray_generator_matches_reference(tag, spec):
+    """The numpy ray generator behind every synthetic fixture / bench batch restates
+    camera_utils.pixels_to_rays (+ convert_to_ndc): pinned by vectors from the reference."""
+    from refnerf_pl_amd import synthetic
+    g = load_golden("camera")
+    w, h, focal, ndc = spec
+    res = synthetic._pixels_to_rays(g[tag + "_pix_x"].astype(np.int64), g[tag + "_pix_y"].astype(np.int64), focal, w, h,
+                                    g[tag + "_camtoworld"].astype(np.float64), ndc_near=ndc)
+    for k, a in zip(("origins", "directions", "viewdirs", "radii", "imageplane"), res):
+        np.testing.assert_allclose(a.reshape(g[f"{tag}_{k}"].shape), g[f"{tag}_{k}"], rtol=0, atol=3e-7, err_msg=k)
