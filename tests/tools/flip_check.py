@@ -1,7 +1,7 @@
 """Are the 1e-4-level gradient differences vs the oracle ReLU flips?  Perturb the weights by 1 ulp-ish noise:
 a smooth function changes its gradient by ~1e-7; isolated flips show up as ~1e-4 jumps, as they do vs the oracle."""
 import sys, numpy as np, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, "."); sys.path.insert(0, "tests")  # run from the repo root
 import refnerf_pl_amd
 from refnerf_pl_amd import _hip as hip, synthetic
 import test_hip_parity as T
