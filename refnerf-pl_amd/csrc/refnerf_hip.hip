@@ -500,7 +500,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   const BwdPlan plan = bwd_plan(R, N);
   if (workspace_bytes < plan.total) return fail(REFNERF_EINVAL, "refnerf_level_backward: workspace too small (see refnerf_backward_workspace_bytes)%s");
   const int rpw = rays_per_wg(N, rn::T_TILE);
-  const size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + rpw * (N + 1) + rn::NGS * rpw * N + 8);
+  const size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + rpw * (N + 1) + rn::NGS * rpw * N +
+                                              32 * rn::NTHREADS + 8);
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget%s");
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {

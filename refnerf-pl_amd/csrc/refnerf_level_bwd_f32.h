@@ -169,6 +169,7 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
   float *HD = X + DIR_PAD * T_TILE;              /* [HD_ROWS][T_TILE] */
   float *TD = HD + HD_ROWS * T_TILE;             /* [rpw][N+1]        */
   float *GS = TD + rpw * (N + 1);                /* [n_tot][NGS]      */
+  unsigned *MS = reinterpret_cast<unsigned *>(GS + n_tot * NGS);   /* [32][NTHREADS] spatial ReLU masks, parked during the dir phases */
 
   bwd_prologue(A, TD, GS, ray0, wave, lane);
   __syncthreads();
@@ -221,6 +222,12 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
       relu_mask_into(out, in, M[7]);
       store_rows<8>(A.act, pitch, ACT_SP + op * WIDTH, gs, h, valid, in);
     }
+    /* the spatial masks are not needed again before the very end of the backward: park them in LDS
+     * (32 registers less across the directional forward + backward chains) */
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) MS[(l * 4 + q) * NTHREADS + tid] = M[l][q];
     {
       v16f hd[5];
       gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0);
@@ -393,6 +400,10 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
     }
     wave_sync();
     /* ---- heads^T, then the spatial MLP, layers 7..0 ---- */
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) M[l][q] = MS[(l * 4 + q) * NTHREADS + tid];
     gemm_op<8, 8, false, false>(rs, PACKED.top[TOP_HEADS].a_off, 0, lane, h, in, out, xl, HEADS_T_STEPS);
     masked_into(out, in, M[7]);
 #pragma unroll 1
