@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 1
+#define REFNERF_ABI_VERSION 2
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {
@@ -138,13 +138,14 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg,
  * weights, history normals_pred; the density-gradient normals, sdist and the
  * resampling inputs are detached there as well), it ACCUMULATES dL/d(params)
  * into d_param_grads (canonical blob, REFNERF_NUM_PARAMS floats).
- * The MLP forward is recomputed inside; d_workspace holds the per-sample layer
- * inputs / output gradients the weight-gradient GEMM contracts. */
+ * d_workspace holds the per-sample output gradients of every layer, which the
+ * weight-gradient GEMM contracts with the saved layer inputs. */
 typedef struct refnerf_level_saved {
   const float *d_sdist;     /* [R,N+1] refnerf_level_out.d_sdist   */
   const float *d_density;   /* [R,N]                               */
   const float *d_rgb;       /* [R,N,3]                             */
   const float *d_weights;   /* [R,N]                               */
+  const void *d_activations; /* the buffer refnerf_level_forward_train filled */
 } refnerf_level_saved;
 
 typedef struct refnerf_level_grads {
@@ -153,6 +154,19 @@ typedef struct refnerf_level_grads {
   const float *d_g_normals_pred;  /* [R,N,3] dL/d ray_history['normals_pred'], or NULL */
 } refnerf_level_grads;
 
+/* Training forward that also keeps every linear layer's input for the backward
+ * (what autograd saves for nn.Linear in the reference): d_activations is a
+ * caller-owned buffer of refnerf_activation_workspace_bytes(R, N) bytes
+ * (17.6 KB per ray-sample) that must stay untouched until the level's
+ * refnerf_level_backward has run.  cfg->training must be 1. */
+size_t refnerf_activation_workspace_bytes(int32_t R, int32_t n_samples);
+int refnerf_level_forward_train(const void *d_packed, const refnerf_level_cfg *cfg,
+                                const refnerf_rays *rays, int32_t R,
+                                const float *d_sdist_in, const float *d_weights_in,
+                                const refnerf_level_out *out, void *d_activations,
+                                size_t activations_bytes, void *stream);
+
+/* Scratch of refnerf_level_backward (per-layer output gradients + split-K partials; 17 KB per ray-sample). */
 size_t refnerf_backward_workspace_bytes(int32_t R, int32_t n_samples);
 
 int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg,

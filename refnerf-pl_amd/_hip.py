@@ -45,7 +45,7 @@ class LevelOut(C.Structure):
 
 
 class LevelSaved(C.Structure):
-    _fields_ = [(n, _FP) for n in ("d_sdist", "d_density", "d_rgb", "d_weights")]
+    _fields_ = [(n, _FP) for n in ("d_sdist", "d_density", "d_rgb", "d_weights", "d_activations")]
 
 
 class LevelGrads(C.Structure):
@@ -81,6 +81,10 @@ def lib():
         L.refnerf_pack_weights.argtypes = [_FP, _FP, C.c_int, _FP]
         L.refnerf_level_forward.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
                                             _FP, _FP, C.POINTER(LevelOut), _FP]
+        L.refnerf_activation_workspace_bytes.restype = C.c_size_t
+        L.refnerf_activation_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.refnerf_level_forward_train.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
+                                                  _FP, _FP, C.POINTER(LevelOut), _FP, C.c_size_t, _FP]
         L.refnerf_backward_workspace_bytes.restype = C.c_size_t
         L.refnerf_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.refnerf_level_backward.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
@@ -94,7 +98,7 @@ def lib():
         L.refnerf_integrated_pos_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
         L.refnerf_integrated_dir_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
         L.refnerf_get_timing.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-        if L.refnerf_abi_version() != 1:
+        if L.refnerf_abi_version() != 2:
             raise HipLibraryError("librefnerf_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -156,9 +160,11 @@ def pack_weights(params: torch.Tensor, packed: torch.Tensor = None, precision=PR
     return packed
 
 
-def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, history=True):
+def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, history=True, save_activations=False):
     """One fused level.  rays: dict of device tensors (origins, directions,
-    viewdirs [R,3]; radii, near, far [R] or [R,1]).  Returns dict of tensors."""
+    viewdirs [R,3]; radii, near, far [R] or [R,1]).  Returns dict of tensors.
+    save_activations (training forward): also keeps the layer inputs for
+    level_backward in res["activations"] (a byte tensor the backward consumes)."""
     require_device()
     dev = sdist_in.device
     R = rays["origins"].shape[0]
@@ -197,7 +203,13 @@ def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, histo
         setattr(out, "d_" + k, t.data_ptr())
     sd = sdist_in.to(torch.float32).contiguous()
     w = weights_in.to(torch.float32).contiguous()
-    check(lib().refnerf_level_forward(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out), stream_ptr()))
+    if save_activations:
+        act = torch.empty(lib().refnerf_activation_workspace_bytes(R, N), dtype=torch.uint8, device=dev)
+        check(lib().refnerf_level_forward_train(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out),
+                                                ptr(act), act.numel(), stream_ptr()))
+        res["activations"] = act
+    else:
+        check(lib().refnerf_level_forward(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out), stream_ptr()))
     return res
 
 
@@ -260,9 +272,9 @@ def backward_workspace(R: int, n_samples: int, device) -> torch.Tensor:
 def level_backward(packed, cfg: LevelCfg, rays: dict, saved: dict, g_r_rgb, g_weights, g_normals_pred,
                    param_grads: torch.Tensor):
     """Backward of one level: accumulates dL/d(params) into `param_grads`
-    (canonical blob).  saved: dict with sdist, density, rgb, weights of the
-    training forward; g_*: upstream gradients (g_weights / g_normals_pred may
-    be None)."""
+    (canonical blob).  saved: dict with sdist, density, rgb, weights and
+    activations of the training forward (save_activations=True); g_*: upstream
+    gradients (g_weights / g_normals_pred may be None)."""
     require_device()
     R = rays["origins"].shape[0]
     N = cfg.n_samples
@@ -277,6 +289,9 @@ def level_backward(packed, cfg: LevelCfg, rays: dict, saved: dict, g_r_rgb, g_we
         t = saved[name].to(torch.float32).contiguous()
         keep.append(t)
         setattr(sv, "d_" + name, t.data_ptr())
+    if saved.get("activations") is None:
+        raise ValueError("level_backward needs the activations saved by level_forward(..., save_activations=True)")
+    sv.d_activations = saved["activations"].data_ptr()
     gr = LevelGrads()
     for name, t in (("d_g_r_rgb", g_r_rgb), ("d_g_weights", g_weights), ("d_g_normals_pred", g_normals_pred)):
         if t is not None:

@@ -302,9 +302,27 @@ static int rays_per_wg(int N, int tile) {
   return 1;   /* last pass partially filled */
 }
 
-int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays,
-                          int32_t R, const float *d_sdist_in, const float *d_weights_in,
-                          const refnerf_level_out *out, void *stream) {
+namespace {
+struct BwdPlan { long long S, pitch; int slices, k_per_slice; size_t act_bytes, delta_off, part_off, total; };
+BwdPlan bwd_plan(int R, int N) {
+  BwdPlan p;
+  p.S = (long long)R * N;
+  p.pitch = (p.S + 127) / 128 * 128;
+  long long sl = (p.S + 2047) / 2048;
+  p.slices = (int)(sl < 1 ? 1 : (sl > 32 ? 32 : sl));
+  long long per = (p.S + p.slices - 1) / p.slices;
+  p.k_per_slice = (int)((per + rn::WG_KT - 1) / rn::WG_KT * rn::WG_KT);
+  p.act_bytes = sizeof(float) * (size_t)rn::ACT_ROWS * p.pitch;
+  p.delta_off = 0;
+  p.part_off = p.delta_off + sizeof(float) * (size_t)rn::DEL_ROWS * p.pitch;
+  p.total = p.part_off + sizeof(float) * (size_t)p.slices * rn::NUM_PARAMS;
+  return p;
+}
+}  // namespace
+
+static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays,
+                              int32_t R, const float *d_sdist_in, const float *d_weights_in,
+                              const refnerf_level_out *out, float *d_act, long long act_pitch, void *stream) {
   if (!d_packed || !cfg || !rays || !out || !d_sdist_in || !d_weights_in)
     return fail(REFNERF_EINVAL, "refnerf_level_forward: null pointer%s");
   if (R <= 0) return fail(REFNERF_EINVAL, "refnerf_level_forward: R must be positive%s");
@@ -361,6 +379,7 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
   a.out = *out;
   a.prof = nullptr;
   a.g_means = nullptr; a.g_covs = nullptr; a.cov_full = 0;
+  a.act = d_act; a.act_pitch = act_pitch;
   if (getenv("REFNERF_PROF")) {
     static long long *d_prof = nullptr;
     if (!d_prof) { HIP_TRY(hipMalloc(&d_prof, 8 * 32 * sizeof(long long))); }
@@ -397,6 +416,25 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, co
     }
   }
   return REFNERF_OK;
+}
+
+int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays,
+                          int32_t R, const float *d_sdist_in, const float *d_weights_in,
+                          const refnerf_level_out *out, void *stream) {
+  return level_forward_impl(d_packed, cfg, rays, R, d_sdist_in, d_weights_in, out, nullptr, 0, stream);
+}
+
+int refnerf_level_forward_train(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays,
+                                int32_t R, const float *d_sdist_in, const float *d_weights_in,
+                                const refnerf_level_out *out, void *d_activations, size_t activations_bytes,
+                                void *stream) {
+  if (!cfg || !d_activations) return fail(REFNERF_EINVAL, "refnerf_level_forward_train: null pointer%s");
+  if (!cfg->training) return fail(REFNERF_EINVAL, "refnerf_level_forward_train: cfg->training must be 1%s");
+  if (R <= 0 || cfg->n_samples <= 1) return fail(REFNERF_EINVAL, "refnerf_level_forward_train: bad R / num_samples%s");
+  const BwdPlan plan = bwd_plan(R, cfg->n_samples);
+  if (activations_bytes < plan.act_bytes)
+    return fail(REFNERF_EINVAL, "refnerf_level_forward_train: activation buffer too small (see refnerf_activation_workspace_bytes)%s");
+  return level_forward_impl(d_packed, cfg, rays, R, d_sdist_in, d_weights_in, out, (float *)d_activations, plan.pitch, stream);
 }
 
 int refnerf_pixels_to_rays(const int32_t *d_pix_x, const int32_t *d_pix_y, const float *d_pixtocams, int32_t pixtocam_per_ray,
@@ -457,27 +495,15 @@ int refnerf_mlp_forward(const void *d_packed, const refnerf_level_cfg *cfg, cons
   return REFNERF_OK;
 }
 
-namespace {
-struct BwdPlan { long long S, pitch; int slices, k_per_slice; size_t act_off, delta_off, part_off, total; };
-BwdPlan bwd_plan(int R, int N) {
-  BwdPlan p;
-  p.S = (long long)R * N;
-  p.pitch = (p.S + 127) / 128 * 128;
-  long long sl = (p.S + 2047) / 2048;
-  p.slices = (int)(sl < 1 ? 1 : (sl > 32 ? 32 : sl));
-  long long per = (p.S + p.slices - 1) / p.slices;
-  p.k_per_slice = (int)((per + rn::WG_KT - 1) / rn::WG_KT * rn::WG_KT);
-  p.act_off = 0;
-  p.delta_off = p.act_off + sizeof(float) * (size_t)rn::ACT_ROWS * p.pitch;
-  p.part_off = p.delta_off + sizeof(float) * (size_t)rn::DEL_ROWS * p.pitch;
-  p.total = p.part_off + sizeof(float) * (size_t)p.slices * rn::NUM_PARAMS;
-  return p;
-}
-}  // namespace
 
 size_t refnerf_backward_workspace_bytes(int32_t R, int32_t n_samples) {
   if (R <= 0 || n_samples <= 1) return 0;
   return bwd_plan(R, n_samples).total;
+}
+
+size_t refnerf_activation_workspace_bytes(int32_t R, int32_t n_samples) {
+  if (R <= 0 || n_samples <= 1) return 0;
+  return bwd_plan(R, n_samples).act_bytes;
 }
 
 int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays, int32_t R,
@@ -492,6 +518,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     return fail(REFNERF_EUNSUPPORTED, "refnerf_level_backward runs in the f32 precision mode only%s");
   if (!saved->d_sdist || !saved->d_density || !saved->d_rgb || !saved->d_weights || !grads->d_g_r_rgb)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: null saved tensor / rendering gradient%s");
+  if (!saved->d_activations)
+    return fail(REFNERF_EINVAL, "refnerf_level_backward: the level was not run through refnerf_level_forward_train (no saved activations)%s");
   if (!rays->d_origins || !rays->d_directions || !rays->d_viewdirs || !rays->d_radii || !rays->d_near || !rays->d_far)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: null ray field%s");
   int rc = ensure_tables();
@@ -500,8 +528,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   const BwdPlan plan = bwd_plan(R, N);
   if (workspace_bytes < plan.total) return fail(REFNERF_EINVAL, "refnerf_level_backward: workspace too small (see refnerf_backward_workspace_bytes)%s");
   const int rpw = rays_per_wg(N, rn::T_TILE);
-  const size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + rpw * (N + 1) + rn::NGS * rpw * N +
-                                              32 * rn::NTHREADS + 8);
+  const size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + rpw * (N + 1) + rn::NGS * rpw * N + 8);
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget%s");
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
@@ -516,7 +543,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   a.rpw = rpw;
   a.sdist = saved->d_sdist; a.density = saved->d_density; a.rgb = saved->d_rgb; a.weights = saved->d_weights;
   a.g_r_rgb = grads->d_g_r_rgb; a.g_weights = grads->d_g_weights; a.g_npred = grads->d_g_normals_pred;
-  a.act = (float *)(ws + plan.act_off);
+  a.act = (const float *)saved->d_activations;
   a.delta = (float *)(ws + plan.delta_off);
   a.pitch = plan.pitch;
   hipStream_t st = (hipStream_t)stream;

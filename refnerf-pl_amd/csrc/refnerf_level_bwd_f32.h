@@ -3,16 +3,18 @@
  *
  * Same decomposition as the forward kernel (workgroup = 4 waves = RPW whole
  * rays, 32-sample blocks per wave, transposed GEMMs with activations in the
- * accumulator registers).  Nothing but the per-sample history that the
- * training forward already wrote is read back: the MLP forward is recomputed
- * here (recording the ReLU sign masks in registers), then the gradient runs
+ * accumulator registers).  The training forward saved every linear layer's
+ * input (the ACT matrix); here only the head and rgb rows are recomputed from
+ * the saved x7 / v7, every ReLU mask is re-derived from the saved activation
+ * of its layer (prefetched under the preceding transposed GEMM), and the
+ * gradient runs
  *   rendering -> alpha weights -> density / sample rgb / predicted normals
  *   -> colour head -> directional MLP -> IDE / reflection -> heads -> spatial MLP
  * through the transposed packed weights (refnerf_layout.h: TOP_*).
  *
- * Weight gradients are NOT accumulated here: every layer's input (ACT) and
- * pre-activation gradient (DELTA) is streamed to HBM as [feature][sample]
- * matrices and refnerf_wgrad.h contracts them over the sample axis.
+ * Weight gradients are NOT accumulated here: every layer's pre-activation
+ * gradient (DELTA) is streamed to HBM as a [feature][sample] matrix like ACT
+ * and refnerf_wgrad.h contracts the two over the sample axis.
  *
  * Restates the autograd of internal/models.py:533-750 + render.py:132-216
  * (SURVEY.md A10); oracle: rn_level_train / mlp_backward.
@@ -35,29 +37,12 @@ struct BwdArgs {
   const float *g_r_rgb;     /* [R,3]   dL/d rendering rgb (after the render map)  */
   const float *g_weights;   /* [R,N]   dL/d history weights, or NULL              */
   const float *g_npred;     /* [R,N,3] dL/d history normals_pred, or NULL         */
-  float *act, *delta;       /* workspace matrices, row pitch `pitch` floats       */
+  const float *act;         /* [ACT_ROWS][pitch] layer inputs saved by the training forward */
+  float *delta;             /* [DEL_ROWS][pitch] written here                       */
   long long pitch;
 };
 
 constexpr int NGS = 7;      /* per-sample upstream gradients in LDS: density, rgb[3], n_pred[3] */
-
-/* rows [row0 + 32*blk + row(r,h)] of a [rows][pitch] matrix, column gs: 128 B
- * contiguous per (row, half-wave).  Uniform 64-bit row base + 32-bit lane offset. */
-template <int NB>
-__device__ __forceinline__ void store_rows(float *base, long long pitch, int row0, size_t gs, int h, bool valid, const v16f *x) {
-  char *ub = reinterpret_cast<char *>(base + (long long)row0 * pitch);
-  const unsigned voff = (unsigned)(((long long)(4 * h) * pitch + (long long)gs) * 4);
-  if (valid) {
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        *reinterpret_cast<float *>(ub + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch * 4 + voff) = x[blk][r];
-  }
-}
-__device__ __forceinline__ void store_row1(float *base, long long pitch, int row, size_t gs, float v) {
-  base[(long long)row * pitch + (long long)gs] = v;
-}
 
 /* Per-ray part of the backward (one wave per ray): rendering gradient through
  * the render-time colour map (render.py:186-216), compositing (152-176) and
@@ -141,17 +126,12 @@ __device__ __forceinline__ v16f load_acc_blk(__amdgpu_buffer_rsrc_t rs, int off,
                 b[2][0], b[2][1], b[2][2], b[2][3], b[3][0], b[3][1], b[3][2], b[3][3]};
 }
 
-__device__ __forceinline__ void shift_masks_down(unsigned (&M)[8][4]) {
+/* delta through a ReLU whose (saved, post-activation) output is `act`: in = out where act > 0 */
+__device__ __forceinline__ void relu_backward_into(const v16f (&out)[8], const v16f (&act)[8], v16f (&in)[8]) {
 #pragma unroll
-  for (int l = 0; l < 7; ++l)
+  for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) M[l][q] = M[l + 1][q];
-}
-__device__ __forceinline__ void shift_masks_up(unsigned (&M)[8][4]) {
-#pragma unroll
-  for (int l = 7; l > 0; --l)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) M[l][q] = M[l - 1][q];
+    for (int r = 0; r < 16; ++r) in[ob][r] = (act[ob][r] > 0.0f) ? out[ob][r] : 0.0f;
 }
 
 __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
@@ -169,7 +149,6 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
   float *HD = X + DIR_PAD * T_TILE;              /* [HD_ROWS][T_TILE] */
   float *TD = HD + HD_ROWS * T_TILE;             /* [rpw][N+1]        */
   float *GS = TD + rpw * (N + 1);                /* [n_tot][NGS]      */
-  unsigned *MS = reinterpret_cast<unsigned *>(GS + n_tot * NGS);   /* [32][NTHREADS] spatial ReLU masks, parked during the dir phases */
 
   bwd_prologue(A, TD, GS, ray0, wave, lane);
   __syncthreads();
@@ -177,7 +156,7 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.packed, 0, PACKED.total * 4, 0x00020000);
   const int col = wave * 32 + sl;
   const float *xl = X + h * T_TILE + col;
-  v16f in[8], out[8];
+  v16f in[8], out[8], pre[8];                    /* pre: saved activations prefetched for the next ReLU mask */
 
   for (int pass0 = 0; pass0 < n_tot; pass0 += T_TILE) {
     const int g = pass0 + col;
@@ -186,65 +165,22 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
     const bool valid = (g < n_tot) && (ray < A.R);
     const int rayc = valid ? ray : (A.R - 1);
     const size_t gs = valid ? (size_t)ray * N + si : 0;
-    float o[3], d[3], v[3];
+    float v[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      o[i] = A.rays.d_origins[(size_t)rayc * 3 + i];
-      d[i] = A.rays.d_directions[(size_t)rayc * 3 + i];
-      v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
-    }
-    /* ================= forward recompute ================= */
-    {
-      float radius = A.rays.d_radii[rayc];
-      const float *td = TD + (valid ? rl : 0) * (N + 1);
-      float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
-      float lm[3], lv[3];
-      cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
-#pragma unroll 1
-      for (int j = 0; j < 16; ++j)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const float f = ipe_feature(lm[b], lv[b], j, h);
-          X[(48 * h + j * 3 + b) * T_TILE + col] = f;
-          if (valid) store_row1(A.act, pitch, ACT_IPE + 48 * h + j * 3 + b, gs, f);
-        }
-    }
-    wave_sync();
-
-    unsigned M[8][4], VM[8][4];                  /* ReLU masks: spatial / directional layers */
-    gemm_op<8, 8, false>(rs, PACKED.op[0].a_off, PACKED.op[0].b_off, lane, h, in, out, xl, PACKED.op[0].lds_steps);
-    relu_mask_into(out, in, M[7]);
-    store_rows<8>(A.act, pitch, ACT_SP, gs, h, valid, in);
-#pragma unroll 1
-    for (int op = 1; op < 8; ++op) {
-      gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
-      shift_masks_down(M);
-      relu_mask_into(out, in, M[7]);
-      store_rows<8>(A.act, pitch, ACT_SP + op * WIDTH, gs, h, valid, in);
-    }
-    /* the spatial masks are not needed again before the very end of the backward: park them in LDS
-     * (32 registers less across the directional forward + backward chains) */
-#pragma unroll
-    for (int l = 0; l < 8; ++l)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) MS[(l * 4 + q) * NTHREADS + tid] = M[l][q];
+    for (int i = 0; i < 3; ++i) v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
+    /* ===== the few forward values the backward needs, from the saved x7 / v7 ===== */
+    load_rows<8>(A.act, pitch, ACT_SP + 7 * WIDTH, gs, h, in);              /* x7: input of the heads */
     {
       v16f hd[5];
       gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0);
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) X[(blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * T_TILE + col] = hd[blk][r];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < HD_ROWS) HD[row * T_TILE + col] = hd[4][r];
       }
-      store_rows<4>(A.act, pitch, ACT_DIN, gs, h, valid, hd);
     }
+    load_rows<8>(A.act, pitch, ACT_VD + 7 * WIDTH, gs, h, in);              /* v7: input of the rgb layer */
     wave_sync();
-
     SampleHeads sh;
     float raw_density, raw_rough, raw_tint[3];
     {
@@ -258,30 +194,6 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
         raw_tint[i] = HD[(8 + i) * T_TILE + col];
       }
       sample_heads(cfg, raw_density, gp, raw_rough, raw_dif, raw_tint, v, sh);
-      float *xi = X + (BNECK + IDE_TERMS * h) * T_TILE + col;
-      ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) {
-        xi[q * T_TILE] = val;
-        if (valid) store_row1(A.act, pitch, ACT_DIN + BNECK + IDE_TERMS * h + q, gs, val);
-      });
-      if (h == 0) {
-        X[(BNECK + IDE_DIM) * T_TILE + col] = sh.dot;
-        if (valid) store_row1(A.act, pitch, ACT_DIN + BNECK + IDE_DIM, gs, sh.dot);
-      } else {
-#pragma unroll
-        for (int q = DIR_IN; q < DIR_PAD; ++q) X[q * T_TILE + col] = 0.0f;
-      }
-    }
-    wave_sync();
-
-    gemm_op<8, 8, false>(rs, PACKED.op[9].a_off, PACKED.op[9].b_off, lane, h, in, out, xl, PACKED.op[9].lds_steps);
-    relu_mask_into(out, in, VM[7]);
-    store_rows<8>(A.act, pitch, ACT_VD, gs, h, valid, in);
-#pragma unroll 1
-    for (int op = 10; op < 17; ++op) {
-      gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
-      shift_masks_down(VM);
-      relu_mask_into(out, in, VM[7]);
-      store_rows<8>(A.act, pitch, ACT_VD + (op - 9) * WIDTH, gs, h, valid, in);
     }
     float raw_rgb[3];
     {
@@ -290,6 +202,8 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(rgbv[0][i], sl, 64);
     }
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) pre[ob] = in[ob];                          /* v7 doubles as the mask of dir layer 7 */
 
     /* ================= backward ================= */
     float gsv[NGS];
@@ -327,7 +241,7 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) out[ob][r] = (w0[r] * g_raw_rgb[0] + w1[r] * g_raw_rgb[1]) + w2[r] * g_raw_rgb[2];
     }
-    masked_into(out, in, VM[7]);
+    relu_backward_into(out, pre, in);
     /* ---- directional MLP, layers 7..0 ---- */
     v16f(&gd)[DIN_BLOCKS] = reinterpret_cast<v16f(&)[DIN_BLOCKS]>(out);   /* gradient w.r.t. the 201 dir inputs */
 #pragma unroll 1
@@ -349,9 +263,9 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
           }
       }
       if (i > 0) {
+        load_rows<8>(A.act, pitch, ACT_VD + (i - 1) * WIDTH, gs, h, pre);   /* lands under the GEMM below */
         gemm_op<8, 8, true, false>(rs, PACKED.top[TOP_VD1 + i - 1].a_off, 0, lane, h, in, out, xl, 0);
-        shift_masks_up(VM);
-        masked_into(out, in, VM[7]);
+        relu_backward_into(out, pre, in);
       }
     }
     /* X rows 0..127: dL/d bottleneck (= head rows 0..127), rows 128..200: dL/d (IDE, n.v) */
@@ -400,19 +314,16 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
     }
     wave_sync();
     /* ---- heads^T, then the spatial MLP, layers 7..0 ---- */
-#pragma unroll
-    for (int l = 0; l < 8; ++l)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) M[l][q] = MS[(l * 4 + q) * NTHREADS + tid];
+    load_rows<8>(A.act, pitch, ACT_SP + 7 * WIDTH, gs, h, pre);
     gemm_op<8, 8, false, false>(rs, PACKED.top[TOP_HEADS].a_off, 0, lane, h, in, out, xl, HEADS_T_STEPS);
-    masked_into(out, in, M[7]);
+    relu_backward_into(out, pre, in);
 #pragma unroll 1
     for (int i = 7; i >= 0; --i) {
       store_rows<8>(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid, in);
       if (i > 0) {
+        load_rows<8>(A.act, pitch, ACT_SP + (i - 1) * WIDTH, gs, h, pre);
         gemm_op<8, 8, true, false>(rs, PACKED.top[i - 1].a_off, 0, lane, h, in, out, xl, 0);
-        shift_masks_up(M);
-        masked_into(out, in, M[7]);
+        relu_backward_into(out, pre, in);
       }
     }
     wave_sync();

@@ -40,6 +40,10 @@ struct LevelArgs {
   const float *g_means;   /* [R,N,3] */
   const float *g_covs;    /* [R,N,3,3] (cov_full) or [R,N,3] diagonal */
   int cov_full;
+  /* training forward: every linear layer's input is saved for the backward as the ACT matrix
+   * [ACT_ROWS][act_pitch] (refnerf_layout.h), or NULL */
+  float *act;
+  long long act_pitch;
 };
 
 #define RN_STAMP(A, slot) do { asm volatile("; RNMARK " #slot); if ((A).prof && blockIdx.x == 0 && (threadIdx.x & 63) == 0) (A).prof[(threadIdx.x >> 6) * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)

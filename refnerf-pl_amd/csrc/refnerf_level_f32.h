@@ -121,6 +121,36 @@ __device__ __forceinline__ void relu_into(const v16f (&out)[8], v16f (&in)[8]) {
     for (int r = 0; r < 16; ++r) in[ob][r] = fmaxf(out[ob][r], 0.0f);
 }
 
+/* rows [row0 + 32*blk + row(r,h)] of a [rows][pitch] matrix, column gs: 128 B
+ * contiguous per (row, half-wave).  Uniform 64-bit row base + 32-bit lane offset. */
+template <int NB>
+__device__ __forceinline__ void store_rows(float *base, long long pitch, int row0, size_t gs, int h, bool valid, const v16f *x) {
+  char *ub = reinterpret_cast<char *>(base + (long long)row0 * pitch);
+  const unsigned voff = (unsigned)(((long long)(4 * h) * pitch + (long long)gs) * 4);
+  if (valid) {
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        *reinterpret_cast<float *>(ub + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch * 4 + voff) = x[blk][r];
+  }
+}
+__device__ __forceinline__ void store_row1(float *base, long long pitch, int row, size_t gs, float v) {
+  base[(long long)row * pitch + (long long)gs] = v;
+}
+
+/* the same rows read back (the accumulator-layout image of a saved activation block) */
+template <int NB>
+__device__ __forceinline__ void load_rows(const float *base, long long pitch, int row0, size_t gs, int h, v16f *x) {
+  const char *ub = reinterpret_cast<const char *>(base + (long long)row0 * pitch);
+  const unsigned voff = (unsigned)(((long long)(4 * h) * pitch + (long long)gs) * 4);
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      x[blk][r] = *reinterpret_cast<const float *>(ub + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch * 4 + voff);
+}
+
 /* ReLU that also records the sign pattern: bit (16*(ob&1) + r) of mk[ob>>1]. */
 __device__ __forceinline__ void relu_mask_into(const v16f (&out)[8], v16f (&in)[8], unsigned (&mk)[4]) {
 #pragma unroll
@@ -235,6 +265,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     const int ray = ray0 + rl;
     const bool valid = (g < n_tot) && (ray < A.R);
     const int rayc = valid ? ray : (A.R - 1);
+    const bool save = TRAIN && !STAGE && A.act != nullptr && valid;   /* keep the layer inputs for the backward */
+    const size_t gsx = valid ? (size_t)ray * N + si : 0;
     float o[3] = {0.0f, 0.0f, 0.0f}, d[3] = {0.0f, 0.0f, 0.0f}, v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -264,7 +296,11 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 #pragma unroll 1
       for (int j = 0; j < 16; ++j)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) X[(48 * h + j * 3 + b) * T_TILE + col] = ipe_feature(lm[b], lv[b], j, h);
+        for (int b = 0; b < 3; ++b) {
+          const float fe = ipe_feature(lm[b], lv[b], j, h);
+          X[(48 * h + j * 3 + b) * T_TILE + col] = fe;
+          if constexpr (TRAIN && !STAGE) { if (save) store_row1(A.act, A.act_pitch, ACT_IPE + 48 * h + j * 3 + b, gsx, fe); }
+        }
     }
     wave_sync();
 
@@ -272,6 +308,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     unsigned M[TRAIN ? 8 : 1][4];                /* ReLU masks of the spatial layers (training) */
     gemm_op<8, 8, false>(rs, PACKED.op[0].a_off, PACKED.op[0].b_off, lane, h, in, out, xl, PACKED.op[0].lds_steps);
     if constexpr (TRAIN) relu_mask_into(out, in, M[7]); else relu_into(out, in);
+    if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<8>(A.act, A.act_pitch, ACT_SP, gsx, h, save, in); }
 #pragma unroll 1
     for (int op = 1; op < 8; ++op) {
       gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
@@ -281,6 +318,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) M[l][q] = M[l + 1][q];
         relu_mask_into(out, in, M[7]);
+        if constexpr (!STAGE) { if (A.act) store_rows<8>(A.act, A.act_pitch, ACT_SP + op * WIDTH, gsx, h, save, in); }
       } else relu_into(out, in);
     }
     /* P3: heads (models.py:582,613,634-645): 4 bottleneck blocks + 1 scalar block */
@@ -297,6 +335,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < HD_ROWS) HD[row * T_TILE + col] = hd[4][r];
       }
+      if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<4>(A.act, A.act_pitch, ACT_DIN, gsx, h, save, hd); }
     }
     wave_sync();
 
@@ -314,9 +353,14 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       }
       sample_heads(cfg, HD[0 * T_TILE + col], gp, HD[4 * T_TILE + col], raw_dif, raw_tint, v, sh);
       float *xi = X + (BNECK + IDE_TERMS * h) * T_TILE + col;
-      ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { xi[q * T_TILE] = val; });
-      if (h == 0) X[(BNECK + IDE_DIM) * T_TILE + col] = sh.dot;
-      else {
+      ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) {
+        xi[q * T_TILE] = val;
+        if constexpr (TRAIN && !STAGE) { if (save) store_row1(A.act, A.act_pitch, ACT_DIN + BNECK + IDE_TERMS * h + q, gsx, val); }
+      });
+      if (h == 0) {
+        X[(BNECK + IDE_DIM) * T_TILE + col] = sh.dot;
+        if constexpr (TRAIN && !STAGE) { if (save) store_row1(A.act, A.act_pitch, ACT_DIN + BNECK + IDE_DIM, gsx, sh.dot); }
+      } else {
 #pragma unroll
         for (int q = DIR_IN; q < DIR_PAD; ++q) X[q * T_TILE + col] = 0.0f;
       }
@@ -326,10 +370,12 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     /* P5: directional MLP (models.py:690-694) + rgb (699-700) */
     gemm_op<8, 8, false>(rs, PACKED.op[9].a_off, PACKED.op[9].b_off, lane, h, in, out, xl, PACKED.op[9].lds_steps);
     relu_into(out, in);
+    if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<8>(A.act, A.act_pitch, ACT_VD, gsx, h, save, in); }
 #pragma unroll 1
     for (int op = 10; op < 17; ++op) {
       gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
       relu_into(out, in);
+      if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<8>(A.act, A.act_pitch, ACT_VD + (op - 9) * WIDTH, gsx, h, save, in); }
     }
     v16f rgbv[1];
     gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0);

@@ -254,10 +254,11 @@ class _LevelFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mlp, cfg, rays, holder, sdist_in, weights_in, *params):
         packed = mlp.packed_weights(cfg.precision)
-        res = _hip.level_forward(packed, cfg, rays, sdist_in, weights_in, history=True)
+        res = _hip.level_forward(packed, cfg, rays, sdist_in, weights_in, history=True, save_activations=True)
         ctx.mlp, ctx.cfg, ctx.rays, ctx.packed = mlp, cfg, rays, packed
         ctx.packed_key = mlp._packed_key
-        ctx.saved = {k: res[k] for k in ("sdist", "density", "rgb", "weights")}
+        ctx.saved = {k: res.pop(k) if k == "activations" else res[k]
+                     for k in ("sdist", "density", "rgb", "weights", "activations")}
         keys = _DIFF_KEYS + tuple(k for k in res if k not in _DIFF_KEYS)
         holder["keys"] = keys                      # autograd Functions return tuples: tell the caller the names
         outs = tuple(res[k] for k in keys)
@@ -273,6 +274,7 @@ class _LevelFunction(torch.autograd.Function):
         if g_rgb is None:
             g_rgb = torch.zeros_like(ctx.saved["sdist"][:, :3])
         _hip.level_backward(ctx.packed, ctx.cfg, ctx.rays, ctx.saved, g_rgb, g_weights, g_npred, grads)
+        ctx.saved = None                           # release the 17.6 KB/sample activation buffer
         out = []
         for spec in layout.PARAM_SPECS:            # same order as MLP.ordered_parameters()
             n = spec.out_dim * spec.in_dim

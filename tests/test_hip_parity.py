@@ -181,7 +181,7 @@ def _hip_train_step(hip, P, rays, gt_rgb, lossmult, kw, lv, mults):
         fine = L == nl - 1
         n = lv.get("num_nerf_samples", 128) if fine else lv.get("num_prop_samples", 128)
         cfg = hip.default_cfg(n_samples=n, n_in=weights.shape[1], precision=0, training=1, **kw)
-        res = hip.level_forward(packed, cfg, r, sdist, weights)
+        res = hip.level_forward(packed, cfg, r, sdist, weights, save_activations=True)
         rgb = res["r_rgb"].clone().requires_grad_(True)
         w = res["weights"].clone().requires_grad_(True)
         npred = res["normals_pred"].clone().requires_grad_(True)
@@ -302,7 +302,7 @@ def test_backward_is_linear_in_the_upstream_gradients(hip):
     sd = torch.tensor([[0.0, 1.0]], device=DEV).repeat(R, 1)
     w = torch.ones((R, 1), device=DEV)
     cfg = hip.default_cfg(n_samples=N, n_in=1, precision=0, training=1)
-    res = hip.level_forward(packed, cfg, r, sd, w)
+    res = hip.level_forward(packed, cfg, r, sd, w, save_activations=True)
     g = torch.Generator(device="cpu").manual_seed(1)
     ga = [torch.randn((R, 3), generator=g).to(DEV) * 1e-3, torch.randn((R, N), generator=g).to(DEV) * 1e-3,
           torch.randn((R, N, 3), generator=g).to(DEV) * 1e-3]
