@@ -549,6 +549,10 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(rn::level_bwd_f32, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());
+  if (plan.pitch > plan.S) {   /* pad columns of both operand matrices must read as zero in the wgrad GEMM */
+    hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(a.act), rn::ACT_ROWS, plan.pitch, plan.S);
+    hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, rn::DEL_ROWS, plan.pitch, plan.S);
+  }
   rn::WgradArgs w;
   w.act = a.act; w.delta = a.delta; w.pitch = plan.pitch; w.S = plan.S; w.k_per_slice = plan.k_per_slice;
   w.part = (float *)(ws + plan.part_off);

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
   const int tm = tl / J.tiles_n, tn = tl - tm * J.tiles_n;
   const long long k_begin = (long long)blockIdx.y * A.k_per_slice;
   long long k_end = k_begin + A.k_per_slice;
-  if (k_end > A.S) k_end = A.S;
+  const long long s_pad = (A.S + WG_KT - 1) / WG_KT * WG_KT;   /* <= pitch; columns >= S hold zeros */
+  if (k_end > s_pad) k_end = s_pad;
 
   v16f acc[2][2];
 #pragma unroll
@@ -96,26 +97,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
   float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;     /* loader: rows lrow + 32p, 4 samples at lc4 */
-  for (long long k0 = k_begin; k0 < k_end; k0 += WG_KT) {
-    v4f dv[4], av[4];
+  /* per-thread row pointers (NULL = outside the job: zero rows) */
+  const float *dp[4], *ap[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int orow = tm * WG_TM + lrow + 32 * p, irow = tn * WG_TN + lrow + 32 * p;
+    dp[p] = (orow < J.n_out) ? A.delta + (long long)(J.d_row + orow) * A.pitch + lc4 : nullptr;
+    ap[p] = (irow < J.n_in) ? A.act + (long long)(J.a_row + irow) * A.pitch + lc4 : nullptr;
+  }
+  v4f dv[4], av[4];
+  /* plain loads, nothing consumes them before the next rendezvous (a tail mask on the loaded values
+   * would put an s_waitcnt right behind every load): the columns [S, pitch) of both matrices are
+   * zeroed by wgrad_zero_tail, and slices end on multiples of WG_KT */
+  auto fetch = [&](long long k0) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int row = lrow + 32 * p;
-      const long long k = k0 + lc4;
-      const int orow = tm * WG_TM + row, irow = tn * WG_TN + row;
       v4f x = {0.0f, 0.0f, 0.0f, 0.0f}, y = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (orow < J.n_out && k < k_end) {
-        x = *reinterpret_cast<const v4f *>(A.delta + (long long)(J.d_row + orow) * A.pitch + k);
-#pragma unroll
-        for (int e = 1; e < 4; ++e) if (k + e >= k_end) x[e] = 0.0f;
-      }
-      if (irow < J.n_in && k < k_end) {
-        y = *reinterpret_cast<const v4f *>(A.act + (long long)(J.a_row + irow) * A.pitch + k);
-#pragma unroll
-        for (int e = 1; e < 4; ++e) if (k + e >= k_end) y[e] = 0.0f;
-      }
+      if (dp[p]) x = *reinterpret_cast<const v4f *>(dp[p] + k0);
+      if (ap[p]) y = *reinterpret_cast<const v4f *>(ap[p] + k0);
       dv[p] = x; av[p] = y;
     }
+  };
+  if (k_begin < k_end) fetch(k_begin);
+  for (long long k0 = k_begin; k0 < k_end; k0 += WG_KT) {
     __syncthreads();                                   /* previous tile fully consumed */
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -124,6 +128,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
       bsum[p] += (dv[p][0] + dv[p][1]) + (dv[p][2] + dv[p][3]);
     }
     __syncthreads();
+    if (k0 + WG_KT < k_end) fetch(k0 + WG_KT);         /* next tile's loads fly under this tile's MFMAs */
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < WG_KT / 8; ++kk) {
       v4f a[2], b[2];
@@ -139,6 +145,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   float *part = A.part + (size_t)blockIdx.y * NUM_PARAMS;
 #pragma unroll
@@ -162,6 +169,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
       if ((tid & 7) == 0 && orow < J.n_out) part[J.b_off + orow] = s;
     }
   }
+}
+
+/* zero the pad columns [S, pitch) of a [rows][pitch] matrix */
+__global__ void wgrad_zero_tail(float *m, int rows, long long pitch, long long S) {
+  const int tail = (int)(pitch - S);
+  const long long n = (long long)rows * tail;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m[(i / tail) * pitch + S + (i % tail)] = 0.0f;
 }
 
 /* grads[i] += sum over slices (fixed order) of PART[slice][i] */
