@@ -198,21 +198,29 @@ __device__ __forceinline__ void bf_slice(Pipe &p, v8bf (&a)[AF], int second, con
  * the fully unrolled kernel was 80 KB of straight-line code cycling through a
  * 64 KB instruction cache, i.e. fetch-bound).  A rolled loop cannot index the
  * destination registers dynamically, so `out` works as a shift register: the
- * new fragments enter at [14],[15] and everything moves down two places; after
- * the 8 slices fragment pair ob sits at [2ob],[2ob+1]. */
+ * new fragments enter at [12..15] and everything moves down four places per
+ * slice pair; after the 8 slices fragment pair ob sits at [2ob],[2ob+1]. */
 template <int KIND0, int REAL0>
 __device__ __forceinline__ void bf_layer(Pipe &p, v8bf (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16]) {
+  /* rolled over slice PAIRS: one shift of the register queue (by four fragments) per two slices */
 #pragma unroll 1
-  for (int ob = 0; ob < 8; ++ob) {
-    v16f acc;
-    bf_slice<KIND0, REAL0>(p, a, second, in, bn, acc);
-    v4uu f0, f1;
-    pack_acc<true>(acc, f0, f1);
+  for (int ob = 0; ob < 8; ob += 2) {
+    v4uu t0, t1, f0, f1;
+    {
+      v16f acc;
+      bf_slice<KIND0, REAL0>(p, a, second, in, bn, acc);
+      pack_acc<true>(acc, t0, t1);
+      __builtin_amdgcn_sched_barrier(0);   /* pack now: do not keep the fp32 tile alive */
+    }
+    {
+      v16f acc;
+      bf_slice<KIND0, REAL0>(p, a, second, in, bn, acc);
+      pack_acc<true>(acc, f0, f1);
+    }
 #pragma unroll
-    for (int e = 0; e < 14; ++e) out[e] = out[e + 2];
-    out[14] = f0;
-    out[15] = f1;
-    __builtin_amdgcn_sched_barrier(0);     /* pack now: do not keep the fp32 tile alive */
+    for (int e = 0; e < 12; ++e) out[e] = out[e + 4];
+    out[12] = t0; out[13] = t1; out[14] = f0; out[15] = f1;
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
