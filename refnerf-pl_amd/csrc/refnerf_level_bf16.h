@@ -202,25 +202,13 @@ __device__ __forceinline__ void bf_slice(Pipe &p, v8bf (&a)[AF], int second, con
  * slice pair; after the 8 slices fragment pair ob sits at [2ob],[2ob+1]. */
 template <int KIND0, int REAL0>
 __device__ __forceinline__ void bf_layer(Pipe &p, v8bf (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16]) {
-  /* rolled over slice PAIRS: one shift of the register queue (by four fragments) per two slices */
-#pragma unroll 1
-  for (int ob = 0; ob < 8; ob += 2) {
-    v4uu t0, t1, f0, f1;
-    {
-      v16f acc;
-      bf_slice<KIND0, REAL0>(p, a, second, in, bn, acc);
-      pack_acc<true>(acc, t0, t1);
-      __builtin_amdgcn_sched_barrier(0);   /* pack now: do not keep the fp32 tile alive */
-    }
-    {
-      v16f acc;
-      bf_slice<KIND0, REAL0>(p, a, second, in, bn, acc);
-      pack_acc<true>(acc, f0, f1);
-    }
+  /* fully unrolled: slice ob packs straight into out[2ob], out[2ob+1] (no register-queue moves) */
 #pragma unroll
-    for (int e = 0; e < 12; ++e) out[e] = out[e + 4];
-    out[12] = t0; out[13] = t1; out[14] = f0; out[15] = f1;
-    __builtin_amdgcn_sched_barrier(0);
+  for (int ob = 0; ob < 8; ++ob) {
+    v16f acc;
+    bf_slice<KIND0, REAL0>(p, a, second, in, bn, acc);
+    pack_acc<true>(acc, out[2 * ob], out[2 * ob + 1]);
+    __builtin_amdgcn_sched_barrier(0);   /* pack now: do not keep the fp32 tile alive */
   }
 }
 
