@@ -84,7 +84,7 @@ def cpu_baseline(blob, args, target_seconds):
 
 def train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync):
     """Secondary figure: one full training step (training forward with density-gradient
-    normals, the three Ref-NeRF losses, HIP backward + weight-gradient GEMM, gradient
+    normals + saved layer inputs, the three Ref-NeRF losses, HIP backward + weight-gradient GEMM, gradient
     all-reduce over the ranks, Adam step) on the same batch; fp32 MFMA (the only
     training arithmetic built so far)."""
     from refnerf_pl_amd import distributed, synthetic, train_utils, utils
@@ -122,8 +122,7 @@ def train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync):
             "dtype": "f32", "loss": float(loss.detach()),
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
                          "frac": tf / PEAK_TFLOPS["f32"],
-                         "note": "whole step incl. losses, optimiser and weight re-pack; algorithmic 7,651,840 FLOP/ray-sample "
-                                 "(the backward recomputes the forward on top of that)"}}
+                         "note": "whole step incl. losses, optimiser and weight re-pack; algorithmic 7,651,840 FLOP/ray-sample"}}
 
 
 def main():

@@ -21,7 +21,7 @@ KERNELS = {"level_fwd_bf16": "rn::level_fwd_bf16", "level_fwd_f32": "rn::level_f
 rows = list(csv.reader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
 with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-image\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-image\n")
     w.writerow(rows[0])
     for r in rows[1:]:
         if r and r[0].startswith("rn::"):
@@ -39,7 +39,7 @@ for path in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
 for short, counters in stats.items():
     with open(os.path.join(dst, f"pmc_{short}.csv"), "w") as f:
         g = meta[short]
-        f.write(f"# rocprofv3 --pmc passes (separate runs) of: python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-image\n")
+        f.write(f"# rocprofv3 --pmc passes (separate runs) of: python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-image\n")
         f.write(f"# kernel {KERNELS[short]}, grid {g[0]}, wg {g[1]}, VGPR {g[2]}, AGPR {g[3]}, SGPR {g[4]}, scratch {g[5]}\n")
         f.write("counter,dispatches,mean_per_dispatch,min,max\n")
         for c in sorted(counters):
