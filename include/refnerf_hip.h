@@ -135,7 +135,8 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg,
  * (internal/nerf_system.py training_step -> autograd through models.py:162-306):
  * given the level's saved forward outputs and dL/d(outputs) for the outputs the
  * reference's losses read (train_utils.py:33-204: rendering rgb, history
- * weights, history normals_pred; the density-gradient normals, sdist and the
+ * weights, history normals_pred; plus rendering acc / distance, which are
+ * linear in the weights; the density-gradient normals, sdist and the
  * resampling inputs are detached there as well), it ACCUMULATES dL/d(params)
  * into d_param_grads (canonical blob, REFNERF_NUM_PARAMS floats).
  * d_workspace holds the per-sample output gradients of every layer, which the
@@ -152,6 +153,8 @@ typedef struct refnerf_level_grads {
   const float *d_g_r_rgb;         /* [R,3]   dL/d renderings['rgb']                  */
   const float *d_g_weights;       /* [R,N]   dL/d ray_history['weights'], or NULL    */
   const float *d_g_normals_pred;  /* [R,N,3] dL/d ray_history['normals_pred'], or NULL */
+  const float *d_g_r_acc;         /* [R]     dL/d renderings['acc'], or NULL             */
+  const float *d_g_r_distance;    /* [R]     dL/d renderings['distance'], or NULL        */
 } refnerf_level_grads;
 
 /* Training forward that also keeps every linear layer's input for the backward

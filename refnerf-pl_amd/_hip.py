@@ -49,7 +49,7 @@ class LevelSaved(C.Structure):
 
 
 class LevelGrads(C.Structure):
-    _fields_ = [(n, _FP) for n in ("d_g_r_rgb", "d_g_weights", "d_g_normals_pred")]
+    _fields_ = [(n, _FP) for n in ("d_g_r_rgb", "d_g_weights", "d_g_normals_pred", "d_g_r_acc", "d_g_r_distance")]
 
 
 class HipLibraryError(RuntimeError):
@@ -270,7 +270,7 @@ def backward_workspace(R: int, n_samples: int, device) -> torch.Tensor:
 
 
 def level_backward(packed, cfg: LevelCfg, rays: dict, saved: dict, g_r_rgb, g_weights, g_normals_pred,
-                   param_grads: torch.Tensor):
+                   param_grads: torch.Tensor, g_r_acc=None, g_r_distance=None):
     """Backward of one level: accumulates dL/d(params) into `param_grads`
     (canonical blob).  saved: dict with sdist, density, rgb, weights and
     activations of the training forward (save_activations=True); g_*: upstream
@@ -293,7 +293,8 @@ def level_backward(packed, cfg: LevelCfg, rays: dict, saved: dict, g_r_rgb, g_we
         raise ValueError("level_backward needs the activations saved by level_forward(..., save_activations=True)")
     sv.d_activations = saved["activations"].data_ptr()
     gr = LevelGrads()
-    for name, t in (("d_g_r_rgb", g_r_rgb), ("d_g_weights", g_weights), ("d_g_normals_pred", g_normals_pred)):
+    for name, t in (("d_g_r_rgb", g_r_rgb), ("d_g_weights", g_weights), ("d_g_normals_pred", g_normals_pred),
+                    ("d_g_r_acc", g_r_acc), ("d_g_r_distance", g_r_distance)):
         if t is not None:
             t = t.to(torch.float32).contiguous()
             keep.append(t)

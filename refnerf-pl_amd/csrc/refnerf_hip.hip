@@ -543,6 +543,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   a.rpw = rpw;
   a.sdist = saved->d_sdist; a.density = saved->d_density; a.rgb = saved->d_rgb; a.weights = saved->d_weights;
   a.g_r_rgb = grads->d_g_r_rgb; a.g_weights = grads->d_g_weights; a.g_npred = grads->d_g_normals_pred;
+  a.g_r_acc = grads->d_g_r_acc; a.g_r_dist = grads->d_g_r_distance;
   a.act = (const float *)saved->d_activations;
   a.delta = (float *)(ws + plan.delta_off);
   a.pitch = plan.pitch;

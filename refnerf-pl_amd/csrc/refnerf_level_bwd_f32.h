@@ -37,6 +37,8 @@ struct BwdArgs {
   const float *g_r_rgb;     /* [R,3]   dL/d rendering rgb (after the render map)  */
   const float *g_weights;   /* [R,N]   dL/d history weights, or NULL              */
   const float *g_npred;     /* [R,N,3] dL/d history normals_pred, or NULL         */
+  const float *g_r_acc;     /* [R]     dL/d rendering acc, or NULL                */
+  const float *g_r_dist;    /* [R]     dL/d rendering distance, or NULL           */
   const float *act;         /* [ACT_ROWS][pitch] layer inputs saved by the training forward */
   float *delta;             /* [DEL_ROWS][pitch] written here                       */
   long long pitch;
@@ -79,12 +81,19 @@ __device__ __forceinline__ void bwd_prologue(const BwdArgs &A, float *TD, float 
       colour_map_backward(pre, mode == REFNERF_SRGB_NORM_LINEAR || mode == REFNERF_SRGB_NORM_SRGB,
                           mode == REFNERF_SRGB_SRGB || mode == REFNERF_SRGB_NORM_SRGB, g_rgb);
     const float gsum = (g_rgb[0] + g_rgb[1] + g_rgb[2]) * cfg.bg_rgb;
-    /* dL/dw_i and the two running sums of the weight backward */
-    double l_dd = 0.0, l_gw = 0.0;
-    for (int i = i0; i < i0 + C && i < N; ++i) {
+    /* acc = sum_i w_i and distance = sum_i w_i t_mid,i are linear in the weights (render.py:161-176) */
+    const float g_acc = A.g_r_acc ? A.g_r_acc[ray] : 0.0f, g_dist = A.g_r_dist ? A.g_r_dist[ray] : 0.0f;
+    auto dLdw = [&](int i) {
       float g = (g_rgb[0] * cg[i * 3] + g_rgb[1] * cg[i * 3 + 1]) + g_rgb[2] * cg[i * 3 + 2];
       if (acc < 1.0f) g -= gsum;                              /* bg weight = max(0, 1 - acc) */
       if (A.g_weights) g += A.g_weights[(size_t)ray * N + i];
+      g += g_acc + g_dist * (0.5f * (td[i] + td[i + 1]));
+      return g;
+    };
+    /* dL/dw_i and the two running sums of the weight backward */
+    double l_dd = 0.0, l_gw = 0.0;
+    for (int i = i0; i < i0 + C && i < N; ++i) {
+      const float g = dLdw(i);
       l_dd += (double)(dg[i] * ((td[i + 1] - td[i]) * norm_d));
       l_gw += (double)(g * wg[i]);
     }
@@ -94,9 +103,7 @@ __device__ __forceinline__ void bwd_prologue(const BwdArgs &A, float *TD, float 
     double run_gw = incl_gw - l_gw;
     for (int i = i0; i < i0 + C && i < N; ++i) {
       const float w = wg[i];
-      float g = (g_rgb[0] * cg[i * 3] + g_rgb[1] * cg[i * 3 + 1]) + g_rgb[2] * cg[i * 3 + 2];
-      if (acc < 1.0f) g -= gsum;
-      if (A.g_weights) g += A.g_weights[(size_t)ray * N + i];
+      const float g = dLdw(i);
       const float delta = (td[i + 1] - td[i]) * norm_d;
       const float dd = dg[i] * delta;
       run_gw += (double)(g * w);

@@ -241,9 +241,10 @@ class MLP(nn.Module):
         return ray_results
 
 
-# outputs of one training level, in the order _LevelFunction returns them; the
-# first three are what the reference's losses differentiate (train_utils.py:33-204)
-_DIFF_KEYS = ("r_rgb", "weights", "normals_pred")
+# outputs of one training level, in the order _LevelFunction returns them; the first three are what
+# the reference's Ref-NeRF losses differentiate (train_utils.py:33-204), acc / distance are linear in
+# the weights and come for free; every other output is marked non-differentiable
+_DIFF_KEYS = ("r_rgb", "weights", "normals_pred", "r_acc", "r_distance")
 
 
 class _LevelFunction(torch.autograd.Function):
@@ -266,14 +267,15 @@ class _LevelFunction(torch.autograd.Function):
         return outs
 
     @staticmethod
-    def backward(ctx, g_rgb, g_weights, g_npred, *unused):
+    def backward(ctx, g_rgb, g_weights, g_npred, g_acc, g_dist, *unused):
         mlp = ctx.mlp
         if mlp._packed_key != ctx.packed_key:
             raise _hip.HipLibraryError("parameters changed between the training forward and backward of a level")
         grads = torch.zeros(layout.NUM_PARAMS, dtype=torch.float32, device=ctx.saved["sdist"].device)
         if g_rgb is None:
             g_rgb = torch.zeros_like(ctx.saved["sdist"][:, :3])
-        _hip.level_backward(ctx.packed, ctx.cfg, ctx.rays, ctx.saved, g_rgb, g_weights, g_npred, grads)
+        _hip.level_backward(ctx.packed, ctx.cfg, ctx.rays, ctx.saved, g_rgb, g_weights, g_npred, grads,
+                            g_r_acc=g_acc, g_r_distance=g_dist)
         ctx.saved = None                           # release the 17.6 KB/sample activation buffer
         out = []
         for spec in layout.PARAM_SPECS:            # same order as MLP.ordered_parameters()

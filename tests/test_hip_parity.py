@@ -322,6 +322,16 @@ def test_backward_is_linear_in_the_upstream_gradients(hip):
     assert float(Z.abs().max()) == 0.0
     A2 = run(ga)                                                   # bit-reproducible (no atomics)
     assert torch.equal(A, A2)
+    # acc = sum_i w_i and distance = sum_i w_i t_mid,i: their seeds equal a weights seed
+    g_acc = torch.randn((R,), generator=g).to(DEV) * 1e-3
+    g_dist = torch.randn((R,), generator=g).to(DEV) * 1e-3
+    t = r["near"][:, None] * (1 - res["sdist"]) + r["far"][:, None] * res["sdist"]      # coord.py:96-98, fn = None
+    tmid = 0.5 * (t[:, 1:] + t[:, :-1])
+    zero = torch.zeros((R, 3), device=DEV)
+    via_w = run([zero, g_acc[:, None] + g_dist[:, None] * tmid, None])
+    out = torch.zeros(hip.NUM_PARAMS, device=DEV)
+    hip.level_backward(packed, cfg, r, res, zero, None, None, out, g_r_acc=g_acc, g_r_distance=g_dist)
+    assert float((out - via_w).norm() / via_w.norm()) < 1e-5
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
