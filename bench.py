@@ -134,8 +134,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # REFNERF_BENCH_BACKEND=gloo + REFNERF_BENCH_SHARE_GPU=1: smoke-test the N>1 code path on a 1-GPU box
+        backend = os.environ.get("REFNERF_BENCH_BACKEND", "nccl")
+        if os.environ.get("REFNERF_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
