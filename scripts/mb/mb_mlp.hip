@@ -171,7 +171,15 @@ __global__ __launch_bounds__(512) void mlp_loop(const char *img, float *out, lon
 #endif
       a[k % AFD] = (k + AFD < 16) ? *reinterpret_cast<const v8bf *>(pc + (k + AFD) * 1024)
                                   : *reinterpret_cast<const v8bf *>(pn + (k + AFD - 16) * 1024);
-#ifdef BAR2
+#if defined(ENDBAR)
+      // waves 4-7 meet the others at the END of their chunk instead of its middle: the two waves of a SIMD run
+      // half a chunk out of phase (same barrier count, same 3-slot ring; they refill the slot they just left)
+      if (wave < 4 ? k == 7 : k == 15) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue(wave < 4 ? fil : cur);
+      }
+#elif defined(BAR2)
       // 4-slot ring: rendezvous every second chunk, two chunks issued behind it
       if (k == 7 && (c & 1) == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

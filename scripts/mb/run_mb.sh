@@ -1,4 +1,4 @@
 #!/bin/bash
-# builds happen in the container (hipcc cross-compiles); this just runs the variants on the GPU box
-cd $(dirname $0)
-for b in bin5/*; do ./$b 2048; done
+# run every built variant (scripts/mb/build_mb.sh) on the GPU of this box: 2048 workgroups, 272 chunks each
+cd "$(dirname "$0")"
+for b in bin/*; do ./$b 2048; done
