@@ -455,6 +455,39 @@ def test_device_ray_generation(hip, tag):
         assert float(rays.far.min()) == 6.0
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+def test_c_abi_without_torch(hip, precision, tmp_path):
+    """examples/c_abi_demo.cpp -- a C++ host that uses only include/refnerf_hip.h (hipMalloc'd buffers,
+    no PyTorch) -- renders the same view as the Python host mirror, to the last few ulps."""
+    import os
+    import subprocess
+    import __graft_entry__ as ge
+    from refnerf_pl_amd import camera_utils, configs, models, synthetic, utils
+    exe = ge.build_c_demo()
+    W, H, focal = 24, 16, 30.0
+    blob = synthetic.make_params(seed=2, bias_scale=0.05, sharpen=20.0)
+    c2w, _ = synthetic.blender_camera(seed=3)
+    blob.astype(np.float32).tofile(tmp_path / "w.f32")
+    c2w.astype(np.float32).tofile(tmp_path / "c2w.f32")
+    out = subprocess.run([exe, str(tmp_path / "w.f32"), str(tmp_path / "c2w.f32"), str(W), str(H), str(focal), str(precision),
+                          str(tmp_path / "rgb.f32")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    rgb_c = np.fromfile(tmp_path / "rgb.f32", np.float32).reshape(H, W, 3)
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                            ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 64",
+                                             f"Config.hip_precision = '{'bf16' if precision else 'f32'}'"])
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).eval()
+    model.nerf_mlp.load_flat_params(blob)
+    rays = camera_utils.cast_pinhole_rays(c2w.astype(np.float32), H, W, focal, 2.0, 6.0, device=torch.device(DEV))
+    with torch.no_grad():
+        rend, _ = model(rays.reshape(H * W, -1), 1.0, False)
+    rgb_py = rend[1]["rgb"].reshape(H, W, 3).cpu().numpy()
+    np.testing.assert_allclose(rgb_c, rgb_py, rtol=0, atol=2e-6)
+    assert "mean rgb" in out.stdout
+
+
 def test_model_training_step_autograd(hip):
     """Model.__call__ in training mode + the reference-shaped losses + loss.backward():
     the 46 nn.Parameters receive the reference's gradients (golden autograd vectors)."""
