@@ -533,6 +533,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute((const void *)rn::level_bwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)rn::wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4);
   });
   char *ws = (char *)d_workspace;
   rn::BwdArgs a;
@@ -558,7 +559,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   w.act = a.act; w.delta = a.delta; w.pitch = plan.pitch; w.S = plan.S; w.k_per_slice = plan.k_per_slice;
   w.part = (float *)(ws + plan.part_off);
   const int slices = (int)((plan.S + plan.k_per_slice - 1) / plan.k_per_slice);
-  hipLaunchKernelGGL(rn::wgrad_kernel, dim3(rn::WJOBS.tiles, slices), dim3(256), 0, st, w);
+  hipLaunchKernelGGL(rn::wgrad_kernel, dim3(rn::WJOBS.tiles, slices), dim3(256), (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4, st, w);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(rn::wgrad_reduce, dim3(1024), dim3(256), 0, st, w.part, slices, d_param_grads);
   HIP_TRY(hipGetLastError());

@@ -17,7 +17,7 @@
 namespace rn {
 
 struct WJob { int d_row, n_out, a_row, n_in, w_off, ld, b_off, tiles_n, tile0; };
-constexpr int WG_TM = 128, WG_TN = 128, WG_KT = 32, WG_LDK = 36;
+constexpr int WG_TM = 128, WG_TN = 128, WG_KT = 64, WG_LDK = 68;
 constexpr int MAX_WJOBS = 32;
 struct WJobs { WJob job[MAX_WJOBS]; int n; int tiles; };
 
@@ -71,8 +71,8 @@ struct WgradArgs {
 
 /* grid = (WJOBS.tiles, slices), 256 threads: waves 2x2 over the 128x128 tile. */
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
-  __shared__ __attribute__((aligned(16))) float Ds[WG_TM * WG_LDK];
-  __shared__ __attribute__((aligned(16))) float As[WG_TN * WG_LDK];
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  float *Ds = wsm, *As = wsm + WG_TM * WG_LDK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, sl = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -94,24 +94,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float bsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
-  const int lrow = tid >> 3, lc4 = (tid & 7) * 4;     /* loader: rows lrow + 32p, 4 samples at lc4 */
+  const int lrow = tid >> 4, lc4 = (tid & 15) * 4;    /* loader: rows lrow + 16p (p = 0..7), 4 samples at lc4 */
   /* per-thread row pointers (NULL = outside the job: zero rows) */
-  const float *dp[4], *ap[4];
+  const float *dp[8], *ap[8];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int orow = tm * WG_TM + lrow + 32 * p, irow = tn * WG_TN + lrow + 32 * p;
+  for (int p = 0; p < 8; ++p) {
+    const int orow = tm * WG_TM + lrow + 16 * p, irow = tn * WG_TN + lrow + 16 * p;
     dp[p] = (orow < J.n_out) ? A.delta + (long long)(J.d_row + orow) * A.pitch + lc4 : nullptr;
     ap[p] = (irow < J.n_in) ? A.act + (long long)(J.a_row + irow) * A.pitch + lc4 : nullptr;
   }
-  v4f dv[4], av[4];
+  v4f dv[8], av[8];
   /* plain loads, nothing consumes them before the next rendezvous (a tail mask on the loaded values
    * would put an s_waitcnt right behind every load): the columns [S, pitch) of both matrices are
    * zeroed by wgrad_zero_tail, and slices end on multiples of WG_KT */
   auto fetch = [&](long long k0) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < 8; ++p) {
       v4f x = {0.0f, 0.0f, 0.0f, 0.0f}, y = {0.0f, 0.0f, 0.0f, 0.0f};
       if (dp[p]) x = *reinterpret_cast<const v4f *>(dp[p] + k0);
       if (ap[p]) y = *reinterpret_cast<const v4f *>(ap[p] + k0);
@@ -122,9 +122,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
   for (long long k0 = k_begin; k0 < k_end; k0 += WG_KT) {
     __syncthreads();                                   /* previous tile fully consumed */
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<v4f *>(Ds + (lrow + 32 * p) * WG_LDK + lc4) = dv[p];
-      *reinterpret_cast<v4f *>(As + (lrow + 32 * p) * WG_LDK + lc4) = av[p];
+    for (int p = 0; p < 8; ++p) {
+      *reinterpret_cast<v4f *>(Ds + (lrow + 16 * p) * WG_LDK + lc4) = dv[p];
+      *reinterpret_cast<v4f *>(As + (lrow + 16 * p) * WG_LDK + lc4) = av[p];
       bsum[p] += (dv[p][0] + dv[p][1]) + (dv[p][2] + dv[p][3]);
     }
     __syncthreads();
@@ -160,13 +160,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
       }
     }
   if (tn == 0 && J.b_off >= 0) {
-    /* bias gradient: the 8 loader threads of a row hold its partial sums */
+    /* bias gradient: the 16 loader threads of a row hold its partial sums */
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < 8; ++p) {
       float s = bsum[p];
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-      const int orow = tm * WG_TM + lrow + 32 * p;
-      if ((tid & 7) == 0 && orow < J.n_out) part[J.b_off + orow] = s;
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+      const int orow = tm * WG_TM + lrow + 16 * p;
+      if ((tid & 15) == 0 && orow < J.n_out) part[J.b_off + orow] = s;
     }
   }
 }
