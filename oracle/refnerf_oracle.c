@@ -2,7 +2,7 @@
  * refnerf_oracle.c -- CPU restatement of the Ref-NeRF rendering inner loop.
  *
  * TEST INFRASTRUCTURE ONLY (see refnerf_oracle.h).  Parity status: PINNED by
- * tests/golden/*.npz (captured from the upstream reference in the build
+ * the .npz files under tests/golden (captured from the upstream reference in the build
  * container by tests/golden/make_golden.py).
  *
  * Reference citations are file:line relative to the upstream repo root.
