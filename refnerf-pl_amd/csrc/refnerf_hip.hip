@@ -350,7 +350,9 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   };
   /* bf16: the per-ray phases (resample, compositing) occupy one wave per ray, so take as many rays per
    * workgroup as the LDS holds (up to one per wave): the other waves idle for a shorter share of the pass */
-  if (bf) while (2 * rpw <= rn::BF_NW && 2 * rpw * N <= 640 && lds_bytes(2 * rpw) <= 160 * 1024) rpw *= 2;
+  if (bf) while (2 * rpw <= rn::BF_NW && 2 * rpw * N <= 640 && lds_bytes(2 * rpw) <= 160 * 1024 &&
+                 R / (2 * rpw) >= 512)        /* ... but keep at least two workgroups per CU in flight */
+    rpw *= 2;
   if (rpw * N > 640) return fail(REFNERF_EINVAL, "n_samples too large for the LDS budget (rays_per_wg*N must be <= 640)%s");
   size_t lds = lds_bytes(rpw);
   {
