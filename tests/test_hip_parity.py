@@ -488,6 +488,36 @@ def test_c_abi_without_torch(hip, precision, tmp_path):
     assert "mean rgb" in out.stdout
 
 
+def test_hip_graph_replay(hip):
+    """graphs.GraphedForward: the two level launches of an eval step captured in a HIP graph and replayed
+    on new rays give exactly the eager results."""
+    import os
+    from refnerf_pl_amd import configs, graphs, models, synthetic, utils
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                            ["Config.hip_precision = 'bf16'"])
+    model = models.construct_model(utils.dummy_rays(), configs.Config()).to(DEV).eval()
+    model.nerf_mlp.load_flat_params(synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0))
+    a = utils.rays_from_dict(synthetic.blender_rays(512, seed=1, center_frac=0.5), DEV)
+    b = utils.rays_from_dict(synthetic.blender_rays(512, seed=2, center_frac=0.5), DEV)
+    g = graphs.GraphedForward(model, a)
+    with torch.no_grad():
+        want_b = model(b, 1.0, True)
+        want_a = model(a, 1.0, True)
+    for rays, want in ((b, want_b), (a, want_a)):
+        rend, hist = g(rays)
+        torch.cuda.synchronize()
+        for L in range(2):
+            for k in ("rgb", "acc", "distance_median"):
+                assert torch.equal(rend[L][k], want[0][L][k]), k
+            assert torch.equal(hist[L]["weights"], want[1][L]["weights"])
+    with pytest.raises(ValueError):
+        g(utils.rays_from_dict(synthetic.blender_rays(64, seed=1), DEV))
+    model.train()
+    with pytest.raises(ValueError):
+        graphs.GraphedForward(model, a)
+
+
 def test_model_training_step_autograd(hip):
     """Model.__call__ in training mode + the reference-shaped losses + loss.backward():
     the 46 nn.Parameters receive the reference's gradients (golden autograd vectors)."""
