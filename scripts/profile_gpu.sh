@@ -8,10 +8,12 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-image ${BENCH_ARGS:-}"
+# counters do not depend on the clock state: short runs keep the per-dispatch CSVs small
+PARGS="$ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-image ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ARGS > $OUT/trace.log 2>&1
 for pmc in "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pmc | tr ' ' '+' | cut -c1-40)
-  rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_$name -o pmc -- python3 $ARGS > $OUT/pmc_$name.log 2>&1
+  rocprofv3 --pmc $pmc --output-format csv -d $OUT/pmc_$name -o pmc -- python3 $PARGS > $OUT/pmc_$name.log 2>&1
 done
 find $OUT -name "*.db" -delete
 find $OUT -size +8M -delete

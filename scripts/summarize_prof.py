@@ -39,7 +39,7 @@ for path in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
 for short, counters in stats.items():
     with open(os.path.join(dst, f"pmc_{short}.csv"), "w") as f:
         g = meta[short]
-        f.write(f"# rocprofv3 --pmc passes (separate runs) of: python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-image\n")
+        f.write(f"# rocprofv3 --pmc passes (separate runs) of: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-image\n")
         f.write(f"# kernel {KERNELS[short]}, grid {g[0]}, wg {g[1]}, VGPR {g[2]}, AGPR {g[3]}, SGPR {g[4]}, scratch {g[5]}\n")
         f.write("counter,dispatches,mean_per_dispatch,min,max\n")
         for c in sorted(counters):
