@@ -607,6 +607,45 @@ def test_opaque_background(hip, O, precision):
         np.testing.assert_allclose(res["r_acc"], 1.0, rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_shapes_vs_oracle(hip, O, seed):
+    """Seeded sweep over ragged (R, N_prop, N_fine, levels, ray shape, colour options): both arithmetic
+    modes against the oracle (fp32: indices bit-exact, RGB 1e-5; bf16: RGB 2e-4)."""
+    from refnerf_pl_amd import synthetic
+    rng = np.random.default_rng(100 + seed)
+    R = int(rng.integers(1, 41))
+    nprop, nfine = int(rng.integers(2, 200)), int(rng.integers(2, 260))
+    levels = int(rng.integers(1, 4))
+    kw = dict(ray_shape=int(rng.integers(0, 2)), opaque_background=int(rng.integers(0, 2)),
+              srgb_mapping=int(rng.integers(0, 2)), render_srgb_mode=int(rng.integers(0, 5)))
+    lv = dict(num_levels=levels, num_prop_samples=nprop, num_nerf_samples=nfine)
+    P = synthetic.make_params(seed=seed, bias_scale=0.05, sharpen=float(rng.choice([1.0, 8.0, 20.0])))
+    rays = (synthetic.blender_rays if seed % 2 == 0 else synthetic.llff_rays)(R, seed=seed + 3)
+    ref = O.model_forward(P, rays, **lv, **kw)
+    f32 = run_hip_model(hip, P, rays, kw, lv, precision=0)
+    bf = run_hip_model(hip, P, rays, kw, lv, precision=1)
+    ok = np.ones(R, bool)                 # rays whose sample indices agree with the oracle at every level so far
+    for L in range(levels):
+        eq = f32[L]["bin_idx"] == ref[L]["bin_idx"]
+        if L == 0:
+            assert eq.all()               # identical inputs: the sampler itself is bit-exact
+        else:
+            # deeper levels resample from the previous level's weights, which differ from the oracle's by
+            # MLP summation order (1e-7): a quantile within an ulp of a CDF knot may take the neighbouring bin
+            assert eq.mean() >= 0.999, (L, R, nprop, nfine, kw, eq.mean())
+        ok &= eq.all(-1)
+        for k in ("r_rgb", "r_acc", "r_distance", "weights"):
+            a, b = f32[L][k], ref[L][k].reshape(f32[L][k].shape)
+            np.testing.assert_allclose(a[ok], b[ok], rtol=0, atol=1e-5, err_msg=f"f32 L{L} {k}")
+        assert np.isfinite(f32[L]["r_rgb"]).all() and np.isfinite(bf[L]["r_rgb"]).all()
+    # bf16: compare the final level only where its CDF bins agree with the fp32 mode (a flipped bin moves a sample)
+    same = ok.copy()
+    for L in range(1, levels):
+        same &= (bf[L]["bin_idx"] == f32[L]["bin_idx"]).all(-1)
+    if same.any():
+        np.testing.assert_allclose(bf[-1]["r_rgb"][same], ref[-1]["r_rgb"][same], rtol=0, atol=2e-4)
+
+
 def test_full_size_properties(hip):
     """BASELINE configs[1] size (4096 x 128 x 2): size-independent properties --
     weights >= 0, acc = sum(w) <= 1, sdist monotone in [0,1], level-0 sampling
