@@ -269,6 +269,9 @@ class _LevelFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_weights, g_npred, g_acc, g_dist, *unused):
         mlp = ctx.mlp
+        if ctx.saved is None:
+            raise RuntimeError("this level's saved activations were released by its first backward "
+                               "(a second backward through the same graph / retain_graph is not supported)")
         if mlp._packed_key != ctx.packed_key:
             raise _hip.HipLibraryError("parameters changed between the training forward and backward of a level")
         grads = torch.zeros(layout.NUM_PARAMS, dtype=torch.float32, device=ctx.saved["sdist"].device)
