@@ -344,7 +344,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
   auto lds_bytes = [&](int rays) -> size_t {
     const int np = bf ? rn::NPS_EVAL : rn::NPS_TRAIN, tile = bf ? rn::BT : rn::T_TILE;
-    const size_t per_wg = sizeof(float) * (size_t)(2 * rays * (N + 1) + np * rays * N + 3 * tile + 8);
+    const size_t per_wg = sizeof(float) * (size_t)(2 * rays * (N + 1) + np * rays * N + 3 * tile + 8 + 12 * rays);
     if (bf) return (size_t)rn::BF_RING_BYTES + rn::BF_X_BYTES + sizeof(float) * rn::HD_ROWS * rn::BT + per_wg;
     return sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE) + per_wg;
   };

@@ -232,7 +232,8 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   float *XP = TD + rpw * (N + 1);                            /* [rpw][N+1]               */
   float *PS = XP + rpw * (N + 1);                            /* [n_tot][NPS_EVAL]        */
   float *PX = PS + n_tot * NPS_EVAL;                         /* [BT][3] grad_pred of the pass */
-  float *NRM = PX + 3 * BT;                                  /* [rpw] |direction| per ray */
+  float *NRM = PX + 3 * BT;                                  /* [8] |direction| per ray  */
+  const float *RY = NRM + 8;                                 /* [rpw][12] o, d, viewdir, radius per ray */
 
   const int h = lane >> 5, n = lane & 31;
   const int col = wave * 32 + n;                             /* this lane's sample column */
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
       float v[3], gp[3], raw_dif[3], raw_tint[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
+        v[i] = RY[(valid ? rl : 0) * 12 + 6 + i];
         gp[i] = HD[(1 + i) * BT + col];
         raw_dif[i] = HD[(5 + i) * BT + col];
         raw_tint[i] = HD[(8 + i) * BT + col];
@@ -302,9 +303,10 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
       if (phase == 0) {
         /* P1: conical frustum -> lifted Gaussian -> IPE (half h computes block h: sin / cos) */
         float o[3], d[3];
+        const float *ry = RY + (valid ? rl : 0) * 12;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { o[i] = A.rays.d_origins[(size_t)rayc * 3 + i]; d[i] = A.rays.d_directions[(size_t)rayc * 3 + i]; }
-        float radius = A.rays.d_radii[rayc];
+        for (int i = 0; i < 3; ++i) { o[i] = ry[i]; d[i] = ry[3 + i]; }
+        float radius = ry[9];
         const float *td = TD + (valid ? rl : 0) * (N + 1);
         float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
         float lm[3], lv[3];

@@ -216,10 +216,20 @@ __device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratc
     sample_intervals_wave<EXACT>(t_in, lg, cw, c, M, N, cfg.s_near, cfg.s_far, sd,
                           A.out.d_bin_idx ? A.out.d_bin_idx + (size_t)ray * N : nullptr, lane);
     float nearv = A.rays.d_near[ray], farv = A.rays.d_far[ray];
-    /* |d| for the compositing phase (NRM[rpw] in LDS): P7 would otherwise start with a global-load round trip */
-    if (!EXACT && lane == 0) {                 /* bf16 kernel only: the fp32 kernels keep their proven code path */
-      float dx = A.rays.d_directions[(size_t)ray * 3], dy = A.rays.d_directions[(size_t)ray * 3 + 1], dz = A.rays.d_directions[(size_t)ray * 3 + 2];
-      NRM[rl] = sqrtf((dx * dx + dy * dy) + dz * dz);
+    /* bf16 kernel only (the fp32 kernels keep their proven code path): the ray's geometry goes to LDS once --
+     * NRM[rl] = |d| for the compositing phase and, behind the rpw norms, 12 floats per ray
+     * [o(3) d(3) viewdir(3) radius] that the per-sample phases then read as LDS broadcasts instead of
+     * 64 identical global loads per phase */
+    if (!EXACT) {
+      float *RY = NRM + 8 + rl * 12;
+      if (lane < 10) {
+        const float val = lane < 3 ? A.rays.d_origins[(size_t)ray * 3 + lane]
+                        : lane < 6 ? A.rays.d_directions[(size_t)ray * 3 + lane - 3]
+                        : lane < 9 ? A.rays.d_viewdirs[(size_t)ray * 3 + lane - 6] : A.rays.d_radii[ray];
+        RY[lane] = val;
+        const float dx = __shfl(val, 3, 64), dy = __shfl(val, 4, 64), dz = __shfl(val, 5, 64);
+        if (lane == 0) NRM[rl] = sqrtf((dx * dx + dy * dy) + dz * dz);
+      }
     }
     #pragma clang loop unroll(disable)
     for (int k = lane; k <= N; k += 64) {
