@@ -43,7 +43,11 @@ constexpr int BF_NW = 8;                              /* waves per workgroup */
 constexpr int BF_NTHREADS = 64 * BF_NW;
 constexpr int BF_RING_BYTES = 3 * BF_CHUNK_BYTES;     /* 51 KB */
 constexpr int BF_X_BYTES = (IPE_DIM / 8) * BT * 16;   /* 12 k-groups x 256 x 16 B = 48 KB */
-constexpr int AF = 4;                                 /* A-fragment ring depth (k-steps ahead) */
+#ifndef REFNERF_BF_AF
+#define REFNERF_BF_AF 4
+#endif
+constexpr int AF = REFNERF_BF_AF;                     /* A-fragment ring depth (k-steps ahead) */
+static_assert(AF >= 1 && AF <= 4, "the ring may only run into the next chunk after that chunk's rendezvous (8-step chunks: k >= 4)");
 
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -157,7 +161,10 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, v8bf (&a)[AF], const v4uu (&in
       const int kl2 = k + 2 - L0;                       /* LDS step to fetch now */
       if (kl2 >= 0 && kl2 < 8 && !(KIND == BF_LDS8 && kl2 < 2)) xr[kl2 & 1] = lds_b<REAL_L>(p, kl2);
     }
-    if (k == KS / 2 - 1) {
+#ifndef REFNERF_BF_RDV
+#define REFNERF_BF_RDV (KS / 2 - 1)
+#endif
+    if (k == REFNERF_BF_RDV) {
       /* mid-chunk rendezvous: chunk c+1 is complete for every wave, chunk c-1's slot is free */
 #ifdef REFNERF_PROF_WAITS
       long long t0 = (long long)__builtin_readcyclecounter();
@@ -259,7 +266,9 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
 
   /* static priority for the younger wave of each SIMD (waves 4-7): age-based
    * arbitration otherwise lets waves 0-3 run ahead and idle at every rendezvous */
+#ifndef REFNERF_BF_NOPRIO
   if (wave >= BF_NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   v4uu R0[16], R1[16], bn[8];
   v8bf ar[AF];
 #pragma unroll
