@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 2
+#define REFNERF_ABI_VERSION 3
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {
@@ -155,6 +155,17 @@ typedef struct refnerf_level_grads {
   const float *d_g_normals_pred;  /* [R,N,3] dL/d ray_history['normals_pred'], or NULL */
   const float *d_g_r_acc;         /* [R]     dL/d renderings['acc'], or NULL             */
   const float *d_g_r_distance;    /* [R]     dL/d renderings['distance'], or NULL        */
+  /* ABI v3: optional per-sample seeds on the remaining differentiable entries of ray_history
+   * (internal/models.py:731-750), consumed by the regularisers of internal/train_utils.py:207-325.
+   * Per-RAY seeds on renderings['diffuse' / 'specular' / 'normals' / 'normals_pred' / 'tint' /
+   * 'roughness'] are linear in (weights, history) -- render.py:161-165,227-231 -- and are folded into
+   * d_g_weights and these per-sample seeds by the host (refnerf-pl_amd/models.py::_fold_ray_seeds). */
+  const float *d_g_density;       /* [R,N]   dL/d ray_history['density'], or NULL           */
+  const float *d_g_rgb;           /* [R,N,3] dL/d ray_history['rgb'], or NULL               */
+  const float *d_g_diffuse;       /* [R,N,3] dL/d ray_history['diffuse'], or NULL           */
+  const float *d_g_specular;      /* [R,N,3] dL/d ray_history['specular'], or NULL          */
+  const float *d_g_tint;          /* [R,N,3] dL/d ray_history['tint'], or NULL              */
+  const float *d_g_roughness;     /* [R,N]   dL/d ray_history['roughness'], or NULL         */
 } refnerf_level_grads;
 
 /* Training forward that also keeps every linear layer's input for the backward

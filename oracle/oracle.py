@@ -323,3 +323,42 @@ def model_train(params, rays: dict, gt_rgb, num_levels=2, num_prop_samples=128, 
         sdist, weights = res["sdist"], res["weights"]
     losses["total"] = losses["data"] + losses["orientation"] + losses["normal"]
     return losses, grads, levels
+
+
+_SEED_FIELDS = ("g_r_rgb", "g_r_diffuse", "g_r_specular", "g_r_acc", "g_r_distance", "g_r_normals",
+                "g_r_normals_pred", "g_r_tint", "g_r_roughness", "g_weights", "g_density", "g_roughness",
+                "g_rgb", "g_normals_pred", "g_tint", "g_diffuse", "g_specular")
+
+
+class LevelSeeds(C.Structure):
+    _fields_ = [(n, _FP) for n in _SEED_FIELDS]
+
+
+def level_backward(params, cfg: LevelCfg, rays: dict, sdist_in, weights_in, seeds: dict, grads=None, n_threads=0):
+    """rn_level_backward: upstream gradients on any of the level's differentiable outputs
+    (keys of _SEED_FIELDS without the "g_" prefix: r_* per ray, the others per sample) ->
+    accumulated into `grads` (canonical blob, float32)."""
+    lib().rn_level_backward.restype = C.c_int
+    p, pp = _f(params)
+    rs, keep = _rays_struct(rays)
+    R = keep["origins"].shape[0]
+    N, M = cfg.n_samples, cfg.n_in
+    sd_in, sdp = _f(np.asarray(sdist_in).reshape(R, M + 1))
+    w_in, wp = _f(np.asarray(weights_in).reshape(R, M))
+    st = LevelSeeds()
+    hold = []
+    for k, v in seeds.items():
+        if v is None:
+            continue
+        if "g_" + k not in _SEED_FIELDS:
+            raise KeyError(k)
+        a, ap = _f(v)
+        hold.append(a)
+        setattr(st, "g_" + k, ap)
+    if grads is None:
+        grads = np.zeros(p.shape[0], np.float32)
+    rc = lib().rn_level_backward(pp, C.byref(cfg), C.byref(rs), C.c_int(R), sdp, wp, C.byref(st),
+                                 grads.ctypes.data_as(_FP), C.c_int(n_threads))
+    if rc != 0:
+        raise ValueError(f"rn_level_backward failed with code {rc}")
+    return grads

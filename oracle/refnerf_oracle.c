@@ -853,8 +853,24 @@ static void dense_backward(const float *W, int in, int out, const float *d, cons
 }
 
 /* backward of one sample: upstream grads w.r.t. density, sample rgb, n_pred */
+/* torch.clip(linear_to_srgb(x), 0, 1) backward for one channel (models.py:718-719, render.py:204-206) */
+static float srgb_clip_grad(float x) {
+  float yv = rn_linear_to_srgb(x);
+  return (yv >= 0.0f && yv <= 1.0f) ? srgb_grad(x) : 0.0f;
+}
+
+/* extra[0..2] = dL/d history diffuse, [3..5] = dL/d history specular, [6..8] = dL/d history tint,
+ * [9] = dL/d history roughness (NULL = none). */
+static void mlp_backward_x(const rn_model *M, const rn_level_cfg *cfg, const rn_cache *c, const float *v,
+                           float g_density, const float *g_rgb_out, const float *g_npred_loss,
+                           const float *extra, float *G);
 static void mlp_backward(const rn_model *M, const rn_level_cfg *cfg, const rn_cache *c, const float *v,
                          float g_density, const float *g_rgb_out, const float *g_npred_loss, float *G) {
+  mlp_backward_x(M, cfg, c, v, g_density, g_rgb_out, g_npred_loss, NULL, G);
+}
+static void mlp_backward_x(const rn_model *M, const rn_level_cfg *cfg, const rn_cache *c, const float *v,
+                           float g_density, const float *g_rgb_out, const float *g_npred_loss,
+                           const float *extra, float *G) {
   const rn_param_offsets *L = &M->L;
   const float *P = M->P;
   const float LOG3 = 1.0986122886681098f;
@@ -892,9 +908,14 @@ static void mlp_backward(const rn_model *M, const rn_level_cfg *cfg, const rn_ca
   }
   float g_tint[3], g_raw_rgb[3], g_raw_diff[3];
   for (int i = 0; i < 3; ++i) {
-    g_tint[i] = g_col[i] * sg[i];
-    g_raw_rgb[i] = (g_col[i] * c->tint[i]) * sg[i] * (1.0f - sg[i]) * cfg->rgb_premultiplier;
-    g_raw_diff[i] = g_col[i] * dl[i] * (1.0f - dl[i]);
+    float g_dl = g_col[i], g_sp = g_col[i];
+    if (extra) {   /* the history's own diffuse / specular: clip(srgb(.)) of the linear colours, or the colours */
+      g_dl += extra[i] * (cfg->srgb_mapping ? srgb_clip_grad(dl[i]) : 1.0f);
+      g_sp += extra[3 + i] * (cfg->srgb_mapping ? srgb_clip_grad(spec[i]) : 1.0f);
+    }
+    g_tint[i] = g_sp * sg[i] + (extra ? extra[6 + i] : 0.0f);
+    g_raw_rgb[i] = (g_sp * c->tint[i]) * sg[i] * (1.0f - sg[i]) * cfg->rgb_premultiplier;
+    g_raw_diff[i] = g_dl * dl[i] * (1.0f - dl[i]);
   }
   /* ---- directional MLP ---- */
   float d[RN_WIDTH + RN_DIR_IN], gin[RN_WIDTH + RN_DIR_IN], g_din[RN_DIR_IN];
@@ -926,6 +947,7 @@ static void mlp_backward(const rn_model *M, const rn_level_cfg *cfg, const rn_ca
     float live = (c->nrm2 > EPS32) ? 1.0f : (c->nrm2 == EPS32 ? 0.5f : 0.0f);
     for (int i = 0; i < 3; ++i) g_gp[i] = -(g_np[i] / rs - live * c->gp[i] * gdotg / (s * rs));
   }
+  if (extra) g_rough += extra[9];
   float g_raw_rough = g_rough * softplus_grad(c->raw_rough + cfg->roughness_bias);
   float g_raw_tint[3];
   for (int i = 0; i < 3; ++i) g_raw_tint[i] = g_tint[i] * c->tint[i] * (1.0f - c->tint[i]);
@@ -1085,5 +1107,134 @@ int rn_level_train(const float *params, const rn_level_cfg *cfg_in, const rn_ray
   }
   model_free(&model);
   if (loss3) { loss3[0] = l_data; loss3[1] = l_or; loss3[2] = l_nm; }
+  return 0;
+}
+
+/* ---- generic backward of one level: arbitrary upstream gradients on every differentiable output ----
+ * (what autograd does for any loss written on renderings / ray_history: train_utils.py:207-329) */
+static void render_map_backward(int mode, int allow_norm, const float *pre, float *g) {
+  if (mode == RN_SRGB_NONE) return;
+  int srgb = (mode == RN_SRGB_SRGB || mode == RN_SRGB_NORM_SRGB);
+  int normed = allow_norm && (mode == RN_SRGB_NORM_LINEAR || mode == RN_SRGB_NORM_SRGB);
+  float norm = 1.0f, mxc = fmaxf(fmaxf(pre[0], pre[1]), pre[2]);
+  if (normed) norm = fmaxf(mxc, 1.0f);
+  float gu[3], gnorm = 0.0f;
+  for (int c = 0; c < 3; ++c) {
+    float u = pre[c] / norm;
+    float yv = srgb ? rn_linear_to_srgb(u) : u;
+    float pass = (yv >= 0.0f && yv <= 1.0f) ? 1.0f : 0.0f;
+    gu[c] = g[c] * pass * (srgb ? srgb_grad(u) : 1.0f);
+  }
+  for (int c = 0; c < 3; ++c) { g[c] = gu[c] / norm; gnorm += -gu[c] * pre[c] / (norm * norm); }
+  if (normed) {
+    float gm = (mxc > 1.0f) ? gnorm : (mxc == 1.0f ? 0.5f * gnorm : 0.0f);
+    if (gm != 0.0f) {
+      int cnt = 0;
+      for (int c = 0; c < 3; ++c) cnt += (pre[c] == mxc);
+      for (int c = 0; c < 3; ++c) if (pre[c] == mxc) g[c] += gm / (float)cnt;
+    }
+  }
+}
+
+static float dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+int rn_level_backward(const float *params, const rn_level_cfg *cfg_in, const rn_rays *rays, int R,
+                      const float *sdist_in, const float *weights_in, const rn_level_seeds *sd_,
+                      float *grads, int n_threads) {
+  rn_level_cfg cfgv = *cfg_in;
+  cfgv.training = 1;
+  const rn_level_cfg *cfg = &cfgv;
+  const int N = cfg->n_samples, M = cfg->n_in;
+  if (N <= 1) return -1;
+  rn_model model;
+  model_init(&model, params);
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel
+  {
+    float *G = (float *)calloc((size_t)model.L.total, sizeof(float));
+    rn_cache *cache = (rn_cache *)malloc(sizeof(rn_cache) * (size_t)N);
+    rn_sample_out *so = (rn_sample_out *)malloc(sizeof(rn_sample_out) * (size_t)N);
+    float *buf = (float *)malloc(sizeof(float) * (size_t)(M + 5 * (N + 1)));
+    float *logits = buf, *sd = buf + M, *td = sd + (N + 1), *dens = td + (N + 1), *wts = dens + (N + 1), *gw = wts + (N + 1);
+#pragma omp for schedule(dynamic, 1)
+    for (int r = 0; r < R; ++r) {
+      const float *o = rays->origins + 3 * r, *d = rays->directions + 3 * r, *v = rays->viewdirs + 3 * r;
+      float nearv = rays->near[r], farv = rays->far[r], radius = rays->radii[r];
+      rn_resample_logits(sdist_in + (size_t)r * (M + 1), weights_in + (size_t)r * M, M, cfg->anneal, cfg->resample_padding, logits);
+      rn_sample_intervals(sdist_in + (size_t)r * (M + 1), logits, M, N, cfg->s_near, cfg->s_far, sd, NULL);
+      for (int i = 0; i <= N; ++i) td[i] = rn_s_to_t(sd[i], nearv, farv);
+      for (int i = 0; i < N; ++i) {
+        float lm[3], lv[3];
+        rn_cast_sample(o, d, radius, td[i], td[i + 1], cfg->ray_shape, lm, lv, NULL);
+        mlp_block(&model, cfg, lm, lv, v, 1, &so[i]);
+        mlp_forward_cached(&model, cfg, lm, lv, v, &cache[i], NULL);
+        dens[i] = so[i].density;
+      }
+      rn_alpha_weights(dens, td, d, N, cfg->opaque_background, wts);
+      /* composites before the render-time map (render.py:161-165) */
+      float acc = 0.0f, pre[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      for (int i = 0; i < N; ++i) {
+        acc += wts[i];
+        for (int c = 0; c < 3; ++c) {
+          pre[0][c] += wts[i] * so[i].rgb[c];
+          pre[1][c] += wts[i] * so[i].diffuse[c];
+          pre[2][c] += wts[i] * so[i].specular[c];
+        }
+      }
+      float bg_w = fmaxf(0.0f, 1.0f - acc);
+      float g3[3][3];
+      const float *src3[3] = {sd_->g_r_rgb, sd_->g_r_diffuse, sd_->g_r_specular};
+      float gsum = 0.0f;
+      for (int k = 0; k < 3; ++k) {
+        for (int c = 0; c < 3; ++c) { pre[k][c] += bg_w * cfg->bg_rgb; g3[k][c] = src3[k] ? src3[k][3 * r + c] : 0.0f; }
+        render_map_backward(cfg->render_srgb_mode, k == 0, pre[k], g3[k]);
+        gsum += ((g3[k][0] + g3[k][1]) + g3[k][2]) * cfg->bg_rgb;
+      }
+      const float g_acc = sd_->g_r_acc ? sd_->g_r_acc[r] : 0.0f, g_dist = sd_->g_r_distance ? sd_->g_r_distance[r] : 0.0f;
+      const float zero3[3] = {0, 0, 0};
+      const float *g_rn = sd_->g_r_normals ? sd_->g_r_normals + 3 * r : zero3;
+      const float *g_rnp = sd_->g_r_normals_pred ? sd_->g_r_normals_pred + 3 * r : zero3;
+      const float *g_rt = sd_->g_r_tint ? sd_->g_r_tint + 3 * r : zero3;
+      const float g_rr = sd_->g_r_roughness ? sd_->g_r_roughness[r] : 0.0f;
+      for (int i = 0; i < N; ++i) {
+        float g = (dot3(g3[0], so[i].rgb) + dot3(g3[1], so[i].diffuse)) + dot3(g3[2], so[i].specular);
+        if (acc < 1.0f) g -= gsum;
+        g += g_acc + g_dist * (0.5f * (td[i] + td[i + 1]));
+        g += (dot3(g_rn, so[i].normals) + dot3(g_rnp, so[i].normals_pred)) + (dot3(g_rt, so[i].tint) + g_rr * so[i].roughness);
+        if (sd_->g_weights) g += sd_->g_weights[(size_t)r * N + i];
+        gw[i] = g;
+      }
+      float norm_d = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+      double suffix = 0.0, cum = 0.0;
+      for (int i = 0; i < N; ++i) cum += (double)(dens[i] * ((td[i + 1] - td[i]) * norm_d));
+      for (int i = N - 1; i >= 0; --i) {
+        const size_t si = (size_t)r * N + i;
+        float delta = (td[i + 1] - td[i]) * norm_d;
+        float dd = dens[i] * delta;
+        cum -= (double)dd;
+        float g_dd = gw[i] * expf(-dd) * expf(-(float)cum) - (float)suffix;
+        suffix += (double)(gw[i] * wts[i]);
+        float g_density = g_dd * delta;
+        if (cfg->opaque_background && i == N - 1) g_density = 0.0f;
+        if (sd_->g_density) g_density += sd_->g_density[si];
+        float g_rgb_s[3], g_np[3], extra[10];
+        for (int c = 0; c < 3; ++c) {
+          g_rgb_s[c] = wts[i] * g3[0][c] + (sd_->g_rgb ? sd_->g_rgb[si * 3 + c] : 0.0f);
+          g_np[c] = wts[i] * g_rnp[c] + (sd_->g_normals_pred ? sd_->g_normals_pred[si * 3 + c] : 0.0f);
+          extra[c] = wts[i] * g3[1][c] + (sd_->g_diffuse ? sd_->g_diffuse[si * 3 + c] : 0.0f);
+          extra[3 + c] = wts[i] * g3[2][c] + (sd_->g_specular ? sd_->g_specular[si * 3 + c] : 0.0f);
+          extra[6 + c] = wts[i] * g_rt[c] + (sd_->g_tint ? sd_->g_tint[si * 3 + c] : 0.0f);
+        }
+        extra[9] = wts[i] * g_rr + (sd_->g_roughness ? sd_->g_roughness[si] : 0.0f);
+        mlp_backward_x(&model, cfg, &cache[i], v, g_density, g_rgb_s, g_np, extra, G);
+      }
+    }
+#pragma omp critical
+    { for (int k = 0; k < model.L.total; ++k) grads[k] += G[k]; }
+    free(G); free(cache); free(so); free(buf);
+  }
+  model_free(&model);
   return 0;
 }

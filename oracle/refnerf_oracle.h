@@ -187,6 +187,25 @@ int rn_level_train(const float *params, const rn_level_cfg *cfg, const rn_rays *
                    const float *lossmult /*[R]*/, const rn_loss_cfg *lc, rn_level_out *out,
                    float *grads, double *loss3, int n_threads);
 
+/* ---- generic backward of one level: upstream gradients ("seeds") on every
+ * differentiable output of the level instead of the three built-in losses.  Any loss of
+ * train_utils.py written on renderings / ray_history (consistency :207-310, accumulated weights
+ * :313-316, weights entropy :318-329, depth smoothness :90-119) back-propagates through this.
+ * All pointers optional (NULL = zero).  The level's forward is recomputed (training mode);
+ * sdist / the resampling inputs are detached as in models.py:205-216.  `grads` is ACCUMULATED into. */
+typedef struct rn_level_seeds {
+  const float *g_r_rgb, *g_r_diffuse, *g_r_specular;        /* [R,3] renderings (after the render-time map) */
+  const float *g_r_acc, *g_r_distance;                      /* [R]   */
+  const float *g_r_normals, *g_r_normals_pred, *g_r_tint;   /* [R,3] extras (normals: detached, weights only) */
+  const float *g_r_roughness;                               /* [R]   */
+  const float *g_weights, *g_density, *g_roughness;         /* [R,N]   ray_history */
+  const float *g_rgb, *g_normals_pred, *g_tint, *g_diffuse, *g_specular;   /* [R,N,3] ray_history */
+} rn_level_seeds;
+
+int rn_level_backward(const float *params, const rn_level_cfg *cfg, const rn_rays *rays, int R,
+                      const float *sdist_in, const float *weights_in, const rn_level_seeds *seeds,
+                      float *grads, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
 
 PREC_F32, PREC_BF16 = 0, 1
+ABI_VERSION = 3   # REFNERF_ABI_VERSION
 SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 4}
 
 _FP = C.c_void_p
@@ -49,7 +50,9 @@ class LevelSaved(C.Structure):
 
 
 class LevelGrads(C.Structure):
-    _fields_ = [(n, _FP) for n in ("d_g_r_rgb", "d_g_weights", "d_g_normals_pred", "d_g_r_acc", "d_g_r_distance")]
+    _fields_ = [(n, _FP) for n in ("d_g_r_rgb", "d_g_weights", "d_g_normals_pred", "d_g_r_acc", "d_g_r_distance",
+                                   "d_g_density", "d_g_rgb", "d_g_diffuse", "d_g_specular", "d_g_tint",
+                                   "d_g_roughness")]
 
 
 class HipLibraryError(RuntimeError):
@@ -98,7 +101,7 @@ def lib():
         L.refnerf_integrated_pos_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
         L.refnerf_integrated_dir_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
         L.refnerf_get_timing.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-        if L.refnerf_abi_version() != 2:
+        if L.refnerf_abi_version() != ABI_VERSION:
             raise HipLibraryError("librefnerf_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -270,11 +273,12 @@ def backward_workspace(R: int, n_samples: int, device) -> torch.Tensor:
 
 
 def level_backward(packed, cfg: LevelCfg, rays: dict, saved: dict, g_r_rgb, g_weights, g_normals_pred,
-                   param_grads: torch.Tensor, g_r_acc=None, g_r_distance=None):
+                   param_grads: torch.Tensor, g_r_acc=None, g_r_distance=None, sample_seeds=None):
     """Backward of one level: accumulates dL/d(params) into `param_grads`
     (canonical blob).  saved: dict with sdist, density, rgb, weights and
     activations of the training forward (save_activations=True); g_*: upstream
-    gradients (g_weights / g_normals_pred may be None)."""
+    gradients (g_weights / g_normals_pred may be None); sample_seeds: optional dict of
+    per-sample seeds on ray_history {density, rgb, diffuse, specular, tint, roughness}."""
     require_device()
     R = rays["origins"].shape[0]
     N = cfg.n_samples
@@ -294,7 +298,8 @@ def level_backward(packed, cfg: LevelCfg, rays: dict, saved: dict, g_r_rgb, g_we
     sv.d_activations = saved["activations"].data_ptr()
     gr = LevelGrads()
     for name, t in (("d_g_r_rgb", g_r_rgb), ("d_g_weights", g_weights), ("d_g_normals_pred", g_normals_pred),
-                    ("d_g_r_acc", g_r_acc), ("d_g_r_distance", g_r_distance)):
+                    ("d_g_r_acc", g_r_acc), ("d_g_r_distance", g_r_distance)) + tuple(
+                        ("d_g_" + k, v) for k, v in (sample_seeds or {}).items()):
         if t is not None:
             t = t.to(torch.float32).contiguous()
             keep.append(t)

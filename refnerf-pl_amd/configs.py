@@ -4,10 +4,12 @@ Mirror of the reference's ``internal/configs.py:28-194`` for the fields the hot
 path and its callers read.  gin-config / absl are not installable in the build
 image, so ``parse_config_files_and_bindings`` implements exactly the syntax the
 shipped ``configs/*.gin`` use: ``Name.param = <python literal>``, ``#``
-comments and backslash line continuations.
+comments, backslash line continuations and ``include 'other.gin'`` (resolved
+next to the including file).
 """
 import ast
 import dataclasses
+import os
 from typing import Any, Callable, Dict, Optional, Tuple
 
 import numpy as np
@@ -24,14 +26,20 @@ def bindings_for(name: str) -> Dict[str, Any]:
 
 
 def parse_config_files_and_bindings(files=None, bindings=None, skip_unknown=True):
-    text = []
     for f in (files or []):
         with open(f) as fh:
-            text.append(fh.read())
-    text.extend(bindings or [])
-    src = "\n".join(text).replace("\\\n", " ")
-    for raw in src.splitlines():
+            _parse_text(fh.read(), os.path.dirname(os.path.abspath(f)))
+    _parse_text("\n".join(bindings or []), os.getcwd())
+
+
+def _parse_text(src: str, base_dir: str):
+    for raw in src.replace("\\\n", " ").splitlines():
         line = _strip_comment(raw).strip()
+        if line.startswith("include ") and "=" not in line:
+            inc = ast.literal_eval(line[len("include "):].strip())
+            with open(inc if os.path.isabs(inc) else os.path.join(base_dir, inc)) as fh:
+                _parse_text(fh.read(), os.path.dirname(os.path.abspath(os.path.join(base_dir, inc))))
+            continue
         if not line or "=" not in line:
             continue
         lhs, rhs = line.split("=", 1)

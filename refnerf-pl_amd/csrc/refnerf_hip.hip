@@ -547,6 +547,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   a.sdist = saved->d_sdist; a.density = saved->d_density; a.rgb = saved->d_rgb; a.weights = saved->d_weights;
   a.g_r_rgb = grads->d_g_r_rgb; a.g_weights = grads->d_g_weights; a.g_npred = grads->d_g_normals_pred;
   a.g_r_acc = grads->d_g_r_acc; a.g_r_dist = grads->d_g_r_distance;
+  a.g_s_density = grads->d_g_density; a.g_s_rgb = grads->d_g_rgb; a.g_s_diffuse = grads->d_g_diffuse;
+  a.g_s_specular = grads->d_g_specular; a.g_s_tint = grads->d_g_tint; a.g_s_rough = grads->d_g_roughness;
   a.act = (const float *)saved->d_activations;
   a.delta = (float *)(ws + plan.delta_off);
   a.pitch = plan.pitch;

@@ -39,6 +39,13 @@ struct BwdArgs {
   const float *g_npred;     /* [R,N,3] dL/d history normals_pred, or NULL         */
   const float *g_r_acc;     /* [R]     dL/d rendering acc, or NULL                */
   const float *g_r_dist;    /* [R]     dL/d rendering distance, or NULL           */
+  /* optional per-sample seeds on the other differentiable history outputs (models.py:731-750) */
+  const float *g_s_density; /* [R,N]   dL/d history density                        */
+  const float *g_s_rgb;     /* [R,N,3] dL/d history rgb (padded colour)            */
+  const float *g_s_diffuse; /* [R,N,3] dL/d history diffuse                        */
+  const float *g_s_specular;/* [R,N,3] dL/d history specular                       */
+  const float *g_s_tint;    /* [R,N,3] dL/d history tint                           */
+  const float *g_s_rough;   /* [R,N]   dL/d history roughness                      */
   const float *act;         /* [ACT_ROWS][pitch] layer inputs saved by the training forward */
   float *delta;             /* [DEL_ROWS][pitch] written here                       */
   long long pitch;
@@ -114,10 +121,10 @@ __device__ __forceinline__ void bwd_prologue(const BwdArgs &A, float *TD, float 
       float g_density = g_dd * delta;
       if (cfg.opaque_background && i == N - 1) g_density = 0.0f;
       float *gs = GS + (size_t)(rl * N + i) * NGS;
-      gs[0] = g_density;
+      gs[0] = g_density + (A.g_s_density ? A.g_s_density[(size_t)ray * N + i] : 0.0f);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        gs[1 + c] = w * g_rgb[c];
+        gs[1 + c] = w * g_rgb[c] + (A.g_s_rgb ? A.g_s_rgb[((size_t)ray * N + i) * 3 + c] : 0.0f);
         gs[4 + c] = A.g_npred ? A.g_npred[((size_t)ray * N + i) * 3 + c] : 0.0f;
       }
     }
@@ -229,11 +236,31 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
         g_col[i] = gsv[1 + i] * pad_scale;
       }
       if (cfg.srgb_mapping) colour_map_backward(colr, cfg.srgb_mapping_normalization != 0, true, g_col);
+      /* seeds on the history's own diffuse / specular (clip(srgb(.)) of the linear colours when
+       * srgb_mapping, models.py:718-719, else the linear colours) and tint */
+      float g_dl[3], g_sp[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { g_dl[i] = g_col[i]; g_sp[i] = g_col[i]; }
+      if (A.g_s_diffuse || A.g_s_specular) {
+        float e_dl[3], e_sp[3], spl[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          e_dl[i] = (valid && A.g_s_diffuse) ? A.g_s_diffuse[gs * 3 + i] : 0.0f;
+          e_sp[i] = (valid && A.g_s_specular) ? A.g_s_specular[gs * 3 + i] : 0.0f;
+          spl[i] = sh.tint[i] * sg[i];
+        }
+        if (cfg.srgb_mapping) {
+          colour_map_backward(dl, false, true, e_dl);
+          colour_map_backward(spl, false, true, e_sp);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { g_dl[i] += e_dl[i]; g_sp[i] += e_sp[i]; }
+      }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        g_tint[i] = g_col[i] * sg[i];
-        g_raw_rgb[i] = (g_col[i] * sh.tint[i]) * sg[i] * (1.0f - sg[i]) * cfg.rgb_premultiplier;
-        g_raw_diff[i] = g_col[i] * dl[i] * (1.0f - dl[i]);
+        g_tint[i] = g_sp[i] * sg[i] + ((valid && A.g_s_tint) ? A.g_s_tint[gs * 3 + i] : 0.0f);
+        g_raw_rgb[i] = (g_sp[i] * sh.tint[i]) * sg[i] * (1.0f - sg[i]) * cfg.rgb_premultiplier;
+        g_raw_diff[i] = g_dl[i] * dl[i] * (1.0f - dl[i]);
       }
     }
     if (valid && h == 0) {
@@ -296,6 +323,7 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
       const float live = (nrm2 > EPS32) ? 1.0f : (nrm2 == EPS32 ? 0.5f : 0.0f);
 #pragma unroll
       for (int i = 0; i < 3; ++i) g_gp[i] = -(g_np[i] / rsq - live * sh.gp[i] * gdotg / (s * rsq));
+      if (valid && A.g_s_rough) g_rough += A.g_s_rough[gs];
       const float g_raw_rough = g_rough * softplus_grad(raw_rough + cfg.roughness_bias);
       const float g_raw_density = gsv[0] * softplus_grad(raw_density + cfg.density_bias);
       float hrow[11];

@@ -241,10 +241,76 @@ class MLP(nn.Module):
         return ray_results
 
 
-# outputs of one training level, in the order _LevelFunction returns them; the first three are what
-# the reference's Ref-NeRF losses differentiate (train_utils.py:33-204), acc / distance are linear in
-# the weights and come for free; every other output is marked non-differentiable
-_DIFF_KEYS = ("r_rgb", "weights", "normals_pred", "r_acc", "r_distance")
+# Differentiable outputs of one training level.  The first five are consumed by the kernel directly;
+# the per-ray composites of the second group are linear in (weights, history) (render.py:161-165,227-231)
+# and are folded into per-sample seeds by _fold_ray_seeds; the third group are the per-sample history
+# entries (models.py:731-750).  Everything else (sdist, bin_idx, the detached density normals, grad_pred,
+# distance_mean / percentiles) is marked non-differentiable: no loss of the reference's train_utils
+# differentiates them.
+_KERNEL_KEYS = ("r_rgb", "weights", "normals_pred", "r_acc", "r_distance")
+_RAY_KEYS = ("r_diffuse", "r_specular", "r_normals", "r_normals_pred", "r_tint", "r_roughness")
+_SAMPLE_KEYS = ("density", "rgb", "diffuse", "specular", "tint", "roughness")
+_DIFF_KEYS = _KERNEL_KEYS + _RAY_KEYS + _SAMPLE_KEYS
+
+
+def _srgb_grad(x):
+    """d/dx image.linear_to_srgb (image.py:51-59)."""
+    eps = torch.finfo(torch.float32).eps
+    hi = (211.0 / 200.0) * (5.0 / 12.0) * torch.clamp(x, min=eps) ** (-7.0 / 12.0)
+    hi = torch.where(x > eps, hi, torch.zeros_like(x))
+    return torch.where(x <= 0.0031308, torch.full_like(x, 323.0 / 25.0), hi)
+
+
+def _linear_to_srgb(x):
+    eps = torch.finfo(torch.float32).eps
+    return torch.where(x <= 0.0031308, (323.0 / 25.0) * x, (211.0 * torch.clamp(x, min=eps) ** (5.0 / 12.0) - 11.0) / 200.0)
+
+
+def _fold_ray_seeds(cfg, saved, g, g_weights, g_npred):
+    """Per-ray seeds on the secondary composites -> per-sample seeds (the transpose of
+    render.py:161-165 [diffuse / specular incl. the render-time map of :166-216, which for these two
+    is a clip or clip(srgb(.)) without normalisation] and :227-231 [extras = sum_i w_i x_i]).
+    Returns (g_weights, g_normals_pred, sample_seeds)."""
+    w = saved["weights"]
+    seeds = {k: g.get(k) for k in _SAMPLE_KEYS}
+
+    def add(cur, x):
+        return x if cur is None else cur + x
+
+    mode = cfg.render_srgb_mode
+    for rk, sk in (("r_diffuse", "diffuse"), ("r_specular", "specular")):
+        gr = g.get(rk)
+        if gr is None:
+            continue
+        x = saved[sk]
+        acc = w.sum(dim=-1)
+        bg_w = torch.clamp(1.0 - acc, min=0.0)
+        pre = (w[..., None] * x).sum(dim=-2) + bg_w[..., None] * cfg.bg_rgb
+        if mode in (_hip.SRGB_MODES["linear"], _hip.SRGB_MODES["norm_linear"]):
+            gr = gr * ((pre >= 0.0) & (pre <= 1.0)).to(gr.dtype)
+        elif mode in (_hip.SRGB_MODES["srgb"], _hip.SRGB_MODES["norm_srgb"]):
+            y = _linear_to_srgb(pre)
+            gr = gr * ((y >= 0.0) & (y <= 1.0)).to(gr.dtype) * _srgb_grad(pre)
+        gw = (x * gr[:, None, :]).sum(dim=-1) - ((acc < 1.0).to(gr.dtype) * gr.sum(dim=-1) * cfg.bg_rgb)[:, None]
+        g_weights = add(g_weights, gw)
+        seeds[sk] = add(seeds[sk], w[..., None] * gr[:, None, :])
+    for rk, sk in (("r_normals", "normals"), ("r_normals_pred", "normals_pred"), ("r_tint", "tint"),
+                   ("r_roughness", "roughness")):
+        gr = g.get(rk)
+        if gr is None:
+            continue
+        x = saved[sk]
+        if sk == "roughness":
+            g_weights = add(g_weights, x * gr[:, None])
+            seeds[sk] = add(seeds[sk], w * gr[:, None])
+            continue
+        g_weights = add(g_weights, (x * gr[:, None, :]).sum(dim=-1))
+        if sk == "normals_pred":
+            g_npred = add(g_npred, w[..., None] * gr[:, None, :])
+        elif sk == "tint":
+            seeds[sk] = add(seeds[sk], w[..., None] * gr[:, None, :])
+        # the density normals are detached (models.py:603-609): r_normals only reaches the weights
+    return g_weights, g_npred, {k: v for k, v in seeds.items() if v is not None}
 
 
 class _LevelFunction(torch.autograd.Function):
@@ -259,26 +325,32 @@ class _LevelFunction(torch.autograd.Function):
         ctx.mlp, ctx.cfg, ctx.rays, ctx.packed = mlp, cfg, rays, packed
         ctx.packed_key = mlp._packed_key
         ctx.saved = {k: res.pop(k) if k == "activations" else res[k]
-                     for k in ("sdist", "density", "rgb", "weights", "activations")}
-        keys = _DIFF_KEYS + tuple(k for k in res if k not in _DIFF_KEYS)
+                     for k in ("sdist", "density", "rgb", "weights", "activations", "diffuse", "specular", "tint",
+                               "roughness", "normals", "normals_pred")}
+        diff = tuple(k for k in _DIFF_KEYS if k in res)
+        keys = diff + tuple(k for k in res if k not in diff)
         holder["keys"] = keys                      # autograd Functions return tuples: tell the caller the names
+        ctx.diff_keys = diff
         outs = tuple(res[k] for k in keys)
-        ctx.mark_non_differentiable(*outs[len(_DIFF_KEYS):])
+        ctx.mark_non_differentiable(*outs[len(diff):])
         return outs
 
     @staticmethod
-    def backward(ctx, g_rgb, g_weights, g_npred, g_acc, g_dist, *unused):
+    def backward(ctx, *gouts):
         mlp = ctx.mlp
         if ctx.saved is None:
             raise RuntimeError("this level's saved activations were released by its first backward "
                                "(a second backward through the same graph / retain_graph is not supported)")
         if mlp._packed_key != ctx.packed_key:
             raise _hip.HipLibraryError("parameters changed between the training forward and backward of a level")
+        g = {k: v for k, v in zip(ctx.diff_keys, gouts) if v is not None}
         grads = torch.zeros(layout.NUM_PARAMS, dtype=torch.float32, device=ctx.saved["sdist"].device)
+        g_rgb = g.get("r_rgb")
         if g_rgb is None:
             g_rgb = torch.zeros_like(ctx.saved["sdist"][:, :3])
+        g_weights, g_npred, seeds = _fold_ray_seeds(ctx.cfg, ctx.saved, g, g.get("weights"), g.get("normals_pred"))
         _hip.level_backward(ctx.packed, ctx.cfg, ctx.rays, ctx.saved, g_rgb, g_weights, g_npred, grads,
-                            g_r_acc=g_acc, g_r_distance=g_dist)
+                            g_r_acc=g.get("r_acc"), g_r_distance=g.get("r_distance"), sample_seeds=seeds)
         ctx.saved = None                           # release the 17.6 KB/sample activation buffer
         out = []
         for spec in layout.PARAM_SPECS:            # same order as MLP.ordered_parameters()

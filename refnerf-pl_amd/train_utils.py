@@ -1,12 +1,13 @@
-"""The three Ref-NeRF losses of the training step, host side.
+"""Losses of the training step, host side.
 
-Same names / signatures / arithmetic as the reference's
-internal/train_utils.py:33-88 (compute_data_loss), :165-183 (orientation_loss)
-and :186-204 (predicted_normal_loss).  They are a few elementwise torch ops on
-the level outputs; their gradients w.r.t. renderings['rgb'], ray_history
-['weights'] and ray_history['normals_pred'] are what refnerf_level_backward
-consumes.  Everything else in the reference's train_utils (other regularisers,
-optimiser / LR schedule plumbing) is outside the hot path.
+Same names / signatures / arithmetic as the reference's internal/train_utils.py:
+compute_data_loss (:33-88), compute_depth_smoothness_loss (:90-119), orientation_loss (:165-183),
+predicted_normal_loss (:186-204), noisy_consistency_loss (:207-279), noisy_distance_consistency_loss
+(:282-310), accumulated_weights_loss (:313-316), weights_entropy_loss (:318-329) and the loss assembly of
+NeRFSystem.training_step (nerf_system.py:77-188) as `training_losses`.  They are a few elementwise torch
+ops on the level outputs; their gradients w.r.t. the renderings / ray_history entries are the seeds
+refnerf_level_backward consumes (models.py::_LevelFunction).  Optimiser / LR-schedule plumbing is outside
+the hot path.
 """
 import collections
 
@@ -91,14 +92,199 @@ def predicted_normal_loss(model, ray_history, config):
     return total_loss
 
 
-def compute_losses(model, batch, rays, renderings, ray_history, config):
-    """The loss assembly of NeRFSystem.training_step restricted to the Ref-NeRF
-    terms (nerf_system.py:95-140): returns (total, dict of terms)."""
+def _level_mult(i, model, coarse, fine):
+    return coarse if i < model.num_levels - 1 else fine
+
+
+def compute_depth_smoothness_loss(renderings, config):
+    """Edge-aware depth smoothness over [..., H, W, .] patches (train_utils.py:90-119)."""
+    def l1(x):
+        return torch.mean(torch.abs(x))
+
+    def bilateral(x):
+        return torch.exp(-torch.abs(x).mean(-1, keepdim=True))
+    per_level = []
+    for rendering in renderings:
+        depths = rendering['distance']
+        acc00 = rendering['acc'].detach()[..., :-1, :-1, None]
+        guide = rendering['rgb'].detach()
+        v00, v01, v10 = depths[..., :-1, :-1, :], depths[..., :-1, 1:, :], depths[..., 1:, :-1, :]
+        w01 = bilateral(guide[..., :-1, :-1, :] - guide[..., :-1, 1:, :])
+        w10 = bilateral(guide[..., :-1, :-1, :] - guide[..., 1:, :-1, :])
+        per_level.append((l1(acc00 * w01 * (v00 - v01) ** 2) + l1(acc00 * w10 * (v00 - v10) ** 2)) / 2)
+    per_level = torch.stack(per_level)
+    return config.depth_smoothness_coarse_loss_mult * torch.sum(per_level[:-1]) + \
+        config.depth_smoothness_loss_mult * per_level[-1]
+
+
+def _colour_consistency(kind, clean, noisy, mask):
+    """One of the three colour-consistency measures of train_utils.py:224-250 between the clean ray
+    [n,1,3] and its noisy copies [n,a,3]; `mask` [n,1] selects the rays that count."""
+    if kind == 'mse':
+        per_ray = ((clean - noisy) ** 2).mean(dim=1, keepdim=True)
+    elif kind == 'avg_mse':
+        per_ray = ((clean - noisy.mean(dim=1, keepdim=True)) ** 2).mean(dim=1, keepdim=True)
+    elif kind == 'var':
+        both = torch.cat([clean, noisy], dim=1)
+        return both.var(dim=1, keepdim=True).mean(dim=-1, keepdim=True).sum(dim=-1)[mask].mean()
+    else:
+        raise ValueError(f'unknown consistency loss type {kind!r}')
+    return per_ray.sum(dim=-1)[mask].mean()
+
+
+def noisy_consistency_loss(model, renderings, renderings_noise, config, warmup_ratio=1.):
+    """Diffuse / specular / normal consistency between each of the first n rays and its
+    `sample_noise_angles` perturbed copies (train_utils.py:207-279).  Returns the three totals."""
+    n = config.sample_noise_size // config.patch_size ** 2
+    a = config.sample_noise_angles
+    totals = [0., 0., 0.]
+    for i, (clean, noisy) in enumerate(zip(renderings, renderings_noise)):
+        def group(x):
+            return x.reshape((n, a) + tuple(x.shape[1:]))
+        mask = clean['acc'][:n, None] > config.acc_threshold_for_consistency_loss
+        diffuse = _colour_consistency(config.consistency_diffuse_loss_type, clean['diffuse'][:n, None],
+                                      group(noisy['diffuse']), mask)
+        # the specular term is maximised: view-dependent colour is pushed into the specular branch
+        specular = -_colour_consistency(config.consistency_specular_loss_type, clean['specular'][:n, None],
+                                        group(noisy['specular']), mask)
+        if clean.get('normals') is None or clean.get('normals_pred') is None:
+            raise ValueError('Predicted normals and gradient normals cannot be None if consistency loss is on.')
+        target = config.consistency_normal_loss_target
+        if target not in ('normals', 'normals_pred'):
+            raise ValueError('Given an unknown type of consistency_normal_loss_target.')
+        cos = torch.sum(clean[target][:n, None] * group(noisy[target]), dim=-1)
+        normal = (1.0 - cos).mean(dim=1, keepdim=True)[mask].mean()
+        for j, (term, coarse, fine) in enumerate((
+                (diffuse, config.consistency_diffuse_coarse_loss_mult, config.consistency_diffuse_loss_mult),
+                (specular, config.consistency_specular_coarse_loss_mult, config.consistency_specular_loss_mult),
+                (normal, config.consistency_normal_coarse_loss_mult, config.consistency_normal_loss_mult))):
+            totals[j] = totals[j] + warmup_ratio * _level_mult(i, model, coarse, fine) * term
+    return tuple(totals)
+
+
+def noisy_distance_consistency_loss(model, rays, noisy_rays, renderings, renderings_noise, config, warmup_ratio=1.):
+    """The clean ray and its noisy copies should hit the same 3-D point (train_utils.py:282-310)."""
+    n = config.sample_noise_size // config.patch_size ** 2
+    a = config.sample_noise_angles
+    total = 0.
+    for i, (clean, noisy) in enumerate(zip(renderings, renderings_noise)):
+        dev = clean['distance'].device
+
+        def f32(x):
+            return torch.as_tensor(x, dtype=torch.float32, device=dev)
+        hit = f32(rays.origins)[:n, None] + f32(rays.directions)[:n, None] * clean['distance'][:n, None]
+        hit_n = f32(noisy_rays.origins).reshape(n, a, 3) + \
+            f32(noisy_rays.directions).reshape(n, a, 3) * noisy['distance'].reshape(n, a, 1)
+        mask = clean['acc'][:n, None] > config.acc_threshold_for_consistency_loss
+        if config.consistency_distance_loss_type != 'mse':
+            raise ValueError('consistency_distance_loss_type must be mse')
+        loss = ((hit - hit_n) ** 2).mean(dim=1, keepdim=True).sum(dim=-1)[mask].mean()
+        total = total + warmup_ratio * _level_mult(i, model, config.consistency_distance_coarse_loss_mult,
+                                                   config.consistency_distance_loss_mult) * loss
+    return total
+
+
+def accumulated_weights_loss(renderings, config):
+    """Pushes the fine level's accumulated opacity towards 1 (train_utils.py:313-316)."""
+    return config.accumulated_weights_loss_mult * ((1 - renderings[-1]['acc']) ** 2).mean()
+
+
+def weights_entropy_loss(model, renderings, ray_history, config, warmup_ratio):
+    """Entropy of the compositing weights on rays that hit something (train_utils.py:318-329)."""
+    total = 0.
+    for i, (rendering, ray_results) in enumerate(zip(renderings, ray_history)):
+        w = ray_results['weights'][rendering['acc'] > config.acc_threshold_for_weights_entropy_loss]
+        loss = (-w * (w + 1e-10).log()).sum(dim=-1).mean()
+        total = total + warmup_ratio * _level_mult(i, model, config.weights_entropy_coarse_loss_mult,
+                                                   config.weights_entropy_loss_mult) * loss
+    return total
+
+
+def consistency_warmup_ratio(config, global_step):
+    """Warm-up / decay schedule of the consistency terms (nerf_system.py:92-108)."""
+    if config.consistency_warmup_steps > config.consistency_decay_steps:
+        raise ValueError("Consistency loss decay should be after whole warmup.")
+    ratio = 1.
+    if 0. < config.consistency_warmup_steps <= 1.:
+        ratio = min(1., global_step / (config.consistency_warmup_steps * config.max_steps))
+    if 0. < config.consistency_decay_steps <= 1. and global_step >= config.consistency_decay_steps * config.max_steps:
+        left = config.max_steps - global_step
+        ratio = max(0., left / (config.max_steps - config.consistency_decay_steps * config.max_steps))
+    return ratio
+
+
+def _any_positive(config, *names):
+    return any(getattr(config, n) > 0 for n in names)
+
+
+_CONSISTENCY_MULTS = tuple(f"consistency_{k}_{lvl}loss_mult" for k in ("diffuse", "specular", "normal")
+                           for lvl in ("coarse_", ""))
+
+
+def wants_noisy_pass(config):
+    """nerf_system.py:110-116: the second, perturbed-ray forward is needed."""
+    return config.sample_noise_size > 0 and _any_positive(config, *_CONSISTENCY_MULTS)
+
+
+def training_losses(model, batch, rays, config, train_frac=1.0, global_step=None, noisy_rays=None):
+    """Forward(s) + every loss term of NeRFSystem.training_step (nerf_system.py:77-188).
+
+    Runs Model.__call__ on `rays` and, when a consistency term is on, on the perturbed rays of
+    sample_utils.sample_noisy_rays (or on `noisy_rays` if given: reproducible tests).  Returns
+    (total, dict of terms, stats, aux) with aux = dict(renderings, ray_history, noisy_rays, ...)."""
+    from . import sample_utils
+    compute_extras = bool(config.compute_disp_metrics or config.compute_normal_metrics or config.sample_noise_size > 0)
+    renderings, ray_history = model(rays, train_frac, compute_extras)
+    step = config.max_steps if global_step is None else global_step
+    ratio = consistency_warmup_ratio(config, step)
+    renderings_noise = None
+    if wants_noisy_pass(config):
+        if config.patch_size ** 2 > config.sample_noise_size:
+            raise ValueError(f'Patch size {config.patch_size}^2 too large for '
+                             f'sampling noise view points {config.sample_noise_size}')
+        if noisy_rays is None:
+            noisy_rays = sample_utils.sample_noisy_rays(
+                rays, renderings[-1], config.sample_angle_range, config.sample_noise_size // config.patch_size ** 2,
+                config.sample_noise_angles, ratio)
+        renderings_noise, _ = model(noisy_rays, train_frac, True)
+    total, losses, stats = compute_losses(model, batch, rays, renderings, ray_history, config,
+                                          renderings_noise=renderings_noise, noisy_rays=noisy_rays, warmup_ratio=ratio)
+    return total, losses, stats, dict(renderings=renderings, ray_history=ray_history, noisy_rays=noisy_rays,
+                                      renderings_noise=renderings_noise, warmup_ratio=ratio)
+
+
+def compute_losses(model, batch, rays, renderings, ray_history, config, renderings_noise=None, noisy_rays=None,
+                   warmup_ratio=1.):
+    """The loss assembly of NeRFSystem.training_step (nerf_system.py:118-180) on already computed
+    renderings: returns (total, dict of terms, stats)."""
     losses = {}
     data_loss, stats = compute_data_loss(batch, renderings, rays, config)
     losses['data'] = data_loss
-    if config.orientation_coarse_loss_mult > 0 or config.orientation_loss_mult > 0:
+    if config.interlevel_loss_mult > 0:
+        if model.single_mlp:
+            # the single-MLP Ref-NeRF family has no proposal network to supervise (all shipped refnerf
+            # configs set the multiplier to 0); the separate-PropMLP variant is SURVEY.md 8f-4
+            raise ValueError('interlevel_loss_mult > 0 needs the separate-PropMLP variant (not built)')
+    if _any_positive(config, 'orientation_coarse_loss_mult', 'orientation_loss_mult'):
         losses['orientation'] = orientation_loss(rays, model, ray_history, config)
-    if config.predicted_normal_coarse_loss_mult > 0 or config.predicted_normal_loss_mult > 0:
+    if _any_positive(config, 'predicted_normal_coarse_loss_mult', 'predicted_normal_loss_mult'):
         losses['predicted_normals'] = predicted_normal_loss(model, ray_history, config)
-    return sum(losses.values()), losses, stats
+    if config.patch_size > 1 and _any_positive(config, 'depth_smoothness_coarse_loss_mult', 'depth_smoothness_loss_mult'):
+        losses['smoothness'] = compute_depth_smoothness_loss(renderings, config)
+    if wants_noisy_pass(config):
+        if renderings_noise is None:
+            raise ValueError('the consistency losses need the renderings of the noisy rays (training_losses)')
+        (losses['diffuse_consistency'], losses['specular_consistency'],
+         losses['normals_consistency']) = noisy_consistency_loss(model, renderings, renderings_noise, config, warmup_ratio)
+    if config.accumulated_weights_loss_mult > 0:
+        losses['acc'] = accumulated_weights_loss(renderings, config)
+    if _any_positive(config, 'consistency_distance_loss_mult', 'consistency_distance_coarse_loss_mult'):
+        if renderings_noise is None or noisy_rays is None:
+            raise ValueError('the distance consistency loss needs the noisy rays and their renderings')
+        losses['distance_consistency'] = noisy_distance_consistency_loss(
+            model, rays, noisy_rays, renderings, renderings_noise, config, warmup_ratio)
+    if _any_positive(config, 'weights_entropy_loss_mult', 'weights_entropy_coarse_loss_mult'):
+        losses['weights_entropy'] = weights_entropy_loss(model, renderings, ray_history, config, warmup_ratio)
+    total = torch.sum(torch.stack([torch.as_tensor(v, dtype=torch.float32, device=data_loss.device)
+                                   for v in losses.values()]))
+    return total, losses, stats

@@ -304,7 +304,157 @@ def golden_camera():
     save("camera", **out)
 
 
+GEOMETRY_BINDINGS = [
+    # the loss set of configs/llff_refnerf_geometry_losses.gin (sizes reduced; multipliers raised so that every
+    # term moves the gradient by a measurable amount)
+    "NerfMLP.srgb_mapping = False", "Config.srgb_mapping_when_rendering = True",
+    "Config.srgb_mapping_type = 'norm_linear'", "Config.near = 0.", "Config.far = 1.",
+    "Model.num_prop_samples = 64", "Model.num_nerf_samples = 64",
+    "Config.sample_noise_size = 6", "Config.sample_noise_angles = 3", "Config.sample_angle_range = 5",
+    "Config.consistency_warmup_steps = 0.6",
+    "Config.acc_threshold_for_consistency_loss = 0.1", "Config.acc_threshold_for_weights_entropy_loss = 0.1",
+    "Config.accumulated_weights_loss_mult = 10.0",
+    "Config.consistency_diffuse_coarse_loss_mult = 30.0", "Config.consistency_diffuse_loss_mult = 300.0",
+    "Config.consistency_diffuse_loss_type = 'var'",
+    "Config.consistency_specular_coarse_loss_mult = 30.0", "Config.consistency_specular_loss_mult = 300.0",
+    "Config.consistency_specular_loss_type = 'var'",
+    "Config.consistency_normal_coarse_loss_mult = 0.003", "Config.consistency_normal_loss_mult = 0.03",
+    "Config.consistency_normal_loss_target = 'normals'",
+    "Config.consistency_distance_coarse_loss_mult = 0.003", "Config.consistency_distance_loss_mult = 0.03",
+    "Config.weights_entropy_coarse_loss_mult = 0.003", "Config.weights_entropy_loss_mult = 0.03",
+    "Config.orientation_coarse_loss_mult = 0.01", "Config.orientation_loss_mult = 0.1",
+    "Config.predicted_normal_coarse_loss_mult = 3e-3", "Config.predicted_normal_loss_mult = 3e-2",
+    "Config.interlevel_loss_mult = 0.0", "Config.distortion_loss_mult = 0.0",
+]
+
+
+def golden_geometry():
+    """One training step of NeRFSystem.training_step (nerf_system.py:77-188) with the full regulariser set of
+    llff_refnerf_geometry_losses.gin: clean pass, noisy-ray pass, all losses, backward.  Two variants of the
+    colour-consistency measure ('var' as shipped, 'mse' + normals_pred target + sRGB MLP colours)."""
+    from internal import sample_utils
+    variants = {
+        "geometry_var": (GEOMETRY_BINDINGS, synthetic.llff_rays(14, seed=11)),
+        "geometry_mse_srgb": ([b for b in GEOMETRY_BINDINGS if "srgb_mapping" not in b and "loss_type" not in b
+                               and "loss_target" not in b and "Config.near" not in b and "Config.far" not in b
+                               and "consistency_diffuse" not in b and "consistency_specular" not in b] + [
+            "Config.consistency_diffuse_coarse_loss_mult = 3000.0", "Config.consistency_diffuse_loss_mult = 30000.0",
+            "Config.consistency_specular_coarse_loss_mult = 3000.0", "Config.consistency_specular_loss_mult = 30000.0",
+            "Config.consistency_diffuse_loss_type = 'mse'", "Config.consistency_specular_loss_type = 'avg_mse'",
+            "Config.consistency_normal_loss_target = 'normals_pred'"], synthetic.blender_rays(14, seed=12, center_frac=0.4)),
+    }
+    for name, (bindings, rays) in variants.items():
+        pk = dict(seed=4, bias_scale=0.05, sharpen=20.0)
+        model, cfg = build_model(bindings, pk)
+        model.train()
+        model.zero_grad()
+        r = to_rays(rays)
+        R = rays["origins"].shape[0]
+        gt = synthetic.target_rgb(R, seed=2)
+        step = int(0.8 * cfg.max_steps)
+        ratio = min(1., step / (cfg.consistency_warmup_steps * cfg.max_steps))
+        rend, hist = model(r, 1.0, True)
+        torch.manual_seed(5)
+        n = cfg.sample_noise_size // cfg.patch_size ** 2
+        noisy = sample_utils.sample_noisy_rays(r, rend[-1], cfg.sample_angle_range, n, cfg.sample_noise_angles, ratio)
+        rend_n, hist_n = model(noisy, 1.0, True)
+        batch = utils.Batch(rays=r, rgb=gt)
+        losses = {}
+        losses["data"], _ = train_utils.compute_data_loss(batch, rend, r, cfg)
+        losses["orientation"] = train_utils.orientation_loss(r, model, hist, cfg)
+        losses["predicted_normals"] = train_utils.predicted_normal_loss(model, hist, cfg)
+        (losses["diffuse_consistency"], losses["specular_consistency"],
+         losses["normals_consistency"]) = train_utils.noisy_consistency_loss(model, rend, rend_n, cfg, ratio)
+        losses["acc"] = train_utils.accumulated_weights_loss(rend, cfg)
+        losses["distance_consistency"] = train_utils.noisy_distance_consistency_loss(model, r, noisy, rend, rend_n, cfg, ratio)
+        losses["weights_entropy"] = train_utils.weights_entropy_loss(model, rend, hist, cfg, ratio)
+        total = torch.sum(torch.stack(list(losses.values())))
+        total.backward()
+        res = {"loss_" + k: float(v) for k, v in losses.items()}
+        res["loss_total"] = float(total)
+        res["warmup_ratio"] = ratio
+        res["global_step"] = step
+        g = np.zeros(layout.NUM_PARAMS, np.float32)
+        named = dict(model.nerf_mlp.named_parameters())
+        for spec in layout.PARAM_SPECS:
+            g[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = named[spec.name + ".weight"].grad.numpy().reshape(-1)
+            g[spec.b_off:spec.b_off + spec.out_dim] = named[spec.name + ".bias"].grad.numpy()
+        res["grads_sub"] = g[::97].copy()
+        res["grads_l2"] = float(np.linalg.norm(g))
+        res["grads_tensor_l2"] = np.array([[np.linalg.norm(g[s.w_off:s.w_off + s.out_dim * s.in_dim]),
+                                            np.linalg.norm(g[s.b_off:s.b_off + s.out_dim])] for s in layout.PARAM_SPECS])
+        # a fixed random projection of the full gradient (64 directions): a second, dense fingerprint
+        proj_rng = np.random.default_rng(123)
+        res["grads_proj"] = np.array([float(np.dot(g.astype(np.float64), proj_rng.standard_normal(g.size))) for _ in range(16)])
+        for lvl, (rd, rdn) in enumerate(zip(rend, rend_n)):
+            for k in ("rgb", "diffuse", "specular", "distance", "acc", "normals", "normals_pred"):
+                res[f"L{lvl}_r_{k}"] = rd[k].detach().numpy()
+                res[f"L{lvl}_noisy_r_{k}"] = rdn[k].detach().numpy()
+        res["bindings"] = np.array(bindings)
+        res["param_kw"] = np.array([pk["seed"], pk["bias_scale"], pk["sharpen"], 0.0])
+        for k, v in rays.items():
+            res["rays_" + k] = v
+        for k in ("origins", "directions", "viewdirs", "radii", "imageplane", "lossmult", "near", "far", "cam_idx"):
+            res["noisy_" + k] = getattr(noisy, k).detach().numpy()
+        res["gt_rgb"] = gt
+        save(name, **res)
+
+
+SEED_KEYS = ("r_rgb", "r_diffuse", "r_specular", "r_acc", "r_distance", "r_normals", "r_normals_pred", "r_tint",
+             "r_roughness", "weights", "density", "roughness", "rgb", "normals_pred", "tint", "diffuse", "specular")
+
+
+def seed_array(key_index, level, shape):
+    """The upstream gradient used for output `SEED_KEYS[key_index]` of level `level` (test and generator share it)."""
+    return np.random.default_rng(1000 + 10 * key_index + level).standard_normal(tuple(shape)).astype(np.float32)
+
+
+def grad_fingerprint(g):
+    rng = np.random.default_rng(123)
+    return np.concatenate([[np.linalg.norm(g)], g[::997].astype(np.float64),
+                           [float(np.dot(g.astype(np.float64), rng.standard_normal(g.size))) for _ in range(8)]])
+
+
+def golden_seeds():
+    """Autograd of the reference for ONE random upstream gradient on ONE output at a time (both levels):
+    pins the generic backward (oracle rn_level_backward / refnerf_level_backward) output by output."""
+    variants = {
+        "seeds_llff_linear": ([b for b in GEOMETRY_BINDINGS if b.startswith(("NerfMLP", "Model", "Config.srgb", "Config.near", "Config.far"))],
+                              synthetic.llff_rays(10, seed=13)),
+        "seeds_blender_srgb": (["Model.num_prop_samples = 48", "Model.num_nerf_samples = 64"],
+                               synthetic.blender_rays(10, seed=14, center_frac=0.4)),
+    }
+    for name, (bindings, rays) in variants.items():
+        pk = dict(seed=4, bias_scale=0.05, sharpen=20.0)
+        model, cfg = build_model(bindings, pk)
+        model.train()
+        r = to_rays(rays)
+        rend, hist = model(r, 1.0, True)
+        res = {}
+        named = dict(model.nerf_mlp.named_parameters())
+        for ki, key in enumerate(SEED_KEYS):
+            model.zero_grad()
+            loss = 0.
+            for lvl in range(len(rend)):
+                x = rend[lvl][key[2:]] if key.startswith("r_") else hist[lvl][key]
+                loss = loss + (x * torch.tensor(seed_array(ki, lvl, x.shape))).sum()
+            loss.backward(retain_graph=True)
+            g = np.zeros(layout.NUM_PARAMS, np.float32)
+            for spec in layout.PARAM_SPECS:
+                if named[spec.name + ".weight"].grad is not None:
+                    g[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = named[spec.name + ".weight"].grad.numpy().reshape(-1)
+                if named[spec.name + ".bias"].grad is not None:
+                    g[spec.b_off:spec.b_off + spec.out_dim] = named[spec.name + ".bias"].grad.numpy()
+            res["fp_" + key] = grad_fingerprint(g)
+            res["loss_" + key] = float(loss)
+        res["bindings"] = np.array(bindings)
+        res["param_kw"] = np.array([pk["seed"], pk["bias_scale"], pk["sharpen"], 0.0])
+        for k, v in rays.items():
+            res["rays_" + k] = v
+        save(name, **res)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds"]
     for w in which:
         globals()["golden_" + w]()
