@@ -66,12 +66,16 @@ def cpu_baseline(blob, args, target_seconds):
     from oracle import oracle as O
     from refnerf_pl_amd import synthetic
     cores = os.cpu_count() or 1
-    probe = synthetic.blender_rays(64, seed=1, center_frac=0.5)
-    O.model_forward(blob, probe, num_prop_samples=args.samples, num_nerf_samples=args.samples, n_threads=cores, history=True)
-    t0 = time.time()
-    O.model_forward(blob, probe, num_prop_samples=args.samples, num_nerf_samples=args.samples, n_threads=cores, history=True)
-    rate = 64 * args.samples * 2 / max(time.time() - t0, 1e-6)
-    n_rays = int(min(4 * args.rays, max(64, rate * target_seconds / (args.samples * 2))))
+    # two calibration rounds (64 rays, then ~2 s worth) so that the timed sample lands in the 10-30 s window
+    # whatever the core count: the first call also pays for thread start-up and page faults
+    n_probe, rate = 64, None
+    for _ in range(3):
+        probe = synthetic.blender_rays(n_probe, seed=1, center_frac=0.5)
+        t0 = time.time()
+        O.model_forward(blob, probe, num_prop_samples=args.samples, num_nerf_samples=args.samples, n_threads=cores, history=True)
+        rate = n_probe * args.samples * 2 / max(time.time() - t0, 1e-6)
+        n_probe = max(64, min(4096, int(rate * 2.0 / (args.samples * 2)) // 64 * 64))
+    n_rays = int(min(16 * args.rays, max(64, rate * target_seconds / (args.samples * 2))))
     n_rays = max(64, (n_rays // 64) * 64)
     rays = synthetic.blender_rays(n_rays, seed=1, center_frac=0.5)
     t0 = time.time()

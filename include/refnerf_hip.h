@@ -41,6 +41,13 @@ enum {
   REFNERF_PREC_BF16 = 1  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate                   */
 };
 
+/* arithmetic of the weight-gradient GEMM of refnerf_level_backward (dW = DELTA x ACT^T over the samples) */
+enum {
+  REFNERF_WGRAD_F32 = 0,    /* v_mfma_f32_32x32x2_f32: fp32 products                                     */
+  REFNERF_WGRAD_BF16X3 = 1  /* operands split hi + lo into bf16 pairs, hi*hi + hi*lo + lo*hi on
+                               v_mfma_f32_32x32x16_bf16, fp32 accumulate: 2^-16 per product, HBM-bound (default) */
+};
+
 enum { REFNERF_SRGB_NONE = 0, REFNERF_SRGB_LINEAR = 1, REFNERF_SRGB_NORM_LINEAR = 2,
        REFNERF_SRGB_SRGB = 3, REFNERF_SRGB_NORM_SRGB = 4 };
 
@@ -57,6 +64,7 @@ typedef struct refnerf_level_cfg {
   int32_t opaque_background;  /* Model.opaque_background (render.py:139-143)               */
   int32_t ray_shape;          /* 0 'cone', 1 'cylinder' (render.py:121-126)                */
   int32_t precision;          /* REFNERF_PREC_*                                            */
+  int32_t wgrad_mode;         /* REFNERF_WGRAD_*: arithmetic of the weight-gradient GEMM (backward only) */
   float anneal;               /* models.py:190-195                                         */
   float resample_padding;     /* Model.resample_padding (:202)                             */
   float s_near, s_far;        /* Model.init_s_near / init_s_far (:213)                     */

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
 
 PREC_F32, PREC_BF16 = 0, 1
 ABI_VERSION = 3   # REFNERF_ABI_VERSION
+WGRAD_F32, WGRAD_BF16X3 = 0, 1
 SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 4}
 
 _FP = C.c_void_p
@@ -26,7 +27,7 @@ class LevelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_samples", "n_in", "training", "compute_extras", "srgb_mapping",
         "srgb_mapping_normalization", "render_srgb_mode", "opaque_background",
-        "ray_shape", "precision")] + [(n, C.c_float) for n in (
+        "ray_shape", "precision", "wgrad_mode")] + [(n, C.c_float) for n in (
             "anneal", "resample_padding", "s_near", "s_far", "density_bias",
             "roughness_bias", "rgb_premultiplier", "rgb_bias", "rgb_padding", "bg_rgb")]
 

@@ -28,6 +28,7 @@
 #include "refnerf_level_bf16.h"
 #include "refnerf_level_bwd_f32.h"
 #include "refnerf_wgrad.h"
+#include "refnerf_wgrad_bf16x3.h"
 #include "refnerf_rays.h"
 
 namespace rn {
@@ -255,7 +256,7 @@ void refnerf_level_cfg_default(refnerf_level_cfg *c) {
   memset(c, 0, sizeof(*c));
   c->n_samples = 128; c->n_in = 1; c->training = 0; c->compute_extras = 1;
   c->srgb_mapping = 1; c->srgb_mapping_normalization = 1; c->render_srgb_mode = REFNERF_SRGB_NONE;
-  c->opaque_background = 0; c->ray_shape = 0; c->precision = REFNERF_PREC_F32;
+  c->opaque_background = 0; c->ray_shape = 0; c->precision = REFNERF_PREC_F32; c->wgrad_mode = REFNERF_WGRAD_BF16X3;
   c->anneal = 1.0f; c->resample_padding = 0.01f; c->s_near = 0.0f; c->s_far = 1.0f;
   c->density_bias = 0.5f; c->roughness_bias = -1.0f;
   c->rgb_premultiplier = 1.0f; c->rgb_bias = 0.0f; c->rgb_padding = 0.001f; c->bg_rgb = 1.0f;
@@ -518,6 +519,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   if (cfg->ray_shape != 0 && cfg->ray_shape != 1) return fail(REFNERF_EINVAL, "ray_shape must be 'cone' or 'cylinder'%s");
   if (cfg->precision != REFNERF_PREC_F32)
     return fail(REFNERF_EUNSUPPORTED, "refnerf_level_backward runs in the f32 precision mode only%s");
+  if (cfg->wgrad_mode != REFNERF_WGRAD_F32 && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
+    return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown wgrad_mode%s");
   if (!saved->d_sdist || !saved->d_density || !saved->d_rgb || !saved->d_weights || !grads->d_g_r_rgb)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: null saved tensor / rendering gradient%s");
   if (!saved->d_activations)
@@ -536,6 +539,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute((const void *)rn::level_bwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)rn::wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4);
+    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rn::WB_LDS);
   });
   char *ws = (char *)d_workspace;
   rn::BwdArgs a;
@@ -563,7 +567,10 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   w.act = a.act; w.delta = a.delta; w.pitch = plan.pitch; w.S = plan.S; w.k_per_slice = plan.k_per_slice;
   w.part = (float *)(ws + plan.part_off);
   const int slices = (int)((plan.S + plan.k_per_slice - 1) / plan.k_per_slice);
-  hipLaunchKernelGGL(rn::wgrad_kernel, dim3(rn::WJOBS.tiles, slices), dim3(256), (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4, st, w);
+  if (cfg->wgrad_mode == REFNERF_WGRAD_BF16X3)
+    hipLaunchKernelGGL(rn::wgrad_bf16x3_kernel, dim3(8 * ((slices + 7) / 8) * rn::WJOBS.tiles), dim3(256), rn::WB_LDS, st, w, slices);
+  else
+    hipLaunchKernelGGL(rn::wgrad_kernel, dim3(rn::WJOBS.tiles, slices), dim3(256), (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4, st, w);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(rn::wgrad_reduce, dim3(1024), dim3(256), 0, st, w.part, slices, d_param_grads);
   HIP_TRY(hipGetLastError());

@@ -40,13 +40,10 @@ constexpr WJobs make_wjobs() {
       if (i == 5) add(dr, WIDTH, ACT_IPE, IPE_DIM, CANON.sp_w[i] + WIDTH, ld, -1);
     }
   }
-  const int x7 = ACT_SP + 7 * WIDTH;             /* heads (models.py:582,613,634-645) */
-  add(DEL_HEADS, BNECK, x7, WIDTH, CANON.bneck_w, WIDTH, CANON.bneck_b);
-  add(DEL_HEADS + HROW_DENSITY, 1, x7, WIDTH, CANON.density_w, WIDTH, CANON.density_b);
-  add(DEL_HEADS + HROW_GRAD, 3, x7, WIDTH, CANON.gradpred_w, WIDTH, CANON.gradpred_b);
-  add(DEL_HEADS + HROW_ROUGH, 1, x7, WIDTH, CANON.rough_w, WIDTH, CANON.rough_b);
-  add(DEL_HEADS + HROW_DIFFUSE, 3, x7, WIDTH, CANON.diffuse_w, WIDTH, CANON.diffuse_b);
-  add(DEL_HEADS + HROW_TINT, 3, x7, WIDTH, CANON.tint_w, WIDTH, CANON.tint_b);
+  /* heads (models.py:582,613,634-645): ONE job over the 139 contiguous head rows of DELTA, so that the
+   * shared input x7 is read once instead of six times; the six tensors sit at different places of the
+   * canonical blob, hence a row -> offset table (HEAD_ROWS, marked by ld = 0) instead of (w_off, ld) */
+  add(DEL_HEADS, HROWS, ACT_SP + 7 * WIDTH, WIDTH, 0, 0, 0);
   for (int i = 0; i < DEPTH; ++i) {            /* directional MLP (models.py:690-694) */
     const int dr = DEL_VD + i * WIDTH, ld = CANON.vd_in[i];
     if (i == 0) add(dr, WIDTH, ACT_DIN, DIR_IN, CANON.vd_w[0], ld, CANON.vd_b[0]);
@@ -60,6 +57,27 @@ constexpr WJobs make_wjobs() {
   return J;
 }
 constexpr WJobs WJOBS = make_wjobs();
+
+struct HeadRows { int w[HROWS], b[HROWS]; };
+constexpr HeadRows make_head_rows() {
+  HeadRows H{};
+  auto put = [&](int row0, int n, int w_off, int b_off) {
+    for (int i = 0; i < n; ++i) { H.w[row0 + i] = w_off + i * WIDTH; H.b[row0 + i] = b_off + i; }
+  };
+  put(0, BNECK, CANON.bneck_w, CANON.bneck_b);
+  put(HROW_DENSITY, 1, CANON.density_w, CANON.density_b);
+  put(HROW_GRAD, 3, CANON.gradpred_w, CANON.gradpred_b);
+  put(HROW_ROUGH, 1, CANON.rough_w, CANON.rough_b);
+  put(HROW_DIFFUSE, 3, CANON.diffuse_w, CANON.diffuse_b);
+  put(HROW_TINT, 3, CANON.tint_w, CANON.tint_b);
+  return H;
+}
+constexpr HeadRows HEAD_ROWS = make_head_rows();
+/* blob offsets of output row `orow` of job J: weights row start, bias element */
+__device__ __forceinline__ size_t wjob_row_off(const WJob &J, int orow) {
+  return J.ld ? (size_t)J.w_off + (size_t)orow * J.ld : (size_t)HEAD_ROWS.w[orow];
+}
+__device__ __forceinline__ int wjob_bias_off(const WJob &J, int orow) { return J.ld ? J.b_off + orow : HEAD_ROWS.b[orow]; }
 
 struct WgradArgs {
   const float *act, *delta;
@@ -156,7 +174,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int orow = tm * WG_TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (orow < J.n_out && colk < J.n_in) part[J.w_off + (size_t)orow * J.ld + colk] = acc[i][j][r];
+        if (orow < J.n_out && colk < J.n_in) part[wjob_row_off(J, orow) + colk] = acc[i][j][r];
       }
     }
   if (tn == 0 && J.b_off >= 0) {
@@ -166,7 +184,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
       float s = bsum[p];
       s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
       const int orow = tm * WG_TM + lrow + 16 * p;
-      if ((tid & 15) == 0 && orow < J.n_out) part[J.b_off + orow] = s;
+      if ((tid & 15) == 0 && orow < J.n_out) part[wjob_bias_off(J, orow)] = s;
     }
   }
 }

@@ -1,0 +1,155 @@
+/*
+ * refnerf_wgrad_bf16x3.h -- the weight-gradient contraction of refnerf_wgrad.h
+ * on the bf16 matrix cores at (near) fp32 accuracy.
+ *
+ * dW[o][k] = sum_s DELTA[o][s] * ACT[k][s] over 5e5 samples is, on
+ * v_mfma_f32_32x32x2_f32, MFMA-bound (12.3 ms per level at C2 for 18 GB of
+ * operands).  Here every fp32 operand is split on the fly into two bf16 values,
+ * x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits), and the
+ * product is formed as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation: 3 MFMAs at 16x the fp32-MFMA rate, relative error per
+ * product 2^-16 (the dropped lo*lo term) -- below the summation-order noise of
+ * an fp32 sum over 1e5 samples.  The contraction becomes HBM-bound, so the
+ * second half of the design is traffic: the workgroup -> (tile, slice) mapping
+ * puts all tiles of one sample slice on ONE XCD (workgroup ids are dealt
+ * round-robin to the 8 XCDs), so the DELTA / ACT row blocks shared by the tiles
+ * of a layer are fetched from HBM once and re-read from that XCD's L2.
+ *
+ * Same job table, split-K slices, PART layout and fixed-order reduction as
+ * refnerf_wgrad.h: bit-reproducible, no atomics.
+ */
+#pragma once
+#include "refnerf_level_bf16.h"
+#include "refnerf_wgrad.h"
+
+namespace rn {
+
+constexpr int WB_KT = 64;                      /* samples per k-step */
+constexpr int WB_ROW = WB_KT * 2 + 16;         /* LDS row pitch in bytes: 144 -> conflict-free ds_read_b128 */
+constexpr int WB_TILE = WG_TM * WB_ROW;        /* one 128-row bf16 operand tile: 18 KB */
+constexpr int WB_LDS = 4 * WB_TILE;            /* D_hi, D_lo, A_hi, A_lo */
+
+/* x0, x1 -> packed bf16 pair of the leading 8 mantissa bits and of the next 8 */
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, unsigned &lo) {
+  hi = cvt_pk_bf16(x0, x1);
+  const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+  lo = cvt_pk_bf16(x0 - h0, x1 - h1);
+}
+
+/* grid = 8 * ceil(slices / 8) * WJOBS.tiles workgroups of 256 threads (waves 2x2 over the 128x128 tile) */
+__global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, int slices) {
+  extern __shared__ __attribute__((aligned(16))) char wbs[];
+  char *Dh = wbs, *Dl = wbs + WB_TILE, *Ah = wbs + 2 * WB_TILE, *Al = wbs + 3 * WB_TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, sl = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  /* XCD-aware decode: id % 8 = XCD; that XCD walks the tiles of slices xcd, xcd + 8, ... one slice at a time */
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int tile = q % WJOBS.tiles, slice = (q / WJOBS.tiles) * 8 + xcd;
+  if (slice >= slices) return;
+  int ji = 0;
+#pragma unroll 1
+  for (int j = 1; j < WJOBS.n; ++j) if (tile >= WJOBS.job[j].tile0) ji = j;
+  const WJob J = WJOBS.job[ji];
+  const int tl = tile - J.tile0;
+  const int tm = tl / J.tiles_n, tn = tl - tm * J.tiles_n;
+  const long long k_begin = (long long)slice * A.k_per_slice;
+  long long k_end = k_begin + A.k_per_slice;
+  const long long s_pad = (A.S + WB_KT - 1) / WB_KT * WB_KT;   /* <= pitch; columns >= S hold zeros */
+  if (k_end > s_pad) k_end = s_pad;
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  float bsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+
+  const int lrow = tid >> 4, lc4 = (tid & 15) * 4;    /* loader: rows lrow + 16p (p = 0..7), 4 samples at lc4 */
+  const float *dp[8], *ap[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int orow = tm * WG_TM + lrow + 16 * p, irow = tn * WG_TN + lrow + 16 * p;
+    dp[p] = (orow < J.n_out) ? A.delta + (long long)(J.d_row + orow) * A.pitch + lc4 : nullptr;
+    ap[p] = (irow < J.n_in) ? A.act + (long long)(J.a_row + irow) * A.pitch + lc4 : nullptr;
+  }
+  v4f dv[8], av[8];
+  auto fetch = [&](long long k0) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      v4f x = {0.0f, 0.0f, 0.0f, 0.0f}, y = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (dp[p]) x = *reinterpret_cast<const v4f *>(dp[p] + k0);
+      if (ap[p]) y = *reinterpret_cast<const v4f *>(ap[p] + k0);
+      dv[p] = x; av[p] = y;
+    }
+  };
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  if (k_begin < k_end) fetch(k_begin);
+  for (long long k0 = k_begin; k0 < k_end; k0 += WB_KT) {
+    __syncthreads();                                   /* previous tile fully consumed */
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int off = (lrow + 16 * p) * WB_ROW + lc4 * 2;
+      unsigned h0, l0, h1, l1;
+      split_pair(dv[p][0], dv[p][1], h0, l0);
+      split_pair(dv[p][2], dv[p][3], h1, l1);
+      *reinterpret_cast<v2u *>(Dh + off) = (v2u){h0, h1};
+      *reinterpret_cast<v2u *>(Dl + off) = (v2u){l0, l1};
+      split_pair(av[p][0], av[p][1], h0, l0);
+      split_pair(av[p][2], av[p][3], h1, l1);
+      *reinterpret_cast<v2u *>(Ah + off) = (v2u){h0, h1};
+      *reinterpret_cast<v2u *>(Al + off) = (v2u){l0, l1};
+      bsum[p] += (dv[p][0] + dv[p][1]) + (dv[p][2] + dv[p][3]);
+    }
+    __syncthreads();
+    if (k0 + WB_KT < k_end) fetch(k0 + WB_KT);         /* next tile's loads fly under this tile's MFMAs */
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < WB_KT / 16; ++kk) {
+      v8bf ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ro = (wm * 64 + i * 32 + sl) * WB_ROW + kk * 32 + h * 16;
+        const int co = (wn * 64 + i * 32 + sl) * WB_ROW + kk * 32 + h * 16;
+        ah[i] = *reinterpret_cast<const v8bf *>(Dh + ro);
+        al[i] = *reinterpret_cast<const v8bf *>(Dl + ro);
+        bh[i] = *reinterpret_cast<const v8bf *>(Ah + co);
+        bl[i] = *reinterpret_cast<const v8bf *>(Al + co);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float *part = A.part + (size_t)slice * NUM_PARAMS;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int colk = tn * WG_TN + wn * 64 + j * 32 + sl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = tm * WG_TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (orow < J.n_out && colk < J.n_in) part[wjob_row_off(J, orow) + colk] = acc[i][j][r];
+      }
+    }
+  if (tn == 0 && J.b_off >= 0) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      float s = bsum[p];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+      const int orow = tm * WG_TM + lrow + 16 * p;
+      if ((tid & 15) == 0 && orow < J.n_out) part[wjob_bias_off(J, orow)] = s;
+    }
+  }
+}
+
+}  // namespace rn

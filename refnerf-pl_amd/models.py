@@ -440,12 +440,15 @@ class Model(nn.Module):
         if mode not in _hip.SRGB_MODES:
             raise ValueError('Mapping types are none, linear, norm_linear, srgb, norm_srgb')  # render.py:218
         prec = getattr(cfg, "hip_precision", "f32")
+        wgrad = {"f32": _hip.WGRAD_F32, "bf16x3": _hip.WGRAD_BF16X3}.get(getattr(cfg, "hip_wgrad_mode", "bf16x3"))
+        if wgrad is None:
+            raise ValueError("Config.hip_wgrad_mode must be 'bf16x3' or 'f32'")
         return _hip.default_cfg(
             n_samples=int(n_samples), n_in=int(n_in), training=int(self.training),
             compute_extras=int(bool(compute_extras)), srgb_mapping=int(mlp.srgb_mapping),
             srgb_mapping_normalization=int(mlp.srgb_mapping_normalization), render_srgb_mode=mode,
             opaque_background=int(self.opaque_background), ray_shape=0 if self.ray_shape == 'cone' else 1,
-            precision=_PREC["f32"] if self.training else _PREC[prec], anneal=float(anneal), resample_padding=float(self.resample_padding),
+            precision=_PREC["f32"] if self.training else _PREC[prec], wgrad_mode=wgrad, anneal=float(anneal), resample_padding=float(self.resample_padding),
             s_near=float(self.init_s_near), s_far=float(self.init_s_far), density_bias=float(mlp.density_bias),
             roughness_bias=float(mlp.roughness_bias), rgb_premultiplier=float(mlp.rgb_premultiplier),
             rgb_bias=float(mlp.rgb_bias), rgb_padding=float(mlp.rgb_padding), bg_rgb=float(bg))
