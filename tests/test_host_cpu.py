@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     assert _hip.packed_weights_bytes(_hip.PREC_F32) > 4 * layout.NUM_PARAMS
     c = _hip.default_cfg()
     assert (c.n_samples, c.resample_padding, c.density_bias) == (128, pytest.approx(0.01), pytest.approx(0.5))
-    assert C.sizeof(_hip.LevelCfg) == 80 and C.sizeof(_hip.LevelOut) == 23 * 8
+    assert C.sizeof(_hip.LevelCfg) == 84 and c.wgrad_mode == _hip.WGRAD_BF16X3 and C.sizeof(_hip.LevelOut) == 23 * 8
 
 
 def test_gin_loader_syntax(tmp_path):
