@@ -107,3 +107,98 @@ def recursive_detach(v):
     elif isinstance(v, list):
         return [recursive_detach(x) for x in v]
     raise ValueError('Contents should be either list or tensor')
+
+
+# ------------------------------------------------------------------------------------------------
+# Data formats either side of the path: the reference's image artefacts and its
+# Lightning checkpoints.
+
+def _to_numpy(x):
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def load_img(pth: str) -> np.ndarray:
+    """utils.py:162-166: any PIL-readable image as float32."""
+    from PIL import Image
+    with open(pth, 'rb') as f:
+        return np.array(Image.open(f), dtype=np.float32)
+
+
+def save_img_u8(img, pth, mask=None):
+    """utils.py:169-182: image in [0, 1] -> uint8 PNG (NaN -> 0, clipped).  With `mask` (the reference
+    uses it for the roughness map matted by `acc`) the image is added to the inverted min-max normalised
+    mask and the sum is min-max normalised again."""
+    from PIL import Image
+    px = (np.clip(np.nan_to_num(_to_numpy(img)), 0., 1.) * 255).astype(np.uint8).squeeze()
+    if mask is not None:
+        m = np.nan_to_num(_to_numpy(mask)).astype(np.float32).squeeze()
+        m = 255 * (m - m.min()) / (m.max() - m.min())
+        s = (255 - m) + px
+        px = np.array(255 * (s - s.min()) / (s.max() - s.min()), dtype=np.uint8)
+    with open(pth, 'wb') as f:
+        Image.fromarray(px).save(f, 'PNG')
+
+
+def save_img_f32(depthmap, pth):
+    """utils.py:185-189: float32 TIFF (NaN -> 0)."""
+    from PIL import Image
+    with open(pth, 'wb') as f:
+        Image.fromarray(np.nan_to_num(_to_numpy(depthmap)).astype(np.float32)).save(f, 'TIFF')
+
+
+def write_render_outputs(rendering, out_dir: str, idx) -> list:
+    """The artefact set of NeRFSystem.test_step (nerf_system.py:506-531) for one rendered view:
+    color_ / diffuse_ / specular_ / normals_pred_ / rho_ PNGs, distance_mean_ / distance_median_ /
+    acc_ float TIFFs, named with the zero-padded view index.  Returns the paths written."""
+    import os
+    idx_str = idx if isinstance(idx, str) else f'{idx:03d}'
+    r = {k: _to_numpy(v).astype(np.float64) for k, v in rendering.items()
+         if k in ('rgb', 'diffuse', 'specular', 'normals_pred', 'acc', 'distance_mean', 'distance_median', 'roughness')}
+    os.makedirs(out_dir, exist_ok=True)
+    done = []
+
+    def out(fn, x, name, **kw):
+        pth = os.path.join(out_dir, name)
+        fn(x, pth, **kw)
+        done.append(pth)
+    out(save_img_u8, r['rgb'], f'color_{idx_str}.png')
+    out(save_img_u8, r['diffuse'], f'diffuse_{idx_str}.png')
+    out(save_img_u8, r['specular'], f'specular_{idx_str}.png')
+    if 'normals_pred' in r:
+        out(save_img_u8, r['normals_pred'] / 2. + 0.5, f'normals_pred_{idx_str}.png')
+    out(save_img_f32, r['distance_mean'], f'distance_mean_{idx_str}.tiff')
+    out(save_img_f32, r['distance_median'], f'distance_median_{idx_str}.tiff')
+    out(save_img_f32, r['acc'], f'acc_{idx_str}.tiff')
+    out(save_img_u8, r['roughness'], f'rho_{idx_str}.png', mask=r['acc'])
+    return done
+
+
+CKPT_PREFIX = 'model.'       # NeRFSystem holds the Model as `self.model` (nerf_system.py:22-33)
+
+
+def load_reference_checkpoint(model, ckpt, strict: bool = True):
+    """Load a checkpoint written by the reference's Lightning system into `model` (refnerf_pl_amd.models.Model).
+
+    `ckpt`: path of a `.ckpt` file, the dict torch.load returns for one, or a bare state_dict.  Keys are the
+    reference's (`model.nerf_mlp.spatial_net.0.weight`, ... and the same 46 tensors again under
+    `model.prop_mlp.*` when Model.single_mlp); the `model.` prefix is optional.  Returns the
+    (missing, unexpected) key lists of load_state_dict."""
+    if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, '__fspath__'):
+        ckpt = torch.load(ckpt, map_location='cpu', weights_only=False)
+    sd = ckpt.get('state_dict', ckpt) if isinstance(ckpt, dict) else ckpt
+    sd = {(k[len(CKPT_PREFIX):] if k.startswith(CKPT_PREFIX) else k): v for k, v in sd.items()}
+    res = model.load_state_dict(sd, strict=strict)
+    mlps = {id(m): m for m in (model.nerf_mlp, model.prop_mlp)}
+    for mlp in mlps.values():                  # the fused path reads the canonical blob: re-alias it
+        mlp._flat = None
+        mlp.flat_params()
+    return list(res.missing_keys), list(res.unexpected_keys)
+
+
+def reference_checkpoint(model, **extra) -> dict:
+    """The Lightning-shaped dict for `model` (`state_dict` with the `model.` prefix) -- what the
+    reference's `NeRFSystem.load_from_checkpoint` / `trainer.fit(ckpt_path=...)` read."""
+    sd = {CKPT_PREFIX + k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    return dict(state_dict=sd, **extra)

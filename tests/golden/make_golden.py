@@ -454,7 +454,43 @@ def golden_seeds():
         save(name, **res)
 
 
+def golden_io():
+    """(a) key names / shapes of the Lightning checkpoint the reference writes (`model.` + Model.state_dict(),
+    nerf_system.py:22-33) -- names and shapes only, the tensors are regenerated from seeds in the test;
+    (b) the reference's image writers (utils.py:169-189) on seeded arrays, decoded back to pixels."""
+    import io
+    from PIL import Image
+    model, cfg = build_model([], dict(seed=0, bias_scale=0.05))
+    sd = model.state_dict()
+    out = {"ckpt_keys": np.array(["model." + k for k in sd.keys()]),
+           "ckpt_shapes": np.array([";".join(map(str, v.shape)) for v in sd.values()])}
+    rng = np.random.default_rng(9)
+    img = (rng.random((12, 10, 3)) * 1.4 - 0.2).astype(np.float64)
+    img[0, 0, 0] = np.nan
+    rough = rng.random((12, 10, 1)).astype(np.float64)
+    acc = rng.random((12, 10)).astype(np.float64)
+    depth = (rng.random((12, 10)) * 5).astype(np.float64)
+    depth[1, 1] = np.nan
+    out.update(img=img, rough=rough, acc=acc, depth=depth)
+    real_open = utils.open_file
+
+    def capture(fn, *a, **k):
+        buf = io.BytesIO()
+        buf.close = lambda: None
+        utils.open_file = lambda pth, mode: buf
+        try:
+            fn(*a, "x", **k)
+        finally:
+            utils.open_file = real_open
+        buf.seek(0)
+        return np.array(Image.open(buf))
+    out["png_rgb"] = capture(utils.save_img_u8, torch.tensor(img))
+    out["png_rho_masked"] = capture(utils.save_img_u8, torch.tensor(rough), mask=torch.tensor(acc))
+    out["tiff_depth"] = capture(utils.save_img_f32, torch.tensor(depth))
+    save("io", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io"]
     for w in which:
         globals()["golden_" + w]()

@@ -173,3 +173,59 @@ def test_losses_match_reference_values(cfg, name, extra):
     hist[0]["normals"] = None
     with pytest.raises(ValueError):
         train_utils.predicted_normal_loss(M, hist, cfg)
+
+
+def test_image_writers_match_reference_pixels(tmp_path):
+    """save_img_u8 (plain and masked) / save_img_f32 / write_render_outputs: decoded pixels equal the
+    reference's writers on the same arrays (tests/golden/io.npz)."""
+    from PIL import Image
+    from refnerf_pl_amd import utils
+    g = np.load(os.path.join(ROOT, "tests", "golden", "io.npz"))
+    utils.save_img_u8(torch.tensor(g["img"]), str(tmp_path / "a.png"))
+    assert np.array_equal(np.array(Image.open(tmp_path / "a.png")), g["png_rgb"])
+    utils.save_img_u8(g["rough"], str(tmp_path / "b.png"), mask=torch.tensor(g["acc"]))
+    assert np.array_equal(np.array(Image.open(tmp_path / "b.png")), g["png_rho_masked"])
+    utils.save_img_f32(g["depth"], str(tmp_path / "c.tiff"))
+    assert np.array_equal(utils.load_img(str(tmp_path / "c.tiff")), g["tiff_depth"])
+    rendering = {"rgb": g["img"], "diffuse": g["img"], "specular": g["img"], "normals_pred": g["img"] * 2 - 1,
+                 "acc": g["acc"], "distance_mean": g["depth"], "distance_median": g["depth"], "roughness": g["rough"],
+                 "tint": g["img"]}
+    paths = utils.write_render_outputs(rendering, str(tmp_path / "out"), 7)
+    assert sorted(os.path.basename(p) for p in paths) == sorted(
+        [f"{n}_007.png" for n in ("color", "diffuse", "specular", "normals_pred", "rho")] +
+        [f"{n}_007.tiff" for n in ("distance_mean", "distance_median", "acc")])
+    assert np.array_equal(np.array(Image.open(tmp_path / "out" / "rho_007.png")), g["png_rho_masked"])
+
+
+def test_reference_checkpoint_round_trip(tmp_path):
+    """A Lightning checkpoint with the reference's 92 key names / shapes (golden) loads into Model and the
+    canonical blob the kernels read follows; reference_checkpoint() writes the same names back."""
+    from refnerf_pl_amd import configs, models, synthetic, utils
+    g = np.load(os.path.join(ROOT, "tests", "golden", "io.npz"))
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([GIN], [])
+    model = models.construct_model(utils.dummy_rays(), configs.Config())
+    blob = synthetic.make_params(seed=11, bias_scale=0.05)
+    sd = {}
+    for key, shp in zip(g["ckpt_keys"], g["ckpt_shapes"]):
+        name = str(key)[len("model."):].split(".", 1)[1]                 # strip model.<nerf|prop>_mlp.
+        spec = next(s for s in layout.PARAM_SPECS if name in (s.name + ".weight", s.name + ".bias"))
+        shape = tuple(int(x) for x in str(shp).split(";"))
+        if name.endswith(".weight"):
+            t = blob[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim].reshape(spec.out_dim, spec.in_dim)
+        else:
+            t = blob[spec.b_off:spec.b_off + spec.out_dim]
+        assert t.shape == shape, key
+        sd[str(key)] = torch.tensor(t)
+    path = tmp_path / "last.ckpt"
+    torch.save({"state_dict": sd, "epoch": 3, "global_step": 1234}, path)
+    missing, unexpected = utils.load_reference_checkpoint(model, str(path))
+    assert missing == [] and unexpected == []
+    assert np.array_equal(model.nerf_mlp.flat_params().numpy(), blob)
+    assert model.prop_mlp is model.nerf_mlp
+    back = utils.reference_checkpoint(model, global_step=1234)
+    assert sorted(back["state_dict"]) == sorted(str(k) for k in g["ckpt_keys"])
+    for k, v in back["state_dict"].items():
+        assert torch.equal(v, sd[k]), k
+    with pytest.raises(RuntimeError):
+        utils.load_reference_checkpoint(model, {"state_dict": {"model.nerf_mlp.nope.weight": torch.zeros(1)}})
