@@ -313,7 +313,7 @@ BwdPlan bwd_plan(int R, int N) {
   p.slices = (int)(sl < 1 ? 1 : (sl > 32 ? 32 : sl));
   long long per = (p.S + p.slices - 1) / p.slices;
   p.k_per_slice = (int)((per + rn::WG_KT - 1) / rn::WG_KT * rn::WG_KT);
-  p.act_bytes = sizeof(float) * (size_t)rn::ACT_ROWS * p.pitch;
+  p.act_bytes = sizeof(float) * (size_t)rn::ACT_ROWS_TOTAL * p.pitch;
   p.delta_off = 0;
   p.part_off = p.delta_off + sizeof(float) * (size_t)rn::DEL_ROWS * p.pitch;
   p.total = p.part_off + sizeof(float) * (size_t)p.slices * rn::NUM_PARAMS;

@@ -144,6 +144,12 @@ constexpr int ACT_SP = ACT_IPE + IPE_DIM;          /* 8 x 256: spatial activatio
 constexpr int ACT_DIN = ACT_SP + 8 * WIDTH;        /* 204: [bottleneck | IDE | n.v | 0 0 0] */
 constexpr int ACT_VD = ACT_DIN + DIR_PAD;          /* 8 x 256: directional activations     */
 constexpr int ACT_ROWS = ACT_VD + 8 * WIDTH;       /* 4396 */
+/* behind the 4396 operand rows: the ReLU sign patterns of the 16 hidden layers as bit masks, so that the
+ * backward re-creates a mask from 4 dwords per lane instead of re-reading the 128 activations:
+ * row ACT_MASK + 8*layer + 4*h + q, column = sample, holds the dword mk[q] of half-wave h
+ * (bit 16*(ob&1) + r of mk[ob>>1] = unit 32*ob + row(r,h) active); layers 0-7 spatial, 8-15 directional */
+constexpr int ACT_MASK = ACT_ROWS;
+constexpr int ACT_ROWS_TOTAL = ACT_MASK + 16 * 8;  /* 4524 */
 constexpr int DEL_SP = 0;                          /* 8 x 256: spatial layer deltas         */
 constexpr int DEL_HEADS = DEL_SP + 8 * WIDTH;      /* 144: head rows (HROW_* order), 139 used */
 constexpr int DEL_VD = DEL_HEADS + 144;            /* 8 x 256: directional layer deltas     */

@@ -140,12 +140,21 @@ __device__ __forceinline__ v16f load_acc_blk(__amdgpu_buffer_rsrc_t rs, int off,
                 b[2][0], b[2][1], b[2][2], b[2][3], b[3][0], b[3][1], b[3][2], b[3][3]};
 }
 
-/* delta through a ReLU whose (saved, post-activation) output is `act`: in = out where act > 0 */
-__device__ __forceinline__ void relu_backward_into(const v16f (&out)[8], const v16f (&act)[8], v16f (&in)[8]) {
+/* the saved ReLU sign patterns of the 8 layers of one trunk (ACT_MASK rows 8*layer0 ...): 4 dwords per layer */
+__device__ __forceinline__ void load_masks(const float *act, long long pitch, int layer0, size_t gs, int h, unsigned (&M)[8][4]) {
 #pragma unroll
-  for (int ob = 0; ob < 8; ++ob)
+  for (int l = 0; l < 8; ++l)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) in[ob][r] = (act[ob][r] > 0.0f) ? out[ob][r] : 0.0f;
+    for (int q = 0; q < 4; ++q)
+      M[l][q] = __builtin_bit_cast(unsigned, act[(long long)(ACT_MASK + 8 * (layer0 + l) + 4 * h + q) * pitch + (long long)gs]);
+}
+
+/* rolled layer loops cannot index the mask registers dynamically: the next layer's mask moves up to M[7] */
+__device__ __forceinline__ void shift_masks(unsigned (&M)[8][4]) {
+#pragma unroll
+  for (int l = 7; l > 0; --l)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) M[l][q] = M[l - 1][q];
 }
 
 __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
@@ -170,7 +179,8 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.packed, 0, PACKED.total * 4, 0x00020000);
   const int col = wave * 32 + sl;
   const float *xl = X + h * T_TILE + col;
-  v16f in[8], out[8], pre[8];                    /* pre: saved activations prefetched for the next ReLU mask */
+  v16f in[8], out[8];
+  unsigned M[8][4];                              /* ReLU masks of the trunk being walked (saved by the training forward) */
 
   for (int pass0 = 0; pass0 < n_tot; pass0 += T_TILE) {
     const int g = pass0 + col;
@@ -216,8 +226,7 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(rgbv[0][i], sl, 64);
     }
-#pragma unroll
-    for (int ob = 0; ob < 8; ++ob) pre[ob] = in[ob];                          /* v7 doubles as the mask of dir layer 7 */
+    load_masks(A.act, pitch, 8, gs, h, M);                                    /* directional trunk */
 
     /* ================= backward ================= */
     float gsv[NGS];
@@ -275,14 +284,16 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) out[ob][r] = (w0[r] * g_raw_rgb[0] + w1[r] * g_raw_rgb[1]) + w2[r] * g_raw_rgb[2];
     }
-    relu_backward_into(out, pre, in);
+    masked_into(out, in, M[7]);
     /* ---- directional MLP, layers 7..0 ---- */
     v16f(&gd)[DIN_BLOCKS] = reinterpret_cast<v16f(&)[DIN_BLOCKS]>(out);   /* gradient w.r.t. the 201 dir inputs */
 #pragma unroll 1
     for (int i = 7; i >= 0; --i) {
-      store_rows<8>(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid, in);
+      /* delta_i leaves through the store hook of the GEMM that consumes it (one row per k-step) */
       if (i == 5 || i == 0) {
-        gemm_op<DIN_BLOCKS, 8, true, false>(rs, PACKED.top[i == 5 ? TOP_VD5_DIN : TOP_VD0].a_off, 0, lane, h, in, gd, xl, 0);
+        if (i == 0) gemm_op<DIN_BLOCKS, 8, true, false>(rs, PACKED.top[TOP_VD0].a_off, 0, lane, h, in, gd, xl, 0,
+                                                        RowStoreHook(A.delta, pitch, DEL_VD, gs, h, valid));
+        else gemm_op<DIN_BLOCKS, 8, true, false>(rs, PACKED.top[TOP_VD5_DIN].a_off, 0, lane, h, in, gd, xl, 0);
         /* layer 5 (skip connection) parks its share in LDS; layer 0 adds it back */
 #pragma unroll
         for (int blk = 0; blk < DIN_BLOCKS; ++blk)
@@ -297,9 +308,10 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
           }
       }
       if (i > 0) {
-        load_rows<8>(A.act, pitch, ACT_VD + (i - 1) * WIDTH, gs, h, pre);   /* lands under the GEMM below */
-        gemm_op<8, 8, true, false>(rs, PACKED.top[TOP_VD1 + i - 1].a_off, 0, lane, h, in, out, xl, 0);
-        relu_backward_into(out, pre, in);
+        gemm_op<8, 8, true, false>(rs, PACKED.top[TOP_VD1 + i - 1].a_off, 0, lane, h, in, out, xl, 0,
+                                   RowStoreHook(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid));
+        shift_masks(M);                                                     /* M[7] <- mask of layer i-1 */
+        masked_into(out, in, M[7]);
       }
     }
     /* X rows 0..127: dL/d bottleneck (= head rows 0..127), rows 128..200: dL/d (IDE, n.v) */
@@ -349,17 +361,17 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
     }
     wave_sync();
     /* ---- heads^T, then the spatial MLP, layers 7..0 ---- */
-    load_rows<8>(A.act, pitch, ACT_SP + 7 * WIDTH, gs, h, pre);
+    load_masks(A.act, pitch, 0, gs, h, M);                                    /* spatial trunk */
     gemm_op<8, 8, false, false>(rs, PACKED.top[TOP_HEADS].a_off, 0, lane, h, in, out, xl, HEADS_T_STEPS);
-    relu_backward_into(out, pre, in);
+    masked_into(out, in, M[7]);
 #pragma unroll 1
     for (int i = 7; i >= 0; --i) {
-      store_rows<8>(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid, in);
       if (i > 0) {
-        load_rows<8>(A.act, pitch, ACT_SP + (i - 1) * WIDTH, gs, h, pre);
-        gemm_op<8, 8, true, false>(rs, PACKED.top[i - 1].a_off, 0, lane, h, in, out, xl, 0);
-        relu_backward_into(out, pre, in);
-      }
+        gemm_op<8, 8, true, false>(rs, PACKED.top[i - 1].a_off, 0, lane, h, in, out, xl, 0,
+                                   RowStoreHook(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid));
+        shift_masks(M);                                                     /* M[7] <- mask of layer i-1 */
+        masked_into(out, in, M[7]);
+      } else store_rows<8>(A.delta, pitch, DEL_SP, gs, h, valid, in);      /* no GEMM consumes delta_0 */
     }
     wave_sync();
   }

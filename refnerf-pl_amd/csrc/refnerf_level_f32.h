@@ -65,10 +65,51 @@ __device__ __forceinline__ void load_acc(__amdgpu_buffer_rsrc_t rs, int off, int
  * of step s+PF" so that hipcc cannot sink the loads back to their uses (it
  * otherwise emits load; s_waitcnt vmcnt(0); mfma).  lds_steps % PF == 0. */
 constexpr int PF = 3;
-template <int NOB, int STRIDE, bool HAS_REG, bool BIAS = true>
+/* cache policy of the activation / delta streams (written once, read by a later kernel): 2 = nt (streaming,
+ * evict-first), so that 9 GB of them per launch do not push the 5 MB weight image out of the 4 MB L2s */
+#ifndef REFNERF_STREAM_AUX
+#define REFNERF_STREAM_AUX 2
+#endif
+struct NoStepHook { __device__ __forceinline__ void operator()(int, float) {} };
+
+/* Hook of gemm_op that streams the op's B operand (the 256 register values of this lane, i.e. a
+ * layer input in the forward / a layer delta in the backward) to its rows of a [rows][pitch] fp32 matrix,
+ * ONE store per k-step.  Issued as a burst of 128 stores at the layer boundary, the same bytes arrive
+ * from all 1024 waves of the chip at the same moment (67 MB per layer at C2) and the next GEMM's first
+ * A-fragment wait sits behind them (vmcnt counts loads and stores in order on gfx9): measured ~20 k
+ * cycles of wait per layer in the backward.  Spread over the GEMM the stores ride under the MFMAs.
+ * Rows follow the accumulator layout: row(r) = (r&3) + 8*(r>>2) (+4h in `voff`), i.e. +1,+1,+1,+5 rows
+ * per step; the buffer descriptor is re-based every 32 rows so that 32-bit offsets suffice for any pitch. */
+struct RowStoreHook {
+  char *base;                 /* matrix + row0 * pitch (wave-uniform) */
+  unsigned long long blk_bytes;   /* 32 rows */
+  unsigned voff;              /* ((4h) * pitch + column) * 4, or 0xfffffff0 for lanes that must not store */
+  unsigned p1, p5;            /* 1 and 5 rows in bytes */
+  unsigned soff;
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ RowStoreHook(float *matrix, long long pitch, int row0, size_t col, int h, bool store) {
+    base = reinterpret_cast<char *>(matrix + (long long)row0 * pitch);
+    blk_bytes = (unsigned long long)pitch * 128ull;
+    voff = store ? (unsigned)(((long long)(4 * h) * pitch + (long long)col) * 4) : 0xfffffff0u;
+    p1 = (unsigned)(pitch * 4);
+    p5 = 5u * p1;
+    soff = 0;
+    rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x80000000, 0x00020000);
+  }
+  __device__ __forceinline__ void operator()(int step, float b) {
+    if ((step & 15) == 0 && step > 0) {
+      rs = __builtin_amdgcn_make_buffer_rsrc(base + (unsigned long long)(step >> 4) * blk_bytes, 0, 0x80000000, 0x00020000);
+      soff = 0;
+    }
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, b), rs, voff, soff, REFNERF_STREAM_AUX);
+    soff += ((step & 3) == 3) ? p5 : p1;
+  }
+};
+
+template <int NOB, int STRIDE, bool HAS_REG, bool BIAS = true, typename Hook = NoStepHook>
 __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
                                         const v16f (&in)[8], v16f (&out)[NOB], const float *xl,
-                                        int lds_steps) {
+                                        int lds_steps, Hook hook = Hook()) {
   constexpr int STEP_BYTES = 64 * STRIDE * 4;
   const int voff = lane * STRIDE * 4;
   int soff = a_off * 4;
@@ -92,6 +133,7 @@ __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, in
       for (int ob = 0; ob < NOB; ++ob)
         out[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step % PF][ob], b, out[ob], 0, 0, 0);
       load_a<NOB, STRIDE>(rs, voff, soff + step * STEP_BYTES, a[step % PF]);
+      hook(step, b);
       __builtin_amdgcn_sched_barrier(0);
     }
     soff += REG_STEPS * STEP_BYTES;
@@ -123,6 +165,13 @@ __device__ __forceinline__ void relu_into(const v16f (&out)[8], v16f (&in)[8]) {
 
 /* rows [row0 + 32*blk + row(r,h)] of a [rows][pitch] matrix, column gs: 128 B
  * contiguous per (row, half-wave).  Uniform 64-bit row base + 32-bit lane offset. */
+__device__ __forceinline__ void stream_store(float *p, float v) {
+#if REFNERF_STREAM_AUX
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 template <int NB>
 __device__ __forceinline__ void store_rows(float *base, long long pitch, int row0, size_t gs, int h, bool valid, const v16f *x) {
   char *ub = reinterpret_cast<char *>(base + (long long)row0 * pitch);
@@ -132,11 +181,11 @@ __device__ __forceinline__ void store_rows(float *base, long long pitch, int row
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        *reinterpret_cast<float *>(ub + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch * 4 + voff) = x[blk][r];
+        stream_store(reinterpret_cast<float *>(ub + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch * 4 + voff), x[blk][r]);
   }
 }
 __device__ __forceinline__ void store_row1(float *base, long long pitch, int row, size_t gs, float v) {
-  base[(long long)row * pitch + (long long)gs] = v;
+  stream_store(base + (long long)row * pitch + (long long)gs, v);
 }
 
 /* the same rows read back (the accumulator-layout image of a saved activation block) */
@@ -308,7 +357,13 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     unsigned M[TRAIN ? 8 : 1][4];                /* ReLU masks of the spatial layers (training) */
     gemm_op<8, 8, false>(rs, PACKED.op[0].a_off, PACKED.op[0].b_off, lane, h, in, out, xl, PACKED.op[0].lds_steps);
     if constexpr (TRAIN) relu_mask_into(out, in, M[7]); else relu_into(out, in);
-    if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<8>(A.act, A.act_pitch, ACT_SP, gsx, h, save, in); }
+    auto save_mask = [&](int layer, const unsigned (&mk)[4]) {
+      if (save) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_row1(A.act, A.act_pitch, ACT_MASK + 8 * layer + 4 * h + q, gsx, __builtin_bit_cast(float, mk[q]));
+      }
+    };
+    if constexpr (TRAIN && !STAGE) { if (A.act) { store_rows<8>(A.act, A.act_pitch, ACT_SP, gsx, h, save, in); save_mask(0, M[7]); } }
 #pragma unroll 1
     for (int op = 1; op < 8; ++op) {
       gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
@@ -318,7 +373,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) M[l][q] = M[l + 1][q];
         relu_mask_into(out, in, M[7]);
-        if constexpr (!STAGE) { if (A.act) store_rows<8>(A.act, A.act_pitch, ACT_SP + op * WIDTH, gsx, h, save, in); }
+        if constexpr (!STAGE) { if (A.act) { store_rows<8>(A.act, A.act_pitch, ACT_SP + op * WIDTH, gsx, h, save, in); save_mask(op, M[7]); } }
       } else relu_into(out, in);
     }
     /* P3: heads (models.py:582,613,634-645): 4 bottleneck blocks + 1 scalar block */
@@ -369,13 +424,19 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 
     /* P5: directional MLP (models.py:690-694) + rgb (699-700) */
     gemm_op<8, 8, false>(rs, PACKED.op[9].a_off, PACKED.op[9].b_off, lane, h, in, out, xl, PACKED.op[9].lds_steps);
-    relu_into(out, in);
-    if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<8>(A.act, A.act_pitch, ACT_VD, gsx, h, save, in); }
+    if constexpr (TRAIN && !STAGE) {
+      unsigned mk[4];
+      relu_mask_into(out, in, mk);
+      if (A.act) { store_rows<8>(A.act, A.act_pitch, ACT_VD, gsx, h, save, in); save_mask(8, mk); }
+    } else relu_into(out, in);
 #pragma unroll 1
     for (int op = 10; op < 17; ++op) {
       gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
-      relu_into(out, in);
-      if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<8>(A.act, A.act_pitch, ACT_VD + (op - 9) * WIDTH, gsx, h, save, in); }
+      if constexpr (TRAIN && !STAGE) {
+        unsigned mk[4];
+        relu_mask_into(out, in, mk);
+        if (A.act) { store_rows<8>(A.act, A.act_pitch, ACT_VD + (op - 9) * WIDTH, gsx, h, save, in); save_mask(op - 1, mk); }
+      } else relu_into(out, in);
     }
     v16f rgbv[1];
     gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0);
