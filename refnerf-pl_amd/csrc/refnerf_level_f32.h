@@ -363,23 +363,32 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         for (int q = 0; q < 4; ++q) store_row1(A.act, A.act_pitch, ACT_MASK + 8 * layer + 4 * h + q, gsx, __builtin_bit_cast(float, mk[q]));
       }
     };
-    if constexpr (TRAIN && !STAGE) { if (A.act) { store_rows<8>(A.act, A.act_pitch, ACT_SP, gsx, h, save, in); save_mask(0, M[7]); } }
+    if constexpr (TRAIN && !STAGE) { if (A.act) save_mask(0, M[7]); }
 #pragma unroll 1
     for (int op = 1; op < 8; ++op) {
-      gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
+      /* training: the layer input leaves for the ACT matrix through the store hook (one row per k-step) */
+      if constexpr (TRAIN && !STAGE)
+        gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
+                            RowStoreHook(A.act, A.act_pitch, ACT_SP + (op - 1) * WIDTH, gsx, h, save));
+      else
+        gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
       if constexpr (TRAIN) {
 #pragma unroll
         for (int l = 0; l < 7; ++l)
 #pragma unroll
           for (int q = 0; q < 4; ++q) M[l][q] = M[l + 1][q];
         relu_mask_into(out, in, M[7]);
-        if constexpr (!STAGE) { if (A.act) { store_rows<8>(A.act, A.act_pitch, ACT_SP + op * WIDTH, gsx, h, save, in); save_mask(op, M[7]); } }
+        if constexpr (!STAGE) { if (A.act) save_mask(op, M[7]); }
       } else relu_into(out, in);
     }
     /* P3: heads (models.py:582,613,634-645): 4 bottleneck blocks + 1 scalar block */
     {
       v16f hd[5];
-      gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0);
+      if constexpr (TRAIN && !STAGE)
+        gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0,
+                            RowStoreHook(A.act, A.act_pitch, ACT_SP + 7 * WIDTH, gsx, h, save));
+      else
+        gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0);
       __builtin_amdgcn_wave_barrier();          /* all IPE reads of this wave are done */
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk)
@@ -427,19 +436,27 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     if constexpr (TRAIN && !STAGE) {
       unsigned mk[4];
       relu_mask_into(out, in, mk);
-      if (A.act) { store_rows<8>(A.act, A.act_pitch, ACT_VD, gsx, h, save, in); save_mask(8, mk); }
+      if (A.act) save_mask(8, mk);
     } else relu_into(out, in);
 #pragma unroll 1
     for (int op = 10; op < 17; ++op) {
-      gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
+      if constexpr (TRAIN && !STAGE)
+        gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
+                            RowStoreHook(A.act, A.act_pitch, ACT_VD + (op - 10) * WIDTH, gsx, h, save));
+      else
+        gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
       if constexpr (TRAIN && !STAGE) {
         unsigned mk[4];
         relu_mask_into(out, in, mk);
-        if (A.act) { store_rows<8>(A.act, A.act_pitch, ACT_VD + (op - 9) * WIDTH, gsx, h, save, in); save_mask(op - 1, mk); }
+        if (A.act) save_mask(op - 1, mk);
       } else relu_into(out, in);
     }
     v16f rgbv[1];
-    gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0);
+    if constexpr (TRAIN && !STAGE)
+      gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0,
+                          RowStoreHook(A.act, A.act_pitch, ACT_VD + 7 * WIDTH, gsx, h, save));
+    else
+      gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0);
     /* rows 0..2 live in half 0, regs 0..2; hand them to half 1 as well */
     float raw_rgb[3];
 #pragma unroll
