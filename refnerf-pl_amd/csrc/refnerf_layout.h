@@ -128,7 +128,7 @@ constexpr Packed make_packed() {
   }
   P.wd_off = p; p += 8 * 32;
   P.wrgb_off = p; p += 3 * 8 * 32;
-  P.total = p + 4 * 64 * 8;   /* tail pad: the A prefetch runs PF steps past an op */
+  P.total = p + 8 * 64 * 8;   /* tail pad: the A prefetch runs PF (<= 8) steps past an op */
   return P;
 }
 constexpr Packed PACKED = make_packed();

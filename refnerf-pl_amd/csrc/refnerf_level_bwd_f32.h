@@ -51,6 +51,12 @@ struct BwdArgs {
   long long pitch;
 };
 
+/* A-fragment prefetch depth of the chain GEMMs: the stores riding in the same in-order vmcnt queue make the
+ * effective latency of an A load longer than in the forward */
+#ifndef REFNERF_PF_BWD
+#define REFNERF_PF_BWD 3
+#endif
+constexpr int PF_BWD = REFNERF_PF_BWD;
 constexpr int NGS = 7;      /* per-sample upstream gradients in LDS: density, rgb[3], n_pred[3] */
 
 /* Per-ray part of the backward (one wave per ray): rendering gradient through
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
           }
       }
       if (i > 0) {
-        gemm_op<8, 8, true, false>(rs, PACKED.top[TOP_VD1 + i - 1].a_off, 0, lane, h, in, out, xl, 0,
+        gemm_op<8, 8, true, false, RowStoreHook, PF_BWD>(rs, PACKED.top[TOP_VD1 + i - 1].a_off, 0, lane, h, in, out, xl, 0,
                                    RowStoreHook(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid));
         shift_masks(M);                                                     /* M[7] <- mask of layer i-1 */
         masked_into(out, in, M[7]);
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
 #pragma unroll 1
     for (int i = 7; i >= 0; --i) {
       if (i > 0) {
-        gemm_op<8, 8, true, false>(rs, PACKED.top[i - 1].a_off, 0, lane, h, in, out, xl, 0,
+        gemm_op<8, 8, true, false, RowStoreHook, PF_BWD>(rs, PACKED.top[i - 1].a_off, 0, lane, h, in, out, xl, 0,
                                    RowStoreHook(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid));
         shift_masks(M);                                                     /* M[7] <- mask of layer i-1 */
         masked_into(out, in, M[7]);

@@ -312,6 +312,19 @@ __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHea
   }
 }
 
+/* the per-sample history (84 B/sample, 48 MB per launch at C2) is written once and read by a later kernel:
+ * non-temporal, so that it does not push the weight image out of the L2s it is streamed from */
+#ifndef REFNERF_HIST_NT
+#define REFNERF_HIST_NT 1
+#endif
+__device__ __forceinline__ void hist_store(float *p, float v) {
+#if REFNERF_HIST_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 /* Per-sample history (models.py:731-750) of one wave's 32-sample block, written
  * from LDS PS with fully coalesced stores: for the [R,N,3] tensors lane L writes
  * flat element 3*sample + channel = L, L+64.  gw0 = first sample (workgroup
@@ -326,11 +339,11 @@ __device__ __forceinline__ void history_flush(const LevelArgs &A, const float *P
     for (int it = 0; it < 2; ++it) {
       const int f = lane + 64 * it;
       const int smp = f / 3, c = f - 3 * smp;
-      if (f < 96 && gw0 + smp < n_tot && gs0 + smp < total) dst[gs0 * 3 + f] = PS[(gw0 + smp) * NP + slot + c];
+      if (f < 96 && gw0 + smp < n_tot && gs0 + smp < total) hist_store(dst + gs0 * 3 + f, PS[(gw0 + smp) * NP + slot + c]);
     }
   };
   auto scal = [&](float *dst, int slot) {
-    if (dst && lane < 32 && gw0 + lane < n_tot && gs0 + lane < total) dst[gs0 + lane] = PS[(gw0 + lane) * NP + slot];
+    if (dst && lane < 32 && gw0 + lane < n_tot && gs0 + lane < total) hist_store(dst + gs0 + lane, PS[(gw0 + lane) * NP + slot]);
   };
   scal(A.out.d_density, PS_DENSITY);
   scal(A.out.d_roughness, PS_ROUGH);
@@ -343,7 +356,7 @@ __device__ __forceinline__ void history_flush(const LevelArgs &A, const float *P
     for (int it = 0; it < 2; ++it) {
       const int f = lane + 64 * it;
       const int smp = f / 3;
-      if (f < 96 && gw0 + smp < n_tot && gs0 + smp < total) A.out.d_grad_pred[gs0 * 3 + f] = PX[gcol0 * 3 + f];
+      if (f < 96 && gw0 + smp < n_tot && gs0 + smp < total) hist_store(A.out.d_grad_pred + gs0 * 3 + f, PX[gcol0 * 3 + f]);
     }
   }
   vec3(A.out.d_tint, PS_TINT);

@@ -64,7 +64,10 @@ __device__ __forceinline__ void load_acc(__amdgpu_buffer_rsrc_t rs, int off, int
  * through a register ring; sched_barrier pins "MFMAs of step s, then the loads
  * of step s+PF" so that hipcc cannot sink the loads back to their uses (it
  * otherwise emits load; s_waitcnt vmcnt(0); mfma).  lds_steps % PF == 0. */
-constexpr int PF = 3;
+#ifndef REFNERF_PF
+#define REFNERF_PF 3
+#endif
+constexpr int PF = REFNERF_PF;
 /* cache policy of the activation / delta streams (written once, read by a later kernel): 2 = nt (streaming,
  * evict-first), so that 9 GB of them per launch do not push the 5 MB weight image out of the 4 MB L2s */
 #ifndef REFNERF_STREAM_AUX
@@ -106,7 +109,7 @@ struct RowStoreHook {
   }
 };
 
-template <int NOB, int STRIDE, bool HAS_REG, bool BIAS = true, typename Hook = NoStepHook>
+template <int NOB, int STRIDE, bool HAS_REG, bool BIAS = true, typename Hook = NoStepHook, int PF = rn::PF>
 __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
                                         const v16f (&in)[8], v16f (&out)[NOB], const float *xl,
                                         int lds_steps, Hook hook = Hook()) {
