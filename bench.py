@@ -89,8 +89,8 @@ def cpu_baseline(blob, args, target_seconds):
 def train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync):
     """Secondary figure: one full training step (training forward with density-gradient
     normals + saved layer inputs, the three Ref-NeRF losses, HIP backward + weight-gradient GEMM, gradient
-    all-reduce over the ranks, Adam step) on the same batch; fp32 MFMA (the only
-    training arithmetic built so far)."""
+    all-reduce over the ranks, Adam step) on the same batch; fp32 MFMA chains, the weight-gradient GEMM on
+    split-bf16 MFMA at fp32 accuracy (Config.hip_wgrad_mode)."""
     from refnerf_pl_amd import distributed, synthetic, train_utils, utils
     model.train()
     gt = synthetic.target_rgb(args.rays, seed=7 + rank)
@@ -123,7 +123,7 @@ def train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync):
     rate = world * args.rays * args.samples * 2 * n / el
     tf = rate / world * TRAIN_FLOP_PER_SAMPLE / 1e12
     return {"value": rate, "unit": "ray-samples/s (fwd+bwd+Adam)", "ms_per_step": 1e3 * el / n, "steps": n,
-            "dtype": "f32", "loss": float(loss.detach()),
+            "dtype": "f32", "wgrad": getattr(cfg, "hip_wgrad_mode", "bf16x3"), "loss": float(loss.detach()),
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
                          "frac": tf / PEAK_TFLOPS["f32"],
                          "note": "whole step incl. losses, optimiser and weight re-pack; algorithmic 7,651,840 FLOP/ray-sample"}}

@@ -179,7 +179,7 @@ typedef struct refnerf_level_grads {
 /* Training forward that also keeps every linear layer's input for the backward
  * (what autograd saves for nn.Linear in the reference): d_activations is a
  * caller-owned buffer of refnerf_activation_workspace_bytes(R, N) bytes
- * (17.6 KB per ray-sample) that must stay untouched until the level's
+ * (18.1 KB per ray-sample) that must stay untouched until the level's
  * refnerf_level_backward has run.  cfg->training must be 1. */
 size_t refnerf_activation_workspace_bytes(int32_t R, int32_t n_samples);
 int refnerf_level_forward_train(const void *d_packed, const refnerf_level_cfg *cfg,

@@ -104,7 +104,9 @@ struct RowStoreHook {
       rs = __builtin_amdgcn_make_buffer_rsrc(base + (unsigned long long)(step >> 4) * blk_bytes, 0, 0x80000000, 0x00020000);
       soff = 0;
     }
+#ifndef REFNERF_EXPERIMENT_NO_STREAM   /* timing experiment only: drops the stream (wrong gradients) */
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, b), rs, voff, soff, REFNERF_STREAM_AUX);
+#endif
     soff += ((step & 3) == 3) ? p5 : p1;
   }
 };
