@@ -2,7 +2,7 @@
 
 Same names / signatures / arithmetic as the reference's internal/train_utils.py:
 compute_data_loss (:33-88), compute_depth_smoothness_loss (:90-119), orientation_loss (:165-183),
-predicted_normal_loss (:186-204), noisy_consistency_loss (:207-279), noisy_distance_consistency_loss
+interlevel_loss (:150-162), predicted_normal_loss (:186-204), noisy_consistency_loss (:207-279), noisy_distance_consistency_loss
 (:282-310), accumulated_weights_loss (:313-316), weights_entropy_loss (:318-329) and the loss assembly of
 NeRFSystem.training_step (nerf_system.py:77-188) as `training_losses`.  They are a few elementwise torch
 ops on the level outputs; their gradients w.r.t. the renderings / ray_history entries are the seeds
@@ -90,6 +90,18 @@ def predicted_normal_loss(model, ray_history, config):
         else:
             total_loss += config.predicted_normal_loss_mult * loss
     return total_loss
+
+
+def interlevel_loss(ray_history, config):
+    """Interlevel (proposal) loss of mip-NeRF 360 (train_utils.py:150-162): the proposal levels' weights must
+    envelope the final level's; the final level is detached, so only the proposal MLP is trained by it."""
+    from . import stepfun
+    c = ray_history[-1]['sdist'].detach()
+    w = ray_history[-1]['weights'].detach()
+    total = 0.
+    for ray_results in ray_history[:-1]:
+        total = total + torch.mean(stepfun.lossfun_outer(c, w, ray_results['sdist'], ray_results['weights']))
+    return config.interlevel_loss_mult * total
 
 
 def _level_mult(i, model, coarse, fine):
@@ -261,10 +273,7 @@ def compute_losses(model, batch, rays, renderings, ray_history, config, renderin
     data_loss, stats = compute_data_loss(batch, renderings, rays, config)
     losses['data'] = data_loss
     if config.interlevel_loss_mult > 0:
-        if model.single_mlp:
-            # the single-MLP Ref-NeRF family has no proposal network to supervise (all shipped refnerf
-            # configs set the multiplier to 0); the separate-PropMLP variant is SURVEY.md 8f-4
-            raise ValueError('interlevel_loss_mult > 0 needs the separate-PropMLP variant (not built)')
+        losses['interlevel'] = interlevel_loss(ray_history, config)
     if _any_positive(config, 'orientation_coarse_loss_mult', 'orientation_loss_mult'):
         losses['orientation'] = orientation_loss(rays, model, ray_history, config)
     if _any_positive(config, 'predicted_normal_coarse_loss_mult', 'predicted_normal_loss_mult'):

@@ -490,7 +490,73 @@ def golden_io():
     save("io", **out)
 
 
+def _set_mlp_params(mlp, blob):
+    sd = mlp.state_dict()
+    for spec in layout.PARAM_SPECS:
+        sd[spec.name + ".weight"].copy_(torch.tensor(blob[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim].reshape(spec.out_dim, spec.in_dim)))
+        sd[spec.name + ".bias"].copy_(torch.tensor(blob[spec.b_off:spec.b_off + spec.out_dim]))
+
+
+def _mlp_grads(mlp):
+    g = np.zeros(layout.NUM_PARAMS, np.float32)
+    named = dict(mlp.named_parameters())
+    for spec in layout.PARAM_SPECS:
+        if named[spec.name + ".weight"].grad is not None:
+            g[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = named[spec.name + ".weight"].grad.numpy().reshape(-1)
+        if named[spec.name + ".bias"].grad is not None:
+            g[spec.b_off:spec.b_off + spec.out_dim] = named[spec.name + ".bias"].grad.numpy()
+    return g
+
+
+def golden_propmlp():
+    """Model.single_mlp = False: a separate PropMLP of the same Ref-NeRF architecture for the proposal level
+    (models.py:120-123,236) trained by the interlevel loss (train_utils.py:150-162, stepfun.py:67-89) next to the
+    data / orientation / predicted-normal terms.  Gradients of BOTH networks."""
+    nerf_b = [ln.strip() for ln in open(REF_CFG) if ln.startswith("NerfMLP.")]
+    bindings = ["Model.single_mlp = False", "Config.interlevel_loss_mult = 1.0", "Model.num_prop_samples = 48",
+                "Model.num_nerf_samples = 64"] + [b.replace("NerfMLP.", "PropMLP.", 1) for b in nerf_b] + [
+                    "PropMLP.density_bias = -3.0"]     # a thin proposal density: the envelope is violated, the loss is > 0
+    model, cfg = build_model(bindings, dict(seed=4, bias_scale=0.05, sharpen=20.0))
+    assert model.prop_mlp is not model.nerf_mlp
+    _set_mlp_params(model.prop_mlp, synthetic.make_params(seed=5, bias_scale=0.05, sharpen=2.0))
+    model.train()
+    model.zero_grad()
+    rays = synthetic.blender_rays(12, seed=15, center_frac=0.4)
+    r = to_rays(rays)
+    gt = synthetic.target_rgb(12, seed=2)
+    rend, hist = model(r, 1.0, False)
+    batch = utils.Batch(rays=r, rgb=gt)
+    losses = {}
+    losses["data"], _ = train_utils.compute_data_loss(batch, rend, r, cfg)
+    losses["interlevel"] = train_utils.interlevel_loss(hist, cfg)
+    losses["orientation"] = train_utils.orientation_loss(r, model, hist, cfg)
+    losses["predicted_normals"] = train_utils.predicted_normal_loss(model, hist, cfg)
+    total = torch.sum(torch.stack(list(losses.values())))
+    total.backward()
+    res = {"loss_" + k: float(v) for k, v in losses.items()}
+    res["loss_total"] = float(total)
+    res["fp_nerf"] = grad_fingerprint(_mlp_grads(model.nerf_mlp))
+    res["fp_prop"] = grad_fingerprint(_mlp_grads(model.prop_mlp))
+    # the interlevel term alone (its gradient reaches the proposal network only)
+    model.zero_grad()
+    rend, hist = model(r, 1.0, False)
+    train_utils.interlevel_loss(hist, cfg).backward()
+    res["fp_prop_interlevel_only"] = grad_fingerprint(_mlp_grads(model.prop_mlp))
+    res["nerf_grad_interlevel_only_l2"] = float(np.linalg.norm(_mlp_grads(model.nerf_mlp)))
+    for lvl, rd in enumerate(rend):
+        res[f"L{lvl}_r_rgb"] = rd["rgb"].detach().numpy()
+        res[f"L{lvl}_h_weights"] = hist[lvl]["weights"].detach().numpy()
+        res[f"L{lvl}_h_sdist"] = hist[lvl]["sdist"].detach().numpy()
+    res["bindings"] = np.array(bindings)
+    res["param_kw"] = np.array([4, 0.05, 20.0, 0.0])
+    res["prop_param_kw"] = np.array([5, 0.05, 2.0, 0.0])
+    for k, v in rays.items():
+        res["rays_" + k] = v
+    res["gt_rgb"] = gt
+    save("propmlp_interlevel", **res)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp"]
     for w in which:
         globals()["golden_" + w]()

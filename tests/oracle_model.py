@@ -18,8 +18,9 @@ _DIFF = _RAY + _SAMPLE
 class _OracleLevel(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, cfg, rays, sdist_in, weights_in, holder):
-        res = O.level_forward(owner.params, cfg, rays, sdist_in.numpy(), weights_in.numpy(), n_threads=owner.n_threads)
-        ctx.owner, ctx.cfg, ctx.rays = owner, cfg, rays
+        params, grads = holder["params"], holder["grads"]
+        res = O.level_forward(params, cfg, rays, sdist_in.numpy(), weights_in.numpy(), n_threads=owner.n_threads)
+        ctx.owner, ctx.cfg, ctx.rays, ctx.params, ctx.grads = owner, cfg, rays, params, grads
         ctx.sd_in, ctx.w_in = sdist_in.numpy().copy(), weights_in.numpy().copy()
         keys = tuple(k for k in _DIFF if k in res) + tuple(k for k in res if k not in _DIFF)
         holder["keys"] = keys
@@ -32,19 +33,22 @@ class _OracleLevel(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         seeds = {k: (None if g is None else g.detach().numpy()) for k, g in zip(ctx.keys[:ctx.n_diff], gs)}
-        O.level_backward(ctx.owner.params, ctx.cfg, ctx.rays, ctx.sd_in, ctx.w_in, seeds, grads=ctx.owner.grads,
+        O.level_backward(ctx.params, ctx.cfg, ctx.rays, ctx.sd_in, ctx.w_in, seeds, grads=ctx.grads,
                          n_threads=ctx.owner.n_threads)
         return (None,) * 6
 
 
 class OracleModel:
     """Model.__call__ (models.py:129-321) over oracle.level_forward / level_backward (training mode)."""
-    single_mlp = True
-
     def __init__(self, params, num_levels=2, num_prop_samples=128, num_nerf_samples=128, n_threads=0, vis_num_rays=16,
-                 **cfg_kw):
+                 prop_params=None, prop_cfg_kw=None, **cfg_kw):
         self.params = np.ascontiguousarray(params, np.float32)
         self.grads = np.zeros_like(self.params)
+        # Model.single_mlp = False: a separate proposal network (same architecture) for the levels before the last
+        self.single_mlp = prop_params is None
+        self.prop_params = self.params if prop_params is None else np.ascontiguousarray(prop_params, np.float32)
+        self.prop_grads = self.grads if prop_params is None else np.zeros_like(self.prop_params)
+        self.prop_cfg_kw = prop_cfg_kw or {}
         self.num_levels, self.num_prop_samples, self.num_nerf_samples = num_levels, num_prop_samples, num_nerf_samples
         self.n_threads, self.cfg_kw, self.vis_num_rays = n_threads, cfg_kw, vis_num_rays
         self._anchor = torch.zeros((), requires_grad=True)     # makes the level nodes part of the graph
@@ -61,9 +65,10 @@ class OracleModel:
         renderings, history = [], []
         for lvl in range(self.num_levels):
             n = self.num_prop_samples if lvl < self.num_levels - 1 else self.num_nerf_samples
-            cfg = O.default_cfg(n_samples=n, n_in=weights.shape[1], training=1, compute_extras=int(bool(compute_extras)),
-                                **self.cfg_kw)
-            holder = {}
+            is_prop = lvl < self.num_levels - 1
+            kw = dict(self.cfg_kw, **(self.prop_cfg_kw if is_prop else {}))
+            cfg = O.default_cfg(n_samples=n, n_in=weights.shape[1], training=1, compute_extras=int(bool(compute_extras)), **kw)
+            holder = {"params": self.prop_params if is_prop else self.params, "grads": self.prop_grads if is_prop else self.grads}
             outs = _OracleLevel.apply(self, cfg, rd, sdist.detach() + 0 * self._anchor, weights.detach(), holder)
             res = dict(zip(holder["keys"], outs))
             sdist, weights = res["sdist"], res["weights"]

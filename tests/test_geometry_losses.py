@@ -208,6 +208,47 @@ def test_oracle_generic_backward_output_by_output(name):
         _check_fingerprint(_fingerprint(model.grads), g["fp_" + key], 1e-4 * loose, key)
 
 
+def _propmlp_setup(g):
+    from refnerf_pl_amd import synthetic
+    cfg = _config(g)
+    pk = g["prop_param_kw"]
+    prop = synthetic.make_params(int(pk[0]), float(pk[1]), float(pk[2]), float(pk[3]))
+    return cfg, prop
+
+
+def test_oracle_separate_propmlp_and_interlevel_loss():
+    """Model.single_mlp = False (models.py:120-123): the proposal level runs its own PropMLP and is trained by
+    the interlevel loss (train_utils.py:150-162; stepfun inner_outer / lossfun_outer on the host): losses and the
+    gradients of BOTH networks against the reference's autograd."""
+    from oracle_model import OracleModel
+    from refnerf_pl_amd import train_utils, utils
+    g = load_golden("propmlp_interlevel")
+    cfg, prop = _propmlp_setup(g)
+    assert cfg.interlevel_loss_mult == 1.0
+    kw, lv = cfg_from_bindings(g["bindings"])
+    rays = utils.rays_from_dict(rays_from_golden(g), "cpu")
+    batch = utils.Batch(rays=rays, rgb=np.asarray(g["gt_rgb"], np.float32))
+
+    def make():
+        return OracleModel(params_from_golden(g), prop_params=prop, prop_cfg_kw=dict(density_bias=-3.0), **lv, **kw)
+    model = make()
+    renderings, history = model(rays, 1.0, False)
+    for lvl in range(2):
+        np.testing.assert_allclose(history[lvl]["sdist"].numpy(), g[f"L{lvl}_h_sdist"], atol=1e-6)
+        np.testing.assert_allclose(history[lvl]["weights"].detach().numpy(), g[f"L{lvl}_h_weights"], atol=2e-6)
+    total, losses, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+    for k in ("data", "interlevel", "orientation", "predicted_normals"):
+        assert float(losses[k].detach()) == pytest.approx(float(g["loss_" + k]), rel=5e-5), k
+    total.backward()
+    _check_fingerprint(_fingerprint(model.grads), g["fp_nerf"], 1e-4, "nerf")
+    _check_fingerprint(_fingerprint(model.prop_grads), g["fp_prop"], 1e-4, "prop")
+    model = make()
+    _, history = model(rays, 1.0, False)
+    train_utils.interlevel_loss(history, cfg).backward()
+    assert np.abs(model.grads).max() == 0.0            # the final level is detached in this loss
+    _check_fingerprint(_fingerprint(model.prop_grads), g["fp_prop_interlevel_only"], 1e-4, "prop, interlevel only")
+
+
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
@@ -309,3 +350,35 @@ def test_hip_backward_output_by_output_vs_reference(name):
             flat[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = lin.weight.grad.reshape(-1).cpu().numpy()
             flat[spec.b_off:spec.b_off + spec.out_dim] = lin.bias.grad.cpu().numpy()
         _check_fingerprint(_fingerprint(flat), g["fp_" + key], 2e-4 * loose, key)
+
+
+@pytest.mark.gpu
+def test_hip_separate_propmlp_and_interlevel_loss():
+    """The same on the HIP path: Model(single_mlp=False) keeps two parameter sets / packed images and the
+    interlevel loss reaches the proposal network through the `weights` seed of its level."""
+    from refnerf_pl_amd import _hip, layout, models, train_utils, utils
+    _hip.require_device()
+    g = load_golden("propmlp_interlevel")
+    cfg, prop = _propmlp_setup(g)
+    model = models.construct_model(utils.dummy_rays(), cfg).to("cuda:0").train()
+    assert model.prop_mlp is not model.nerf_mlp and model.prop_mlp.density_bias == -3.0
+    model.nerf_mlp.load_flat_params(params_from_golden(g))
+    model.prop_mlp.load_flat_params(prop)
+    rays = utils.rays_from_dict(rays_from_golden(g), "cuda:0")
+    batch = utils.Batch(rays=rays, rgb=np.asarray(g["gt_rgb"], np.float32))
+    renderings, history = model(rays, 1.0, False)
+    total, losses, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+    for k in ("data", "interlevel", "orientation", "predicted_normals"):
+        assert float(losses[k].detach()) == pytest.approx(float(g["loss_" + k]), rel=2e-4), k
+    total.backward()
+
+    def flat(mlp):
+        out = np.zeros(layout.NUM_PARAMS, np.float32)
+        for spec, lin in mlp._named_linears():
+            out[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = lin.weight.grad.reshape(-1).cpu().numpy()
+            out[spec.b_off:spec.b_off + spec.out_dim] = lin.bias.grad.cpu().numpy()
+        return out
+    _check_fingerprint(_fingerprint(flat(model.nerf_mlp)), g["fp_nerf"], 2e-4, "nerf")
+    _check_fingerprint(_fingerprint(flat(model.prop_mlp)), g["fp_prop"], 2e-4, "prop")
+    sd = model.state_dict()
+    assert len(sd) == 92 and sd["prop_mlp.rgb.weight"].data_ptr() != sd["nerf_mlp.rgb.weight"].data_ptr()
