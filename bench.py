@@ -237,13 +237,16 @@ def main():
         # rays of the whole view are cast on the device (refnerf_pixels_to_rays), inside the timed region
         from refnerf_pl_amd import camera_utils
         c2w, focal = synthetic.blender_camera(seed=1)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            img = camera_utils.cast_pinhole_rays(c2w.astype(np.float32), 800, 800, focal, 2.0, 6.0, device=dev)
-            rendering = models.render_image(lambda r: model(r, 1.0, True), img, cfg, verbose=False, device=dev)
-        torch.cuda.synchronize()
-        line["full_image_render_ms"] = 1e3 * (time.perf_counter() - t0)
+        # two renders: the first one also pays for the one-off growth of torch's caching allocator (157 chunks of
+        # outputs) and the first launch of the ray-casting kernel; the headline is the steady state
+        for tag in ("full_image_render_first_ms", "full_image_render_ms"):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                img = camera_utils.cast_pinhole_rays(c2w.astype(np.float32), 800, 800, focal, 2.0, 6.0, device=dev)
+                rendering = models.render_image(lambda r: model(r, 1.0, True), img, cfg, verbose=False, device=dev)
+            torch.cuda.synchronize()
+            line[tag] = 1e3 * (time.perf_counter() - t0)
         assert rendering["rgb"].shape == (800, 800, 3)
         # 1008x756 LLFF-style view (NDC rays, near 0 / far 1), same chunked loop
         del img, rendering

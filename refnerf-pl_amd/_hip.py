@@ -187,13 +187,17 @@ def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, histo
         "r_specular": torch.empty((R, 3), **f32), "r_distance": torch.empty((R,), **f32),
         "r_acc": torch.empty((R,), **f32),
     }
-    if history:
-        for k in ("rgb", "normals_pred", "grad_pred", "tint", "diffuse", "specular"):
+    # history: True = every per-sample output (the reference's ray_history), False = none, or the names wanted
+    want = ("rgb", "normals_pred", "grad_pred", "tint", "diffuse", "specular", "density", "roughness", "normals") \
+        if history is True else (tuple(history) if history else ())
+    for k in ("rgb", "normals_pred", "grad_pred", "tint", "diffuse", "specular"):
+        if k in want:
             res[k] = torch.empty((R, N, 3), **f32)
-        res["density"] = torch.empty((R, N), **f32)
-        res["roughness"] = torch.empty((R, N), **f32)
-        if cfg.training:
-            res["normals"] = torch.empty((R, N, 3), **f32)
+    for k in ("density", "roughness"):
+        if k in want:
+            res[k] = torch.empty((R, N), **f32)
+    if cfg.training and "normals" in want:
+        res["normals"] = torch.empty((R, N, 3), **f32)
     if cfg.compute_extras:
         res["r_normals_pred"] = torch.empty((R, 3), **f32)
         res["r_tint"] = torch.empty((R, 3), **f32)

@@ -7,7 +7,9 @@ loop body of ``Model.__call__`` (models.py:162-306) is ONE fused HIP launch per
 level through the C ABI of include/refnerf_hip.h.  There is no PyTorch / CPU
 fallback: without the library or a gfx950 device the call raises.
 """
+import contextlib
 import math as python_math
+import threading
 from typing import Any, Callable, List, Mapping, MutableMapping, Optional, Text, Tuple
 
 import torch
@@ -373,6 +375,26 @@ class PropMLP(MLP):
 _PREC = {"f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16}
 
 
+class _Lean(threading.local):
+    depth = 0
+
+
+_LEAN = _Lean()
+
+
+@contextlib.contextmanager
+def lean_ray_history():
+    """Inside this context an inference-mode Model.__call__ does not materialise the per-sample
+    `ray_history` tensors its caller is going to drop (render_image keeps the renderings only): the
+    kernel gets NULL pointers for them (84 B/sample of stores less), the dict entries are None; `sdist`,
+    `weights` and what the vis rays need stay."""
+    _LEAN.depth += 1
+    try:
+        yield
+    finally:
+        _LEAN.depth -= 1
+
+
 @configs.configurable
 class Model(nn.Module):
     """A mip-NeRF-360 style model holding the MLPs (models.py:50-321)."""
@@ -489,7 +511,9 @@ class Model(nn.Module):
                                             *mlp.ordered_parameters())
                 res = dict(zip(holder["keys"], outs))
             else:
-                res = _hip.level_forward(mlp.packed_weights(cfg.precision), cfg, r, sdist, weights, history=True)
+                lean = _LEAN.depth > 0 and not self.training
+                res = _hip.level_forward(mlp.packed_weights(cfg.precision), cfg, r, sdist, weights,
+                                         history=(("rgb",) if compute_extras else ()) if lean else True)
             sdist, weights = res["sdist"], res["weights"]
 
             def rs(x, *tail):
@@ -514,12 +538,14 @@ class Model(nn.Module):
                 rendering["ray_weights"] = weights[:n, :]
                 rendering["ray_rgbs"] = res["rgb"][:n, :, :]
             renderings.append(rendering)
-            ray_results = {"density": rs(res["density"], N), "rgb": rs(res["rgb"], N, 3),
-                           "normals": rs(res["normals"], N, 3) if self.training else None,
-                           "normals_pred": rs(res["normals_pred"], N, 3),
-                           "grad_pred": rs(res["grad_pred"], N, 3), "tint": rs(res["tint"], N, 3),
-                           "diffuse": rs(res["diffuse"], N, 3), "specular": rs(res["specular"], N, 3),
-                           "roughness": rs(res["roughness"], N, 1),
+            def hist(k, *tail):
+                return rs(res[k], *tail) if k in res else None      # None: training-only / lean_ray_history()
+            ray_results = {"density": hist("density", N), "rgb": hist("rgb", N, 3),
+                           "normals": hist("normals", N, 3) if self.training else None,
+                           "normals_pred": hist("normals_pred", N, 3),
+                           "grad_pred": hist("grad_pred", N, 3), "tint": hist("tint", N, 3),
+                           "diffuse": hist("diffuse", N, 3), "specular": hist("specular", N, 3),
+                           "roughness": hist("roughness", N, 1),
                            "sdist": rs(sdist, N + 1).clone(), "weights": rs(weights, N).clone()}
             ray_history.append(ray_results)
 
@@ -549,15 +575,16 @@ def render_image(render_fn: Callable[[utils.Rays], Tuple[List[Mapping[Text, torc
     num_rays = height * width
     rays = rays.reshape(num_rays, -1)
     chunks = []
-    for idx0 in range(0, num_rays, config.render_chunk_size):
-        chunk_rays = rays[idx0:idx0 + config.render_chunk_size]
-        chunk_rays.to(device)
-        chunk_renderings, _ = render_fn(chunk_rays)
-        chunk_rendering = chunk_renderings[-1]
-        for k in chunk_renderings[0]:
-            if k.startswith('ray_'):
-                chunk_rendering[k] = [r[k] for r in chunk_renderings]
-        chunks.append({k: utils.recursive_detach(v) for k, v in chunk_rendering.items()})
+    with lean_ray_history():               # the per-sample ray_history of a chunk is dropped right below
+        for idx0 in range(0, num_rays, config.render_chunk_size):
+            chunk_rays = rays[idx0:idx0 + config.render_chunk_size]
+            chunk_rays.to(device)
+            chunk_renderings, _ = render_fn(chunk_rays)
+            chunk_rendering = chunk_renderings[-1]
+            for k in chunk_renderings[0]:
+                if k.startswith('ray_'):
+                    chunk_rendering[k] = [r[k] for r in chunk_renderings]
+            chunks.append({k: utils.recursive_detach(v) for k, v in chunk_rendering.items()})
     rendering = utils.merge_chunks(chunks)
     for k, z in rendering.items():
         if not k.startswith('ray_'):
