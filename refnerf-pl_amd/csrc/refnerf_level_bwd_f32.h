@@ -5,19 +5,21 @@
  * rays, 32-sample blocks per wave, transposed GEMMs with activations in the
  * accumulator registers).  The training forward saved every linear layer's
  * input (the ACT matrix); here only the head and rgb rows are recomputed from
- * the saved x7 / v7, every ReLU mask is re-derived from the saved activation
- * of its layer (prefetched under the preceding transposed GEMM), and the
- * gradient runs
+ * the saved x7 / v7, every ReLU mask comes from the bit masks the training
+ * forward saved behind ACT (4 dwords per lane and layer, all 8 layers of a
+ * trunk loaded up front), and the gradient runs
  *   rendering -> alpha weights -> density / sample rgb / predicted normals
  *   -> colour head -> directional MLP -> IDE / reflection -> heads -> spatial MLP
  * through the transposed packed weights (refnerf_layout.h: TOP_*).
  *
  * Weight gradients are NOT accumulated here: every layer's pre-activation
  * gradient (DELTA) is streamed to HBM as a [feature][sample] matrix like ACT
- * and refnerf_wgrad.h contracts the two over the sample axis.
+ * -- one row per k-step through the store hook of the GEMM that consumes it
+ * (RowStoreHook, non-temporal) -- and refnerf_wgrad.h / refnerf_wgrad_bf16x3.h
+ * contract the two over the sample axis.
  *
  * Restates the autograd of internal/models.py:533-750 + render.py:132-216
- * (SURVEY.md A10); oracle: rn_level_train / mlp_backward.
+ * (SURVEY.md A10); oracle: rn_level_train / rn_level_backward.
  */
 #pragma once
 #include "refnerf_level_f32.h"

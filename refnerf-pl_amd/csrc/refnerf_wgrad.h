@@ -4,6 +4,10 @@
  * (the contraction PyTorch autograd performs for every nn.Linear of
  * internal/models.py:497-531).
  *
+ * This file: the job table shared by both arithmetic modes, the fp32-MFMA kernel
+ * (cfg.wgrad_mode = REFNERF_WGRAD_F32) and the fixed-order slice reduction; the
+ * default split-bf16 kernel is refnerf_wgrad_bf16x3.h.
+ *
  * One fp32-MFMA GEMM over all 18 layers: a constexpr job table maps (DELTA row
  * range, ACT row range) to the canonical gradient blob; a workgroup owns one
  * 128x128 output tile and one slice of the sample axis (split-K), accumulates

@@ -428,8 +428,6 @@ class Model(nn.Module):
         self.nerf_mlp = NerfMLP()
         self.prop_mlp = self.nerf_mlp if self.single_mlp else PropMLP()
         unsupported = {}
-        if self.dilation_bias > 0 or self.dilation_multiplier > 0:
-            unsupported["dilation"] = (self.dilation_bias, self.dilation_multiplier)
         if self.raydist_fn is not None:
             unsupported["raydist_fn"] = self.raydist_fn
         if self.disable_integration:
@@ -496,11 +494,26 @@ class Model(nn.Module):
                            torch.full((R, 1), float(self.init_s_far), device=dev)], dim=-1)
         weights = torch.ones((R, 1), device=dev)
         renderings, ray_history = [], []
+        prod_num_samples = 1
         for i_level in range(self.num_levels):
             is_prop = i_level < (self.num_levels - 1)
             num_samples = self.num_prop_samples if is_prop else self.num_nerf_samples
             if num_samples <= 1:
                 raise ValueError(f'num_samples must be > 1, is {num_samples}.')   # stepfun.py:234-235
+            # models.py:167-186: after the first level optionally dilate the step function the next level
+            # resamples from (a few torch ops on the detached [R, M] step function; the kernel then resamples
+            # from 3M-2 intervals)
+            dilation = self.dilation_bias + self.dilation_multiplier * (self.init_s_far - self.init_s_near) / prod_num_samples
+            prod_num_samples *= num_samples
+            if i_level > 0 and (self.dilation_bias > 0 or self.dilation_multiplier > 0):
+                from . import stepfun
+                with torch.no_grad():
+                    sdist, weights = stepfun.max_dilate_weights(sdist.detach(), weights.detach(), dilation,
+                                                                domain=(self.init_s_near, self.init_s_far), renormalize=True)
+                    sdist, weights = sdist[..., 1:-1].contiguous(), weights[..., 1:-1].contiguous()
+                if weights.shape[-1] > 512:
+                    raise ValueError(f'dilated step function has {weights.shape[-1]} intervals; the fused resampler '
+                                     'takes at most 512 (num_samples <= 171 per level with dilation)')
             mlp = self.prop_mlp if is_prop else self.nerf_mlp
             cfg = self._level_cfg(mlp, num_samples, weights.shape[-1], train_frac, compute_extras)
             if self.training and torch.is_grad_enabled():

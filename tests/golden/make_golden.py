@@ -556,7 +556,31 @@ def golden_propmlp():
     save("propmlp_interlevel", **res)
 
 
+def golden_dilation():
+    """Model options of the mip-NeRF 360 sampler on the Ref-NeRF architecture: dilation of the proposal step
+    function (models.py:167-186, stepfun.py:102-131) and weight annealing (models.py:188-201, train_frac = 0.3)."""
+    bindings = ["Model.dilation_bias = 0.0025", "Model.dilation_multiplier = 0.5", "Model.anneal_slope = 10.",
+                "Model.num_prop_samples = 64", "Model.num_nerf_samples = 64"]
+    pk = dict(seed=0, bias_scale=0.05, sharpen=20.0)
+    model, cfg = build_model(bindings, pk)
+    model.eval()
+    rays = synthetic.blender_rays(16, seed=21, center_frac=0.4)
+    with torch.no_grad():
+        rend, hist = model(to_rays(rays), 0.3, True)
+    res = {"train_frac": 0.3}
+    for lvl, (rd, hs) in enumerate(zip(rend, hist)):
+        for k in ("rgb", "acc", "distance", "distance_mean"):
+            res[f"L{lvl}_r_{k}"] = rd[k].numpy()
+        for k in ("sdist", "weights", "density"):
+            res[f"L{lvl}_h_{k}"] = hs[k].numpy()
+    res["bindings"] = np.array(bindings)
+    res["param_kw"] = np.array([pk["seed"], pk["bias_scale"], pk["sharpen"], 0.0])
+    for k, v in rays.items():
+        res["rays_" + k] = v
+    save("model_dilation_anneal_eval", **res)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation"]
     for w in which:
         globals()["golden_" + w]()

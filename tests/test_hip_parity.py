@@ -748,3 +748,31 @@ def test_render_image_lean_history_is_invisible(hip):
     for k in ("rgb", "diffuse", "specular", "acc", "distance_mean", "normals_pred", "roughness"):
         assert torch.equal(rendering[k].reshape(full[-1][k].shape), full[-1][k]), k
     assert len(rendering["ray_rgbs"]) == 2 and rendering["ray_rgbs"][0].shape[-1] == 3
+
+
+def test_dilation_and_anneal_model_options(hip):
+    """Model(dilation_bias, dilation_multiplier, anneal_slope) at train_frac 0.3 end to end on the HIP path
+    against the reference (the dilation runs as host torch ops in front of the level kernel)."""
+    import os
+    from refnerf_pl_amd import configs, models, utils
+    g = load_golden("model_dilation_anneal_eval")
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                            [str(b) for b in g["bindings"]])
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).eval()
+    assert model.dilation_bias == 0.0025 and model.anneal_slope == 10.
+    model.nerf_mlp.load_flat_params(params_from_golden(g))
+    with torch.no_grad():
+        rend, hist = model(utils.rays_from_dict(rays_from_golden(g), DEV), float(g["train_frac"]), True)
+    np.testing.assert_array_equal(hist[0]["sdist"].cpu().numpy(), g["L0_h_sdist"])
+    sd1 = hist[1]["sdist"].cpu().numpy()
+    ok = np.abs(sd1 - g["L1_h_sdist"]).max(-1) < 2e-6
+    assert ok.mean() >= 0.9                                   # a renormalisation sum 1 ulp apart can move a knot
+    np.testing.assert_allclose(rend[1]["rgb"].cpu().numpy()[ok], g["L1_r_rgb"][ok], atol=1e-5)
+    np.testing.assert_allclose(rend[1]["rgb"].cpu().numpy(), g["L1_r_rgb"], atol=1e-3)
+    np.testing.assert_allclose(rend[0]["rgb"].cpu().numpy(), g["L0_r_rgb"], atol=1e-5)
+    big = models.Model(config=cfg, num_prop_samples=192, num_nerf_samples=192, dilation_bias=0.0025, num_levels=2,
+                       single_mlp=True, resample_padding=0.01, anneal_slope=0.).to(DEV).eval()
+    with pytest.raises(ValueError), torch.no_grad():            # 3 * 192 - 2 intervals > 512
+        big(utils.rays_from_dict(rays_from_golden(g), DEV), 1.0, False)

@@ -191,3 +191,32 @@ def test_ray_generator_matches_reference(tag, spec):
                                     g[tag + "_camtoworld"].astype(np.float64), ndc_near=ndc)
     for k, a in zip(("origins", "directions", "viewdirs", "radii", "imageplane"), res):
         np.testing.assert_allclose(a.reshape(g[f"{tag}_{k}"].shape), g[f"{tag}_{k}"], rtol=0, atol=3e-7, err_msg=k)
+
+
+def test_dilation_and_anneal_vs_reference():
+    """Model.dilation_* (models.py:167-186; host stepfun.max_dilate_weights) and Model.anneal_slope
+    (models.py:188-201) at train_frac 0.3: the dilated, annealed resampling of level 1 and its rendering
+    against the reference (fixture model_dilation_anneal_eval)."""
+    import torch
+    from refnerf_pl_amd import stepfun
+    g = load_golden("model_dilation_anneal_eval")
+    P = params_from_golden(g)
+    rays = rays_from_golden(g)
+    R = rays["origins"].shape[0]
+    anneal = (10. * 0.3) / ((10. - 1) * 0.3 + 1)
+    sd0 = np.tile(np.array([[0.0, 1.0]], np.float32), (R, 1))
+    lvl0 = O.level_forward(P, O.default_cfg(n_samples=64, n_in=1, anneal=anneal), rays, sd0, np.ones((R, 1), np.float32))
+    np.testing.assert_array_equal(lvl0["sdist"], g["L0_h_sdist"])
+    np.testing.assert_allclose(lvl0["weights"], g["L0_h_weights"], atol=2e-7)
+    dilation = 0.0025 + 0.5 * (1.0 - 0.0) / 64
+    t, w = stepfun.max_dilate_weights(torch.tensor(g["L0_h_sdist"]), torch.tensor(g["L0_h_weights"]), dilation,
+                                      domain=(0.0, 1.0), renormalize=True)
+    t, w = t[..., 1:-1].numpy(), w[..., 1:-1].numpy()
+    assert t.shape == (R, 3 * 64 - 1) and w.shape == (R, 3 * 64 - 2)
+    lvl1 = O.level_forward(P, O.default_cfg(n_samples=64, n_in=w.shape[1], anneal=anneal), rays, t, w)
+    # annealed logits (0.81 * log(w + padding)) go through exp again: the oracle's exp (rn_det_expf) and torch's differ
+    # by an ulp, which moves interpolated knots by a few 1e-7 -- not the bin they fall in
+    assert np.mean(np.abs(lvl1["sdist"] - g["L1_h_sdist"]) < 2e-6) > 0.999
+    ok = np.abs(lvl1["sdist"] - g["L1_h_sdist"]).max(-1) < 2e-6
+    np.testing.assert_allclose(lvl1["r_rgb"][ok], g["L1_r_rgb"][ok], atol=5e-6)
+    np.testing.assert_allclose(lvl1["weights"][ok], g["L1_h_weights"][ok], atol=5e-6)
