@@ -92,7 +92,8 @@ def test_unsupported_configurations_raise(cfg):
     with pytest.raises(ValueError, match="Specular density is useless"):  # models.py:478-480
         models.MLP(enable_pred_specular_density=True, use_diffuse_color=False)
     with pytest.raises(ValueError, match="outside the fused"):
-        models.Model(config=cfg, dilation_bias=0.0025)
+        models.Model(config=cfg, disable_integration=True)
+    assert models.Model(config=cfg, dilation_bias=0.0025).dilation_bias == 0.0025      # built (host dilation)
 
 
 def test_no_cpu_fallback(cfg):
