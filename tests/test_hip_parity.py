@@ -776,3 +776,38 @@ def test_dilation_and_anneal_model_options(hip):
                        single_mlp=True, resample_padding=0.01, anneal_slope=0.).to(DEV).eval()
     with pytest.raises(ValueError), torch.no_grad():            # 3 * 192 - 2 intervals > 512
         big(utils.rays_from_dict(rays_from_golden(g), DEV), 1.0, False)
+
+
+def test_wgrad_modes_agree(hip):
+    """cfg.wgrad_mode: the split-bf16 weight-gradient GEMM (default) against the fp32-MFMA one on the same
+    saved activations / deltas: fp32-level agreement, both bit-reproducible, unknown modes rejected."""
+    from refnerf_pl_amd import _hip, synthetic
+    R, N = 37, 96
+    P = torch.tensor(synthetic.make_params(0, 0.05, 20.0), device=DEV)
+    rays = dev_rays(synthetic.blender_rays(R, seed=4, center_frac=0.4))
+    packed = _hip.pack_weights(P, precision=0)
+    sd = torch.tensor([[0.0, 1.0]], device=DEV).repeat(R, 1)
+    w = torch.ones((R, 1), device=DEV)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    g_rgb = torch.randn((R, 3), generator=g).to(DEV) * 1e-2
+    g_w = torch.randn((R, N), generator=g).to(DEV) * 1e-2
+    g_np = torch.randn((R, N, 3), generator=g).to(DEV) * 1e-2
+    out = {}
+    for mode in (_hip.WGRAD_F32, _hip.WGRAD_BF16X3):
+        cfg = _hip.default_cfg(n_samples=N, n_in=1, training=1, compute_extras=0, wgrad_mode=mode)
+        for rep in range(2):
+            res = _hip.level_forward(packed, cfg, rays, sd, w, history=True, save_activations=True)
+            grads = torch.zeros(_hip.NUM_PARAMS, device=DEV)
+            _hip.level_backward(packed, cfg, rays, res, g_rgb, g_w, g_np, grads)
+            out[(mode, rep)] = grads.cpu().double()
+        assert torch.equal(out[(mode, 0)], out[(mode, 1)])                 # no atomics: bit-reproducible
+    a, b = out[(_hip.WGRAD_F32, 0)], out[(_hip.WGRAD_BF16X3, 0)]
+    assert float(a.norm()) > 0
+    # 2^-16 per product (the dropped lo*lo term); these random-sign seeds cancel more than a real loss does
+    # (2.4e-7 on the C2 training step, scripts/ab_wgrad.py)
+    assert float((a - b).norm() / a.norm()) < 1e-5
+    assert float((a - b).abs().max()) < 1e-5 * float(a.abs().max())
+    bad = _hip.default_cfg(n_samples=N, n_in=1, training=1, compute_extras=0, wgrad_mode=7)
+    res = _hip.level_forward(packed, bad, rays, sd, w, history=True, save_activations=True)
+    with pytest.raises(ValueError):
+        _hip.level_backward(packed, bad, rays, res, g_rgb, g_w, g_np, torch.zeros(_hip.NUM_PARAMS, device=DEV))
