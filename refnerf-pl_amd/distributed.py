@@ -58,7 +58,14 @@ def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = Tru
     if not params:
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and dist.get_backend(group) != "nccl":
+        # a host-side backend (gloo in the CPU tests / single-GPU smoke runs): stage through host memory rather
+        # than rely on the backend's own device-tensor support; RCCL ("nccl") reduces the device blob in place
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if average:
         flat /= dist.get_world_size(group)
     off = 0
