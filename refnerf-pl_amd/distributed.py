@@ -49,6 +49,13 @@ def shard_rays(rays: utils.Rays, rank: int, world: int) -> utils.Rays:
     return utils.Rays(*[getattr(rays, f.name)[b:e] for f in fields(rays)])
 
 
+def _host_staged(t: torch.Tensor, group) -> bool:
+    """Device tensor + a host-side backend (gloo): stage collectives through host memory instead of relying on the
+    backend's device-tensor support (its all-reduce of the 4.4 MB gradient blob hung in the two-ranks-one-GPU
+    smoke run); RCCL ("nccl") works on the device tensors directly."""
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
 def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = True) -> None:
     """Sum (or average) the .grad of every parameter over the group with one
     all-reduce of the flattened blob.  Parameters without a gradient contribute zeros."""
@@ -58,9 +65,7 @@ def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = Tru
     if not params:
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    if flat.is_cuda and dist.get_backend(group) != "nccl":
-        # a host-side backend (gloo in the CPU tests / single-GPU smoke runs): stage through host memory rather
-        # than rely on the backend's own device-tensor support; RCCL ("nccl") reduces the device blob in place
+    if _host_staged(flat, group):
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         flat.copy_(host)
@@ -85,7 +90,12 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
         return
     with torch.no_grad():
         for p in module.parameters():
-            dist.broadcast(p.data, src=src, group=group)
+            if _host_staged(p.data, group):
+                host = p.data.cpu()
+                dist.broadcast(host, src=src, group=group)
+                p.data.copy_(host)
+            else:
+                dist.broadcast(p.data, src=src, group=group)
 
 
 def render_image_sharded(render_fn, rays: utils.Rays, config, group=None):
@@ -114,8 +124,14 @@ def render_image_sharded(render_fn, rays: utils.Rays, config, group=None):
         v = local[k]
         pad = torch.zeros((biggest,) + v.shape[1:], dtype=v.dtype, device=v.device)
         pad[:v.shape[0]] = v
-        gathered = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(gathered, pad, group=group)
+        if _host_staged(pad, group):
+            hpad = pad.cpu()
+            hg = [torch.empty_like(hpad) for _ in range(world)]
+            dist.all_gather(hg, hpad, group=group)
+            gathered = [x.to(pad.device) for x in hg]
+        else:
+            gathered = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(gathered, pad, group=group)
         full = torch.cat([g[:e - b] for g, (b, e) in zip(gathered, sizes)], dim=0)
         out[k] = full.reshape((height, width) + full.shape[1:])
     return out
