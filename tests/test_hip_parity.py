@@ -811,3 +811,47 @@ def test_wgrad_modes_agree(hip):
     res = _hip.level_forward(packed, bad, rays, sd, w, history=True, save_activations=True)
     with pytest.raises(ValueError):
         _hip.level_backward(packed, bad, rays, res, g_rgb, g_w, g_np, torch.zeros(_hip.NUM_PARAMS, device=DEV))
+
+
+def test_c_abi_training_without_torch(hip, tmp_path):
+    """examples/c_abi_train_demo.cpp: a training step (two refnerf_level_forward_train calls, the data loss by hand,
+    two refnerf_level_backward calls into one gradient blob) from a C++ host that links only the C ABI; loss and
+    gradient equal the Python host's (Model.__call__ autograd nodes + train_utils.compute_data_loss)."""
+    import os
+    import re
+    import subprocess
+    import __graft_entry__ as ge
+    from refnerf_pl_amd import camera_utils, configs, layout, models, synthetic, train_utils, utils
+    exe = ge.build_c_demo("c_abi_train_demo")
+    W, H, focal = 12, 9, 20.0
+    blob = synthetic.make_params(seed=2, bias_scale=0.05, sharpen=20.0)
+    c2w, _ = synthetic.blender_camera(seed=3)
+    gt = synthetic.target_rgb(W * H, seed=5)
+    blob.astype(np.float32).tofile(tmp_path / "w.f32")
+    c2w.astype(np.float32).tofile(tmp_path / "c2w.f32")
+    gt.astype(np.float32).tofile(tmp_path / "gt.f32")
+    out = subprocess.run([exe, str(tmp_path / "w.f32"), str(tmp_path / "c2w.f32"), str(W), str(H), str(focal),
+                          str(tmp_path / "gt.f32"), str(tmp_path / "g.f32")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    g_c = np.fromfile(tmp_path / "g.f32", np.float32)
+    loss_c = float(re.search(r"loss ([0-9.eE+-]+),", out.stdout).group(1))
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                            ["Model.num_prop_samples = 48", "Model.num_nerf_samples = 48",
+                                             "Config.orientation_loss_mult = 0.", "Config.orientation_coarse_loss_mult = 0.",
+                                             "Config.predicted_normal_loss_mult = 0.", "Config.predicted_normal_coarse_loss_mult = 0."])
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
+    model.nerf_mlp.load_flat_params(blob)
+    rays = camera_utils.cast_pinhole_rays(c2w.astype(np.float32), H, W, focal, 2.0, 6.0, device=torch.device(DEV)).reshape(H * W, -1)
+    rend, hist = model(rays, 1.0, False)
+    total, terms, _ = train_utils.compute_losses(model, utils.Batch(rays=rays, rgb=gt), rays, rend, hist, cfg)
+    assert sorted(terms) == ["data"]
+    total.backward()
+    g_py = np.zeros(layout.NUM_PARAMS, np.float32)
+    for spec, lin in model.nerf_mlp._named_linears():
+        g_py[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = lin.weight.grad.reshape(-1).cpu().numpy()
+        g_py[spec.b_off:spec.b_off + spec.out_dim] = lin.bias.grad.cpu().numpy()
+    assert loss_c == pytest.approx(float(total.detach()), rel=1e-5)
+    assert np.linalg.norm(g_py) > 0
+    assert np.linalg.norm(g_c - g_py) / np.linalg.norm(g_py) < 1e-5
