@@ -24,5 +24,8 @@ build b7_half_phase     mb_half.hip -DPRIO -DDMAHI &
 build c0_endbar         mb_mlp.hip -DENDBAR -DLDSPAD=90000 &
 build c1_endbar_prio    mb_mlp.hip -DENDBAR -DPRIO -DLDSPAD=90000 &
 build c2_endbar_epi60   mb_mlp.hip -DENDBAR -DEPI=60 -DLDSPAD=90000 &
+build d0_bar2          mb_mlp.hip -DPRIO -DBAR2 -DLDSPAD=80000 &
+build d1_bar2_epi60    mb_mlp.hip -DPRIO -DBAR2 -DEPI=60 -DLDSPAD=80000 &
+build d2_bar2_nodma    mb_mlp.hip -DPRIO -DBAR2 -DNODMA -DLDSPAD=80000 &
 wait
 ls bin
