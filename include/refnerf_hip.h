@@ -188,7 +188,11 @@ int refnerf_level_forward_train(const void *d_packed, const refnerf_level_cfg *c
                                 const refnerf_level_out *out, void *d_activations,
                                 size_t activations_bytes, void *stream);
 
-/* Scratch of refnerf_level_backward (per-layer output gradients + split-K partials; 17 KB per ray-sample). */
+/* Scratch of refnerf_level_backward (per-layer output gradients + split-K partials; 17 KB per ray-sample).
+ * refnerf_level_backward: d_packed is the REFNERF_PREC_F32 image of refnerf_pack_weights; cfg->precision selects the
+ * arithmetic of the transposed GEMM chains (REFNERF_PREC_F32: exact fp32 MFMA, the parity mode; REFNERF_PREC_BF16:
+ * bf16 MFMA with deltas rounded to bf16 once per layer, gradients within ~1e-3 relative L2 of the f32 mode),
+ * cfg->wgrad_mode that of the weight-gradient GEMM. */
 size_t refnerf_backward_workspace_bytes(int32_t R, int32_t n_samples);
 
 int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg,

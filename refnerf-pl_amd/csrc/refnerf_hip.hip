@@ -126,6 +126,31 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
       }
       out[o.a_off + e] = v;
     }
+  } else if (op < NUM_OPS + 2 * NUM_TOPS) {
+    /* bf16 transposed ops of the bf16-chain backward (refnerf_layout.h: bt_off) */
+    const int t = op - NUM_OPS - NUM_TOPS;
+    if (PACKED.bt_off[t] < 0) return;
+    const Op o = PACKED.top[t];
+    const TopSrc src = PACKED.top_src[t];
+    const int steps = (t == TOP_HEADS) ? BT_HEADS_STEPS : BT_CHAIN_STEPS;
+    __bf16 *dst = reinterpret_cast<__bf16 *>(out + PACKED.bt_off[t]);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < steps * 64 * 8 * 8; idx += gridDim.x * blockDim.x) {
+      const int e = idx & 7, ob = (idx >> 3) & 7, lane = (idx >> 6) & 63, st = idx >> 12;
+      const int h = lane >> 5, in_row = ob * 32 + (lane & 31);
+      float v = 0.0f;
+      if (ob < o.nob) {
+        if (t == TOP_HEADS) {
+          const int hr = 16 * st + 8 * h + e;
+          v = (hr < HROWS) ? canon_w(P, OP_HEADS, hr, in_row) : 0.0f;
+        } else {
+          const int r = 8 * (st & 1) + e;
+          const int oo = 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const bool real_row = (o.nob == 8) || in_row < DIR_IN;       /* DIN ops: rows 201..223 are padding */
+          v = real_row ? canon_w(P, src.fwd_op, oo, src.col0 + in_row) : 0.0f;
+        }
+      }
+      dst[idx] = (__bf16)v;
+    }
   } else {
     /* WD / WRGB: raw_density.weight and rgb_layer.weight rows in accumulator layout [ob][h][16] */
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < 4 * 8 * 32; b += gridDim.x * blockDim.x) {
@@ -282,7 +307,7 @@ size_t refnerf_packed_weights_bytes(int precision) {
 int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, void *stream) {
   if (!d_params || !d_packed) return fail(REFNERF_EINVAL, "refnerf_pack_weights: null pointer%s");
   if (precision == REFNERF_PREC_F32) {
-    dim3 grid(64, rn::NUM_OPS + rn::NUM_TOPS + 1);
+    dim3 grid(64, rn::NUM_OPS + 2 * rn::NUM_TOPS + 1);
     hipLaunchKernelGGL(rn::pack_weights_f32, grid, dim3(256), 0, (hipStream_t)stream, d_params, (float *)d_packed);
   } else if (precision == REFNERF_PREC_BF16) {
     dim3 grid(8, rn::NUM_OPS);
@@ -517,8 +542,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   if (R <= 0) return fail(REFNERF_EINVAL, "refnerf_level_backward: R must be positive%s");
   if (cfg->n_samples <= 1) return fail(REFNERF_EINVAL, "num_samples must be > 1%s");
   if (cfg->ray_shape != 0 && cfg->ray_shape != 1) return fail(REFNERF_EINVAL, "ray_shape must be 'cone' or 'cylinder'%s");
-  if (cfg->precision != REFNERF_PREC_F32)
-    return fail(REFNERF_EUNSUPPORTED, "refnerf_level_backward runs in the f32 precision mode only%s");
+  if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16)
+    return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown precision mode%s");
   if (cfg->wgrad_mode != REFNERF_WGRAD_F32 && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown wgrad_mode%s");
   if (!saved->d_sdist || !saved->d_density || !saved->d_rgb || !saved->d_weights || !grads->d_g_r_rgb)
@@ -538,6 +563,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute((const void *)rn::level_bwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)rn::level_bwd_bf16c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)rn::wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4);
     (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rn::WB_LDS);
   });
@@ -556,9 +582,29 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   a.act = (const float *)saved->d_activations;
   a.delta = (float *)(ws + plan.delta_off);
   a.pitch = plan.pitch;
+  a.prof = nullptr;
+  if (getenv("REFNERF_PROF")) {
+    static long long *d_prof = nullptr;
+    if (!d_prof) { HIP_TRY(hipMalloc(&d_prof, 8 * 32 * sizeof(long long))); }
+    HIP_TRY(hipMemset(d_prof, 0, 8 * 32 * sizeof(long long)));
+    a.prof = d_prof;
+  }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(rn::level_bwd_f32, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
+  /* d_packed is the f32 image in both modes (it carries the bf16 transposed ops behind the fp32 ones) */
+  if (cfg->precision == REFNERF_PREC_BF16)
+    hipLaunchKernelGGL(rn::level_bwd_bf16c, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
+  else
+    hipLaunchKernelGGL(rn::level_bwd_f32, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());
+  if (a.prof) {   /* debug aid (REFNERF_PROF=1): cycle stamps of workgroup 0: prologue | heads recompute | rgb recompute + colour head | seed | dir chain | IDE / heads | spatial chain */
+    long long hbuf[8 * 32];
+    HIP_TRY(hipMemcpy(hbuf, a.prof, sizeof(hbuf), hipMemcpyDeviceToHost));
+    for (int w = 0; w < 4; ++w) {
+      fprintf(stderr, "[prof bwd] wave %d:", w);
+      for (int sl = 1; sl <= 7; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
+      fprintf(stderr, "\n");
+    }
+  }
   if (plan.pitch > plan.S) {   /* pad columns of both operand matrices must read as zero in the wgrad GEMM */
     hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(a.act), rn::ACT_ROWS, plan.pitch, plan.S);
     hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, rn::DEL_ROWS, plan.pitch, plan.S);

@@ -89,7 +89,14 @@ constexpr int DIN_BLOCKS = 7;               /* 201 dir inputs -> 224 rows */
 
 struct Op { int nob; int stride; int reg_steps; int lds_k; int lds_steps; int a_off; int b_off; };
 struct TopSrc { int fwd_op; int col0; };    /* forward op whose weight is transposed, first input column */
-struct Packed { Op op[NUM_OPS]; Op top[NUM_TOPS]; TopSrc top_src[NUM_TOPS]; int wd_off; int wrgb_off; int total; };
+/* bf16 copies of the transposed ops for the bf16-chain backward (cfg.precision = REFNERF_PREC_BF16 in
+ * refnerf_level_backward): A fragments of v_mfma_f32_32x32x16_bf16, [k-step][lane][ob (stride 8)][8 bf16], i.e. per lane
+ * and k-step the fragments of all output blocks contiguous (8 x 16 B), k order = the accumulator order of the
+ * producing MFMA (BT_CHAIN_STEPS = 16 steps: slot (t, h, e) = unit 32 (t >> 1) + row(8 (t & 1) + e, h)); the head
+ * block is read from the fp32 LDS tile in plain order (BT_HEADS_STEPS = 9: k = 16 t + 8 h + e, rows >= 139 zero).
+ * Offsets in floats inside the same image; a_off < 0 = not built (the two IPE-input ops are forward-only). */
+constexpr int BT_CHAIN_STEPS = 16, BT_HEADS_STEPS = 9, BT_STEP_FLOATS = 64 * 8 * 4;
+struct Packed { Op op[NUM_OPS]; Op top[NUM_TOPS]; TopSrc top_src[NUM_TOPS]; int wd_off; int wrgb_off; int bt_off[NUM_TOPS]; int total; };
 
 constexpr Packed make_packed() {
   Packed P{};
@@ -128,7 +135,14 @@ constexpr Packed make_packed() {
   }
   P.wd_off = p; p += 8 * 32;
   P.wrgb_off = p; p += 3 * 8 * 32;
-  P.total = p + 8 * 64 * 8;   /* tail pad: the A prefetch runs PF (<= 8) steps past an op */
+  p += 8 * 64 * 8;            /* tail pad: the fp32 A prefetch runs PF (<= 8) steps past an op */
+  p = (p + 3) & ~3;
+  for (int i = 0; i < NUM_TOPS; ++i) {
+    if (i == TOP_SP5_IPE || i == TOP_SP0) { P.bt_off[i] = -1; continue; }
+    P.bt_off[i] = p;
+    p += ((i == TOP_HEADS) ? BT_HEADS_STEPS : BT_CHAIN_STEPS) * BT_STEP_FLOATS;
+  }
+  P.total = p + 4 * BT_STEP_FLOATS;   /* tail pad: the bf16 A prefetch runs up to 4 steps past an op */
   return P;
 }
 constexpr Packed PACKED = make_packed();

@@ -23,6 +23,7 @@
  */
 #pragma once
 #include "refnerf_level_f32.h"
+#include "refnerf_level_bf16.h"
 
 namespace rn {
 
@@ -51,6 +52,7 @@ struct BwdArgs {
   const float *act;         /* [ACT_ROWS][pitch] layer inputs saved by the training forward */
   float *delta;             /* [DEL_ROWS][pitch] written here                       */
   long long pitch;
+  long long *prof;          /* debug: per-phase cycle stamps of workgroup 0 (REFNERF_PROF=1), else NULL */
 };
 
 /* A-fragment prefetch depth of the chain GEMMs: the stores riding in the same in-order vmcnt queue make the
@@ -157,6 +159,90 @@ __device__ __forceinline__ void load_masks(const float *act, long long pitch, in
       M[l][q] = __builtin_bit_cast(unsigned, act[(long long)(ACT_MASK + 8 * (layer0 + l) + 4 * h + q) * pitch + (long long)gs]);
 }
 
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16 chains (cfg.precision = REFNERF_PREC_BF16 in refnerf_level_backward): the transposed GEMMs of the two
+ * trunks, the two 201-row input blocks and the head block on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), deltas
+ * rounded to bf16 once per layer.  Same kernel structure as the fp32 chains -- every wave streams its own A
+ * fragments from L2 / L1 through a register ring, no LDS staging, no barriers: 1 KB per MFMA and wave is
+ * 128 B/clk per CU at full MFMA rate, twice what the L1 delivers.  Measured: a layer takes ~40 k cycles instead of
+ * the fp32 chains' 65 k (its 128 MFMAs would need 4 k): the loop is bound by the latency of the A stream -- a
+ * fragment is consumed every 32 cycles, the 96-register ring covers 768 cycles, an L2 hit takes ~2000, and a
+ * deeper ring spills (measured: 5 / 7 steps are slower); a per-layer barrier to keep the 4 waves inside the L1
+ * window does not help either.  Sharing the stream through LDS (the eval kernel's ring) is the next step.
+ * The head / rgb recompute and everything per sample stay fp32.
+ * ------------------------------------------------------------------------------------------------ */
+#ifndef REFNERF_PF16
+#define REFNERF_PF16 3
+#endif
+constexpr int PF16 = REFNERF_PF16;
+template <int NOB>
+__device__ __forceinline__ void load_a16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, v8bf (&a)[NOB]) {
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+    a[ob] = __builtin_bit_cast(v8bf, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ob * 16, soff, 0));
+}
+
+/* out[ob] = W^T-block x B.  LDS_STEPS = 0: B = the 16 packed fragments `in` (a layer's delta in accumulator order);
+ * LDS_STEPS > 0: B is built from the fp32 LDS tile `xc` (= X + column), rows 16 s + 8 h + e (the head block).
+ * hook(step): runs once per k-step (delta stores). */
+template <int NOB, int LDS_STEPS = 0, typename Hook = NoStepHook>
+__device__ __forceinline__ void gemm_op_bf16(__amdgpu_buffer_rsrc_t rs, int a_off, int lane, int h, const v4uu (&in)[16],
+                                             v16f (&out)[NOB], const float *xc, Hook hook = Hook()) {
+  constexpr int STEPS = LDS_STEPS ? LDS_STEPS : BT_CHAIN_STEPS;
+  constexpr int STEP_BYTES = BT_STEP_FLOATS * 4;
+  const int voff = lane * 128;
+  int soff = a_off * 4;
+  v8bf a[PF16][NOB];
+#pragma unroll
+  for (int d = 0; d < PF16; ++d) load_a16<NOB>(rs, voff, soff + d * STEP_BYTES, a[d]);
+  soff += PF16 * STEP_BYTES;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[ob][r] = 0.0f;
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int step = 0; step < STEPS; ++step) {
+    v8bf b;
+    if constexpr (LDS_STEPS > 0) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = xc[(16 * step + 8 * h + e) * T_TILE];
+      v4uu pk = {cvt_pk_bf16(x[0], x[1]), cvt_pk_bf16(x[2], x[3]), cvt_pk_bf16(x[4], x[5]), cvt_pk_bf16(x[6], x[7])};
+      b = __builtin_bit_cast(v8bf, pk);
+    } else {
+      b = __builtin_bit_cast(v8bf, in[step]);
+    }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+      out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step % PF16][ob], b, out[ob], 0, 0, 0);
+    load_a16<NOB>(rs, voff, soff + step * STEP_BYTES, a[step % PF16]);
+    hook(step);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+/* delta through a ReLU (recorded mask) and straight into the next GEMM's packed B fragments */
+__device__ __forceinline__ void mask_pack(const v16f (&out)[8], const unsigned (&mk)[4], v4uu (&pk)[16]) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = ((mk[ob >> 1] >> (16 * (ob & 1) + r)) & 1u) ? out[ob][r] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pk[2 * ob][e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+      pk[2 * ob + 1][e] = cvt_pk_bf16(v[8 + 2 * e], v[8 + 2 * e + 1]);
+    }
+  }
+}
+/* element (blk, r) of a packed delta as fp32 (what the weight-gradient GEMM reads back from DELTA) */
+__device__ __forceinline__ float pk_elem(const v4uu (&pk)[16], int blk, int r) {
+  const unsigned w = pk[2 * blk + (r >> 3)][(r & 7) >> 1];
+  return __builtin_bit_cast(float, (r & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+
 /* rolled layer loops cannot index the mask registers dynamically: the next layer's mask moves up to M[7] */
 __device__ __forceinline__ void shift_masks(unsigned (&M)[8][4]) {
 #pragma unroll
@@ -165,7 +251,8 @@ __device__ __forceinline__ void shift_masks(unsigned (&M)[8][4]) {
     for (int q = 0; q < 4; ++q) M[l][q] = M[l - 1][q];
 }
 
-__global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
+template <bool BF>
+__device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples;
@@ -181,8 +268,10 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
   float *TD = HD + HD_ROWS * T_TILE;             /* [rpw][N+1]        */
   float *GS = TD + rpw * (N + 1);                /* [n_tot][NGS]      */
 
+  RN_STAMP(A, 0);
   bwd_prologue(A, TD, GS, ray0, wave, lane);
   __syncthreads();
+  RN_STAMP(A, 1);
 
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.packed, 0, PACKED.total * 4, 0x00020000);
   const int col = wave * 32 + sl;
@@ -211,6 +300,7 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
         if (row < HD_ROWS) HD[row * T_TILE + col] = hd[4][r];
       }
     }
+    RN_STAMP(A, 2);
     load_rows<8>(A.act, pitch, ACT_VD + 7 * WIDTH, gs, h, in);              /* v7: input of the rgb layer */
     wave_sync();
     SampleHeads sh;
@@ -234,6 +324,7 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(rgbv[0][i], sl, 64);
     }
+    RN_STAMP(A, 3);
     load_masks(A.act, pitch, 8, gs, h, M);                                    /* directional trunk */
 
     /* ================= backward ================= */
@@ -292,36 +383,57 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) out[ob][r] = (w0[r] * g_raw_rgb[0] + w1[r] * g_raw_rgb[1]) + w2[r] * g_raw_rgb[2];
     }
-    masked_into(out, in, M[7]);
+    RN_STAMP(A, 4);
+    v4uu pk[BF ? 16 : 1];                          /* packed delta (bf16 chains) */
+    if constexpr (BF) mask_pack(out, M[7], pk); else masked_into(out, in, M[7]);
     /* ---- directional MLP, layers 7..0 ---- */
     v16f(&gd)[DIN_BLOCKS] = reinterpret_cast<v16f(&)[DIN_BLOCKS]>(out);   /* gradient w.r.t. the 201 dir inputs */
+    auto park_din = [&](int i) {
+      /* layer 5 (skip connection) parks its share in LDS; layer 0 adds it back */
+#pragma unroll
+      for (int blk = 0; blk < DIN_BLOCKS; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (blk < 6 || row < DIR_PAD) {
+            float *px = X + row * T_TILE + col;
+            if (i == 0) gd[blk][r] += *px;
+            *px = gd[blk][r];
+          }
+        }
+    };
 #pragma unroll 1
     for (int i = 7; i >= 0; --i) {
       /* delta_i leaves through the store hook of the GEMM that consumes it (one row per k-step) */
-      if (i == 5 || i == 0) {
-        if (i == 0) gemm_op<DIN_BLOCKS, 8, true, false>(rs, PACKED.top[TOP_VD0].a_off, 0, lane, h, in, gd, xl, 0,
-                                                        RowStoreHook(A.delta, pitch, DEL_VD, gs, h, valid));
-        else gemm_op<DIN_BLOCKS, 8, true, false>(rs, PACKED.top[TOP_VD5_DIN].a_off, 0, lane, h, in, gd, xl, 0);
-        /* layer 5 (skip connection) parks its share in LDS; layer 0 adds it back */
+      if constexpr (BF) {
+        RowStoreHook sh_(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid);
+        auto hook = [&](int t) {
 #pragma unroll
-        for (int blk = 0; blk < DIN_BLOCKS; ++blk)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (blk < 6 || row < DIR_PAD) {
-              float *px = X + row * T_TILE + col;
-              if (i == 0) gd[blk][r] += *px;
-              *px = gd[blk][r];
-            }
-          }
-      }
-      if (i > 0) {
-        gemm_op<8, 8, true, false, RowStoreHook, PF_BWD>(rs, PACKED.top[TOP_VD1 + i - 1].a_off, 0, lane, h, in, out, xl, 0,
-                                   RowStoreHook(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid));
-        shift_masks(M);                                                     /* M[7] <- mask of layer i-1 */
-        masked_into(out, in, M[7]);
+          for (int e = 0; e < 8; ++e) sh_(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
+        };
+        if (i == 5) { gemm_op_bf16<DIN_BLOCKS>(rs, PACKED.bt_off[TOP_VD5_DIN], lane, h, pk, gd, nullptr); park_din(5); }
+        if (i == 0) { gemm_op_bf16<DIN_BLOCKS>(rs, PACKED.bt_off[TOP_VD0], lane, h, pk, gd, nullptr, hook); park_din(0); }
+        if (i > 0) {
+          gemm_op_bf16<8>(rs, PACKED.bt_off[TOP_VD1 + i - 1], lane, h, pk, out, nullptr, hook);
+          shift_masks(M);
+          mask_pack(out, M[7], pk);
+        }
+      } else {
+        if (i == 5 || i == 0) {
+          if (i == 0) gemm_op<DIN_BLOCKS, 8, true, false>(rs, PACKED.top[TOP_VD0].a_off, 0, lane, h, in, gd, xl, 0,
+                                                          RowStoreHook(A.delta, pitch, DEL_VD, gs, h, valid));
+          else gemm_op<DIN_BLOCKS, 8, true, false>(rs, PACKED.top[TOP_VD5_DIN].a_off, 0, lane, h, in, gd, xl, 0);
+          park_din(i);
+        }
+        if (i > 0) {
+          gemm_op<8, 8, true, false, RowStoreHook, PF_BWD>(rs, PACKED.top[TOP_VD1 + i - 1].a_off, 0, lane, h, in, out, xl, 0,
+                                     RowStoreHook(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid));
+          shift_masks(M);                                                     /* M[7] <- mask of layer i-1 */
+          masked_into(out, in, M[7]);
+        }
       }
     }
+    RN_STAMP(A, 5);
     /* X rows 0..127: dL/d bottleneck (= head rows 0..127), rows 128..200: dL/d (IDE, n.v) */
     store_rows<4>(A.delta, pitch, DEL_HEADS, gs, h, valid, gd);
     wave_sync();
@@ -369,20 +481,49 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) {
     }
     wave_sync();
     /* ---- heads^T, then the spatial MLP, layers 7..0 ---- */
+    RN_STAMP(A, 6);
     load_masks(A.act, pitch, 0, gs, h, M);                                    /* spatial trunk */
-    gemm_op<8, 8, false, false>(rs, PACKED.top[TOP_HEADS].a_off, 0, lane, h, in, out, xl, HEADS_T_STEPS);
-    masked_into(out, in, M[7]);
+    if constexpr (BF) {
+      gemm_op_bf16<8, BT_HEADS_STEPS>(rs, PACKED.bt_off[TOP_HEADS], lane, h, pk, out, X + col);
+      mask_pack(out, M[7], pk);
 #pragma unroll 1
-    for (int i = 7; i >= 0; --i) {
-      if (i > 0) {
-        gemm_op<8, 8, true, false, RowStoreHook, PF_BWD>(rs, PACKED.top[i - 1].a_off, 0, lane, h, in, out, xl, 0,
-                                   RowStoreHook(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid));
-        shift_masks(M);                                                     /* M[7] <- mask of layer i-1 */
-        masked_into(out, in, M[7]);
-      } else store_rows<8>(A.delta, pitch, DEL_SP, gs, h, valid, in);      /* no GEMM consumes delta_0 */
+      for (int i = 7; i >= 0; --i) {
+        if (i > 0) {
+          RowStoreHook sh_(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid);
+          gemm_op_bf16<8>(rs, PACKED.bt_off[i - 1], lane, h, pk, out, nullptr, [&](int t) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sh_(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
+          });
+          shift_masks(M);
+          mask_pack(out, M[7], pk);
+        } else {                                                             /* no GEMM consumes delta_0 */
+#pragma unroll
+          for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) in[blk][r] = pk_elem(pk, blk, r);
+          store_rows<8>(A.delta, pitch, DEL_SP, gs, h, valid, in);
+        }
+      }
+    } else {
+      gemm_op<8, 8, false, false>(rs, PACKED.top[TOP_HEADS].a_off, 0, lane, h, in, out, xl, HEADS_T_STEPS);
+      masked_into(out, in, M[7]);
+#pragma unroll 1
+      for (int i = 7; i >= 0; --i) {
+        if (i > 0) {
+          gemm_op<8, 8, true, false, RowStoreHook, PF_BWD>(rs, PACKED.top[i - 1].a_off, 0, lane, h, in, out, xl, 0,
+                                     RowStoreHook(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid));
+          shift_masks(M);                                                     /* M[7] <- mask of layer i-1 */
+          masked_into(out, in, M[7]);
+        } else store_rows<8>(A.delta, pitch, DEL_SP, gs, h, valid, in);      /* no GEMM consumes delta_0 */
+      }
     }
+    RN_STAMP(A, 7);
     wave_sync();
   }
 }
+
+__global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) { level_bwd_body<false>(A); }
+/* bf16 chains (cfg.precision = REFNERF_PREC_BF16): gradients at bf16 accuracy */
+__global__ __launch_bounds__(NTHREADS) void level_bwd_bf16c(const BwdArgs A) { level_bwd_body<true>(A); }
 
 }  // namespace rn

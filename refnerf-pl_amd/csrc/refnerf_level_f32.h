@@ -73,7 +73,10 @@ constexpr int PF = REFNERF_PF;
 #ifndef REFNERF_STREAM_AUX
 #define REFNERF_STREAM_AUX 2
 #endif
-struct NoStepHook { __device__ __forceinline__ void operator()(int, float) {} };
+struct NoStepHook {
+  __device__ __forceinline__ void operator()(int, float) {}
+  __device__ __forceinline__ void operator()(int) {}
+};
 
 /* Hook of gemm_op that streams the op's B operand (the 256 register values of this lane, i.e. a
  * layer input in the forward / a layer delta in the backward) to its rows of a [rows][pitch] fp32 matrix,

@@ -326,6 +326,7 @@ class _LevelFunction(torch.autograd.Function):
         res = _hip.level_forward(packed, cfg, rays, sdist_in, weights_in, history=True, save_activations=True)
         ctx.mlp, ctx.cfg, ctx.rays, ctx.packed = mlp, cfg, rays, packed
         ctx.packed_key = mlp._packed_key
+        ctx.bwd_precision = holder.get("bwd_precision", cfg.precision)
         ctx.saved = {k: res.pop(k) if k == "activations" else res[k]
                      for k in ("sdist", "density", "rgb", "weights", "activations", "diffuse", "specular", "tint",
                                "roughness", "normals", "normals_pred")}
@@ -351,7 +352,11 @@ class _LevelFunction(torch.autograd.Function):
         if g_rgb is None:
             g_rgb = torch.zeros_like(ctx.saved["sdist"][:, :3])
         g_weights, g_npred, seeds = _fold_ray_seeds(ctx.cfg, ctx.saved, g, g.get("weights"), g.get("normals_pred"))
-        _hip.level_backward(ctx.packed, ctx.cfg, ctx.rays, ctx.saved, g_rgb, g_weights, g_npred, grads,
+        cfg = ctx.cfg
+        if ctx.bwd_precision != cfg.precision:
+            cfg = type(cfg).from_buffer_copy(cfg)      # same level, bf16 chains in the backward kernel
+            cfg.precision = ctx.bwd_precision
+        _hip.level_backward(ctx.packed, cfg, ctx.rays, ctx.saved, g_rgb, g_weights, g_npred, grads,
                             g_r_acc=g.get("r_acc"), g_r_distance=g.get("r_distance"), sample_seeds=seeds)
         ctx.saved = None                           # release the 17.6 KB/sample activation buffer
         out = []
@@ -519,7 +524,10 @@ class Model(nn.Module):
             if self.training and torch.is_grad_enabled():
                 # one autograd node per level; sdist / resampling inputs are detached (models.py:205-216)
                 mlp.flat_params()
-                holder = {}
+                bwd_prec = getattr(self.config, "hip_bwd_precision", "f32")
+                if bwd_prec not in _PREC:
+                    raise ValueError("Config.hip_bwd_precision must be 'f32' or 'bf16'")
+                holder = {"bwd_precision": _PREC[bwd_prec]}
                 outs = _LevelFunction.apply(mlp, cfg, r, holder, sdist.detach(), weights.detach(),
                                             *mlp.ordered_parameters())
                 res = dict(zip(holder["keys"], outs))

@@ -26,6 +26,7 @@ def child(lib):
     g_w = (torch.randn((R, N), generator=g) * 1e-3).to(dev)
     g_np = (torch.randn((R, N, 3), generator=g) * 1e-3).to(dev)
     res = _hip.level_forward(packed, cfg, rays, sd, w, history=True, save_activations=True)
+    cfg.precision = int(os.environ.get("AB_BWD_PREC", "0"))       # 1: bf16 chains in the backward
     grads = torch.zeros(_hip.NUM_PARAMS, device=dev)
     _hip.level_backward(packed, cfg, rays, res, g_rgb, g_w, g_np, grads)
     ref = grads.double().cpu()

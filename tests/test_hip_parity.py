@@ -855,3 +855,38 @@ def test_c_abi_training_without_torch(hip, tmp_path):
     assert loss_c == pytest.approx(float(total.detach()), rel=1e-5)
     assert np.linalg.norm(g_py) > 0
     assert np.linalg.norm(g_c - g_py) / np.linalg.norm(g_py) < 1e-5
+
+
+def test_bf16_chain_backward_mode(hip):
+    """refnerf_level_backward with cfg.precision = BF16 (Config.hip_bwd_precision = 'bf16'): the transposed GEMM chains
+    on bf16 MFMA with deltas rounded to bf16 once per layer; forward, masks, head recompute and the weight-gradient GEMM
+    unchanged.  Gradients within bf16 accuracy of the f32 mode, every tensor; bit-reproducible."""
+    from refnerf_pl_amd import _hip, layout, synthetic
+    R, N = 48, 96
+    P = torch.tensor(synthetic.make_params(0, 0.05, 20.0), device=DEV)
+    rays = dev_rays(synthetic.blender_rays(R, seed=4, center_frac=0.4))
+    packed = _hip.pack_weights(P, precision=0)
+    sd = torch.tensor([[0.0, 1.0]], device=DEV).repeat(R, 1)
+    w = torch.ones((R, 1), device=DEV)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    g_rgb = torch.randn((R, 3), generator=g).to(DEV) * 1e-2
+    g_w = torch.randn((R, N), generator=g).to(DEV) * 1e-2
+    g_np = torch.randn((R, N, 3), generator=g).to(DEV) * 1e-2
+    out = {}
+    for prec in (_hip.PREC_F32, _hip.PREC_BF16):
+        for rep in range(2):
+            cfg = _hip.default_cfg(n_samples=N, n_in=1, training=1, compute_extras=0)
+            res = _hip.level_forward(packed, cfg, rays, sd, w, history=True, save_activations=True)
+            cfg.precision = prec
+            grads = torch.zeros(_hip.NUM_PARAMS, device=DEV)
+            _hip.level_backward(packed, cfg, rays, res, g_rgb, g_w, g_np, grads)
+            out[(prec, rep)] = grads.cpu().double()
+        assert torch.equal(out[(prec, 0)], out[(prec, 1)])
+    a, b = out[(_hip.PREC_F32, 0)], out[(_hip.PREC_BF16, 0)]
+    assert float((a - b).norm() / a.norm()) < 5e-3
+    for s in layout.PARAM_SPECS:
+        sl = slice(s.w_off, s.w_off + s.out_dim * s.in_dim)
+        assert float((a[sl] - b[sl]).norm()) <= 2e-2 * float(a[sl].norm()) + 1e-9, s.name
+    # the rgb layer and the heads sit above the chains: their gradients do not depend on the chain arithmetic
+    rgbw = slice(layout.PARAM_SPECS[-1].w_off, layout.PARAM_SPECS[-1].w_off + 3 * 256)
+    assert float((a[rgbw] - b[rgbw]).abs().max()) <= 1e-6 * float(a[rgbw].abs().max())
