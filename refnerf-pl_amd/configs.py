@@ -219,6 +219,7 @@ class Config:
     # build-side knob (not in the reference): arithmetic of the MLP contractions,
     # 'f32' (exact fp32 MFMA, the parity mode) or 'bf16'.
     hip_precision: str = 'f32'
+    hip_train_precision: str = 'f32'  # MLP chains of the training forward: 'f32' (parity) | 'bf16' (bf16 MFMA, activations rounded per layer)
     hip_bwd_precision: str = 'f32'  # transposed GEMM chains of the backward: 'f32' (parity) | 'bf16' (bf16 MFMA, gradients at bf16 accuracy)
     hip_wgrad_mode: str = 'bf16x3'  # weight-gradient GEMM of the backward: 'bf16x3' (split-bf16 MFMA, fp32-level accuracy) | 'f32'
 

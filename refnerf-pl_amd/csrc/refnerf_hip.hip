@@ -129,7 +129,6 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
   } else if (op < NUM_OPS + 2 * NUM_TOPS) {
     /* bf16 transposed ops of the bf16-chain backward (refnerf_layout.h: bt_off) */
     const int t = op - NUM_OPS - NUM_TOPS;
-    if (PACKED.bt_off[t] < 0) return;
     const Op o = PACKED.top[t];
     const TopSrc src = PACKED.top_src[t];
     const int steps = (t == TOP_HEADS) ? BT_HEADS_STEPS : BT_CHAIN_STEPS;
@@ -145,8 +144,30 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
         } else {
           const int r = 8 * (st & 1) + e;
           const int oo = 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const bool real_row = (o.nob == 8) || in_row < DIR_IN;       /* DIN ops: rows 201..223 are padding */
-          v = real_row ? canon_w(P, src.fwd_op, oo, src.col0 + in_row) : 0.0f;
+          const int n_rows = (o.nob == 8) ? WIDTH : (o.nob == 3 ? IPE_DIM : DIR_IN);   /* rows beyond are padding */
+          v = (in_row < n_rows) ? canon_w(P, src.fwd_op, oo, src.col0 + in_row) : 0.0f;
+        }
+      }
+      dst[idx] = (__bf16)v;
+    }
+  } else if (op < 2 * NUM_OPS + 2 * NUM_TOPS) {
+    /* bf16 forward ops of the bf16-chain training forward (refnerf_layout.h: bf_off) */
+    const int fo = op - NUM_OPS - 2 * NUM_TOPS;
+    const Op o = PACKED.op[fo];
+    const int rst = bf_reg_steps(fo), steps = rst + bf_lds_steps(fo);
+    const int valid_k = (fo == 0 || fo == 5) ? IPE_DIM : DIR_IN;
+    __bf16 *dst = reinterpret_cast<__bf16 *>(out + PACKED.bf_off[fo]);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < steps * 64 * 8 * 8; idx += gridDim.x * blockDim.x) {
+      const int e = idx & 7, ob = (idx >> 3) & 7, lane = (idx >> 6) & 63, st = idx >> 12;
+      const int h = lane >> 5, row = ob * 32 + (lane & 31);
+      float v = 0.0f;
+      if (ob < o.nob) {
+        if (st < rst) {
+          const int r = 8 * (st & 1) + e;
+          v = canon_w(P, fo, row, 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h);
+        } else {
+          const int kl = 16 * (st - rst) + 8 * h + e;
+          v = (kl < valid_k) ? canon_w(P, fo, row, (rst ? WIDTH : 0) + kl) : 0.0f;
         }
       }
       dst[idx] = (__bf16)v;
@@ -307,7 +328,7 @@ size_t refnerf_packed_weights_bytes(int precision) {
 int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, void *stream) {
   if (!d_params || !d_packed) return fail(REFNERF_EINVAL, "refnerf_pack_weights: null pointer%s");
   if (precision == REFNERF_PREC_F32) {
-    dim3 grid(64, rn::NUM_OPS + 2 * rn::NUM_TOPS + 1);
+    dim3 grid(64, 2 * rn::NUM_OPS + 2 * rn::NUM_TOPS + 1);
     hipLaunchKernelGGL(rn::pack_weights_f32, grid, dim3(256), 0, (hipStream_t)stream, d_params, (float *)d_packed);
   } else if (precision == REFNERF_PREC_BF16) {
     dim3 grid(8, rn::NUM_OPS);
@@ -359,14 +380,15 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   if (cfg->n_in < 1 || cfg->n_in > 512) return fail(REFNERF_EINVAL, "n_in must be in [1,512]%s");
   if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16)
     return fail(REFNERF_EINVAL, "unknown precision mode%s");
-  if (cfg->training && cfg->precision != REFNERF_PREC_F32)
-    return fail(REFNERF_EUNSUPPORTED, "training-mode level (density-gradient normals) runs in the f32 precision mode only%s");
+  /* training + BF16: the fp32-structure kernel with its MLP chains on bf16 MFMA (level_fwd_train_bf16c); d_packed is
+   * the REFNERF_PREC_F32 image in that case (it carries the bf16 copies of the ops) */
+  const bool train_bf = cfg->training && cfg->precision == REFNERF_PREC_BF16;
   if (!rays->d_origins || !rays->d_directions || !rays->d_viewdirs || !rays->d_radii || !rays->d_near || !rays->d_far)
     return fail(REFNERF_EINVAL, "refnerf_level_forward: null ray field%s");
   int rc = ensure_tables();
   if (rc) return rc;
   const int N = cfg->n_samples;
-  const bool bf = cfg->precision == REFNERF_PREC_BF16;
+  const bool bf = cfg->precision == REFNERF_PREC_BF16 && !train_bf;     /* the LDS-ring bf16 eval kernel */
   int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
   auto lds_bytes = [&](int rays) -> size_t {
     const int np = bf ? rn::NPS_EVAL : rn::NPS_TRAIN, tile = bf ? rn::BT : rn::T_TILE;
@@ -394,6 +416,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute((const void *)rn::level_fwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)rn::level_fwd_train_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)rn::level_fwd_train_bf16c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)rn::level_fwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   rn::LevelArgs a;
@@ -426,6 +449,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
     HIP_TRY(hipEventRecord(g_events[g_events_used].first, st));
   }
   if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  else if (train_bf) hipLaunchKernelGGL(rn::level_fwd_train_bf16c, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (cfg->training) hipLaunchKernelGGL(rn::level_fwd_train_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else hipLaunchKernelGGL(rn::level_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());

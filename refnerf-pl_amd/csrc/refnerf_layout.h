@@ -94,9 +94,16 @@ struct TopSrc { int fwd_op; int col0; };    /* forward op whose weight is transp
  * and k-step the fragments of all output blocks contiguous (8 x 16 B), k order = the accumulator order of the
  * producing MFMA (BT_CHAIN_STEPS = 16 steps: slot (t, h, e) = unit 32 (t >> 1) + row(8 (t & 1) + e, h)); the head
  * block is read from the fp32 LDS tile in plain order (BT_HEADS_STEPS = 9: k = 16 t + 8 h + e, rows >= 139 zero).
- * Offsets in floats inside the same image; a_off < 0 = not built (the two IPE-input ops are forward-only). */
+ * Offsets in floats inside the same image. */
 constexpr int BT_CHAIN_STEPS = 16, BT_HEADS_STEPS = 9, BT_STEP_FLOATS = 64 * 8 * 4;
-struct Packed { Op op[NUM_OPS]; Op top[NUM_TOPS]; TopSrc top_src[NUM_TOPS]; int wd_off; int wrgb_off; int bt_off[NUM_TOPS]; int total; };
+/* ... and of the 18 forward ops for the bf16-chain training forward (bf_off): register steps as above (16, or 0 for
+ * the two layers fed from LDS only), then the LDS-fed inputs in plain order k' = 16 s + 8 h + e over the fp32 LDS tile:
+ * BF_IPE_STEPS = 6 (96 IPE features) / BF_DIN_STEPS = 13 (the 204-row dir input, rows >= 201 zero). */
+constexpr int BF_IPE_STEPS = 6, BF_DIN_STEPS = 13;
+struct Packed { Op op[NUM_OPS]; Op top[NUM_TOPS]; TopSrc top_src[NUM_TOPS]; int wd_off; int wrgb_off; int bt_off[NUM_TOPS];
+                int bf_off[NUM_OPS]; int total; };
+constexpr int bf_lds_steps(int op) { return (op == 0 || op == 5) ? BF_IPE_STEPS : ((op == 9 || op == 14) ? BF_DIN_STEPS : 0); }
+constexpr int bf_reg_steps(int op) { return (op == 0 || op == 9) ? 0 : BT_CHAIN_STEPS; }
 
 constexpr Packed make_packed() {
   Packed P{};
@@ -138,9 +145,12 @@ constexpr Packed make_packed() {
   p += 8 * 64 * 8;            /* tail pad: the fp32 A prefetch runs PF (<= 8) steps past an op */
   p = (p + 3) & ~3;
   for (int i = 0; i < NUM_TOPS; ++i) {
-    if (i == TOP_SP5_IPE || i == TOP_SP0) { P.bt_off[i] = -1; continue; }
     P.bt_off[i] = p;
     p += ((i == TOP_HEADS) ? BT_HEADS_STEPS : BT_CHAIN_STEPS) * BT_STEP_FLOATS;
+  }
+  for (int i = 0; i < NUM_OPS; ++i) {
+    P.bf_off[i] = p;
+    p += (bf_reg_steps(i) + bf_lds_steps(i)) * BT_STEP_FLOATS;
   }
   P.total = p + 4 * BT_STEP_FLOATS;   /* tail pad: the bf16 A prefetch runs up to 4 steps past an op */
   return P;

@@ -34,8 +34,6 @@
 
 namespace rn {
 
-typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
-typedef unsigned v4uu __attribute__((ext_vector_type(4)));
 typedef short v2s __attribute__((ext_vector_type(2)));
 
 constexpr int BT = 256;                               /* samples per pass: 8 waves x 32 */
@@ -91,17 +89,6 @@ __device__ __forceinline__ v16f bias16(const char *w, int h) {
                 b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
 }
 
-/* fp32 pair -> packed bf16 (v_cvt_pk_bf16_f32, emitted by the compiler so that
- * the MFMA-result -> VALU-read wait states are honoured: an inline-asm cvt
- * reading a VGPR accumulator straight after the last MFMA returned garbage);
- * ReLU afterwards on the packed pair as v_pk_max_i16(x, 0): a negative bf16 is
- * a negative int16. */
-typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  v2bf r = __builtin_convertvector((v2f){lo, hi}, v2bf);
-  return __builtin_bit_cast(unsigned, r);
-}
 template <bool RELU>
 __device__ __forceinline__ unsigned pack_pair(float lo, float hi) {
   unsigned w = cvt_pk_bf16(lo, hi);

@@ -160,89 +160,6 @@ __device__ __forceinline__ void load_masks(const float *act, long long pitch, in
 }
 
 
-/* ------------------------------------------------------------------------------------------------
- * bf16 chains (cfg.precision = REFNERF_PREC_BF16 in refnerf_level_backward): the transposed GEMMs of the two
- * trunks, the two 201-row input blocks and the head block on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), deltas
- * rounded to bf16 once per layer.  Same kernel structure as the fp32 chains -- every wave streams its own A
- * fragments from L2 / L1 through a register ring, no LDS staging, no barriers: 1 KB per MFMA and wave is
- * 128 B/clk per CU at full MFMA rate, twice what the L1 delivers.  Measured: a layer takes ~40 k cycles instead of
- * the fp32 chains' 65 k (its 128 MFMAs would need 4 k): the loop is bound by the latency of the A stream -- a
- * fragment is consumed every 32 cycles, the 96-register ring covers 768 cycles, an L2 hit takes ~2000, and a
- * deeper ring spills (measured: 5 / 7 steps are slower); a per-layer barrier to keep the 4 waves inside the L1
- * window does not help either.  Sharing the stream through LDS (the eval kernel's ring) is the next step.
- * The head / rgb recompute and everything per sample stay fp32.
- * ------------------------------------------------------------------------------------------------ */
-#ifndef REFNERF_PF16
-#define REFNERF_PF16 3
-#endif
-constexpr int PF16 = REFNERF_PF16;
-template <int NOB>
-__device__ __forceinline__ void load_a16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, v8bf (&a)[NOB]) {
-#pragma unroll
-  for (int ob = 0; ob < NOB; ++ob)
-    a[ob] = __builtin_bit_cast(v8bf, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ob * 16, soff, 0));
-}
-
-/* out[ob] = W^T-block x B.  LDS_STEPS = 0: B = the 16 packed fragments `in` (a layer's delta in accumulator order);
- * LDS_STEPS > 0: B is built from the fp32 LDS tile `xc` (= X + column), rows 16 s + 8 h + e (the head block).
- * hook(step): runs once per k-step (delta stores). */
-template <int NOB, int LDS_STEPS = 0, typename Hook = NoStepHook>
-__device__ __forceinline__ void gemm_op_bf16(__amdgpu_buffer_rsrc_t rs, int a_off, int lane, int h, const v4uu (&in)[16],
-                                             v16f (&out)[NOB], const float *xc, Hook hook = Hook()) {
-  constexpr int STEPS = LDS_STEPS ? LDS_STEPS : BT_CHAIN_STEPS;
-  constexpr int STEP_BYTES = BT_STEP_FLOATS * 4;
-  const int voff = lane * 128;
-  int soff = a_off * 4;
-  v8bf a[PF16][NOB];
-#pragma unroll
-  for (int d = 0; d < PF16; ++d) load_a16<NOB>(rs, voff, soff + d * STEP_BYTES, a[d]);
-  soff += PF16 * STEP_BYTES;
-#pragma unroll
-  for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) out[ob][r] = 0.0f;
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int step = 0; step < STEPS; ++step) {
-    v8bf b;
-    if constexpr (LDS_STEPS > 0) {
-      float x[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = xc[(16 * step + 8 * h + e) * T_TILE];
-      v4uu pk = {cvt_pk_bf16(x[0], x[1]), cvt_pk_bf16(x[2], x[3]), cvt_pk_bf16(x[4], x[5]), cvt_pk_bf16(x[6], x[7])};
-      b = __builtin_bit_cast(v8bf, pk);
-    } else {
-      b = __builtin_bit_cast(v8bf, in[step]);
-    }
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob)
-      out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step % PF16][ob], b, out[ob], 0, 0, 0);
-    load_a16<NOB>(rs, voff, soff + step * STEP_BYTES, a[step % PF16]);
-    hook(step);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-/* delta through a ReLU (recorded mask) and straight into the next GEMM's packed B fragments */
-__device__ __forceinline__ void mask_pack(const v16f (&out)[8], const unsigned (&mk)[4], v4uu (&pk)[16]) {
-#pragma unroll
-  for (int ob = 0; ob < 8; ++ob) {
-    float v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = ((mk[ob >> 1] >> (16 * (ob & 1) + r)) & 1u) ? out[ob][r] : 0.0f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      pk[2 * ob][e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
-      pk[2 * ob + 1][e] = cvt_pk_bf16(v[8 + 2 * e], v[8 + 2 * e + 1]);
-    }
-  }
-}
-/* element (blk, r) of a packed delta as fp32 (what the weight-gradient GEMM reads back from DELTA) */
-__device__ __forceinline__ float pk_elem(const v4uu (&pk)[16], int blk, int r) {
-  const unsigned w = pk[2 * blk + (r >> 3)][(r & 7) >> 1];
-  return __builtin_bit_cast(float, (r & 1) ? (w & 0xffff0000u) : (w << 16));
-}
-
 /* rolled layer loops cannot index the mask registers dynamically: the next layer's mask moves up to M[7] */
 __device__ __forceinline__ void shift_masks(unsigned (&M)[8][4]) {
 #pragma unroll
@@ -411,10 +328,10 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) sh_(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
         };
-        if (i == 5) { gemm_op_bf16<DIN_BLOCKS>(rs, PACKED.bt_off[TOP_VD5_DIN], lane, h, pk, gd, nullptr); park_din(5); }
-        if (i == 0) { gemm_op_bf16<DIN_BLOCKS>(rs, PACKED.bt_off[TOP_VD0], lane, h, pk, gd, nullptr, hook); park_din(0); }
+        if (i == 5) { gemm_op_bf16<DIN_BLOCKS, 16, 0, false>(rs, PACKED.bt_off[TOP_VD5_DIN], 0, lane, h, pk, gd, nullptr); park_din(5); }
+        if (i == 0) { gemm_op_bf16<DIN_BLOCKS, 16, 0, false>(rs, PACKED.bt_off[TOP_VD0], 0, lane, h, pk, gd, nullptr, hook); park_din(0); }
         if (i > 0) {
-          gemm_op_bf16<8>(rs, PACKED.bt_off[TOP_VD1 + i - 1], lane, h, pk, out, nullptr, hook);
+          gemm_op_bf16<8, 16, 0, false>(rs, PACKED.bt_off[TOP_VD1 + i - 1], 0, lane, h, pk, out, nullptr, hook);
           shift_masks(M);
           mask_pack(out, M[7], pk);
         }
@@ -484,13 +401,13 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     RN_STAMP(A, 6);
     load_masks(A.act, pitch, 0, gs, h, M);                                    /* spatial trunk */
     if constexpr (BF) {
-      gemm_op_bf16<8, BT_HEADS_STEPS>(rs, PACKED.bt_off[TOP_HEADS], lane, h, pk, out, X + col);
+      gemm_op_bf16<8, 0, BT_HEADS_STEPS, false>(rs, PACKED.bt_off[TOP_HEADS], 0, lane, h, pk, out, X + col);
       mask_pack(out, M[7], pk);
 #pragma unroll 1
       for (int i = 7; i >= 0; --i) {
         if (i > 0) {
           RowStoreHook sh_(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid);
-          gemm_op_bf16<8>(rs, PACKED.bt_off[i - 1], lane, h, pk, out, nullptr, [&](int t) {
+          gemm_op_bf16<8, 16, 0, false>(rs, PACKED.bt_off[i - 1], 0, lane, h, pk, out, nullptr, [&](int t) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) sh_(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
           });

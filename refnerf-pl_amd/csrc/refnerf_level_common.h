@@ -18,6 +18,21 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 constexpr int NTHREADS = 256;
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef unsigned v4uu __attribute__((ext_vector_type(4)));
+/* fp32 pair -> packed bf16 (v_cvt_pk_bf16_f32, emitted by the compiler so that
+ * the MFMA-result -> VALU-read wait states are honoured: an inline-asm cvt
+ * reading a VGPR accumulator straight after the last MFMA returned garbage);
+ * ReLU afterwards on the packed pair as v_pk_max_i16(x, 0): a negative bf16 is
+ * a negative int16. */
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  v2bf r = __builtin_convertvector((v2f){lo, hi}, v2bf);
+  return __builtin_bit_cast(unsigned, r);
+}
+
 constexpr int HD_ROWS = 12;
 /* Per-sample floats kept in LDS until the rays of the workgroup are composited:
  * PS[sample][slot] with an odd stride NP (conflict-free per-sample access).

@@ -164,6 +164,118 @@ __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, in
   }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * bf16 chains (cfg.precision = REFNERF_PREC_BF16 in refnerf_level_backward): the transposed GEMMs of the two
+ * trunks, the two 201-row input blocks and the head block on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), deltas
+ * rounded to bf16 once per layer.  Same kernel structure as the fp32 chains -- every wave streams its own A
+ * fragments from L2 / L1 through a register ring, no LDS staging, no barriers: 1 KB per MFMA and wave is
+ * 128 B/clk per CU at full MFMA rate, twice what the L1 delivers.  Measured: a layer takes ~40 k cycles instead of
+ * the fp32 chains' 65 k (its 128 MFMAs would need 4 k): the loop is bound by the latency of the A stream -- a
+ * fragment is consumed every 32 cycles, the 96-register ring covers 768 cycles, an L2 hit takes ~2000, and a
+ * deeper ring spills (measured: 5 / 7 steps are slower); a per-layer barrier to keep the 4 waves inside the L1
+ * window does not help either.  Sharing the stream through LDS (the eval kernel's ring) is the next step.
+ * The head / rgb recompute and everything per sample stay fp32.
+ * ------------------------------------------------------------------------------------------------ */
+#ifndef REFNERF_PF16
+#define REFNERF_PF16 3
+#endif
+constexpr int PF16 = REFNERF_PF16;
+template <int NOB>
+__device__ __forceinline__ void load_a16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, v8bf (&a)[NOB]) {
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+    a[ob] = __builtin_bit_cast(v8bf, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ob * 16, soff, 0));
+}
+
+/* out[ob] = (bias +) W-block x B over REG_STEPS k-steps of packed register fragments `in` (a layer's input / delta in
+ * accumulator order) followed by LDS_STEPS k-steps built from the fp32 LDS tile `xc` (= X + column), rows
+ * 16 s + 8 h + e (encodings / the head block).  b_off: bias image of the fp32 ops (accumulator layout) when BIAS.
+ * hook(step): runs once per register k-step (activation / delta stores). */
+template <int NOB, int REG_STEPS16, int LDS_STEPS, bool BIAS, typename Hook = NoStepHook, int LDS_MAXROW = (1 << 30)>
+__device__ __forceinline__ void gemm_op_bf16(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
+                                             const v4uu (&in)[16], v16f (&out)[NOB], const float *xc, Hook hook = Hook()) {
+  constexpr int STEPS = REG_STEPS16 + LDS_STEPS;
+  constexpr int STEP_BYTES = BT_STEP_FLOATS * 4;
+  const int voff = lane * 128;
+  int soff = a_off * 4;
+  v8bf a[PF16][NOB];
+#pragma unroll
+  for (int d = 0; d < PF16; ++d) load_a16<NOB>(rs, voff, soff + d * STEP_BYTES, a[d]);
+  soff += PF16 * STEP_BYTES;
+  if constexpr (BIAS) load_acc<NOB>(rs, b_off, h, out);
+  else {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[ob][r] = 0.0f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int step = 0; step < STEPS; ++step) {
+    v8bf b;
+    if (step >= REG_STEPS16) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int row = 16 * (step - REG_STEPS16) + 8 * h + e;
+        if (row > LDS_MAXROW) row = LDS_MAXROW;          /* pad rows (zero weights) must still read finite values */
+        x[e] = xc[row * T_TILE];
+      }
+      v4uu pk = {cvt_pk_bf16(x[0], x[1]), cvt_pk_bf16(x[2], x[3]), cvt_pk_bf16(x[4], x[5]), cvt_pk_bf16(x[6], x[7])};
+      b = __builtin_bit_cast(v8bf, pk);
+    } else {
+      b = __builtin_bit_cast(v8bf, in[step < 16 ? step : 0]);
+    }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+      out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step % PF16][ob], b, out[ob], 0, 0, 0);
+    load_a16<NOB>(rs, voff, soff + step * STEP_BYTES, a[step % PF16]);
+    if (step < REG_STEPS16) hook(step);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+/* delta through a ReLU (recorded mask) and straight into the next GEMM's packed B fragments */
+__device__ __forceinline__ void mask_pack(const v16f (&out)[8], const unsigned (&mk)[4], v4uu (&pk)[16]) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = ((mk[ob >> 1] >> (16 * (ob & 1) + r)) & 1u) ? out[ob][r] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pk[2 * ob][e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+      pk[2 * ob + 1][e] = cvt_pk_bf16(v[8 + 2 * e], v[8 + 2 * e + 1]);
+    }
+  }
+}
+/* element (blk, r) of a packed delta as fp32 (what the weight-gradient GEMM reads back from DELTA) */
+__device__ __forceinline__ float pk_elem(const v4uu (&pk)[16], int blk, int r) {
+  const unsigned w = pk[2 * blk + (r >> 3)][(r & 7) >> 1];
+  return __builtin_bit_cast(float, (r & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+
+/* forward: ReLU, its sign pattern (bit 16 (ob & 1) + r of mk[ob >> 1]) and the packed bf16 input of the next layer */
+__device__ __forceinline__ void relu_mask_pack(const v16f (&out)[8], unsigned (&mk)[4], v4uu (&pk)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) mk[q] = 0u;
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool p = out[ob][r] > 0.0f;
+      v[r] = p ? out[ob][r] : 0.0f;
+      mk[ob >> 1] |= p ? (1u << (16 * (ob & 1) + r)) : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pk[2 * ob][e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+      pk[2 * ob + 1][e] = cvt_pk_bf16(v[8 + 2 * e], v[8 + 2 * e + 1]);
+    }
+  }
+}
+
 __device__ __forceinline__ void relu_into(const v16f (&out)[8], v16f (&in)[8]) {
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob)
@@ -284,10 +396,44 @@ __device__ __forceinline__ void density_normals(__amdgpu_buffer_rsrc_t rs, int l
   for (int b = 0; b < 3; ++b) nrm_out[b] = -(gx[b] / ng);
 }
 
+
+/* density_normals on the bf16 chains: same VJP, deltas rounded to bf16 once per layer */
+__device__ __forceinline__ void density_normals_bf16(__amdgpu_buffer_rsrc_t rs, int lane, int h, v16f (&out)[8], v4uu (&pk)[16],
+                                                     unsigned (&M)[8][4], const float lm[3], const float lv[3], float nrm_out[3]) {
+  load_acc<8>(rs, PACKED.wd_off, h, out);
+  mask_pack(out, M[7], pk);
+  float gl[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+  for (int i = 7; i >= 0; --i) {
+    if (i == 5 || i == 0) {
+      v16f gi[3];
+      gemm_op_bf16<3, 16, 0, false>(rs, PACKED.bt_off[i == 5 ? TOP_SP5_IPE : TOP_SP0], 0, lane, h, pk, gi, nullptr);
+      ipe_vjp_accum(gi, lm, lv, h, gl);
+    }
+    if (i > 0) {
+      gemm_op_bf16<8, 16, 0, false>(rs, PACKED.bt_off[i - 1], 0, lane, h, pk, out, nullptr);
+#pragma unroll
+      for (int l = 7; l > 0; --l)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[l][q] = M[l - 1][q];
+      mask_pack(out, M[7], pk);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 3; ++b) gl[b] += __shfl_xor(gl[b], 32, 64);
+  const float gx[3] = {-gl[2], -gl[1], -gl[0]};
+  const float ng = sqrtf(fmaxf((gx[0] * gx[0] + gx[1] * gx[1]) + gx[2] * gx[2], EPS32));
+#pragma unroll
+  for (int b = 0; b < 3; ++b) nrm_out[b] = -(gx[b] / ng);
+}
+
 /* STAGE: MLP.__call__ on caller-supplied Gaussians (no resampling, no compositing): the per-sample
  * outputs of models.py:533-750 for means / covariances given per sample. */
-template <bool TRAIN, bool STAGE = false>
+/* BFC (training forward only): the MLP chains on v_mfma_f32_32x32x16_bf16 (cfg.precision = BF16 with cfg.training):
+ * activations rounded to bf16 once per layer (what ACT then holds), everything per sample fp32. */
+template <bool TRAIN, bool STAGE = false, bool BFC = false>
 __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
+  static_assert(!BFC || (TRAIN && !STAGE), "bf16 chains: training forward only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples;
@@ -315,6 +461,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   const int col = wave * 32 + sl;                /* this lane's column in X / HD */
   const float *xl = X + h * T_TILE + col;
   v16f in[8], out[8];
+  v4uu pk[16];                                   /* packed bf16 layer input (bf16 chains only; dead otherwise) */
+  const float *xc = X + col;
 
   for (int pass0 = 0; pass0 < n_tot; pass0 += T_TILE) {
     const int g = pass0 + col;                   /* sample index inside the workgroup */
@@ -363,8 +511,19 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 
     /* P2: spatial MLP (models.py:576-580) */
     unsigned M[TRAIN ? 8 : 1][4];                /* ReLU masks of the spatial layers (training) */
-    gemm_op<8, 8, false>(rs, PACKED.op[0].a_off, PACKED.op[0].b_off, lane, h, in, out, xl, PACKED.op[0].lds_steps);
-    if constexpr (TRAIN) relu_mask_into(out, in, M[7]); else relu_into(out, in);
+    auto act_hook = [&](int row0) {              /* bf16 chains: the packed layer input leaves for ACT, 8 rows per k-step */
+      return [&, hk = RowStoreHook(A.act, A.act_pitch, row0, gsx, h, save)](int t) mutable {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hk(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
+      };
+    };
+    if constexpr (BFC) {
+      gemm_op_bf16<8, 0, BF_IPE_STEPS, true>(rs, PACKED.bf_off[0], PACKED.op[0].b_off, lane, h, pk, out, xc);
+      relu_mask_pack(out, M[7], pk);
+    } else {
+      gemm_op<8, 8, false>(rs, PACKED.op[0].a_off, PACKED.op[0].b_off, lane, h, in, out, xl, PACKED.op[0].lds_steps);
+      if constexpr (TRAIN) relu_mask_into(out, in, M[7]); else relu_into(out, in);
+    }
     auto save_mask = [&](int layer, const unsigned (&mk)[4]) {
       if (save) {
 #pragma unroll
@@ -375,7 +534,12 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 #pragma unroll 1
     for (int op = 1; op < 8; ++op) {
       /* training: the layer input leaves for the ACT matrix through the store hook (one row per k-step) */
-      if constexpr (TRAIN && !STAGE)
+      if constexpr (BFC) {
+        if (op == 5) gemm_op_bf16<8, 16, BF_IPE_STEPS, true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, pk, out, xc,
+                                                            act_hook(ACT_SP + (op - 1) * WIDTH));
+        else gemm_op_bf16<8, 16, 0, true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, pk, out, xc,
+                                          act_hook(ACT_SP + (op - 1) * WIDTH));
+      } else if constexpr (TRAIN && !STAGE)
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
                             RowStoreHook(A.act, A.act_pitch, ACT_SP + (op - 1) * WIDTH, gsx, h, save));
       else
@@ -385,14 +549,17 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         for (int l = 0; l < 7; ++l)
 #pragma unroll
           for (int q = 0; q < 4; ++q) M[l][q] = M[l + 1][q];
-        relu_mask_into(out, in, M[7]);
+        if constexpr (BFC) relu_mask_pack(out, M[7], pk); else relu_mask_into(out, in, M[7]);
         if constexpr (!STAGE) { if (A.act) save_mask(op, M[7]); }
       } else relu_into(out, in);
     }
     /* P3: heads (models.py:582,613,634-645): 4 bottleneck blocks + 1 scalar block */
     {
       v16f hd[5];
-      if constexpr (TRAIN && !STAGE)
+      if constexpr (BFC)
+        gemm_op_bf16<5, 16, 0, true>(rs, PACKED.bf_off[OP_HEADS], PACKED.op[OP_HEADS].b_off, lane, h, pk, hd, xc,
+                                     act_hook(ACT_SP + 7 * WIDTH));
+      else if constexpr (TRAIN && !STAGE)
         gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0,
                             RowStoreHook(A.act, A.act_pitch, ACT_SP + 7 * WIDTH, gsx, h, save));
       else
@@ -412,7 +579,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     wave_sync();
 
     SampleHeads sh;
-    if constexpr (TRAIN) density_normals(rs, lane, h, in, out, M, lm, lv, xl, sh.normals);
+    if constexpr (BFC) density_normals_bf16(rs, lane, h, out, pk, M, lm, lv, sh.normals);
+    else if constexpr (TRAIN) density_normals(rs, lane, h, in, out, M, lm, lv, xl, sh.normals);
 
     /* P4: activations, reflection, IDE (models.py:611-686) */
     {
@@ -440,27 +608,41 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     wave_sync();
 
     /* P5: directional MLP (models.py:690-694) + rgb (699-700) */
-    gemm_op<8, 8, false>(rs, PACKED.op[9].a_off, PACKED.op[9].b_off, lane, h, in, out, xl, PACKED.op[9].lds_steps);
-    if constexpr (TRAIN && !STAGE) {
+    if constexpr (BFC) {
       unsigned mk[4];
-      relu_mask_into(out, in, mk);
+      gemm_op_bf16<8, 0, BF_DIN_STEPS, true, NoStepHook, DIR_PAD - 1>(rs, PACKED.bf_off[9], PACKED.op[9].b_off, lane, h, pk, out, xc);
+      relu_mask_pack(out, mk, pk);
       if (A.act) save_mask(8, mk);
-    } else relu_into(out, in);
+    } else {
+      gemm_op<8, 8, false>(rs, PACKED.op[9].a_off, PACKED.op[9].b_off, lane, h, in, out, xl, PACKED.op[9].lds_steps);
+      if constexpr (TRAIN && !STAGE) {
+        unsigned mk[4];
+        relu_mask_into(out, in, mk);
+        if (A.act) save_mask(8, mk);
+      } else relu_into(out, in);
+    }
 #pragma unroll 1
     for (int op = 10; op < 17; ++op) {
-      if constexpr (TRAIN && !STAGE)
+      if constexpr (BFC) {
+        if (op == 14) gemm_op_bf16<8, 16, BF_DIN_STEPS, true, decltype(act_hook(0)), DIR_PAD - 1>(
+            rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, pk, out, xc, act_hook(ACT_VD + (op - 10) * WIDTH));
+        else gemm_op_bf16<8, 16, 0, true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, pk, out, xc,
+                                          act_hook(ACT_VD + (op - 10) * WIDTH));
+      } else if constexpr (TRAIN && !STAGE)
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
                             RowStoreHook(A.act, A.act_pitch, ACT_VD + (op - 10) * WIDTH, gsx, h, save));
       else
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
       if constexpr (TRAIN && !STAGE) {
         unsigned mk[4];
-        relu_mask_into(out, in, mk);
+        if constexpr (BFC) relu_mask_pack(out, mk, pk); else relu_mask_into(out, in, mk);
         if (A.act) save_mask(op - 1, mk);
       } else relu_into(out, in);
     }
     v16f rgbv[1];
-    if constexpr (TRAIN && !STAGE)
+    if constexpr (BFC)
+      gemm_op_bf16<1, 16, 0, true>(rs, PACKED.bf_off[OP_RGB], PACKED.op[OP_RGB].b_off, lane, h, pk, rgbv, xc, act_hook(ACT_VD + 7 * WIDTH));
+    else if constexpr (TRAIN && !STAGE)
       gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0,
                           RowStoreHook(A.act, A.act_pitch, ACT_VD + 7 * WIDTH, gsx, h, save));
     else
@@ -484,6 +666,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 __global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false>(A); }
 /* training forward: + density-gradient normals (models.py:603-609) */
 __global__ __launch_bounds__(NTHREADS) void level_fwd_train_f32(const LevelArgs A) { level_fwd_f32_body<true>(A); }
+/* training forward with the MLP chains on bf16 MFMA (cfg.training && cfg.precision = REFNERF_PREC_BF16) */
+__global__ __launch_bounds__(NTHREADS) void level_fwd_train_bf16c(const LevelArgs A) { level_fwd_f32_body<true, false, true>(A); }
 /* MLP.__call__ stage entry (eval / training) */
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false, true>(A); }
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_train_f32(const LevelArgs A) { level_fwd_f32_body<true, true>(A); }

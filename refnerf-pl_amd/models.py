@@ -322,11 +322,11 @@ class _LevelFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mlp, cfg, rays, holder, sdist_in, weights_in, *params):
-        packed = mlp.packed_weights(cfg.precision)
+        packed = mlp.packed_weights(_hip.PREC_F32)       # training kernels read the f32 image (it carries the bf16 chain ops)
         res = _hip.level_forward(packed, cfg, rays, sdist_in, weights_in, history=True, save_activations=True)
         ctx.mlp, ctx.cfg, ctx.rays, ctx.packed = mlp, cfg, rays, packed
         ctx.packed_key = mlp._packed_key
-        ctx.bwd_precision = holder.get("bwd_precision", cfg.precision)
+        ctx.bwd_precision = holder.get("bwd_precision", _hip.PREC_F32)
         ctx.saved = {k: res.pop(k) if k == "activations" else res[k]
                      for k in ("sdist", "density", "rgb", "weights", "activations", "diffuse", "specular", "tint",
                                "roughness", "normals", "normals_pred")}
@@ -473,7 +473,7 @@ class Model(nn.Module):
             compute_extras=int(bool(compute_extras)), srgb_mapping=int(mlp.srgb_mapping),
             srgb_mapping_normalization=int(mlp.srgb_mapping_normalization), render_srgb_mode=mode,
             opaque_background=int(self.opaque_background), ray_shape=0 if self.ray_shape == 'cone' else 1,
-            precision=_PREC["f32"] if self.training else _PREC[prec], wgrad_mode=wgrad, anneal=float(anneal), resample_padding=float(self.resample_padding),
+            precision=_PREC[getattr(cfg, "hip_train_precision", "f32")] if self.training else _PREC[prec], wgrad_mode=wgrad, anneal=float(anneal), resample_padding=float(self.resample_padding),
             s_near=float(self.init_s_near), s_far=float(self.init_s_far), density_bias=float(mlp.density_bias),
             roughness_bias=float(mlp.roughness_bias), rgb_premultiplier=float(mlp.rgb_premultiplier),
             rgb_bias=float(mlp.rgb_bias), rgb_padding=float(mlp.rgb_padding), bg_rgb=float(bg))
@@ -533,7 +533,7 @@ class Model(nn.Module):
                 res = dict(zip(holder["keys"], outs))
             else:
                 lean = _LEAN.depth > 0 and not self.training
-                res = _hip.level_forward(mlp.packed_weights(cfg.precision), cfg, r, sdist, weights,
+                res = _hip.level_forward(mlp.packed_weights(_hip.PREC_F32 if cfg.training else cfg.precision), cfg, r, sdist, weights,
                                          history=(("rgb",) if compute_extras else ()) if lean else True)
             sdist, weights = res["sdist"], res["weights"]
 
