@@ -86,13 +86,14 @@ def cpu_baseline(blob, args, target_seconds):
                       f"eval forward, fp32, {dt:.1f} s"}
 
 
-def train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync):
+def train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync, chains="f32"):
     """Secondary figure: one full training step (training forward with density-gradient
     normals + saved layer inputs, the three Ref-NeRF losses, HIP backward + weight-gradient GEMM, gradient
     all-reduce over the ranks, Adam step) on the same batch; fp32 MFMA chains, the weight-gradient GEMM on
     split-bf16 MFMA at fp32 accuracy (Config.hip_wgrad_mode)."""
     from refnerf_pl_amd import distributed, synthetic, train_utils, utils
     model.train()
+    cfg.hip_train_precision = cfg.hip_bwd_precision = chains      # 'f32' (parity mode) | 'bf16' (bf16 MFMA chains)
     gt = synthetic.target_rgb(args.rays, seed=7 + rank)
     batch = utils.Batch(rays=rays, rgb=gt)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
@@ -119,14 +120,16 @@ def train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     model.eval()
+    cfg.hip_train_precision = cfg.hip_bwd_precision = "f32"
     assert torch.isfinite(loss.detach()).all()
     rate = world * args.rays * args.samples * 2 * n / el
     tf = rate / world * TRAIN_FLOP_PER_SAMPLE / 1e12
     return {"value": rate, "unit": "ray-samples/s (fwd+bwd+Adam)", "ms_per_step": 1e3 * el / n, "steps": n,
-            "dtype": "f32", "wgrad": getattr(cfg, "hip_wgrad_mode", "bf16x3"), "loss": float(loss.detach()),
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
-                         "frac": tf / PEAK_TFLOPS["f32"],
-                         "note": "whole step incl. losses, optimiser and weight re-pack; algorithmic 7,651,840 FLOP/ray-sample"}}
+            "dtype": chains, "wgrad": getattr(cfg, "hip_wgrad_mode", "bf16x3"), "loss": float(loss.detach()),
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[chains], "unit": "TFLOP/s",
+                         "frac": tf / PEAK_TFLOPS[chains],
+                         "note": "whole step incl. losses, optimiser and weight re-pack; algorithmic 7,651,840 FLOP/ray-sample; "
+                                 "the weight-gradient GEMM runs on split-bf16 MFMA in both modes and is HBM-bound"}}
 
 
 def main():
@@ -260,7 +263,8 @@ def main():
         line["llff_image_render_ms"] = 1e3 * (time.perf_counter() - t0)
         assert rendering["rgb"].shape == (756, 1008, 3)
     if not args.no_train:
-        line["train_step"] = train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync)
+        line["train_step"] = train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync, "f32")
+        line["train_step_bf16"] = train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync, "bf16")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(blob, args, args.cpu_seconds)
     if rank == 0:

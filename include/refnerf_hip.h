@@ -180,7 +180,9 @@ typedef struct refnerf_level_grads {
  * (what autograd saves for nn.Linear in the reference): d_activations is a
  * caller-owned buffer of refnerf_activation_workspace_bytes(R, N) bytes
  * (18.1 KB per ray-sample) that must stay untouched until the level's
- * refnerf_level_backward has run.  cfg->training must be 1. */
+ * refnerf_level_backward has run.  cfg->training must be 1.  d_packed is the REFNERF_PREC_F32 image;
+ * cfg->precision = REFNERF_PREC_BF16 runs the MLP chains (and the density-normal VJP) on bf16 MFMA with the
+ * activations rounded to bf16 once per layer (RGB within 1e-4 of the f32 mode); REFNERF_PREC_F32 is the parity mode. */
 size_t refnerf_activation_workspace_bytes(int32_t R, int32_t n_samples);
 int refnerf_level_forward_train(const void *d_packed, const refnerf_level_cfg *cfg,
                                 const refnerf_rays *rays, int32_t R,

@@ -16,7 +16,8 @@ src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 KERNELS = {"level_fwd_bf16": "rn::level_fwd_bf16", "level_fwd_f32": "rn::level_fwd_f32",
            "level_fwd_train_f32": "rn::level_fwd_train_f32", "level_bwd_f32": "rn::level_bwd_f32",
-           "wgrad_kernel": "rn::wgrad_kernel", "wgrad_bf16x3_kernel": "rn::wgrad_bf16x3_kernel"}
+           "wgrad_kernel": "rn::wgrad_kernel", "wgrad_bf16x3_kernel": "rn::wgrad_bf16x3_kernel", "level_bwd_bf16c": "rn::level_bwd_bf16c",
+           "level_fwd_train_bf16c": "rn::level_fwd_train_bf16c"}
 
 rows = list(csv.reader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
 with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as f:
