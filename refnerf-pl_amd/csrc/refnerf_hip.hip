@@ -134,7 +134,7 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
     const int steps = (t == TOP_HEADS) ? BT_HEADS_STEPS : BT_CHAIN_STEPS;
     __bf16 *dst = reinterpret_cast<__bf16 *>(out + PACKED.bt_off[t]);
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < steps * 64 * 8 * 8; idx += gridDim.x * blockDim.x) {
-      const int e = idx & 7, ob = (idx >> 3) & 7, lane = (idx >> 6) & 63, st = idx >> 12;
+      const int e = idx & 7, lane = (idx >> 3) & 63, ob = (idx >> 9) & 7, st = idx >> 12;   /* [step][ob][lane][8] */
       const int h = lane >> 5, in_row = ob * 32 + (lane & 31);
       float v = 0.0f;
       if (ob < o.nob) {
@@ -158,7 +158,7 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
     const int valid_k = (fo == 0 || fo == 5) ? IPE_DIM : DIR_IN;
     __bf16 *dst = reinterpret_cast<__bf16 *>(out + PACKED.bf_off[fo]);
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < steps * 64 * 8 * 8; idx += gridDim.x * blockDim.x) {
-      const int e = idx & 7, ob = (idx >> 3) & 7, lane = (idx >> 6) & 63, st = idx >> 12;
+      const int e = idx & 7, lane = (idx >> 3) & 63, ob = (idx >> 9) & 7, st = idx >> 12;   /* [step][ob][lane][8] */
       const int h = lane >> 5, row = ob * 32 + (lane & 31);
       float v = 0.0f;
       if (ob < o.nob) {
@@ -625,7 +625,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     HIP_TRY(hipMemcpy(hbuf, a.prof, sizeof(hbuf), hipMemcpyDeviceToHost));
     for (int w = 0; w < 4; ++w) {
       fprintf(stderr, "[prof bwd] wave %d:", w);
-      for (int sl = 1; sl <= 7; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
+      for (int sl = 1; sl <= 10; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
       fprintf(stderr, "\n");
     }
   }

@@ -90,8 +90,8 @@ constexpr int DIN_BLOCKS = 7;               /* 201 dir inputs -> 224 rows */
 struct Op { int nob; int stride; int reg_steps; int lds_k; int lds_steps; int a_off; int b_off; };
 struct TopSrc { int fwd_op; int col0; };    /* forward op whose weight is transposed, first input column */
 /* bf16 copies of the transposed ops for the bf16-chain backward (cfg.precision = REFNERF_PREC_BF16 in
- * refnerf_level_backward): A fragments of v_mfma_f32_32x32x16_bf16, [k-step][lane][ob (stride 8)][8 bf16], i.e. per lane
- * and k-step the fragments of all output blocks contiguous (8 x 16 B), k order = the accumulator order of the
+ * refnerf_level_backward): A fragments of v_mfma_f32_32x32x16_bf16, [k-step][ob (stride 8)][lane][8 bf16], i.e. one
+ * 1 KB-contiguous load per (k-step, output block), k order = the accumulator order of the
  * producing MFMA (BT_CHAIN_STEPS = 16 steps: slot (t, h, e) = unit 32 (t >> 1) + row(8 (t & 1) + e, h)); the head
  * block is read from the fp32 LDS tile in plain order (BT_HEADS_STEPS = 9: k = 16 t + 8 h + e, rows >= 139 zero).
  * Offsets in floats inside the same image. */

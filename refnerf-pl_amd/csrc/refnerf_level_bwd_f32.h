@@ -331,9 +331,12 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
         if (i == 5) { gemm_op_bf16<DIN_BLOCKS, 16, 0, false>(rs, PACKED.bt_off[TOP_VD5_DIN], 0, lane, h, pk, gd, nullptr); park_din(5); }
         if (i == 0) { gemm_op_bf16<DIN_BLOCKS, 16, 0, false>(rs, PACKED.bt_off[TOP_VD0], 0, lane, h, pk, gd, nullptr, hook); park_din(0); }
         if (i > 0) {
+          if (i == 7) RN_STAMP(A, 8);
           gemm_op_bf16<8, 16, 0, false>(rs, PACKED.bt_off[TOP_VD1 + i - 1], 0, lane, h, pk, out, nullptr, hook);
+          if (i == 7) RN_STAMP(A, 9);
           shift_masks(M);
           mask_pack(out, M[7], pk);
+          if (i == 7) RN_STAMP(A, 10);
         }
       } else {
         if (i == 5 || i == 0) {

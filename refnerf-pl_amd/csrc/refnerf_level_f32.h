@@ -182,9 +182,11 @@ __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, in
 constexpr int PF16 = REFNERF_PF16;
 template <int NOB>
 __device__ __forceinline__ void load_a16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, v8bf (&a)[NOB]) {
+  /* image layout [k-step][ob][lane][8 bf16]: one instruction = 64 lanes x 16 B = 1 KB contiguous (8 cache lines); the
+   * first layout, [k-step][lane][ob], made every instruction touch 64 lines (one per lane) and the chains TA-bound */
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob)
-    a[ob] = __builtin_bit_cast(v8bf, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ob * 16, soff, 0));
+    a[ob] = __builtin_bit_cast(v8bf, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + ob * 1024, 0));
 }
 
 /* out[ob] = (bias +) W-block x B over REG_STEPS k-steps of packed register fragments `in` (a layer's input / delta in
@@ -196,7 +198,7 @@ __device__ __forceinline__ void gemm_op_bf16(__amdgpu_buffer_rsrc_t rs, int a_of
                                              const v4uu (&in)[16], v16f (&out)[NOB], const float *xc, Hook hook = Hook()) {
   constexpr int STEPS = REG_STEPS16 + LDS_STEPS;
   constexpr int STEP_BYTES = BT_STEP_FLOATS * 4;
-  const int voff = lane * 128;
+  const int voff = lane * 16;
   int soff = a_off * 4;
   v8bf a[PF16][NOB];
 #pragma unroll

@@ -16,7 +16,9 @@ def child(lib, R, N):
     configs.clear_config()
     configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", "refnerf_blender.gin")], [
         f"Model.num_prop_samples = {N}", f"Model.num_nerf_samples = {N}", f"Config.batch_size = {R}",
-        "Config.hip_precision = '%s'" % os.environ.get("AB_PREC", "f32")])
+        "Config.hip_precision = '%s'" % os.environ.get("AB_PREC", "f32"),
+        "Config.hip_train_precision = '%s'" % os.environ.get("AB_TRAIN_PREC", "f32"),
+        "Config.hip_bwd_precision = '%s'" % os.environ.get("AB_TRAIN_PREC", "f32")])
     cfg = configs.Config()
     model = models.construct_model(None, cfg).to(dev)
     model.nerf_mlp.load_flat_params(synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0))
