@@ -169,15 +169,15 @@ __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, in
  * trunks, the two 201-row input blocks and the head block on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), deltas
  * rounded to bf16 once per layer.  Same kernel structure as the fp32 chains -- every wave streams its own A
  * fragments from L2 / L1 through a register ring, no LDS staging, no barriers: 1 KB per MFMA and wave is
- * 128 B/clk per CU at full MFMA rate, twice what the L1 delivers.  Measured: a layer takes ~40 k cycles instead of
- * the fp32 chains' 65 k (its 128 MFMAs would need 4 k): the loop is bound by the latency of the A stream -- a
- * fragment is consumed every 32 cycles, the 96-register ring covers 768 cycles, an L2 hit takes ~2000, and a
- * deeper ring spills (measured: 5 / 7 steps are slower); a per-layer barrier to keep the 4 waves inside the L1
- * window does not help either.  Sharing the stream through LDS (the eval kernel's ring) is the next step.
+ * 128 B/clk per CU at full MFMA rate, twice what the L1 delivers.  The image is laid out [k-step][block][lane][8 bf16]
+ * so that every A-fragment load is one contiguous KB (a first [k-step][lane][block] layout touched 64 cache lines per
+ * instruction and made the chains address-bound: 35 k cycles per layer).  Measured now: ~20 k cycles per chain layer
+ * against 65 k for the fp32 chains (its 128 MFMAs need 4 k); a 2-step register ring is best (deeper rings spill), barriers
+ * that keep the 4 waves in the same L1 window change nothing.
  * The head / rgb recompute and everything per sample stay fp32.
  * ------------------------------------------------------------------------------------------------ */
 #ifndef REFNERF_PF16
-#define REFNERF_PF16 3
+#define REFNERF_PF16 2
 #endif
 constexpr int PF16 = REFNERF_PF16;
 template <int NOB>
