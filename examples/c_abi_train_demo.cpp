@@ -119,7 +119,7 @@ int main(int argc, char **argv) {
   void *d_ws = nullptr;
   HIP_OK(hipMalloc(&d_ws, ws_bytes));
   for (int l = 1; l >= 0; --l) {
-    refnerf_level_saved saved = {d_sd[l], d_dens[l], d_hrgb[l], d_w[l], d_act[l]};
+    refnerf_level_saved saved = {d_sd[l], d_dens[l], d_hrgb[l], d_w[l], d_act[l], REFNERF_ACT_F32};
     refnerf_level_grads seeds = {};
     seeds.d_g_r_rgb = d_g_rgb[l];
     RN_OK(refnerf_level_backward(d_packed, &cfg[l], &rays, R, &saved, &seeds, d_grads, d_ws, ws_bytes, nullptr));

@@ -48,6 +48,10 @@ enum {
                                v_mfma_f32_32x32x16_bf16, fp32 accumulate: 2^-16 per product, HBM-bound (default) */
 };
 
+/* element type of the saved layer inputs: fp32 rows (f32 training forward) or bf16 rows (bf16-chain training forward,
+ * whose activations are bf16-exact: half the stream); the 128 rows of ReLU mask words are 32-bit in both */
+enum { REFNERF_ACT_F32 = 0, REFNERF_ACT_BF16 = 1 };
+
 enum { REFNERF_SRGB_NONE = 0, REFNERF_SRGB_LINEAR = 1, REFNERF_SRGB_NORM_LINEAR = 2,
        REFNERF_SRGB_SRGB = 3, REFNERF_SRGB_NORM_SRGB = 4 };
 
@@ -155,6 +159,7 @@ typedef struct refnerf_level_saved {
   const float *d_rgb;       /* [R,N,3]                             */
   const float *d_weights;   /* [R,N]                               */
   const void *d_activations; /* the buffer refnerf_level_forward_train filled */
+  int32_t activations_format; /* REFNERF_ACT_*: how that forward wrote it (its cfg->precision)              */
 } refnerf_level_saved;
 
 typedef struct refnerf_level_grads {

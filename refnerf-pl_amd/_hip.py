@@ -47,7 +47,8 @@ class LevelOut(C.Structure):
 
 
 class LevelSaved(C.Structure):
-    _fields_ = [(n, _FP) for n in ("d_sdist", "d_density", "d_rgb", "d_weights", "d_activations")]
+    _fields_ = [(n, _FP) for n in ("d_sdist", "d_density", "d_rgb", "d_weights", "d_activations")] + [
+        ("activations_format", C.c_int32)]
 
 
 class LevelGrads(C.Structure):
@@ -216,6 +217,7 @@ def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, histo
         check(lib().refnerf_level_forward_train(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out),
                                                 ptr(act), act.numel(), stream_ptr()))
         res["activations"] = act
+        res["activations_format"] = int(cfg.precision)                   # REFNERF_ACT_F32 / REFNERF_ACT_BF16
     else:
         check(lib().refnerf_level_forward(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out), stream_ptr()))
     return res
@@ -301,6 +303,7 @@ def level_backward(packed, cfg: LevelCfg, rays: dict, saved: dict, g_r_rgb, g_we
     if saved.get("activations") is None:
         raise ValueError("level_backward needs the activations saved by level_forward(..., save_activations=True)")
     sv.d_activations = saved["activations"].data_ptr()
+    sv.activations_format = int(saved.get("activations_format", 0))      # REFNERF_ACT_*: the forward's precision
     gr = LevelGrads()
     for name, t in (("d_g_r_rgb", g_r_rgb), ("d_g_weights", g_weights), ("d_g_normals_pred", g_normals_pred),
                     ("d_g_r_acc", g_r_acc), ("d_g_r_distance", g_r_distance)) + tuple(

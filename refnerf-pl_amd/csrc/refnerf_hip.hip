@@ -589,7 +589,10 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     (void)hipFuncSetAttribute((const void *)rn::level_bwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)rn::level_bwd_bf16c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)rn::wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4);
-    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rn::WB_LDS);
+    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::WB_LDS);
+    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::WB_LDS);
+    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::WB_LDS);
+    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::WB_LDS);
   });
   char *ws = (char *)d_workspace;
   rn::BwdArgs a;
@@ -606,6 +609,12 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   a.act = (const float *)saved->d_activations;
   a.delta = (float *)(ws + plan.delta_off);
   a.pitch = plan.pitch;
+  const bool act16 = saved->activations_format == REFNERF_ACT_BF16, del16 = cfg->precision == REFNERF_PREC_BF16 && (REFNERF_DELTA16 != 0);
+  if (saved->activations_format != REFNERF_ACT_F32 && saved->activations_format != REFNERF_ACT_BF16)
+    return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown activations_format%s");
+  if ((act16 || del16) && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
+    return fail(REFNERF_EUNSUPPORTED, "bf16 activation / delta rows need wgrad_mode = REFNERF_WGRAD_BF16X3%s");
+  a.act16 = act16 ? 1 : 0;
   a.prof = nullptr;
   if (getenv("REFNERF_PROF")) {
     static long long *d_prof = nullptr;
@@ -630,15 +639,23 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     }
   }
   if (plan.pitch > plan.S) {   /* pad columns of both operand matrices must read as zero in the wgrad GEMM */
-    hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(a.act), rn::ACT_ROWS, plan.pitch, plan.S);
-    hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, rn::DEL_ROWS, plan.pitch, plan.S);
+    if (act16) hipLaunchKernelGGL(rn::wgrad_zero_tail16, dim3(256), dim3(256), 0, st, (unsigned short *)const_cast<float *>(a.act), rn::ACT_ROWS, plan.pitch, plan.S);
+    else hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(a.act), rn::ACT_ROWS, plan.pitch, plan.S);
+    if (del16) hipLaunchKernelGGL(rn::wgrad_zero_tail16, dim3(256), dim3(256), 0, st, (unsigned short *)a.delta, rn::DEL_ROWS, plan.pitch, plan.S);
+    else hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, rn::DEL_ROWS, plan.pitch, plan.S);
   }
   rn::WgradArgs w;
   w.act = a.act; w.delta = a.delta; w.pitch = plan.pitch; w.S = plan.S; w.k_per_slice = plan.k_per_slice;
   w.part = (float *)(ws + plan.part_off);
   const int slices = (int)((plan.S + plan.k_per_slice - 1) / plan.k_per_slice);
   if (cfg->wgrad_mode == REFNERF_WGRAD_BF16X3)
-    hipLaunchKernelGGL(rn::wgrad_bf16x3_kernel, dim3(8 * ((slices + 7) / 8) * rn::WJOBS.tiles), dim3(256), rn::WB_LDS, st, w, slices);
+  {
+    const dim3 wg_grid(8 * ((slices + 7) / 8) * rn::WJOBS.tiles);
+    if (del16 && act16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, true>), wg_grid, dim3(256), rn::WB_LDS, st, w, slices);
+    else if (del16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, false>), wg_grid, dim3(256), rn::WB_LDS, st, w, slices);
+    else if (act16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<false, true>), wg_grid, dim3(256), rn::WB_LDS, st, w, slices);
+    else hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<false, false>), wg_grid, dim3(256), rn::WB_LDS, st, w, slices);
+  }
   else
     hipLaunchKernelGGL(rn::wgrad_kernel, dim3(rn::WJOBS.tiles, slices), dim3(256), (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4, st, w);
   HIP_TRY(hipGetLastError());

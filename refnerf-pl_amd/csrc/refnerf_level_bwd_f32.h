@@ -52,6 +52,7 @@ struct BwdArgs {
   const float *act;         /* [ACT_ROWS][pitch] layer inputs saved by the training forward */
   float *delta;             /* [DEL_ROWS][pitch] written here                       */
   long long pitch;
+  int act16;                /* ACT holds bf16 rows (written by the bf16-chain training forward), masks stay 32-bit */
   long long *prof;          /* debug: per-phase cycle stamps of workgroup 0 (REFNERF_PROF=1), else NULL */
 };
 
@@ -61,6 +62,10 @@ struct BwdArgs {
 #define REFNERF_PF_BWD 3
 #endif
 constexpr int PF_BWD = REFNERF_PF_BWD;
+/* DELTA as bf16 rows in the bf16-chain backward (the chain deltas are bf16-exact; the head / rgb rows get rounded) */
+#ifndef REFNERF_DELTA16
+#define REFNERF_DELTA16 1
+#endif
 constexpr int NGS = 7;      /* per-sample upstream gradients in LDS: density, rgb[3], n_pred[3] */
 
 /* Per-ray part of the backward (one wave per ray): rendering gradient through
@@ -170,6 +175,7 @@ __device__ __forceinline__ void shift_masks(unsigned (&M)[8][4]) {
 
 template <bool BF>
 __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
+  constexpr bool D16 = BF && (REFNERF_DELTA16 != 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples;
@@ -207,7 +213,8 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
     /* ===== the few forward values the backward needs, from the saved x7 / v7 ===== */
-    load_rows<8>(A.act, pitch, ACT_SP + 7 * WIDTH, gs, h, in);              /* x7: input of the heads */
+    if (A.act16) load_rows<8, true>(A.act, pitch, ACT_SP + 7 * WIDTH, gs, h, in);   /* x7: input of the heads */
+    else load_rows<8>(A.act, pitch, ACT_SP + 7 * WIDTH, gs, h, in);
     {
       v16f hd[5];
       gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0);
@@ -218,7 +225,8 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
       }
     }
     RN_STAMP(A, 2);
-    load_rows<8>(A.act, pitch, ACT_VD + 7 * WIDTH, gs, h, in);              /* v7: input of the rgb layer */
+    if (A.act16) load_rows<8, true>(A.act, pitch, ACT_VD + 7 * WIDTH, gs, h, in);   /* v7: input of the rgb layer */
+    else load_rows<8>(A.act, pitch, ACT_VD + 7 * WIDTH, gs, h, in);
     wave_sync();
     SampleHeads sh;
     float raw_density, raw_rough, raw_tint[3];
@@ -290,7 +298,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     }
     if (valid && h == 0) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) store_row1(A.delta, pitch, DEL_RGB + i, gs, g_raw_rgb[i]);
+      for (int i = 0; i < 3; ++i) store_row1<D16>(A.delta, pitch, DEL_RGB + i, gs, g_raw_rgb[i]);
     }
     /* ---- seed of the directional chain: W_rgb^T g_raw_rgb through the last ReLU ---- */
 #pragma unroll
@@ -323,7 +331,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     for (int i = 7; i >= 0; --i) {
       /* delta_i leaves through the store hook of the GEMM that consumes it (one row per k-step) */
       if constexpr (BF) {
-        RowStoreHook sh_(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid);
+        RowStoreHookT<D16> sh_(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid);
         auto hook = [&](int t) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) sh_(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
@@ -355,7 +363,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     }
     RN_STAMP(A, 5);
     /* X rows 0..127: dL/d bottleneck (= head rows 0..127), rows 128..200: dL/d (IDE, n.v) */
-    store_rows<4>(A.delta, pitch, DEL_HEADS, gs, h, valid, gd);
+    store_rows<4, D16>(A.delta, pitch, DEL_HEADS, gs, h, valid, gd);
     wave_sync();
     /* ---- IDE, reflection, predicted normal, head activations (models.py:611-686) ---- */
     {
@@ -392,7 +400,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
 #pragma unroll
         for (int i = 0; i < 11; ++i) {
           X[(HROW_DENSITY + i) * T_TILE + col] = hrow[i];
-          if (valid) store_row1(A.delta, pitch, DEL_HEADS + HROW_DENSITY + i, gs, hrow[i]);
+          if (valid) store_row1<D16>(A.delta, pitch, DEL_HEADS + HROW_DENSITY + i, gs, hrow[i]);
         }
       } else {
 #pragma unroll
@@ -409,7 +417,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
 #pragma unroll 1
       for (int i = 7; i >= 0; --i) {
         if (i > 0) {
-          RowStoreHook sh_(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid);
+          RowStoreHookT<D16> sh_(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid);
           gemm_op_bf16<8, 16, 0, false>(rs, PACKED.bt_off[i - 1], 0, lane, h, pk, out, nullptr, [&](int t) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) sh_(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
@@ -421,7 +429,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
           for (int blk = 0; blk < 8; ++blk)
 #pragma unroll
             for (int r = 0; r < 16; ++r) in[blk][r] = pk_elem(pk, blk, r);
-          store_rows<8>(A.delta, pitch, DEL_SP, gs, h, valid, in);
+          store_rows<8, D16>(A.delta, pitch, DEL_SP, gs, h, valid, in);
         }
       }
     } else {

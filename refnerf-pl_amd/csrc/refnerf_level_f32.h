@@ -86,18 +86,21 @@ struct NoStepHook {
  * cycles of wait per layer in the backward.  Spread over the GEMM the stores ride under the MFMAs.
  * Rows follow the accumulator layout: row(r) = (r&3) + 8*(r>>2) (+4h in `voff`), i.e. +1,+1,+1,+5 rows
  * per step; the buffer descriptor is re-based every 32 rows so that 32-bit offsets suffice for any pitch. */
-struct RowStoreHook {
+/* H16: the matrix holds bf16 rows (the bf16-chain kernels: the values are bf16-exact, the stream is half as large) */
+template <bool H16 = false>
+struct RowStoreHookT {
   char *base;                 /* matrix + row0 * pitch (wave-uniform) */
   unsigned long long blk_bytes;   /* 32 rows */
   unsigned voff;              /* ((4h) * pitch + column) * 4, or 0xfffffff0 for lanes that must not store */
   unsigned p1, p5;            /* 1 and 5 rows in bytes */
   unsigned soff;
   __amdgpu_buffer_rsrc_t rs;
-  __device__ __forceinline__ RowStoreHook(float *matrix, long long pitch, int row0, size_t col, int h, bool store) {
-    base = reinterpret_cast<char *>(matrix + (long long)row0 * pitch);
-    blk_bytes = (unsigned long long)pitch * 128ull;
-    voff = store ? (unsigned)(((long long)(4 * h) * pitch + (long long)col) * 4) : 0xfffffff0u;
-    p1 = (unsigned)(pitch * 4);
+  static constexpr int ESZ = H16 ? 2 : 4;
+  __device__ __forceinline__ RowStoreHookT(float *matrix, long long pitch, int row0, size_t col, int h, bool store) {
+    base = reinterpret_cast<char *>(matrix) + (long long)row0 * pitch * ESZ;
+    blk_bytes = (unsigned long long)pitch * 32ull * ESZ;
+    voff = store ? (unsigned)(((long long)(4 * h) * pitch + (long long)col) * ESZ) : 0xfffffff0u;
+    p1 = (unsigned)(pitch * ESZ);
     p5 = 5u * p1;
     soff = 0;
     rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x80000000, 0x00020000);
@@ -108,11 +111,13 @@ struct RowStoreHook {
       soff = 0;
     }
 #ifndef REFNERF_EXPERIMENT_NO_STREAM   /* timing experiment only: drops the stream (wrong gradients) */
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, b), rs, voff, soff, REFNERF_STREAM_AUX);
+    if constexpr (H16) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(__builtin_bit_cast(unsigned, b) >> 16), rs, voff, soff, REFNERF_STREAM_AUX);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, b), rs, voff, soff, REFNERF_STREAM_AUX);
 #endif
     soff += ((step & 3) == 3) ? p5 : p1;
   }
 };
+typedef RowStoreHookT<false> RowStoreHook;
 
 template <int NOB, int STRIDE, bool HAS_REG, bool BIAS = true, typename Hook = NoStepHook, int PF = rn::PF>
 __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
@@ -294,32 +299,49 @@ __device__ __forceinline__ void stream_store(float *p, float v) {
   *p = v;
 #endif
 }
-template <int NB>
+/* element `idx` of a matrix of fp32 or (H16) bf16 rows */
+template <bool H16>
+__device__ __forceinline__ void stream_store_e(float *base, long long idx, float v) {
+  if constexpr (H16) {
+    unsigned short *q = reinterpret_cast<unsigned short *>(base) + idx;
+    const unsigned short w = __builtin_bit_cast(unsigned short, (__bf16)v);
+#if REFNERF_STREAM_AUX
+    __builtin_nontemporal_store(w, q);
+#else
+    *q = w;
+#endif
+  } else stream_store(base + idx, v);
+}
+template <bool H16>
+__device__ __forceinline__ float load_e(const float *base, long long idx) {
+  if constexpr (H16) return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short *>(base)[idx] << 16);
+  else return base[idx];
+}
+template <int NB, bool H16 = false>
 __device__ __forceinline__ void store_rows(float *base, long long pitch, int row0, size_t gs, int h, bool valid, const v16f *x) {
-  char *ub = reinterpret_cast<char *>(base + (long long)row0 * pitch);
-  const unsigned voff = (unsigned)(((long long)(4 * h) * pitch + (long long)gs) * 4);
+  const long long e0 = (long long)(row0 + 4 * h) * pitch + (long long)gs;
   if (valid) {
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        stream_store(reinterpret_cast<float *>(ub + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch * 4 + voff), x[blk][r]);
+        stream_store_e<H16>(base, e0 + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch, x[blk][r]);
   }
 }
+template <bool H16 = false>
 __device__ __forceinline__ void store_row1(float *base, long long pitch, int row, size_t gs, float v) {
-  stream_store(base + (long long)row * pitch + (long long)gs, v);
+  stream_store_e<H16>(base, (long long)row * pitch + (long long)gs, v);
 }
 
 /* the same rows read back (the accumulator-layout image of a saved activation block) */
-template <int NB>
+template <int NB, bool H16 = false>
 __device__ __forceinline__ void load_rows(const float *base, long long pitch, int row0, size_t gs, int h, v16f *x) {
-  const char *ub = reinterpret_cast<const char *>(base + (long long)row0 * pitch);
-  const unsigned voff = (unsigned)(((long long)(4 * h) * pitch + (long long)gs) * 4);
+  const long long e0 = (long long)(row0 + 4 * h) * pitch + (long long)gs;
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      x[blk][r] = *reinterpret_cast<const float *>(ub + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch * 4 + voff);
+      x[blk][r] = load_e<H16>(base, e0 + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch);
 }
 
 /* ReLU that also records the sign pattern: bit (16*(ob&1) + r) of mk[ob>>1]. */
@@ -506,7 +528,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         for (int b = 0; b < 3; ++b) {
           const float fe = ipe_feature(lm[b], lv[b], j, h);
           X[(48 * h + j * 3 + b) * T_TILE + col] = fe;
-          if constexpr (TRAIN && !STAGE) { if (save) store_row1(A.act, A.act_pitch, ACT_IPE + 48 * h + j * 3 + b, gsx, fe); }
+          if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, A.act_pitch, ACT_IPE + 48 * h + j * 3 + b, gsx, fe); }
         }
     }
     wave_sync();
@@ -514,7 +536,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     /* P2: spatial MLP (models.py:576-580) */
     unsigned M[TRAIN ? 8 : 1][4];                /* ReLU masks of the spatial layers (training) */
     auto act_hook = [&](int row0) {              /* bf16 chains: the packed layer input leaves for ACT, 8 rows per k-step */
-      return [&, hk = RowStoreHook(A.act, A.act_pitch, row0, gsx, h, save)](int t) mutable {
+      return [&, hk = RowStoreHookT<true>(A.act, A.act_pitch, row0, gsx, h, save)](int t) mutable {
 #pragma unroll
         for (int e = 0; e < 8; ++e) hk(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
       };
@@ -576,7 +598,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < HD_ROWS) HD[row * T_TILE + col] = hd[4][r];
       }
-      if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<4>(A.act, A.act_pitch, ACT_DIN, gsx, h, save, hd); }
+      if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<4, BFC>(A.act, A.act_pitch, ACT_DIN, gsx, h, save, hd); }
     }
     wave_sync();
 
@@ -597,11 +619,11 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       float *xi = X + (BNECK + IDE_TERMS * h) * T_TILE + col;
       ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) {
         xi[q * T_TILE] = val;
-        if constexpr (TRAIN && !STAGE) { if (save) store_row1(A.act, A.act_pitch, ACT_DIN + BNECK + IDE_TERMS * h + q, gsx, val); }
+        if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, A.act_pitch, ACT_DIN + BNECK + IDE_TERMS * h + q, gsx, val); }
       });
       if (h == 0) {
         X[(BNECK + IDE_DIM) * T_TILE + col] = sh.dot;
-        if constexpr (TRAIN && !STAGE) { if (save) store_row1(A.act, A.act_pitch, ACT_DIN + BNECK + IDE_DIM, gsx, sh.dot); }
+        if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, A.act_pitch, ACT_DIN + BNECK + IDE_DIM, gsx, sh.dot); }
       } else {
 #pragma unroll
         for (int q = DIR_IN; q < DIR_PAD; ++q) X[q * T_TILE + col] = 0.0f;

@@ -37,6 +37,8 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, uns
 }
 
 /* grid = 8 * ceil(slices / 8) * WJOBS.tiles workgroups of 256 threads (waves 2x2 over the 128x128 tile) */
+/* D16 / A16: that operand is a matrix of bf16 rows (written by the bf16-chain kernels): read as is, its low half is 0 */
+template <bool D16, bool A16>
 __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, int slices) {
   extern __shared__ __attribute__((aligned(16))) char wbs[];
   char *Dh = wbs, *Dl = wbs + WB_TILE, *Ah = wbs + 2 * WB_TILE, *Al = wbs + 3 * WB_TILE;
@@ -68,24 +70,34 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
   float bsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
   const int lrow = tid >> 4, lc4 = (tid & 15) * 4;    /* loader: rows lrow + 16p (p = 0..7), 4 samples at lc4 */
-  const float *dp[8], *ap[8];
+  constexpr int DSZ = D16 ? 2 : 4, ASZ = A16 ? 2 : 4;
+  const char *dp[8], *ap[8];
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int orow = tm * WG_TM + lrow + 16 * p, irow = tn * WG_TN + lrow + 16 * p;
-    dp[p] = (orow < J.n_out) ? A.delta + (long long)(J.d_row + orow) * A.pitch + lc4 : nullptr;
-    ap[p] = (irow < J.n_in) ? A.act + (long long)(J.a_row + irow) * A.pitch + lc4 : nullptr;
+    dp[p] = (orow < J.n_out) ? reinterpret_cast<const char *>(A.delta) + ((long long)(J.d_row + orow) * A.pitch + lc4) * DSZ : nullptr;
+    ap[p] = (irow < J.n_in) ? reinterpret_cast<const char *>(A.act) + ((long long)(J.a_row + irow) * A.pitch + lc4) * ASZ : nullptr;
   }
-  v4f dv[8], av[8];
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  /* 4 samples of one row as raw dwords: fp32 (16 B) or bf16 (8 B: two packed pairs in [0], [1]).  Kept as integers:
+   * a packed bf16 pair is not a well-formed float (it may look like a denormal) and must not pass through float registers'
+   * canonicalisation */
+  v4u dv[8], av[8];
   auto fetch = [&](long long k0) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      v4f x = {0.0f, 0.0f, 0.0f, 0.0f}, y = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (dp[p]) x = *reinterpret_cast<const v4f *>(dp[p] + k0);
-      if (ap[p]) y = *reinterpret_cast<const v4f *>(ap[p] + k0);
+      v4u x = {0u, 0u, 0u, 0u}, y = {0u, 0u, 0u, 0u};
+      if (dp[p]) {
+        if constexpr (D16) { const v2u q = *reinterpret_cast<const v2u *>(dp[p] + k0 * 2); x[0] = q[0]; x[1] = q[1]; }
+        else x = *reinterpret_cast<const v4u *>(dp[p] + k0 * 4);
+      }
+      if (ap[p]) {
+        if constexpr (A16) { const v2u q = *reinterpret_cast<const v2u *>(ap[p] + k0 * 2); y[0] = q[0]; y[1] = q[1]; }
+        else y = *reinterpret_cast<const v4u *>(ap[p] + k0 * 4);
+      }
       dv[p] = x; av[p] = y;
     }
   };
-  typedef unsigned v2u __attribute__((ext_vector_type(2)));
   if (k_begin < k_end) fetch(k_begin);
   for (long long k0 = k_begin; k0 < k_end; k0 += WB_KT) {
     __syncthreads();                                   /* previous tile fully consumed */
@@ -93,15 +105,26 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
     for (int p = 0; p < 8; ++p) {
       const int off = (lrow + 16 * p) * WB_ROW + lc4 * 2;
       unsigned h0, l0, h1, l1;
-      split_pair(dv[p][0], dv[p][1], h0, l0);
-      split_pair(dv[p][2], dv[p][3], h1, l1);
+      auto f = [](unsigned u) { return __builtin_bit_cast(float, u); };
+      if constexpr (D16) {
+        h0 = dv[p][0]; h1 = dv[p][1]; l0 = 0u; l1 = 0u;
+        bsum[p] += (__builtin_bit_cast(float, h0 << 16) + __builtin_bit_cast(float, h0 & 0xffff0000u)) +
+                   (__builtin_bit_cast(float, h1 << 16) + __builtin_bit_cast(float, h1 & 0xffff0000u));
+      } else {
+        split_pair(f(dv[p][0]), f(dv[p][1]), h0, l0);
+        split_pair(f(dv[p][2]), f(dv[p][3]), h1, l1);
+        bsum[p] += (f(dv[p][0]) + f(dv[p][1])) + (f(dv[p][2]) + f(dv[p][3]));
+      }
       *reinterpret_cast<v2u *>(Dh + off) = (v2u){h0, h1};
       *reinterpret_cast<v2u *>(Dl + off) = (v2u){l0, l1};
-      split_pair(av[p][0], av[p][1], h0, l0);
-      split_pair(av[p][2], av[p][3], h1, l1);
+      if constexpr (A16) {
+        h0 = av[p][0]; h1 = av[p][1]; l0 = 0u; l1 = 0u;
+      } else {
+        split_pair(f(av[p][0]), f(av[p][1]), h0, l0);
+        split_pair(f(av[p][2]), f(av[p][3]), h1, l1);
+      }
       *reinterpret_cast<v2u *>(Ah + off) = (v2u){h0, h1};
       *reinterpret_cast<v2u *>(Al + off) = (v2u){l0, l1};
-      bsum[p] += (dv[p][0] + dv[p][1]) + (dv[p][2] + dv[p][3]);
     }
     __syncthreads();
     if (k0 + WB_KT < k_end) fetch(k0 + WB_KT);         /* next tile's loads fly under this tile's MFMAs */

@@ -327,9 +327,9 @@ class _LevelFunction(torch.autograd.Function):
         ctx.mlp, ctx.cfg, ctx.rays, ctx.packed = mlp, cfg, rays, packed
         ctx.packed_key = mlp._packed_key
         ctx.bwd_precision = holder.get("bwd_precision", _hip.PREC_F32)
-        ctx.saved = {k: res.pop(k) if k == "activations" else res[k]
-                     for k in ("sdist", "density", "rgb", "weights", "activations", "diffuse", "specular", "tint",
-                               "roughness", "normals", "normals_pred")}
+        ctx.saved = {k: res.pop(k) if k in ("activations", "activations_format") else res[k]
+                     for k in ("sdist", "density", "rgb", "weights", "activations", "activations_format", "diffuse",
+                               "specular", "tint", "roughness", "normals", "normals_pred")}
         diff = tuple(k for k in _DIFF_KEYS if k in res)
         keys = diff + tuple(k for k in res if k not in diff)
         holder["keys"] = keys                      # autograd Functions return tuples: tell the caller the names

@@ -888,9 +888,9 @@ def test_bf16_chain_backward_mode(hip):
     for s in layout.PARAM_SPECS:
         sl = slice(s.w_off, s.w_off + s.out_dim * s.in_dim)
         assert float((a[sl] - b[sl]).norm()) <= 2e-2 * float(a[sl].norm()) + 1e-9, s.name
-    # the rgb layer and the heads sit above the chains: their gradients do not depend on the chain arithmetic
+    # the rgb layer sits above the chains: its gradient only sees the rounding of its 3 delta rows to the bf16 DELTA format
     rgbw = slice(layout.PARAM_SPECS[-1].w_off, layout.PARAM_SPECS[-1].w_off + 3 * 256)
-    assert float((a[rgbw] - b[rgbw]).abs().max()) <= 1e-6 * float(a[rgbw].abs().max())
+    assert float((a[rgbw] - b[rgbw]).norm()) <= 2e-3 * float(a[rgbw].norm())
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
