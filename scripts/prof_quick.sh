@@ -18,7 +18,7 @@ python3 - <<PY
 import csv, glob, collections
 for f in glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True):
     for row in list(csv.DictReader(open(f))):
-        if row["Name"].startswith("rn::"):
+        if row["Name"].startswith("rn::") or row["Name"].startswith("void rn::"):
             print(row["Name"][:60], row["Calls"], "avg_us", float(row["AverageNs"])/1e3)
 for f in glob.glob("$OUT/pmc_*/**/*counter_collection.csv", recursive=True):
     acc = collections.defaultdict(list)

@@ -25,14 +25,14 @@ with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-image\n")
     w.writerow(rows[0])
     for r in rows[1:]:
-        if r and r[0].startswith("rn::"):
+        if r and (r[0].startswith("rn::") or r[0].startswith("void rn::")):
             w.writerow(r)
 
 stats = defaultdict(lambda: defaultdict(list))
 meta = {}
 for path in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].split("(")[0]
+        name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "")
         for short, full in KERNELS.items():
             if name == full:
                 stats[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
