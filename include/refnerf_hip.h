@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 3
+#define REFNERF_ABI_VERSION 4   /* v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {

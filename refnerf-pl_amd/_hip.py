@@ -15,7 +15,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
 
 PREC_F32, PREC_BF16 = 0, 1
-ABI_VERSION = 3   # REFNERF_ABI_VERSION
+ABI_VERSION = 4   # REFNERF_ABI_VERSION
 WGRAD_F32, WGRAD_BF16X3 = 0, 1
 SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 4}
 
