@@ -81,7 +81,9 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
     int n_b = o.nob * 32;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_a + n_b; e += gridDim.x * blockDim.x) {
       if (e < n_a) {
-        int ob = e % o.stride, lane = (e / o.stride) % 64, step = e / (o.stride * 64);
+        int ob, lane, step = e / (o.stride * 64);
+        if (o.stride == 8) { const int rem = e % 512; ob = (rem >> 8) * 4 + (rem & 3); lane = (rem & 255) >> 2; }   /* [step][q][lane][4] */
+        else { ob = e % o.stride; lane = (e / o.stride) % 64; }
         int h = lane >> 5, row = ob * 32 + (lane & 31);
         float v = 0.0f;
         if (ob < o.nob) {
@@ -111,7 +113,9 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
     const TopSrc src = PACKED.top_src[t];
     int n_a = (o.reg_steps + o.lds_steps) * 64 * o.stride;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_a; e += gridDim.x * blockDim.x) {
-      int ob = e % o.stride, lane = (e / o.stride) % 64, step = e / (o.stride * 64);
+      int ob, lane, step = e / (o.stride * 64);
+        if (o.stride == 8) { const int rem = e % 512; ob = (rem >> 8) * 4 + (rem & 3); lane = (rem & 255) >> 2; }   /* [step][q][lane][4] */
+        else { ob = e % o.stride; lane = (e / o.stride) % 64; }
       int h = lane >> 5, in_row = ob * 32 + (lane & 31);
       float v = 0.0f;
       if (ob < o.nob) {

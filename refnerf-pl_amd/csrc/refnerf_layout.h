@@ -61,6 +61,8 @@ static_assert(CANON.total == NUM_PARAMS, "canonical layout");
  * (k = row) values the next op needs as its B operand for the K=2 step
  * (block kb, reg r).  The weight image is therefore stored per step as
  *   A[step][lane][ob] = W[32*ob + (lane&31)][ kidx(step, lane>>5) ]
+ * (8-block ops: stored as two planes [step][q][lane][4 blocks], q = ob / 4, so that each dwordx4 load of the wave is
+ * one contiguous KB; 3- / 1-block ops: [step][lane][stride])
  * "register" steps (kb,r): kidx = 32*kb + (r&3) + 8*(r>>2) + 4*h,
  * "LDS" steps s (encoded inputs staged in LDS): kidx = 2*s + h.
  * Bias image: B[ob][h][reg] = bias[32*ob + row(reg,h)] (accumulator seed). */

@@ -26,12 +26,14 @@ constexpr int T_TILE = 128;  /* samples per pass: 4 waves x 32 */
 template <int NOB, int STRIDE>
 __device__ __forceinline__ void load_a(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float (&a)[NOB]) {
   if constexpr (STRIDE == 8) {
+    /* a k-step of an 8-block op is two 1 KB planes [q][lane][4 blocks]: each dwordx4 load is contiguous over the wave
+     * (the lane-major [lane][8 blocks] form made every load touch twice the cache lines it used) */
     v4f x = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
     a[0] = x[0];
     if constexpr (NOB > 1) { a[1] = x[1]; a[2] = x[2]; a[3] = x[3]; }
-    if constexpr (NOB == 5) a[4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 16, soff, 0));
+    if constexpr (NOB == 5) a[4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + 1024, 0));
     if constexpr (NOB > 5) {
-      v4f y = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, soff, 0));
+      v4f y = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + 1024, 0));
 #pragma unroll
       for (int i = 4; i < NOB; ++i) a[i] = y[i - 4];
     }
@@ -124,7 +126,7 @@ __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, in
                                         const v16f (&in)[8], v16f (&out)[NOB], const float *xl,
                                         int lds_steps, Hook hook = Hook()) {
   constexpr int STEP_BYTES = 64 * STRIDE * 4;
-  const int voff = lane * STRIDE * 4;
+  const int voff = lane * (STRIDE == 8 ? 16 : STRIDE * 4);
   int soff = a_off * 4;
   float a[PF][NOB];
 #pragma unroll
