@@ -49,7 +49,9 @@ enum {
 };
 
 /* element type of the saved layer inputs: fp32 rows (f32 training forward) or bf16 rows (bf16-chain training forward,
- * whose activations are bf16-exact: half the stream); the 128 rows of ReLU mask words are 32-bit in both */
+ * whose activations are bf16-exact: half the stream; rows 2j and 2j+1 share the dwords of pair-row j, low / high half --
+ * the buffer is opaque to the caller, only its size (rows x pitch x 4 bytes) is part of the ABI); the 128 rows of ReLU
+ * mask words are 32-bit in both */
 enum { REFNERF_ACT_F32 = 0, REFNERF_ACT_BF16 = 1 };
 
 enum { REFNERF_SRGB_NONE = 0, REFNERF_SRGB_LINEAR = 1, REFNERF_SRGB_NORM_LINEAR = 2,

@@ -643,9 +643,9 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     }
   }
   if (plan.pitch > plan.S) {   /* pad columns of both operand matrices must read as zero in the wgrad GEMM */
-    if (act16) hipLaunchKernelGGL(rn::wgrad_zero_tail16, dim3(256), dim3(256), 0, st, (unsigned short *)const_cast<float *>(a.act), rn::ACT_ROWS, plan.pitch, plan.S);
+    if (act16) hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(a.act), rn::ACT_ROWS / 2, plan.pitch, plan.S);   /* pair-rows of dwords */
     else hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(a.act), rn::ACT_ROWS, plan.pitch, plan.S);
-    if (del16) hipLaunchKernelGGL(rn::wgrad_zero_tail16, dim3(256), dim3(256), 0, st, (unsigned short *)a.delta, rn::DEL_ROWS, plan.pitch, plan.S);
+    if (del16) hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, rn::DEL_ROWS / 2, plan.pitch, plan.S);
     else hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, rn::DEL_ROWS, plan.pitch, plan.S);
   }
   rn::WgradArgs w;

@@ -331,10 +331,15 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     for (int i = 7; i >= 0; --i) {
       /* delta_i leaves through the store hook of the GEMM that consumes it (one row per k-step) */
       if constexpr (BF) {
-        RowStoreHookT<D16> sh_(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid);
+        std::conditional_t<D16, PairStoreHook, RowStoreHook> sh_(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid);
         auto hook = [&](int t) {
+          if constexpr (D16) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) sh_(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
+            for (int e = 0; e < 4; ++e) sh_(4 * t + e, pk[t][e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sh_(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
+          }
         };
         if (i == 5) { gemm_op_bf16<DIN_BLOCKS, 16, 0, false>(rs, PACKED.bt_off[TOP_VD5_DIN], 0, lane, h, pk, gd, nullptr); park_din(5); }
         if (i == 0) { gemm_op_bf16<DIN_BLOCKS, 16, 0, false>(rs, PACKED.bt_off[TOP_VD0], 0, lane, h, pk, gd, nullptr, hook); park_din(0); }
@@ -417,10 +422,15 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
 #pragma unroll 1
       for (int i = 7; i >= 0; --i) {
         if (i > 0) {
-          RowStoreHookT<D16> sh_(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid);
+          std::conditional_t<D16, PairStoreHook, RowStoreHook> sh_(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid);
           gemm_op_bf16<8, 16, 0, false>(rs, PACKED.bt_off[i - 1], 0, lane, h, pk, out, nullptr, [&](int t) {
+            if constexpr (D16) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sh_(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
+              for (int e = 0; e < 4; ++e) sh_(4 * t + e, pk[t][e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) sh_(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
+            }
           });
           shift_masks(M);
           mask_pack(out, M[7], pk);

@@ -121,6 +121,35 @@ struct RowStoreHookT {
 };
 typedef RowStoreHookT<false> RowStoreHook;
 
+/* The bf16-row variant: operator()(j, dword) stores the packed pair of features (accumulator registers 2j, 2j+1 of the
+ * 128 a lane holds = rows row(2j), row(2j)+1) as one dword of pair-row row(2j)/2.  Pair-rows of a 32-row block: {0,1,4,5,
+ * 8,9,12,13} + 2h, i.e. +1,+3 alternating; 16 pair-rows per block; j = 0..63. */
+struct PairStoreHook {
+  char *base;
+  unsigned long long blk_bytes;
+  unsigned voff, p1, p3, soff;
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ PairStoreHook(float *matrix, long long pitch, int row0, size_t col, int h, bool store) {
+    base = reinterpret_cast<char *>(matrix) + (long long)(row0 >> 1) * pitch * 4;
+    blk_bytes = (unsigned long long)pitch * 64ull;
+    voff = store ? (unsigned)(((long long)(2 * h) * pitch + (long long)col) * 4) : 0xfffffff0u;
+    p1 = (unsigned)(pitch * 4);
+    p3 = 3u * p1;
+    soff = 0;
+    rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x80000000, 0x00020000);
+  }
+  __device__ __forceinline__ void operator()(int j, unsigned dword) {
+    if ((j & 7) == 0 && j > 0) {
+      rs = __builtin_amdgcn_make_buffer_rsrc(base + (unsigned long long)(j >> 3) * blk_bytes, 0, 0x80000000, 0x00020000);
+      soff = 0;
+    }
+#ifndef REFNERF_EXPERIMENT_NO_STREAM
+    __builtin_amdgcn_raw_buffer_store_b32(dword, rs, voff, soff, REFNERF_STREAM_AUX);
+#endif
+    soff += (j & 1) ? p3 : p1;
+  }
+};
+
 template <int NOB, int STRIDE, bool HAS_REG, bool BIAS = true, typename Hook = NoStepHook, int PF = rn::PF>
 __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
                                         const v16f (&in)[8], v16f (&out)[NOB], const float *xl,
@@ -301,7 +330,14 @@ __device__ __forceinline__ void stream_store(float *p, float v) {
   *p = v;
 #endif
 }
-/* element `idx` of a matrix of fp32 or (H16) bf16 rows */
+/* Element (row, col) of a [rows][pitch] matrix: fp32 rows, or (H16) bf16 rows stored in PAIRS -- rows 2j and 2j+1 share
+ * the dwords of pair-row j (low / high half), so that a lane's two adjacent features (exactly a packed B-fragment dword)
+ * leave in one 4-byte store and a half-wave writes a full 128-B line segment. */
+template <bool H16>
+__device__ __forceinline__ long long elem_index(int row, long long col, long long pitch) {
+  if constexpr (H16) return ((long long)(row >> 1) * pitch + col) * 2 + (row & 1);
+  else return (long long)row * pitch + col;
+}
 template <bool H16>
 __device__ __forceinline__ void stream_store_e(float *base, long long idx, float v) {
   if constexpr (H16) {
@@ -321,29 +357,37 @@ __device__ __forceinline__ float load_e(const float *base, long long idx) {
 }
 template <int NB, bool H16 = false>
 __device__ __forceinline__ void store_rows(float *base, long long pitch, int row0, size_t gs, int h, bool valid, const v16f *x) {
-  const long long e0 = (long long)(row0 + 4 * h) * pitch + (long long)gs;
+  /* one 64-bit origin per lane, compile-time row offsets on top (row0 is even: the pair-row of row0 + 4h + c is that of
+   * row0 + 4h plus c / 2, its half c & 1) */
+  const long long e0 = (H16 ? (long long)((row0 + 4 * h) >> 1) : (long long)(row0 + 4 * h)) * pitch + (long long)gs;
   if (valid) {
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stream_store_e<H16>(base, e0 + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch, x[blk][r]);
+      for (int r = 0; r < 16; ++r) {
+        const int c = blk * 32 + (r & 3) + 8 * (r >> 2);
+        if constexpr (H16) stream_store_e<true>(base, (e0 + (long long)(c >> 1) * pitch) * 2 + (c & 1), x[blk][r]);
+        else stream_store_e<false>(base, e0 + (long long)c * pitch, x[blk][r]);
+      }
   }
 }
 template <bool H16 = false>
 __device__ __forceinline__ void store_row1(float *base, long long pitch, int row, size_t gs, float v) {
-  stream_store_e<H16>(base, (long long)row * pitch + (long long)gs, v);
+  stream_store_e<H16>(base, elem_index<H16>(row, (long long)gs, pitch), v);
 }
 
 /* the same rows read back (the accumulator-layout image of a saved activation block) */
 template <int NB, bool H16 = false>
 __device__ __forceinline__ void load_rows(const float *base, long long pitch, int row0, size_t gs, int h, v16f *x) {
-  const long long e0 = (long long)(row0 + 4 * h) * pitch + (long long)gs;
+  const long long e0 = (H16 ? (long long)((row0 + 4 * h) >> 1) : (long long)(row0 + 4 * h)) * pitch + (long long)gs;
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      x[blk][r] = load_e<H16>(base, e0 + (long long)(blk * 32 + (r & 3) + 8 * (r >> 2)) * pitch);
+    for (int r = 0; r < 16; ++r) {
+      const int c = blk * 32 + (r & 3) + 8 * (r >> 2);
+      if constexpr (H16) x[blk][r] = load_e<true>(base, (e0 + (long long)(c >> 1) * pitch) * 2 + (c & 1));
+      else x[blk][r] = load_e<false>(base, e0 + (long long)c * pitch);
+    }
 }
 
 /* ReLU that also records the sign pattern: bit (16*(ob&1) + r) of mk[ob>>1]. */
@@ -538,9 +582,9 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     /* P2: spatial MLP (models.py:576-580) */
     unsigned M[TRAIN ? 8 : 1][4];                /* ReLU masks of the spatial layers (training) */
     auto act_hook = [&](int row0) {              /* bf16 chains: the packed layer input leaves for ACT, 8 rows per k-step */
-      return [&, hk = RowStoreHookT<true>(A.act, A.act_pitch, row0, gsx, h, save)](int t) mutable {
+      return [&, hk = PairStoreHook(A.act, A.act_pitch, row0, gsx, h, save)](int t) mutable {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) hk(8 * t + e, pk_elem(pk, t >> 1, 8 * (t & 1) + e));
+        for (int e = 0; e < 4; ++e) hk(4 * t + e, pk[t][e]);       /* the k-step's B fragment as it is */
       };
     };
     if constexpr (BFC) {

@@ -201,14 +201,6 @@ __global__ void wgrad_zero_tail(float *m, int rows, long long pitch, long long S
     m[(i / tail) * pitch + S + (i % tail)] = 0.0f;
 }
 
-/* the same for a matrix of 16-bit rows */
-__global__ void wgrad_zero_tail16(unsigned short *m, int rows, long long pitch, long long S) {
-  const int tail = (int)(pitch - S);
-  const long long n = (long long)rows * tail;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    m[(i / tail) * pitch + S + (i % tail)] = 0;
-}
-
 /* grads[i] += sum over slices (fixed order) of PART[slice][i] */
 __global__ void wgrad_reduce(const float *__restrict__ part, int slices, float *__restrict__ grads) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NUM_PARAMS; i += gridDim.x * blockDim.x) {

@@ -69,45 +69,58 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
   float bsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
-  const int lrow = tid >> 4, lc4 = (tid & 15) * 4;    /* loader: rows lrow + 16p (p = 0..7), 4 samples at lc4 */
-  constexpr int DSZ = D16 ? 2 : 4, ASZ = A16 ? 2 : 4;
+  const int lrow = tid >> 4, lc4 = (tid & 15) * 4;    /* loader: 8 rows of the tile per thread, 4 samples at lc4 */
+  /* fp32 operand: rows lrow + 16p.  bf16 operand (rows stored in pairs, refnerf_level_f32.h elem_index): the thread owns
+   * four PAIRS of rows -- one 16-B load brings 4 samples of both rows; p = 2*pp + half.  The pair index is a bit
+   * permutation of lrow that puts the two row groups of a half-wave 8 rows (32 LDS banks) apart. */
+  const int lpair = (lrow & 8) | ((lrow & 1) << 2) | ((lrow >> 1) & 3);
+  auto tile_row = [&](int p, bool h16) { return h16 ? 2 * lpair + 32 * (p >> 1) + (p & 1) : lrow + 16 * p; };
   const char *dp[8], *ap[8];
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
-    const int orow = tm * WG_TM + lrow + 16 * p, irow = tn * WG_TN + lrow + 16 * p;
-    dp[p] = (orow < J.n_out) ? reinterpret_cast<const char *>(A.delta) + ((long long)(J.d_row + orow) * A.pitch + lc4) * DSZ : nullptr;
-    ap[p] = (irow < J.n_in) ? reinterpret_cast<const char *>(A.act) + ((long long)(J.a_row + irow) * A.pitch + lc4) * ASZ : nullptr;
+    const int orow = tm * WG_TM + tile_row(p, D16), irow = tn * WG_TN + tile_row(p, A16);
+    /* (all row origins of the job table are even, so a tile's row pairs are the matrices' row pairs) */
+    if constexpr (D16) dp[p] = (orow < J.n_out) ? reinterpret_cast<const char *>(A.delta) + ((long long)((J.d_row + orow) >> 1) * A.pitch + lc4) * 4 : nullptr;
+    else dp[p] = (orow < J.n_out) ? reinterpret_cast<const char *>(A.delta) + ((long long)(J.d_row + orow) * A.pitch + lc4) * 4 : nullptr;
+    if constexpr (A16) ap[p] = (irow < J.n_in) ? reinterpret_cast<const char *>(A.act) + ((long long)((J.a_row + irow) >> 1) * A.pitch + lc4) * 4 : nullptr;
+    else ap[p] = (irow < J.n_in) ? reinterpret_cast<const char *>(A.act) + ((long long)(J.a_row + irow) * A.pitch + lc4) * 4 : nullptr;
   }
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
-  /* 4 samples of one row as raw dwords: fp32 (16 B) or bf16 (8 B: two packed pairs in [0], [1]).  Kept as integers:
-   * a packed bf16 pair is not a well-formed float (it may look like a denormal) and must not pass through float registers'
-   * canonicalisation */
+  /* 4 samples as raw dwords: of one fp32 row, or of a PAIR of bf16 rows (dword = {row 2j | row 2j+1 << 16}; held in the
+   * even slot, the odd slot stays unused).  Kept as integers: a packed bf16 pair is not a well-formed float (it may
+   * look like a denormal) and must not pass through float registers' canonicalisation */
   v4u dv[8], av[8];
   auto fetch = [&](long long k0) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      v4u x = {0u, 0u, 0u, 0u}, y = {0u, 0u, 0u, 0u};
-      if (dp[p]) {
-        if constexpr (D16) { const v2u q = *reinterpret_cast<const v2u *>(dp[p] + k0 * 2); x[0] = q[0]; x[1] = q[1]; }
-        else x = *reinterpret_cast<const v4u *>(dp[p] + k0 * 4);
+      if (!(D16 && (p & 1))) {
+        v4u x = {0u, 0u, 0u, 0u};
+        if (dp[p]) x = *reinterpret_cast<const v4u *>(dp[p] + k0 * 4);
+        dv[p] = x;
       }
-      if (ap[p]) {
-        if constexpr (A16) { const v2u q = *reinterpret_cast<const v2u *>(ap[p] + k0 * 2); y[0] = q[0]; y[1] = q[1]; }
-        else y = *reinterpret_cast<const v4u *>(ap[p] + k0 * 4);
+      if (!(A16 && (p & 1))) {
+        v4u y = {0u, 0u, 0u, 0u};
+        if (ap[p]) y = *reinterpret_cast<const v4u *>(ap[p] + k0 * 4);
+        av[p] = y;
       }
-      dv[p] = x; av[p] = y;
     }
+  };
+  /* samples (0,1) and (2,3) of the even (odd) row of a pair as packed bf16 pairs */
+  auto unpair = [](const v4u q, int half, bool live, unsigned &s01, unsigned &s23) {
+    const unsigned sel = half ? 0x07060302u : 0x05040100u;
+    s01 = live ? __builtin_amdgcn_perm(q[1], q[0], sel) : 0u;
+    s23 = live ? __builtin_amdgcn_perm(q[3], q[2], sel) : 0u;
   };
   if (k_begin < k_end) fetch(k_begin);
   for (long long k0 = k_begin; k0 < k_end; k0 += WB_KT) {
     __syncthreads();                                   /* previous tile fully consumed */
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      const int off = (lrow + 16 * p) * WB_ROW + lc4 * 2;
+      const int offd = tile_row(p, D16) * WB_ROW + lc4 * 2, offa = tile_row(p, A16) * WB_ROW + lc4 * 2;
       unsigned h0, l0, h1, l1;
       auto f = [](unsigned u) { return __builtin_bit_cast(float, u); };
       if constexpr (D16) {
-        h0 = dv[p][0]; h1 = dv[p][1]; l0 = 0u; l1 = 0u;
+        unpair(dv[p & ~1], p & 1, dp[p] != nullptr, h0, h1); l0 = 0u; l1 = 0u;
         bsum[p] += (__builtin_bit_cast(float, h0 << 16) + __builtin_bit_cast(float, h0 & 0xffff0000u)) +
                    (__builtin_bit_cast(float, h1 << 16) + __builtin_bit_cast(float, h1 & 0xffff0000u));
       } else {
@@ -115,16 +128,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
         split_pair(f(dv[p][2]), f(dv[p][3]), h1, l1);
         bsum[p] += (f(dv[p][0]) + f(dv[p][1])) + (f(dv[p][2]) + f(dv[p][3]));
       }
-      *reinterpret_cast<v2u *>(Dh + off) = (v2u){h0, h1};
-      *reinterpret_cast<v2u *>(Dl + off) = (v2u){l0, l1};
+      *reinterpret_cast<v2u *>(Dh + offd) = (v2u){h0, h1};
+      *reinterpret_cast<v2u *>(Dl + offd) = (v2u){l0, l1};
       if constexpr (A16) {
-        h0 = av[p][0]; h1 = av[p][1]; l0 = 0u; l1 = 0u;
+        unpair(av[p & ~1], p & 1, ap[p] != nullptr, h0, h1); l0 = 0u; l1 = 0u;
       } else {
         split_pair(f(av[p][0]), f(av[p][1]), h0, l0);
         split_pair(f(av[p][2]), f(av[p][3]), h1, l1);
       }
-      *reinterpret_cast<v2u *>(Ah + off) = (v2u){h0, h1};
-      *reinterpret_cast<v2u *>(Al + off) = (v2u){l0, l1};
+      *reinterpret_cast<v2u *>(Ah + offa) = (v2u){h0, h1};
+      *reinterpret_cast<v2u *>(Al + offa) = (v2u){l0, l1};
     }
     __syncthreads();
     if (k0 + WB_KT < k_end) fetch(k0 + WB_KT);         /* next tile's loads fly under this tile's MFMAs */
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
     for (int p = 0; p < 8; ++p) {
       float s = bsum[p];
       s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-      const int orow = tm * WG_TM + lrow + 16 * p;
+      const int orow = tm * WG_TM + tile_row(p, D16);
       if ((tid & 15) == 0 && orow < J.n_out) part[wjob_bias_off(J, orow)] = s;
     }
   }
