@@ -593,10 +593,10 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     (void)hipFuncSetAttribute((const void *)rn::level_bwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)rn::level_bwd_bf16c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)rn::wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4);
-    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::WB_LDS);
-    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::WB_LDS);
-    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::WB_LDS);
-    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::WB_LDS);
+    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::wb_lds(false, false));
+    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::wb_lds(false, true));
+    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::wb_lds(true, false));
+    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::wb_lds(true, true));
   });
   char *ws = (char *)d_workspace;
   rn::BwdArgs a;
@@ -655,10 +655,10 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   if (cfg->wgrad_mode == REFNERF_WGRAD_BF16X3)
   {
     const dim3 wg_grid(8 * ((slices + 7) / 8) * rn::WJOBS.tiles);
-    if (del16 && act16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, true>), wg_grid, dim3(256), rn::WB_LDS, st, w, slices);
-    else if (del16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, false>), wg_grid, dim3(256), rn::WB_LDS, st, w, slices);
-    else if (act16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<false, true>), wg_grid, dim3(256), rn::WB_LDS, st, w, slices);
-    else hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<false, false>), wg_grid, dim3(256), rn::WB_LDS, st, w, slices);
+    if (del16 && act16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, true>), wg_grid, dim3(256), rn::wb_lds(true, true), st, w, slices);
+    else if (del16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, false>), wg_grid, dim3(256), rn::wb_lds(true, false), st, w, slices);
+    else if (act16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<false, true>), wg_grid, dim3(256), rn::wb_lds(false, true), st, w, slices);
+    else hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<false, false>), wg_grid, dim3(256), rn::wb_lds(false, false), st, w, slices);
   }
   else
     hipLaunchKernelGGL(rn::wgrad_kernel, dim3(rn::WJOBS.tiles, slices), dim3(256), (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4, st, w);

@@ -28,6 +28,8 @@ constexpr int WB_KT = 64;                      /* samples per k-step */
 constexpr int WB_ROW = WB_KT * 2 + 16;         /* LDS row pitch in bytes: 144 -> conflict-free ds_read_b128 */
 constexpr int WB_TILE = WG_TM * WB_ROW;        /* one 128-row bf16 operand tile: 18 KB */
 constexpr int WB_LDS = 4 * WB_TILE;            /* D_hi, D_lo, A_hi, A_lo */
+/* a bf16 operand has no low tile: 72 / 54 / 36 KB per workgroup */
+constexpr int wb_lds(bool d16, bool a16) { return (2 + (d16 ? 0 : 1) + (a16 ? 0 : 1)) * WB_TILE; }
 
 /* x0, x1 -> packed bf16 pair of the leading 8 mantissa bits and of the next 8 */
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, unsigned &lo) {
@@ -41,7 +43,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, uns
 template <bool D16, bool A16>
 __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, int slices) {
   extern __shared__ __attribute__((aligned(16))) char wbs[];
-  char *Dh = wbs, *Dl = wbs + WB_TILE, *Ah = wbs + 2 * WB_TILE, *Al = wbs + 3 * WB_TILE;
+  char *Dh = wbs, *Dl = wbs + WB_TILE, *Ah = wbs + (D16 ? 1 : 2) * WB_TILE, *Al = Ah + WB_TILE;   /* Dl / Al: only for fp32 operands */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, sl = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
         bsum[p] += (f(dv[p][0]) + f(dv[p][1])) + (f(dv[p][2]) + f(dv[p][3]));
       }
       *reinterpret_cast<v2u *>(Dh + offd) = (v2u){h0, h1};
-      *reinterpret_cast<v2u *>(Dl + offd) = (v2u){l0, l1};
+      if constexpr (!D16) *reinterpret_cast<v2u *>(Dl + offd) = (v2u){l0, l1};   /* a bf16 operand has no low part */
       if constexpr (A16) {
         unpair(av[p & ~1], p & 1, ap[p] != nullptr, h0, h1); l0 = 0u; l1 = 0u;
       } else {
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
         split_pair(f(av[p][2]), f(av[p][3]), h1, l1);
       }
       *reinterpret_cast<v2u *>(Ah + offa) = (v2u){h0, h1};
-      *reinterpret_cast<v2u *>(Al + offa) = (v2u){l0, l1};
+      if constexpr (!A16) *reinterpret_cast<v2u *>(Al + offa) = (v2u){l0, l1};
     }
     __syncthreads();
     if (k0 + WB_KT < k_end) fetch(k0 + WB_KT);         /* next tile's loads fly under this tile's MFMAs */
@@ -150,16 +152,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
         const int ro = (wm * 64 + i * 32 + sl) * WB_ROW + kk * 32 + h * 16;
         const int co = (wn * 64 + i * 32 + sl) * WB_ROW + kk * 32 + h * 16;
         ah[i] = *reinterpret_cast<const v8bf *>(Dh + ro);
-        al[i] = *reinterpret_cast<const v8bf *>(Dl + ro);
+        if constexpr (!D16) al[i] = *reinterpret_cast<const v8bf *>(Dl + ro);
         bh[i] = *reinterpret_cast<const v8bf *>(Ah + co);
-        bl[i] = *reinterpret_cast<const v8bf *>(Al + co);
+        if constexpr (!A16) bl[i] = *reinterpret_cast<const v8bf *>(Al + co);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          /* the low-part products exist only for fp32 operands: 3, 2 or 1 MFMA per product */
+          if constexpr (!D16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          if constexpr (!A16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
