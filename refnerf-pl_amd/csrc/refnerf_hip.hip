@@ -354,7 +354,7 @@ static int rays_per_wg(int N, int tile) {
 }
 
 namespace {
-struct BwdPlan { long long S, pitch; int slices, k_per_slice; size_t act_bytes, delta_off, part_off, total; };
+struct BwdPlan { long long S, pitch; int slices, k_per_slice; size_t act_bytes, delta_off, part_off, seed_off, total; };
 BwdPlan bwd_plan(int R, int N) {
   BwdPlan p;
   p.S = (long long)R * N;
@@ -366,7 +366,8 @@ BwdPlan bwd_plan(int R, int N) {
   p.act_bytes = sizeof(float) * (size_t)rn::ACT_ROWS_TOTAL * p.pitch;
   p.delta_off = 0;
   p.part_off = p.delta_off + sizeof(float) * (size_t)rn::DEL_ROWS * p.pitch;
-  p.total = p.part_off + sizeof(float) * (size_t)p.slices * rn::NUM_PARAMS;
+  p.seed_off = p.part_off + sizeof(float) * (size_t)p.slices * rn::NUM_PARAMS;
+  p.total = p.seed_off + sizeof(float) * (size_t)rn::NGS * p.pitch;
   return p;
 }
 }  // namespace
@@ -414,6 +415,11 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
     if (scratch > (bf ? (size_t)rn::BF_X_BYTES : sizeof(float) * rn::DIR_PAD * rn::T_TILE))
       return fail(REFNERF_EINVAL, "n_in / n_samples too large for the resampler scratch of this precision mode%s");
   }
+  /* bf16 chains: the shared weight-stream ring comes on top; fewer rays per workgroup (a partly filled last pass)
+   * when the whole-pass choice no longer fits */
+  while (train_bf && rpw > 1 && (lds + 15) / 16 * 16 + rn::RING_BYTES > 160 * 1024) { rpw /= 2; lds = lds_bytes(rpw); }
+  const size_t ring_off = (lds + 15) / 16 * 16;
+  if (train_bf) lds = ring_off + rn::RING_BYTES;
   if (const char *padenv = getenv("REFNERF_LDS_PAD")) lds += (size_t)atoi(padenv);   /* debug: force 1 workgroup/CU */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget of this precision mode%s");
   static std::once_flag attr_once;
@@ -435,6 +441,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   a.prof = nullptr;
   a.g_means = nullptr; a.g_covs = nullptr; a.cov_full = 0;
   a.act = d_act; a.act_pitch = act_pitch;
+  a.ring_off = (int)ring_off;
   if (getenv("REFNERF_PROF")) {
     static long long *d_prof = nullptr;
     if (!d_prof) { HIP_TRY(hipMalloc(&d_prof, 8 * 32 * sizeof(long long))); }
@@ -586,7 +593,9 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   const BwdPlan plan = bwd_plan(R, N);
   if (workspace_bytes < plan.total) return fail(REFNERF_EINVAL, "refnerf_level_backward: workspace too small (see refnerf_backward_workspace_bytes)%s");
   const int rpw = rays_per_wg(N, rn::T_TILE);
-  const size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + rpw * (N + 1) + rn::NGS * rpw * N + 8);
+  size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + rpw * (N + 1) + 8);
+  const size_t ring_off = (lds + 15) / 16 * 16;
+  if (cfg->precision == REFNERF_PREC_BF16) lds = ring_off + rn::RING_BYTES;       /* the chains' shared weight-stream ring */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget%s");
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
@@ -612,6 +621,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   a.g_s_specular = grads->d_g_specular; a.g_s_tint = grads->d_g_tint; a.g_s_rough = grads->d_g_roughness;
   a.act = (const float *)saved->d_activations;
   a.delta = (float *)(ws + plan.delta_off);
+  a.seeds = (float *)(ws + plan.seed_off);
   a.pitch = plan.pitch;
   const bool act16 = saved->activations_format == REFNERF_ACT_BF16, del16 = cfg->precision == REFNERF_PREC_BF16 && (REFNERF_DELTA16 != 0);
   if (saved->activations_format != REFNERF_ACT_F32 && saved->activations_format != REFNERF_ACT_BF16)
@@ -619,6 +629,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   if ((act16 || del16) && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
     return fail(REFNERF_EUNSUPPORTED, "bf16 activation / delta rows need wgrad_mode = REFNERF_WGRAD_BF16X3%s");
   a.act16 = act16 ? 1 : 0;
+  a.ring_off = (int)ring_off;
   a.prof = nullptr;
   if (getenv("REFNERF_PROF")) {
     static long long *d_prof = nullptr;
@@ -627,6 +638,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     a.prof = d_prof;
   }
   hipStream_t st = (hipStream_t)stream;
+  /* per-ray seeds first (one wave per ray), then the per-sample backward */
+  hipLaunchKernelGGL(rn::bwd_seed_kernel, dim3((R + 3) / 4), dim3(rn::NTHREADS), sizeof(float) * 4 * (size_t)(N + 1), st, a);
   /* d_packed is the f32 image in both modes (it carries the bf16 transposed ops behind the fp32 ones) */
   if (cfg->precision == REFNERF_PREC_BF16)
     hipLaunchKernelGGL(rn::level_bwd_bf16c, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);

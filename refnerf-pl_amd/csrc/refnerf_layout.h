@@ -176,6 +176,15 @@ constexpr int ACT_ROWS = ACT_VD + 8 * WIDTH;       /* 4396 */
  * (bit 16*(ob&1) + r of mk[ob>>1] = unit 32*ob + row(r,h) active); layers 0-7 spatial, 8-15 directional */
 constexpr int ACT_MASK = ACT_ROWS;
 constexpr int ACT_ROWS_TOTAL = ACT_MASK + 16 * 8;  /* 4524 */
+/* bf16 format (REFNERF_ACT_BF16): the rows are bf16 pairs and fill float-rows [0, ACT_ROWS / 2); what the backward reads
+ * back PER SAMPLE -- x7, v7 (the packed B fragments of the heads / rgb GEMMs) and the 16 layers' ReLU masks -- is kept a
+ * second time as a sample-major block behind them: 48 16-byte slots per lane (x7: 0..15, v7: 16..31, masks: 32 + layer),
+ * laid out [32-sample chunk][slot][h][sample in chunk][16 B] so that every store / load instruction of a wave is one
+ * contiguous 1 KB.  Row-wise reads of those 320 rows (each row 2 MB from the next: a page and a DRAM row per 128 B)
+ * were 0.15 of the backward.  The mask rows stay unused in this format. */
+constexpr int SMB_SLOTS = 48, SMB_X7 = 0, SMB_V7 = 16, SMB_MASK = 32;
+constexpr int SMB_ROW0 = ACT_ROWS / 2 + 2;         /* first float-row of the block: 2200 */
+static_assert((long long)(ACT_MASK - SMB_ROW0) * 4 >= SMB_SLOTS * 2 * 16 + 64, "sample-major block must fit in front of the mask rows");
 constexpr int DEL_SP = 0;                          /* 8 x 256: spatial layer deltas         */
 constexpr int DEL_HEADS = DEL_SP + 8 * WIDTH;      /* 144: head rows (HROW_* order), 139 used */
 constexpr int DEL_VD = DEL_HEADS + 144;            /* 8 x 256: directional layer deltas     */

@@ -51,7 +51,9 @@ struct BwdArgs {
   const float *g_s_rough;   /* [R,N]   dL/d history roughness                      */
   const float *act;         /* [ACT_ROWS][pitch] layer inputs saved by the training forward */
   float *delta;             /* [DEL_ROWS][pitch] written here                       */
+  float *seeds;             /* [NGS][pitch] per-sample seeds: bwd_seed_kernel -> level_bwd_* */
   long long pitch;
+  int ring_off;             /* byte offset of the shared weight-stream ring in dynamic LDS (bf16 chains) */
   int act16;                /* ACT holds bf16 rows (written by the bf16-chain training forward), masks stay 32-bit */
   long long *prof;          /* debug: per-phase cycle stamps of workgroup 0 (REFNERF_PROF=1), else NULL */
 };
@@ -66,14 +68,14 @@ constexpr int PF_BWD = REFNERF_PF_BWD;
 #ifndef REFNERF_DELTA16
 #define REFNERF_DELTA16 1
 #endif
-constexpr int NGS = 7;      /* per-sample upstream gradients in LDS: density, rgb[3], n_pred[3] */
+constexpr int NGS = 7;      /* per-sample upstream gradients (SEEDS rows): density, rgb[3], n_pred[3] */
 
 /* Per-ray part of the backward (one wave per ray): rendering gradient through
  * the render-time colour map (render.py:186-216), compositing (152-176) and
  * the alpha weights (132-149) down to per-sample gradients in GS. */
-__device__ __forceinline__ void bwd_prologue(const BwdArgs &A, float *TD, float *GS, int ray0, int wave, int lane) {
+__device__ __forceinline__ void bwd_seed_rays(const BwdArgs &A, float *TD, int ray0, int rpw, int wave, int lane) {
   const refnerf_level_cfg &cfg = A.cfg;
-  const int N = cfg.n_samples, rpw = A.rpw;
+  const int N = cfg.n_samples;
   for (int rl = wave; rl < rpw; rl += 4) {
     const int ray = ray0 + rl;
     if (ray >= A.R) break;
@@ -135,12 +137,12 @@ __device__ __forceinline__ void bwd_prologue(const BwdArgs &A, float *TD, float 
       cum += (double)dd;
       float g_density = g_dd * delta;
       if (cfg.opaque_background && i == N - 1) g_density = 0.0f;
-      float *gs = GS + (size_t)(rl * N + i) * NGS;
+      float *gs = A.seeds + ((size_t)ray * N + i);
       gs[0] = g_density + (A.g_s_density ? A.g_s_density[(size_t)ray * N + i] : 0.0f);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        gs[1 + c] = w * g_rgb[c] + (A.g_s_rgb ? A.g_s_rgb[((size_t)ray * N + i) * 3 + c] : 0.0f);
-        gs[4 + c] = A.g_npred ? A.g_npred[((size_t)ray * N + i) * 3 + c] : 0.0f;
+        gs[(size_t)(1 + c) * A.pitch] = w * g_rgb[c] + (A.g_s_rgb ? A.g_s_rgb[((size_t)ray * N + i) * 3 + c] : 0.0f);
+        gs[(size_t)(4 + c) * A.pitch] = A.g_npred ? A.g_npred[((size_t)ray * N + i) * 3 + c] : 0.0f;
       }
     }
   }
@@ -155,8 +157,40 @@ __device__ __forceinline__ v16f load_acc_blk(__amdgpu_buffer_rsrc_t rs, int off,
                 b[2][0], b[2][1], b[2][2], b[2][3], b[3][0], b[3][1], b[3][2], b[3][3]};
 }
 
+/* block 4 (the 12 scalar head rows) of the fp32 heads op alone: same k order and accumulation as gemm_op<5, 8, true>
+ * gives that block, a fifth of the MFMAs and of the A stream (plane 1, first dword of each lane's 16 bytes) */
+__device__ __forceinline__ void heads_scalar_block_f32(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
+                                                       const v16f (&in)[8], v16f &o) {
+  constexpr int STEP_BYTES = 64 * 8 * 4, D = 4;
+  const int voff = lane * 16;
+  const int soff = a_off * 4 + 1024;
+  float a[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) a[d] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + d * STEP_BYTES, 0));
+  v16f acc[1];
+  load_acc<1>(rs, b_off + 4 * 32, h, acc);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int step = 0; step < REG_STEPS; ++step) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step % D], in[step >> 4][step & 15], acc[0], 0, 0, 0);
+    /* (loads past the op's last k-step stay inside the image: the next op follows) */
+    a[step % D] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + (step + D) * STEP_BYTES, 0));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  o = acc[0];
+}
+
 /* the saved ReLU sign patterns of the 8 layers of one trunk (ACT_MASK rows 8*layer0 ...): 4 dwords per layer */
-__device__ __forceinline__ void load_masks(const float *act, long long pitch, int layer0, size_t gs, int h, unsigned (&M)[8][4]) {
+__device__ __forceinline__ void load_masks(const float *act, long long pitch, int layer0, size_t gs, int h, unsigned (&M)[8][4], bool act16) {
+  if (act16) {                                   /* bf16 format: one 16-B slot per layer in the sample-major block */
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      const v4u w = *smb_slot(act, pitch, gs, h, SMB_MASK + layer0 + l);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) M[l][q] = w[q];
+    }
+    return;
+  }
 #pragma unroll
   for (int l = 0; l < 8; ++l)
 #pragma unroll
@@ -189,10 +223,15 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
   float *X = smem;                               /* [DIR_PAD][T_TILE] */
   float *HD = X + DIR_PAD * T_TILE;              /* [HD_ROWS][T_TILE] */
   float *TD = HD + HD_ROWS * T_TILE;             /* [rpw][N+1]        */
-  float *GS = TD + rpw * (N + 1);                /* [n_tot][NGS]      */
+  char *ring = reinterpret_cast<char *>(smem) + A.ring_off;   /* bf16 chains: the shared weight-stream ring (RING_BYTES) */
 
   RN_STAMP(A, 0);
-  bwd_prologue(A, TD, GS, ray0, wave, lane);
+  for (int rl = wave; rl < rpw; rl += 4) {       /* the t-distances of this workgroup's rays */
+    const int ray = ray0 + rl;
+    if (ray >= A.R) break;
+    const float nearv = A.rays.d_near[ray], farv = A.rays.d_far[ray];
+    for (int k = lane; k <= N; k += 64) TD[rl * (N + 1) + k] = s_to_t(A.sdist[(size_t)ray * (N + 1) + k], nearv, farv);
+  }
   __syncthreads();
   RN_STAMP(A, 1);
 
@@ -213,20 +252,48 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
     /* ===== the few forward values the backward needs, from the saved x7 / v7 ===== */
-    if (A.act16) load_rows<8, true>(A.act, pitch, ACT_SP + 7 * WIDTH, gs, h, in);   /* x7: input of the heads */
-    else load_rows<8>(A.act, pitch, ACT_SP + 7 * WIDTH, gs, h, in);
+    /* Only the scalar block of the heads (rows 128..139: density, grad_pred, roughness, diffuse, tint) is needed here --
+     * the bottleneck comes back from its ACT_DIN rows.  bf16 chains on a bf16 forward: the forward's own GEMM (same
+     * image, same packed x7) -> the forward's own raw head values, bit for bit. */
     {
-      v16f hd[5];
-      gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0);
+      v16f hd4[1];
+      bool done = false;
+      if constexpr (BF) {
+        if (A.act16) {
+          v4uu xpk[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) { const v4u w = *smb_slot(A.act, pitch, gs, h, SMB_X7 + t); xpk[t] = (v4uu){w[0], w[1], w[2], w[3]}; }
+          gemm_op_bf16<1, 16, 0, true>(rs, PACKED.bf_off[OP_HEADS] + 4 * 256, PACKED.op[OP_HEADS].b_off + 4 * 32, lane, h, xpk, hd4, nullptr);
+          done = true;
+        }
+      }
+      if (!done) {
+        if (A.act16) smb_load_rows(A.act, pitch, gs, h, SMB_X7, in);                  /* x7: input of the heads */
+        else load_rows<8>(A.act, pitch, ACT_SP + 7 * WIDTH, gs, h, in);
+        heads_scalar_block_f32(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd4[0]);
+      }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < HD_ROWS) HD[row * T_TILE + col] = hd[4][r];
+        if (row < HD_ROWS) HD[row * T_TILE + col] = hd4[0][r];
       }
     }
     RN_STAMP(A, 2);
-    if (A.act16) load_rows<8, true>(A.act, pitch, ACT_VD + 7 * WIDTH, gs, h, in);   /* v7: input of the rgb layer */
-    else load_rows<8>(A.act, pitch, ACT_VD + 7 * WIDTH, gs, h, in);
+    bool rgb_bf = false;
+    v16f rgbv[1];
+    if constexpr (BF) {
+      if (A.act16) {                                 /* the forward's own rgb GEMM on the packed v7 */
+        v4uu xpk[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const v4u w = *smb_slot(A.act, pitch, gs, h, SMB_V7 + t); xpk[t] = (v4uu){w[0], w[1], w[2], w[3]}; }
+        gemm_op_bf16<1, 16, 0, true>(rs, PACKED.bf_off[OP_RGB], PACKED.op[OP_RGB].b_off, lane, h, xpk, rgbv, nullptr);
+        rgb_bf = true;
+      }
+    }
+    if (!rgb_bf) {
+      if (A.act16) smb_load_rows(A.act, pitch, gs, h, SMB_V7, in);                  /* v7: input of the rgb layer */
+      else load_rows<8>(A.act, pitch, ACT_VD + 7 * WIDTH, gs, h, in);
+    }
     wave_sync();
     SampleHeads sh;
     float raw_density, raw_rough, raw_tint[3];
@@ -244,18 +311,17 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     }
     float raw_rgb[3];
     {
-      v16f rgbv[1];
-      gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0);
+      if (!rgb_bf) gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0);
 #pragma unroll
       for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(rgbv[0][i], sl, 64);
     }
     RN_STAMP(A, 3);
-    load_masks(A.act, pitch, 8, gs, h, M);                                    /* directional trunk */
+    load_masks(A.act, pitch, 8, gs, h, M, A.act16);                                    /* directional trunk */
 
     /* ================= backward ================= */
     float gsv[NGS];
 #pragma unroll
-    for (int i = 0; i < NGS; ++i) gsv[i] = valid ? GS[(size_t)g * NGS + i] : 0.0f;
+    for (int i = 0; i < NGS; ++i) gsv[i] = valid ? A.seeds[(size_t)i * pitch + gs] : 0.0f;
     /* ---- colour head (models.py:699-729) ---- */
     float g_tint[3], g_raw_rgb[3], g_raw_diff[3];
     {
@@ -345,7 +411,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
         if (i == 0) { gemm_op_bf16<DIN_BLOCKS, 16, 0, false>(rs, PACKED.bt_off[TOP_VD0], 0, lane, h, pk, gd, nullptr, hook); park_din(0); }
         if (i > 0) {
           if (i == 7) RN_STAMP(A, 8);
-          gemm_op_bf16<8, 16, 0, false>(rs, PACKED.bt_off[TOP_VD1 + i - 1], 0, lane, h, pk, out, nullptr, hook);
+          gemm_chain_bf16_shared<false>(rs, PACKED.bt_off[TOP_VD1 + i - 1], 0, lane, h, wave, pk, out, ring, hook);
           if (i == 7) RN_STAMP(A, 9);
           shift_masks(M);
           mask_pack(out, M[7], pk);
@@ -415,7 +481,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     wave_sync();
     /* ---- heads^T, then the spatial MLP, layers 7..0 ---- */
     RN_STAMP(A, 6);
-    load_masks(A.act, pitch, 0, gs, h, M);                                    /* spatial trunk */
+    load_masks(A.act, pitch, 0, gs, h, M, A.act16);                                    /* spatial trunk */
     if constexpr (BF) {
       gemm_op_bf16<8, 0, BT_HEADS_STEPS, false>(rs, PACKED.bt_off[TOP_HEADS], 0, lane, h, pk, out, X + col);
       mask_pack(out, M[7], pk);
@@ -423,7 +489,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
       for (int i = 7; i >= 0; --i) {
         if (i > 0) {
           std::conditional_t<D16, PairStoreHook, RowStoreHook> sh_(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid);
-          gemm_op_bf16<8, 16, 0, false>(rs, PACKED.bt_off[i - 1], 0, lane, h, pk, out, nullptr, [&](int t) {
+          gemm_chain_bf16_shared<false>(rs, PACKED.bt_off[i - 1], 0, lane, h, wave, pk, out, ring, [&](int t) {
             if constexpr (D16) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) sh_(4 * t + e, pk[t][e]);
@@ -458,6 +524,14 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     RN_STAMP(A, 7);
     wave_sync();
   }
+}
+
+/* The per-ray part of the backward (compositing, colour map, weight backward: a dependent scan along each ray) as its own
+ * launch, one wave per ray: inside the level kernel it ran on one wave of a 1-workgroup-per-CU kernel with nothing to hide
+ * its load latencies behind (88 k of the 570 k cycles of a bf16 pass).  grid = ceil(R / 4), dynamic LDS 4 (N + 1) floats. */
+__global__ __launch_bounds__(NTHREADS) void bwd_seed_kernel(const BwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bwd_seed_rays(A, smem, blockIdx.x * 4, 4, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) { level_bwd_body<false>(A); }

@@ -59,9 +59,10 @@ struct LevelArgs {
    * [ACT_ROWS][act_pitch] (refnerf_layout.h), or NULL */
   float *act;
   long long act_pitch;
+  int ring_off;           /* bf16 chains: byte offset of the shared weight-stream ring (RING_BYTES) in dynamic LDS */
 };
 
-#define RN_STAMP(A, slot) do { asm volatile("; RNMARK " #slot); if ((A).prof && blockIdx.x == 0 && (threadIdx.x & 63) == 0) (A).prof[(threadIdx.x >> 6) * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define RN_STAMP(A, slot) do { asm volatile("; RNMARK " #slot); if ((A).prof && blockIdx.x == (gridDim.x >> 1) && (threadIdx.x & 63) == 0) (A).prof[(threadIdx.x >> 6) * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

@@ -229,17 +229,20 @@ __device__ __forceinline__ void load_a16(__amdgpu_buffer_rsrc_t rs, int voff, in
  * accumulator order) followed by LDS_STEPS k-steps built from the fp32 LDS tile `xc` (= X + column), rows
  * 16 s + 8 h + e (encodings / the head block).  b_off: bias image of the fp32 ops (accumulator layout) when BIAS.
  * hook(step): runs once per register k-step (activation / delta stores). */
-template <int NOB, int REG_STEPS16, int LDS_STEPS, bool BIAS, typename Hook = NoStepHook, int LDS_MAXROW = (1 << 30)>
+/* PFD: depth of the A register ring; a one-block op (NOB = 1) takes its whole stream up front (PFD = 16): at depth 2 its
+ * 16 short k-steps paid an L2 latency every second step */
+template <int NOB, int REG_STEPS16, int LDS_STEPS, bool BIAS, typename Hook = NoStepHook, int LDS_MAXROW = (1 << 30), int PFD = (NOB == 1 ? 16 : PF16)>
 __device__ __forceinline__ void gemm_op_bf16(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
                                              const v4uu (&in)[16], v16f (&out)[NOB], const float *xc, Hook hook = Hook()) {
   constexpr int STEPS = REG_STEPS16 + LDS_STEPS;
   constexpr int STEP_BYTES = BT_STEP_FLOATS * 4;
   const int voff = lane * 16;
   int soff = a_off * 4;
-  v8bf a[PF16][NOB];
+  static_assert(PFD <= REG_STEPS16 + LDS_STEPS, "ring deeper than the op");
+  v8bf a[PFD][NOB];
 #pragma unroll
-  for (int d = 0; d < PF16; ++d) load_a16<NOB>(rs, voff, soff + d * STEP_BYTES, a[d]);
-  soff += PF16 * STEP_BYTES;
+  for (int d = 0; d < PFD; ++d) load_a16<NOB>(rs, voff, soff + d * STEP_BYTES, a[d]);
+  soff += PFD * STEP_BYTES;
   if constexpr (BIAS) load_acc<NOB>(rs, b_off, h, out);
   else {
 #pragma unroll
@@ -266,11 +269,113 @@ __device__ __forceinline__ void gemm_op_bf16(__amdgpu_buffer_rsrc_t rs, int a_of
     }
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
-      out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step % PF16][ob], b, out[ob], 0, 0, 0);
-    load_a16<NOB>(rs, voff, soff + step * STEP_BYTES, a[step % PF16]);
+      out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step % PFD][ob], b, out[ob], 0, 0, 0);
+    if (PFD <= PF16 || step + PFD < STEPS) load_a16<NOB>(rs, voff, soff + step * STEP_BYTES, a[step % PFD]);
     if (step < REG_STEPS16) hook(step);
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+/* sample-major block of the bf16 ACT format (refnerf_layout.h SMB_*): slot `slot` of lane (gs, h) */
+__device__ __forceinline__ v4u *smb_slot(const float *act, long long pitch, size_t gs, int h, int slot) {
+  char *base = reinterpret_cast<char *>(const_cast<float *>(act)) + (size_t)SMB_ROW0 * (size_t)pitch * 4;
+  return reinterpret_cast<v4u *>(base + ((((gs >> 5) * SMB_SLOTS + slot) * 64 + h * 32 + (gs & 31)) << 4));
+}
+__device__ __forceinline__ void smb_store(float *act, long long pitch, size_t gs, int h, int slot, v4u w) {
+#ifndef REFNERF_EXPERIMENT_NO_STREAM
+  __builtin_nontemporal_store(w, smb_slot(act, pitch, gs, h, slot));
+#endif
+}
+__device__ __forceinline__ void smb_store_pk(float *act, long long pitch, size_t gs, int h, int slot0, const v4uu (&pk)[16]) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) smb_store(act, pitch, gs, h, slot0 + t, (v4u){pk[t][0], pk[t][1], pk[t][2], pk[t][3]});
+}
+/* the block's x7 / v7 back as the fp32 accumulator image (bf16 values widened) */
+__device__ __forceinline__ void smb_load_rows(const float *act, long long pitch, size_t gs, int h, int slot0, v16f (&x)[8]) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const v4u w = *smb_slot(act, pitch, gs, h, slot0 + t);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x[t >> 1][8 * (t & 1) + 2 * e] = __builtin_bit_cast(float, w[e] << 16);
+      x[t >> 1][8 * (t & 1) + 2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xffff0000u);
+    }
+  }
+}
+
+/* A 256 -> 256 chain layer with the weight stream SHARED by the four waves of the workgroup: per k-step every wave
+ * fetches a quarter of the 8 KB image block (2 of the 8 row blocks: two 16-B loads per lane, two k-steps ahead), the
+ * quarters meet in a two-slot LDS ring, and every wave reads its eight A fragments from there -- a quarter of the L2 -> L1
+ * traffic of the per-wave stream (which ran at ~1250 cycles per k-step for 256 cycles of MFMA).  One s_barrier per
+ * k-step, no memory fence: the history stores of the hook stay in flight across it (only this wave's ds_writes are
+ * waited for).  Must be called by all four waves of the workgroup, the same number of times. */
+constexpr int RING_SLOTS = 3;
+constexpr int RING_BYTES = RING_SLOTS * BT_STEP_FLOATS * 4;
+/* BIAS: the accumulators start from the op's bias rows (forward); else from zero (backward: W^T delta) */
+template <bool BIAS, typename Hook>
+__device__ __forceinline__ void gemm_chain_bf16_shared(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h, int wave,
+                                                       const v4uu (&in)[16], v16f (&out)[8], char *ring, Hook hook) {
+  constexpr int STEPS = 16;
+  constexpr int STEP_BYTES = BT_STEP_FLOATS * 4;                /* 8 KB: [ob][lane][8 bf16] */
+  const int voff = wave * 2048 + lane * 16;
+  const int soff = a_off * 4;
+  char *wr = ring + wave * 2048 + lane * 16;
+  const char *rd = ring + lane * 16;
+  auto fetch = [&](int step, v4u (&g)[2]) {
+    g[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + step * STEP_BYTES, 0);
+    g[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 1024, soff + step * STEP_BYTES, 0);
+  };
+  auto stage = [&](int step, const v4u (&g)[2]) {
+    *reinterpret_cast<v4u *>(wr + (step % RING_SLOTS) * STEP_BYTES) = g[0];
+    *reinterpret_cast<v4u *>(wr + (step % RING_SLOTS) * STEP_BYTES + 1024) = g[1];
+  };
+  auto frags = [&](int step, v8bf (&a)[8]) {
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) a[ob] = *reinterpret_cast<const v8bf *>(rd + (step % RING_SLOTS) * STEP_BYTES + ob * 1024);
+  };
+  auto rendezvous = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  /* step s: [fragments of s+1 <- slot (s+1)%3] [MFMAs of s] [stage s+2 -> slot (s+2)%3, fetch s+4] [rendezvous].
+   * Slot (s+2)%3 was last read as step s-1, before the rendezvous of step s-1 that every wave has passed. */
+  v4u g[2][2];
+  v8bf a[2][8];
+  fetch(0, g[0]);
+  fetch(1, g[1]);
+  if constexpr (BIAS) load_acc<8>(rs, b_off, h, out);
+  else {
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[ob][r] = 0.0f;
+  }
+  stage(0, g[0]);
+  fetch(2, g[0]);
+  stage(1, g[1]);
+  fetch(3, g[1]);
+  rendezvous();
+  frags(0, a[0]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int step = 0; step < STEPS; ++step) {
+    if (step + 1 < STEPS) frags(step + 1, a[(step + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    const v8bf b = __builtin_bit_cast(v8bf, in[step]);
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob)
+      out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step & 1][ob], b, out[ob], 0, 0, 0);
+    if (step + 2 < STEPS) {
+      stage(step + 2, g[step & 1]);
+      if (step + 4 < STEPS) fetch(step + 4, g[step & 1]);
+    }
+    hook(step);
+    if (step + 2 < STEPS) rendezvous();               /* the last two steps' slots are already complete */
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  /* the next call stages into slots 0 and 1 right away: their last readers (steps 15 and 13) must be done */
+  rendezvous();
 }
 
 /* delta through a ReLU (recorded mask) and straight into the next GEMM's packed B fragments */
@@ -385,8 +490,13 @@ __device__ __forceinline__ void load_rows(const float *base, long long pitch, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c = blk * 32 + (r & 3) + 8 * (r >> 2);
-      if constexpr (H16) x[blk][r] = load_e<true>(base, (e0 + (long long)(c >> 1) * pitch) * 2 + (c & 1));
-      else x[blk][r] = load_e<false>(base, e0 + (long long)c * pitch);
+      if constexpr (H16) {
+        if ((r & 1) == 0) {                        /* registers r, r + 1 are the two halves of one pair-row dword */
+          const unsigned w = reinterpret_cast<const unsigned *>(base)[e0 + (long long)(c >> 1) * pitch];
+          x[blk][r] = __builtin_bit_cast(float, w << 16);
+          x[blk][r + 1] = __builtin_bit_cast(float, w & 0xffff0000u);
+        }
+      } else x[blk][r] = load_e<false>(base, e0 + (long long)c * pitch);
     }
 }
 
@@ -468,7 +578,7 @@ __device__ __forceinline__ void density_normals(__amdgpu_buffer_rsrc_t rs, int l
 
 
 /* density_normals on the bf16 chains: same VJP, deltas rounded to bf16 once per layer */
-__device__ __forceinline__ void density_normals_bf16(__amdgpu_buffer_rsrc_t rs, int lane, int h, v16f (&out)[8], v4uu (&pk)[16],
+__device__ __forceinline__ void density_normals_bf16(__amdgpu_buffer_rsrc_t rs, int lane, int h, int wave, char *ring, v16f (&out)[8], v4uu (&pk)[16],
                                                      unsigned (&M)[8][4], const float lm[3], const float lv[3], float nrm_out[3]) {
   load_acc<8>(rs, PACKED.wd_off, h, out);
   mask_pack(out, M[7], pk);
@@ -481,7 +591,7 @@ __device__ __forceinline__ void density_normals_bf16(__amdgpu_buffer_rsrc_t rs, 
       ipe_vjp_accum(gi, lm, lv, h, gl);
     }
     if (i > 0) {
-      gemm_op_bf16<8, 16, 0, false>(rs, PACKED.bt_off[i - 1], 0, lane, h, pk, out, nullptr);
+      gemm_chain_bf16_shared<false>(rs, PACKED.bt_off[i - 1], 0, lane, h, wave, pk, out, ring, NoStepHook());
 #pragma unroll
       for (int l = 7; l > 0; --l)
 #pragma unroll
@@ -595,7 +705,9 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       if constexpr (TRAIN) relu_mask_into(out, in, M[7]); else relu_into(out, in);
     }
     auto save_mask = [&](int layer, const unsigned (&mk)[4]) {
-      if (save) {
+      if constexpr (BFC) {
+        if (save) smb_store(A.act, A.act_pitch, gsx, h, SMB_MASK + layer, (v4u){mk[0], mk[1], mk[2], mk[3]});
+      } else if (save) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) store_row1(A.act, A.act_pitch, ACT_MASK + 8 * layer + 4 * h + q, gsx, __builtin_bit_cast(float, mk[q]));
       }
@@ -607,8 +719,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       if constexpr (BFC) {
         if (op == 5) gemm_op_bf16<8, 16, BF_IPE_STEPS, true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, pk, out, xc,
                                                             act_hook(ACT_SP + (op - 1) * WIDTH));
-        else gemm_op_bf16<8, 16, 0, true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, pk, out, xc,
-                                          act_hook(ACT_SP + (op - 1) * WIDTH));
+        else gemm_chain_bf16_shared<true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, wave, pk, out,
+                                          reinterpret_cast<char *>(smem) + A.ring_off, act_hook(ACT_SP + (op - 1) * WIDTH));
       } else if constexpr (TRAIN && !STAGE)
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
                             RowStoreHook(A.act, A.act_pitch, ACT_SP + (op - 1) * WIDTH, gsx, h, save));
@@ -626,6 +738,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     /* P3: heads (models.py:582,613,634-645): 4 bottleneck blocks + 1 scalar block */
     {
       v16f hd[5];
+      if constexpr (BFC) { if (save) smb_store_pk(A.act, A.act_pitch, gsx, h, SMB_X7, pk); }
       if constexpr (BFC)
         gemm_op_bf16<5, 16, 0, true>(rs, PACKED.bf_off[OP_HEADS], PACKED.op[OP_HEADS].b_off, lane, h, pk, hd, xc,
                                      act_hook(ACT_SP + 7 * WIDTH));
@@ -649,7 +762,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     wave_sync();
 
     SampleHeads sh;
-    if constexpr (BFC) density_normals_bf16(rs, lane, h, out, pk, M, lm, lv, sh.normals);
+    if constexpr (BFC) density_normals_bf16(rs, lane, h, wave, reinterpret_cast<char *>(smem) + A.ring_off, out, pk, M, lm, lv, sh.normals);
     else if constexpr (TRAIN) density_normals(rs, lane, h, in, out, M, lm, lv, xl, sh.normals);
 
     /* P4: activations, reflection, IDE (models.py:611-686) */
@@ -696,8 +809,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       if constexpr (BFC) {
         if (op == 14) gemm_op_bf16<8, 16, BF_DIN_STEPS, true, decltype(act_hook(0)), DIR_PAD - 1>(
             rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, pk, out, xc, act_hook(ACT_VD + (op - 10) * WIDTH));
-        else gemm_op_bf16<8, 16, 0, true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, pk, out, xc,
-                                          act_hook(ACT_VD + (op - 10) * WIDTH));
+        else gemm_chain_bf16_shared<true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, wave, pk, out,
+                                          reinterpret_cast<char *>(smem) + A.ring_off, act_hook(ACT_VD + (op - 10) * WIDTH));
       } else if constexpr (TRAIN && !STAGE)
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
                             RowStoreHook(A.act, A.act_pitch, ACT_VD + (op - 10) * WIDTH, gsx, h, save));
@@ -710,6 +823,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       } else relu_into(out, in);
     }
     v16f rgbv[1];
+    if constexpr (BFC) { if (save) smb_store_pk(A.act, A.act_pitch, gsx, h, SMB_V7, pk); }
     if constexpr (BFC)
       gemm_op_bf16<1, 16, 0, true>(rs, PACKED.bf_off[OP_RGB], PACKED.op[OP_RGB].b_off, lane, h, pk, rgbv, xc, act_hook(ACT_VD + 7 * WIDTH));
     else if constexpr (TRAIN && !STAGE)

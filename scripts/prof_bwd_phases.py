@@ -12,8 +12,8 @@ sd=torch.tensor([[0.0,1.0]],device=dev).repeat(R,1); w=torch.ones((R,1),device=d
 g_rgb=torch.randn((R,3),device=dev)*1e-3; g_w=torch.randn((R,N),device=dev)*1e-3; g_np=torch.randn((R,N,3),device=dev)*1e-3
 for prec in (0,1):
     cfg=_hip.default_cfg(n_samples=N,n_in=1,training=1,compute_extras=0)
+    cfg.precision=prec                       # the forward in the same mode (bf16: bf16 ACT rows + sample-major block)
     res=_hip.level_forward(packed,cfg,rays,sd,w,history=True,save_activations=True)
-    cfg.precision=prec
     grads=torch.zeros(_hip.NUM_PARAMS,device=dev)
     _hip.level_backward(packed,cfg,rays,res,g_rgb,g_w,g_np,grads)
     torch.cuda.synchronize()
