@@ -651,7 +651,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     HIP_TRY(hipMemcpy(hbuf, a.prof, sizeof(hbuf), hipMemcpyDeviceToHost));
     for (int w = 0; w < 4; ++w) {
       fprintf(stderr, "[prof bwd] wave %d:", w);
-      for (int sl = 1; sl <= 10; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
+      for (int sl = 1; sl <= 14; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
       fprintf(stderr, "\n");
     }
   }

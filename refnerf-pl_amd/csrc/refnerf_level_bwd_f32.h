@@ -218,7 +218,6 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
   const int rpw = A.rpw;
   const int ray0 = blockIdx.x * rpw;
   const int n_tot = rpw * N;
-  const long long pitch = A.pitch;
 
   float *X = smem;                               /* [DIR_PAD][T_TILE] */
   float *HD = X + DIR_PAD * T_TILE;              /* [HD_ROWS][T_TILE] */
@@ -235,13 +234,20 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
   __syncthreads();
   RN_STAMP(A, 1);
 
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.packed, 0, PACKED.total * 4, 0x00020000);
   const int col = wave * 32 + sl;
   const float *xl = X + h * T_TILE + col;
   v16f in[8], out[8];
   unsigned M[8][4];                              /* ReLU masks of the trunk being walked (saved by the training forward) */
 
   for (int pass0 = 0; pass0 < n_tot; pass0 += T_TILE) {
+    /* The image descriptor is rebuilt from a laundered pointer in every pass: with a loop-invariant descriptor the
+     * compiler hoisted ~100 weight / bias loads of the pass in front of the loop (one pass per workgroup at the usual
+     * shapes: nothing gained) and spilled them -- 24 k cycles of spill traffic before the first pass began. */
+    const void *packed_l = A.packed;
+    long long pitch = A.pitch;                     /* same for the row pitch: ~140 hoisted 64-bit row origins, all spilled */
+    asm volatile("" : "+s"(packed_l), "+s"(pitch));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)packed_l, 0, PACKED.total * 4, 0x00020000);
+    RN_STAMP(A, 14);
     const int g = pass0 + col;
     const int rl = g / N, si = g - rl * N;
     const int ray = ray0 + rl;

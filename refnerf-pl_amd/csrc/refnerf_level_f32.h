@@ -615,6 +615,7 @@ template <bool TRAIN, bool STAGE = false, bool BFC = false>
 __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   static_assert(!BFC || (TRAIN && !STAGE), "bf16 chains: training forward only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  RN_STAMP(A, 0);
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -637,14 +638,22 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   }
 
   /* ---------------- per-pass MLP over 32-sample blocks ---------------- */
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)A.packed, 0, PACKED.total * 4, 0x00020000);
   const int col = wave * 32 + sl;                /* this lane's column in X / HD */
   const float *xl = X + h * T_TILE + col;
   v16f in[8], out[8];
   v4uu pk[16];                                   /* packed bf16 layer input (bf16 chains only; dead otherwise) */
   const float *xc = X + col;
 
+  RN_STAMP(A, 1);
   for (int pass0 = 0; pass0 < n_tot; pass0 += T_TILE) {
+    RN_STAMP(A, 2);
+    /* The image descriptor is rebuilt from a laundered pointer in every pass: with a loop-invariant descriptor the
+     * compiler hoisted ~100 weight / bias loads of the pass in front of the loop (one pass per workgroup at the usual
+     * shapes: nothing gained) and spilled them -- 24 k cycles of spill traffic before the first pass began. */
+    const void *packed_l = A.packed;
+    long long act_pitch = A.act_pitch;             /* same for the row pitch of ACT: hoisted 64-bit row origins, all spilled */
+    asm volatile("" : "+s"(packed_l), "+s"(act_pitch));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)packed_l, 0, PACKED.total * 4, 0x00020000);
     const int g = pass0 + col;                   /* sample index inside the workgroup */
     const int rl = g / N, si = g - rl * N;
     const int ray = ray0 + rl;
@@ -684,15 +693,16 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         for (int b = 0; b < 3; ++b) {
           const float fe = ipe_feature(lm[b], lv[b], j, h);
           X[(48 * h + j * 3 + b) * T_TILE + col] = fe;
-          if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, A.act_pitch, ACT_IPE + 48 * h + j * 3 + b, gsx, fe); }
+          if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, act_pitch, ACT_IPE + 48 * h + j * 3 + b, gsx, fe); }
         }
     }
     wave_sync();
 
+    RN_STAMP(A, 3);
     /* P2: spatial MLP (models.py:576-580) */
     unsigned M[TRAIN ? 8 : 1][4];                /* ReLU masks of the spatial layers (training) */
     auto act_hook = [&](int row0) {              /* bf16 chains: the packed layer input leaves for ACT, 8 rows per k-step */
-      return [&, hk = PairStoreHook(A.act, A.act_pitch, row0, gsx, h, save)](int t) mutable {
+      return [&, hk = PairStoreHook(A.act, act_pitch, row0, gsx, h, save)](int t) mutable {
 #pragma unroll
         for (int e = 0; e < 4; ++e) hk(4 * t + e, pk[t][e]);       /* the k-step's B fragment as it is */
       };
@@ -706,10 +716,10 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     }
     auto save_mask = [&](int layer, const unsigned (&mk)[4]) {
       if constexpr (BFC) {
-        if (save) smb_store(A.act, A.act_pitch, gsx, h, SMB_MASK + layer, (v4u){mk[0], mk[1], mk[2], mk[3]});
+        if (save) smb_store(A.act, act_pitch, gsx, h, SMB_MASK + layer, (v4u){mk[0], mk[1], mk[2], mk[3]});
       } else if (save) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) store_row1(A.act, A.act_pitch, ACT_MASK + 8 * layer + 4 * h + q, gsx, __builtin_bit_cast(float, mk[q]));
+        for (int q = 0; q < 4; ++q) store_row1(A.act, act_pitch, ACT_MASK + 8 * layer + 4 * h + q, gsx, __builtin_bit_cast(float, mk[q]));
       }
     };
     if constexpr (TRAIN && !STAGE) { if (A.act) save_mask(0, M[7]); }
@@ -723,7 +733,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
                                           reinterpret_cast<char *>(smem) + A.ring_off, act_hook(ACT_SP + (op - 1) * WIDTH));
       } else if constexpr (TRAIN && !STAGE)
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
-                            RowStoreHook(A.act, A.act_pitch, ACT_SP + (op - 1) * WIDTH, gsx, h, save));
+                            RowStoreHook(A.act, act_pitch, ACT_SP + (op - 1) * WIDTH, gsx, h, save));
       else
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
       if constexpr (TRAIN) {
@@ -735,16 +745,17 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         if constexpr (!STAGE) { if (A.act) save_mask(op, M[7]); }
       } else relu_into(out, in);
     }
+    RN_STAMP(A, 4);
     /* P3: heads (models.py:582,613,634-645): 4 bottleneck blocks + 1 scalar block */
     {
       v16f hd[5];
-      if constexpr (BFC) { if (save) smb_store_pk(A.act, A.act_pitch, gsx, h, SMB_X7, pk); }
+      if constexpr (BFC) { if (save) smb_store_pk(A.act, act_pitch, gsx, h, SMB_X7, pk); }
       if constexpr (BFC)
         gemm_op_bf16<5, 16, 0, true>(rs, PACKED.bf_off[OP_HEADS], PACKED.op[OP_HEADS].b_off, lane, h, pk, hd, xc,
                                      act_hook(ACT_SP + 7 * WIDTH));
       else if constexpr (TRAIN && !STAGE)
         gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0,
-                            RowStoreHook(A.act, A.act_pitch, ACT_SP + 7 * WIDTH, gsx, h, save));
+                            RowStoreHook(A.act, act_pitch, ACT_SP + 7 * WIDTH, gsx, h, save));
       else
         gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0);
       __builtin_amdgcn_wave_barrier();          /* all IPE reads of this wave are done */
@@ -757,14 +768,16 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < HD_ROWS) HD[row * T_TILE + col] = hd[4][r];
       }
-      if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<4, BFC>(A.act, A.act_pitch, ACT_DIN, gsx, h, save, hd); }
+      if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<4, BFC>(A.act, act_pitch, ACT_DIN, gsx, h, save, hd); }
     }
     wave_sync();
 
     SampleHeads sh;
+    RN_STAMP(A, 5);
     if constexpr (BFC) density_normals_bf16(rs, lane, h, wave, reinterpret_cast<char *>(smem) + A.ring_off, out, pk, M, lm, lv, sh.normals);
     else if constexpr (TRAIN) density_normals(rs, lane, h, in, out, M, lm, lv, xl, sh.normals);
 
+    RN_STAMP(A, 6);
     /* P4: activations, reflection, IDE (models.py:611-686) */
     {
       float gp[3], raw_dif[3], raw_tint[3];
@@ -778,11 +791,11 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       float *xi = X + (BNECK + IDE_TERMS * h) * T_TILE + col;
       ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) {
         xi[q * T_TILE] = val;
-        if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, A.act_pitch, ACT_DIN + BNECK + IDE_TERMS * h + q, gsx, val); }
+        if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, act_pitch, ACT_DIN + BNECK + IDE_TERMS * h + q, gsx, val); }
       });
       if (h == 0) {
         X[(BNECK + IDE_DIM) * T_TILE + col] = sh.dot;
-        if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, A.act_pitch, ACT_DIN + BNECK + IDE_DIM, gsx, sh.dot); }
+        if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, act_pitch, ACT_DIN + BNECK + IDE_DIM, gsx, sh.dot); }
       } else {
 #pragma unroll
         for (int q = DIR_IN; q < DIR_PAD; ++q) X[q * T_TILE + col] = 0.0f;
@@ -790,6 +803,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     }
     wave_sync();
 
+    RN_STAMP(A, 7);
     /* P5: directional MLP (models.py:690-694) + rgb (699-700) */
     if constexpr (BFC) {
       unsigned mk[4];
@@ -813,7 +827,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
                                           reinterpret_cast<char *>(smem) + A.ring_off, act_hook(ACT_VD + (op - 10) * WIDTH));
       } else if constexpr (TRAIN && !STAGE)
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
-                            RowStoreHook(A.act, A.act_pitch, ACT_VD + (op - 10) * WIDTH, gsx, h, save));
+                            RowStoreHook(A.act, act_pitch, ACT_VD + (op - 10) * WIDTH, gsx, h, save));
       else
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
       if constexpr (TRAIN && !STAGE) {
@@ -822,13 +836,14 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         if (A.act) save_mask(op - 1, mk);
       } else relu_into(out, in);
     }
+    RN_STAMP(A, 8);
     v16f rgbv[1];
-    if constexpr (BFC) { if (save) smb_store_pk(A.act, A.act_pitch, gsx, h, SMB_V7, pk); }
+    if constexpr (BFC) { if (save) smb_store_pk(A.act, act_pitch, gsx, h, SMB_V7, pk); }
     if constexpr (BFC)
       gemm_op_bf16<1, 16, 0, true>(rs, PACKED.bf_off[OP_RGB], PACKED.op[OP_RGB].b_off, lane, h, pk, rgbv, xc, act_hook(ACT_VD + 7 * WIDTH));
     else if constexpr (TRAIN && !STAGE)
       gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0,
-                          RowStoreHook(A.act, A.act_pitch, ACT_VD + 7 * WIDTH, gsx, h, save));
+                          RowStoreHook(A.act, act_pitch, ACT_VD + 7 * WIDTH, gsx, h, save));
     else
       gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0);
     /* rows 0..2 live in half 0, regs 0..2; hand them to half 1 as well */
@@ -836,6 +851,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(rgbv[0][i], sl, 64);
 
+    RN_STAMP(A, 9);
     /* P6: colour head (models.py:699-729) */
     if (valid && h == 0) colour_store(A, sh, raw_rgb, PS, PX, n_tot, g, col);
     wave_sync();
@@ -844,6 +860,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   }
   __syncthreads();
 
+  RN_STAMP(A, 10);
   if constexpr (!STAGE) composite_phase(A, TD, XP, PS, n_tot, ray0, wave, lane, X, NRM);   /* P7 */
 }
 
