@@ -309,6 +309,9 @@ __device__ __forceinline__ void smb_load_rows(const float *act, long long pitch,
  * traffic of the per-wave stream (which ran at ~1250 cycles per k-step for 256 cycles of MFMA).  One s_barrier per
  * k-step, no memory fence: the history stores of the hook stay in flight across it (only this wave's ds_writes are
  * waited for).  Must be called by all four waves of the workgroup, the same number of times. */
+#ifndef REFNERF_RING_FETCH
+#define REFNERF_RING_FETCH 4   /* an L2 round trip under load outlasts two k-steps */
+#endif
 constexpr int RING_SLOTS = 3;
 constexpr int RING_BYTES = RING_SLOTS * BT_STEP_FLOATS * 4;
 /* BIAS: the accumulators start from the op's bias rows (forward); else from zero (backward: W^T delta) */
@@ -340,10 +343,11 @@ __device__ __forceinline__ void gemm_chain_bf16_shared(__amdgpu_buffer_rsrc_t rs
   };
   /* step s: [fragments of s+1 <- slot (s+1)%3] [MFMAs of s] [stage s+2 -> slot (s+2)%3, fetch s+4] [rendezvous].
    * Slot (s+2)%3 was last read as step s-1, before the rendezvous of step s-1 that every wave has passed. */
-  v4u g[2][2];
+  constexpr int GD = REFNERF_RING_FETCH;                        /* k-steps between a quarter's fetch and its LDS write */
+  v4u g[GD][2];
   v8bf a[2][8];
-  fetch(0, g[0]);
-  fetch(1, g[1]);
+#pragma unroll
+  for (int d = 0; d < GD; ++d) fetch(d, g[d]);
   if constexpr (BIAS) load_acc<8>(rs, b_off, h, out);
   else {
 #pragma unroll
@@ -352,25 +356,40 @@ __device__ __forceinline__ void gemm_chain_bf16_shared(__amdgpu_buffer_rsrc_t rs
       for (int r = 0; r < 16; ++r) out[ob][r] = 0.0f;
   }
   stage(0, g[0]);
-  fetch(2, g[0]);
+  fetch(GD, g[0]);
   stage(1, g[1]);
-  fetch(3, g[1]);
+  fetch(GD + 1, g[1]);
   rendezvous();
   frags(0, a[0]);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int step = 0; step < STEPS; ++step) {
     if (step + 1 < STEPS) frags(step + 1, a[(step + 1) & 1]);
-    __builtin_amdgcn_sched_barrier(0);
     const v8bf b = __builtin_bit_cast(v8bf, in[step]);
 #pragma unroll
     for (int ob = 0; ob < 8; ++ob)
       out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[step & 1][ob], b, out[ob], 0, 0, 0);
     if (step + 2 < STEPS) {
-      stage(step + 2, g[step & 1]);
-      if (step + 4 < STEPS) fetch(step + 4, g[step & 1]);
+      stage(step + 2, g[(step + 2) % GD]);
+      if (step + 2 + GD < STEPS) fetch(step + 2 + GD, g[(step + 2) % GD]);
     }
     hook(step);
+    /* one wave per SIMD: everything else rides in the issue gaps of the 8 MFMAs -- the fragment reads of the next step
+     * in the first four gaps (left behind the MFMAs they waited a full LDS round trip in front of the rendezvous),
+     * then the stream's loads, its LDS writes and the history stores */
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
     if (step + 2 < STEPS) rendezvous();               /* the last two steps' slots are already complete */
     __builtin_amdgcn_sched_barrier(0);
   }
