@@ -154,7 +154,8 @@ int refnerf_level_forward(const void *d_packed, const refnerf_level_cfg *cfg,
  * resampling inputs are detached there as well), it ACCUMULATES dL/d(params)
  * into d_param_grads (canonical blob, REFNERF_NUM_PARAMS floats).
  * d_workspace holds the per-sample output gradients of every layer, which the
- * weight-gradient GEMM contracts with the saved layer inputs. */
+ * weight-gradient GEMM contracts with the saved layer inputs, the split-K
+ * partial sums and the per-sample seeds of the per-ray pre-pass. */
 typedef struct refnerf_level_saved {
   const float *d_sdist;     /* [R,N+1] refnerf_level_out.d_sdist   */
   const float *d_density;   /* [R,N]                               */
