@@ -922,22 +922,24 @@ def test_bf16_chain_training_forward(hip, O, name):
         assert np.median(cos) > 0.999 and np.mean(cos > 0.99) > 0.8 and np.mean(cos > 0.9) > 0.95
 
 
-def test_bf16_chain_training_step(hip):
+@pytest.mark.parametrize("n_rays,n_prop,n_nerf", [(70, 64, 96), (37, 40, 72)])
+def test_bf16_chain_training_step(hip, n_rays, n_prop, n_nerf):
     """Whole training step with Config.hip_train_precision = hip_bwd_precision = 'bf16' against the all-f32 step:
-    same loss to 1e-4, gradient within bf16 accuracy, rendering within 1e-4."""
+    same loss to 1e-4, gradient within bf16 accuracy, rendering within 1e-4.  The second shape is ragged on purpose:
+    sample counts that fill neither a 128-sample pass nor the 32-sample chunks of the sample-major block."""
     import os
     from refnerf_pl_amd import configs, models, synthetic, train_utils, utils
     res = {}
     for mode in ("f32", "bf16"):
         configs.clear_config()
         configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
-                                                ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 96",
+                                                [f"Model.num_prop_samples = {n_prop}", f"Model.num_nerf_samples = {n_nerf}",
                                                  f"Config.hip_train_precision = '{mode}'", f"Config.hip_bwd_precision = '{mode}'"])
         cfg = configs.Config()
         model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
         model.nerf_mlp.load_flat_params(synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0))
-        rays = utils.rays_from_dict(synthetic.blender_rays(70, seed=9, center_frac=0.4), DEV)
-        batch = utils.Batch(rays=rays, rgb=synthetic.target_rgb(70, seed=3))
+        rays = utils.rays_from_dict(synthetic.blender_rays(n_rays, seed=9, center_frac=0.4), DEV)
+        batch = utils.Batch(rays=rays, rgb=synthetic.target_rgb(n_rays, seed=3))
         rend, hist = model(rays, 1.0, True)
         total, _, _ = train_utils.compute_losses(model, batch, rays, rend, hist, cfg)
         total.backward()
