@@ -930,11 +930,11 @@ def test_bf16_chain_training_step(hip, n_rays, n_prop, n_nerf):
     import os
     from refnerf_pl_amd import configs, models, synthetic, train_utils, utils
     res = {}
-    for mode in ("f32", "bf16"):
+    for mode, bwd_mode in (("f32", "f32"), ("bf16", "bf16"), ("bf16", "f32")):
         configs.clear_config()
         configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
                                                 [f"Model.num_prop_samples = {n_prop}", f"Model.num_nerf_samples = {n_nerf}",
-                                                 f"Config.hip_train_precision = '{mode}'", f"Config.hip_bwd_precision = '{mode}'"])
+                                                 f"Config.hip_train_precision = '{mode}'", f"Config.hip_bwd_precision = '{bwd_mode}'"])
         cfg = configs.Config()
         model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
         model.nerf_mlp.load_flat_params(synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0))
@@ -944,11 +944,14 @@ def test_bf16_chain_training_step(hip, n_rays, n_prop, n_nerf):
         total, _, _ = train_utils.compute_losses(model, batch, rays, rend, hist, cfg)
         total.backward()
         grad = torch.cat([p.grad.flatten() for p in model.nerf_mlp.ordered_parameters()]).double().cpu()
-        res[mode] = (float(total.detach()), grad, rend[1]["rgb"].detach().cpu())
-    (la, ga, ra), (lb, gb, rb) = res["f32"], res["bf16"]
+        res[mode, bwd_mode] = (float(total.detach()), grad, rend[1]["rgb"].detach().cpu())
+    (la, ga, ra), (lb, gb, rb) = res["f32", "f32"], res["bf16", "bf16"]
     assert lb == pytest.approx(la, rel=1e-4)
     assert float((ra - rb).abs().max()) <= 1e-4
     assert float((ga - gb).norm() / ga.norm()) < 1e-2
+    lc, gc, rc = res["bf16", "f32"]                     # bf16 forward (bf16 ACT rows + sample-major block) into the f32 backward
+    assert lc == lb and bool((rc == rb).all())
+    assert float((ga - gc).norm() / ga.norm()) < 1e-2
     with pytest.raises(ValueError):
         configs.clear_config()
         configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
