@@ -191,11 +191,12 @@ __device__ __forceinline__ void load_masks(const float *act, long long pitch, in
     }
     return;
   }
+  const long long e0 = (long long)(ACT_MASK + 8 * layer0 + 4 * h) * pitch + (long long)gs;   /* one origin, compile-time row offsets */
 #pragma unroll
   for (int l = 0; l < 8; ++l)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      M[l][q] = __builtin_bit_cast(unsigned, act[(long long)(ACT_MASK + 8 * (layer0 + l) + 4 * h + q) * pitch + (long long)gs]);
+      M[l][q] = __builtin_bit_cast(unsigned, act[e0 + (long long)(8 * l + q) * pitch]);
 }
 
 
@@ -246,6 +247,8 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     const void *packed_l = A.packed;
     long long pitch = A.pitch;                     /* same for the row pitch: ~140 hoisted 64-bit row origins, all spilled */
     asm volatile("" : "+s"(packed_l), "+s"(pitch));
+    int hdb = DIR_PAD * T_TILE + col;                /* the HD tile (beyond the 64 KB immediate range) through one laundered base */
+    asm volatile("" : "+v"(hdb));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)packed_l, 0, PACKED.total * 4, 0x00020000);
     RN_STAMP(A, 14);
     const int g = pass0 + col;
@@ -259,7 +262,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     for (int i = 0; i < 3; ++i) v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
     /* ===== the few forward values the backward needs, from the saved x7 / v7 ===== */
     /* Only the scalar block of the heads (rows 128..139: density, grad_pred, roughness, diffuse, tint) is needed here --
-     * the bottleneck comes back from its ACT_DIN rows.  bf16 chains on a bf16 forward: the forward's own GEMM (same
+     * the bottleneck enters the backward only as a weight-gradient operand (its ACT_DIN rows).  bf16 chains on a bf16 forward: the forward's own GEMM (same
      * image, same packed x7) -> the forward's own raw head values, bit for bit. */
     {
       v16f hd4[1];
@@ -281,7 +284,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < HD_ROWS) HD[row * T_TILE + col] = hd4[0][r];
+        if (row < HD_ROWS) X[hdb + row * T_TILE] = hd4[0][r];
       }
     }
     RN_STAMP(A, 2);
@@ -305,13 +308,13 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     float raw_density, raw_rough, raw_tint[3];
     {
       float gp[3], raw_dif[3];
-      raw_density = HD[0 * T_TILE + col];
-      raw_rough = HD[4 * T_TILE + col];
+      raw_density = X[hdb + 0 * T_TILE];
+      raw_rough = X[hdb + 4 * T_TILE];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        gp[i] = HD[(1 + i) * T_TILE + col];
-        raw_dif[i] = HD[(5 + i) * T_TILE + col];
-        raw_tint[i] = HD[(8 + i) * T_TILE + col];
+        gp[i] = X[hdb + (1 + i) * T_TILE];
+        raw_dif[i] = X[hdb + (5 + i) * T_TILE];
+        raw_tint[i] = X[hdb + (8 + i) * T_TILE];
       }
       sample_heads(cfg, raw_density, gp, raw_rough, raw_dif, raw_tint, v, sh);
     }
@@ -385,6 +388,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     if constexpr (BF) mask_pack(out, M[7], pk); else masked_into(out, in, M[7]);
     /* ---- directional MLP, layers 7..0 ---- */
     v16f(&gd)[DIN_BLOCKS] = reinterpret_cast<v16f(&)[DIN_BLOCKS]>(out);   /* gradient w.r.t. the 201 dir inputs */
+    const int din_hi = tile_hi(col);
     auto park_din = [&](int i) {
       /* layer 5 (skip connection) parks its share in LDS; layer 0 adds it back */
 #pragma unroll
@@ -393,7 +397,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
         for (int r = 0; r < 16; ++r) {
           const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (blk < 6 || row < DIR_PAD) {
-            float *px = X + row * T_TILE + col;
+            float *px = X + (blk < 4 ? row * T_TILE + col : (row - 128) * T_TILE + din_hi);
             if (i == 0) gd[blk][r] += *px;
             *px = gd[blk][r];
           }
@@ -445,8 +449,9 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     /* ---- IDE, reflection, predicted normal, head activations (models.py:611-686) ---- */
     {
       float g_ref[3], g_rough;
-      ide_grad(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, [&](int q) { return X[(BNECK + q) * T_TILE + col]; }, g_ref, g_rough);
-      const float g_dot = X[(BNECK + IDE_DIM) * T_TILE + col];
+      const int xhi = tile_hi(col);              /* rows >= 128 of the tile through one laundered base (tile_idx) */
+      ide_grad(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, [&](int q) { return X[tile_idx(BNECK + q, col, xhi)]; }, g_ref, g_rough);
+      const float g_dot = X[tile_idx(BNECK + IDE_DIM, col, xhi)];
       const float w3[3] = {-v[0], -v[1], -v[2]};
       const float ndw = (sh.npred[0] * w3[0] + sh.npred[1] * w3[1]) + sh.npred[2] * w3[2];
       const float grn = (g_ref[0] * sh.npred[0] + g_ref[1] * sh.npred[1]) + g_ref[2] * sh.npred[2];
@@ -476,12 +481,12 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
       if (h == 0) {
 #pragma unroll
         for (int i = 0; i < 11; ++i) {
-          X[(HROW_DENSITY + i) * T_TILE + col] = hrow[i];
+          X[tile_idx(HROW_DENSITY + i, col, xhi)] = hrow[i];
           if (valid) store_row1<D16>(A.delta, pitch, DEL_HEADS + HROW_DENSITY + i, gs, hrow[i]);
         }
       } else {
 #pragma unroll
-        for (int q = HROWS; q < 2 * HEADS_T_STEPS + 2; ++q) X[q * T_TILE + col] = 0.0f;
+        for (int q = HROWS; q < 2 * HEADS_T_STEPS + 2; ++q) X[tile_idx(q, col, xhi)] = 0.0f;
       }
     }
     wave_sync();

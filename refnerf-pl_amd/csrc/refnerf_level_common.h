@@ -64,6 +64,17 @@ struct LevelArgs {
 
 #define RN_STAMP(A, slot) do { asm volatile("; RNMARK " #slot); if ((A).prof && blockIdx.x == (gridDim.x >> 1) && (threadIdx.x & 63) == 0) (A).prof[(threadIdx.x >> 6) * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
+/* Index into an LDS tile of 128-float rows for a compile-time row: rows whose byte offset passes the 64 KB immediate
+ * range of the ds instructions go through `hi` = a LAUNDERED 128 * 128 + column (tile_hi()), so that one register
+ * serves all of them.  Left to itself the compiler materialises one address register per such row, hoists them in
+ * front of the pass loop and spills them: the 73 reads of ide_grad took 44 k cycles of scratch reloads (2.4 k now). */
+__device__ __forceinline__ int tile_hi(int col) {
+  int hi = 128 * 128 + col;
+  asm volatile("" : "+v"(hi));
+  return hi;
+}
+__device__ __forceinline__ int tile_idx(int row, int col, int hi) { return row < 128 ? row * 128 + col : (row - 128) * 128 + hi; }
+
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();

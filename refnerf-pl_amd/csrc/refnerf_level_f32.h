@@ -238,6 +238,8 @@ __device__ __forceinline__ void gemm_op_bf16(__amdgpu_buffer_rsrc_t rs, int a_of
   constexpr int STEP_BYTES = BT_STEP_FLOATS * 4;
   const int voff = lane * 16;
   int soff = a_off * 4;
+  int hi = 128 * T_TILE;                         /* LDS rows >= 128: one laundered base (see tile_hi) */
+  if constexpr (LDS_STEPS * 16 > 128) asm volatile("" : "+v"(hi));
   static_assert(PFD <= REG_STEPS16 + LDS_STEPS, "ring deeper than the op");
   v8bf a[PFD][NOB];
 #pragma unroll
@@ -260,7 +262,7 @@ __device__ __forceinline__ void gemm_op_bf16(__amdgpu_buffer_rsrc_t rs, int a_of
       for (int e = 0; e < 8; ++e) {
         int row = 16 * (step - REG_STEPS16) + 8 * h + e;
         if (row > LDS_MAXROW) row = LDS_MAXROW;          /* pad rows (zero weights) must still read finite values */
-        x[e] = xc[row * T_TILE];
+        x[e] = (16 * (step - REG_STEPS16) + 15 < 128) ? xc[row * T_TILE] : xc[(row - 128) * T_TILE + hi];
       }
       v4uu pk = {cvt_pk_bf16(x[0], x[1]), cvt_pk_bf16(x[2], x[3]), cvt_pk_bf16(x[4], x[5]), cvt_pk_bf16(x[6], x[7])};
       b = __builtin_bit_cast(v8bf, pk);
@@ -672,6 +674,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     const void *packed_l = A.packed;
     long long act_pitch = A.act_pitch;             /* same for the row pitch of ACT: hoisted 64-bit row origins, all spilled */
     asm volatile("" : "+s"(packed_l), "+s"(act_pitch));
+    int hdb = DIR_PAD * T_TILE + col;                /* the HD tile (beyond the 64 KB immediate range) through one laundered base */
+    asm volatile("" : "+v"(hdb));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)packed_l, 0, PACKED.total * 4, 0x00020000);
     const int g = pass0 + col;                   /* sample index inside the workgroup */
     const int rl = g / N, si = g - rl * N;
@@ -785,7 +789,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < HD_ROWS) HD[row * T_TILE + col] = hd[4][r];
+        if (row < HD_ROWS) X[hdb + row * T_TILE] = hd[4][r];
       }
       if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<4, BFC>(A.act, act_pitch, ACT_DIN, gsx, h, save, hd); }
     }
@@ -802,22 +806,23 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       float gp[3], raw_dif[3], raw_tint[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        gp[i] = HD[(1 + i) * T_TILE + col];
-        raw_dif[i] = HD[(5 + i) * T_TILE + col];
-        raw_tint[i] = HD[(8 + i) * T_TILE + col];
+        gp[i] = X[hdb + (1 + i) * T_TILE];
+        raw_dif[i] = X[hdb + (5 + i) * T_TILE];
+        raw_tint[i] = X[hdb + (8 + i) * T_TILE];
       }
-      sample_heads(cfg, HD[0 * T_TILE + col], gp, HD[4 * T_TILE + col], raw_dif, raw_tint, v, sh);
-      float *xi = X + (BNECK + IDE_TERMS * h) * T_TILE + col;
+      sample_heads(cfg, X[hdb + 0 * T_TILE], gp, X[hdb + 4 * T_TILE], raw_dif, raw_tint, v, sh);
+      const int xhi = tile_hi(col);
+      float *xi = X + xhi + IDE_TERMS * h * T_TILE;   /* row BNECK (= 128) + 36 h */
       ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) {
         xi[q * T_TILE] = val;
         if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, act_pitch, ACT_DIN + BNECK + IDE_TERMS * h + q, gsx, val); }
       });
       if (h == 0) {
-        X[(BNECK + IDE_DIM) * T_TILE + col] = sh.dot;
+        X[tile_idx(BNECK + IDE_DIM, col, xhi)] = sh.dot;
         if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, act_pitch, ACT_DIN + BNECK + IDE_DIM, gsx, sh.dot); }
       } else {
 #pragma unroll
-        for (int q = DIR_IN; q < DIR_PAD; ++q) X[q * T_TILE + col] = 0.0f;
+        for (int q = DIR_IN; q < DIR_PAD; ++q) X[tile_idx(q, col, xhi)] = 0.0f;
       }
     }
     wave_sync();
