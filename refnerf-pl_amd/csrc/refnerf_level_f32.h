@@ -564,6 +564,30 @@ __device__ __forceinline__ void ipe_vjp_accum(const v16f (&gi)[3], const float l
     }
 }
 
+/* The same from the (e sin, e cos) bf16 pairs P1 left in tile rows 128 + kk (bf16 chains): d/dm [e sin(m 2^j)] =
+ * (e cos) 2^j, d/dm [e cos(m 2^j)] = -(e sin) 2^j -- 48 LDS reads and ~5 VALU each instead of 48 expf + cosf with
+ * range reduction (2 x 20 k cycles per pass).  Row k = c + 4h of a lane: sin / cos row by c alone (no c in 44..47),
+ * (j, b) of kk = c' + 4h one of two compile-time pairs; a half-wave-1 lane's b is (c' + 1) % 3: rotated at the end. */
+__device__ __forceinline__ void ipe_vjp_accum_lds(const v16f (&gi)[3], const float *X, int col, int h, float gl[3]) {
+  int base = (BNECK * T_TILE + col + 4 * h * T_TILE) * 2;        /* ushort index of row 128 + 4h, this column */
+  asm volatile("" : "+v"(base));
+  const unsigned short *xs = reinterpret_cast<const unsigned short *>(X) + base;
+  float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = blk * 32 + (r & 3) + 8 * (r >> 2);
+      const int cb = c >= 48, cc = cb ? c - 48 : c;                /* cos row?  kk = cc + 4h */
+      const float sc0 = (float)(1 << (cc / 3)), sc1 = (float)(1 << ((cc + 4) / 3));
+      const float f = __builtin_bit_cast(float, (unsigned)xs[(cc * T_TILE) * 2 + (cb ? 0 : 1)] << 16);
+      const float sc = h ? sc1 : sc0;
+      acc[cc % 3] += (gi[blk][r] * f) * (cb ? -sc : sc);
+    }
+#pragma unroll
+  for (int b = 0; b < 3; ++b) gl[b] += h ? acc[(b + 2) % 3] : acc[b];
+}
+
 /* Density-gradient normals (models.py:603-609): VJP of raw_density through the
  * spatial MLP (transposed packed ops, recorded ReLU masks) and the IPE, then
  * -normalize.  `in`/`out` are scratch; M[l] = mask of layer l (consumed). */
@@ -600,7 +624,7 @@ __device__ __forceinline__ void density_normals(__amdgpu_buffer_rsrc_t rs, int l
 
 /* density_normals on the bf16 chains: same VJP, deltas rounded to bf16 once per layer */
 __device__ __forceinline__ void density_normals_bf16(__amdgpu_buffer_rsrc_t rs, int lane, int h, int wave, char *ring, v16f (&out)[8], v4uu (&pk)[16],
-                                                     unsigned (&M)[8][4], const float lm[3], const float lv[3], float nrm_out[3]) {
+                                                     unsigned (&M)[8][4], const float *X, int col, float nrm_out[3]) {
   load_acc<8>(rs, PACKED.wd_off, h, out);
   mask_pack(out, M[7], pk);
   float gl[3] = {0.0f, 0.0f, 0.0f};
@@ -609,7 +633,7 @@ __device__ __forceinline__ void density_normals_bf16(__amdgpu_buffer_rsrc_t rs, 
     if (i == 5 || i == 0) {
       v16f gi[3];
       gemm_op_bf16<3, 16, 0, false>(rs, PACKED.bt_off[i == 5 ? TOP_SP5_IPE : TOP_SP0], 0, lane, h, pk, gi, nullptr);
-      ipe_vjp_accum(gi, lm, lv, h, gl);
+      ipe_vjp_accum_lds(gi, X, col, h, gl);
     }
     if (i > 0) {
       gemm_chain_bf16_shared<false>(rs, PACKED.bt_off[i - 1], 0, lane, h, wave, pk, out, ring, NoStepHook());
@@ -716,6 +740,9 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         for (int b = 0; b < 3; ++b) {
           const float fe = ipe_feature(lm[b], lv[b], j, h);
           X[(48 * h + j * 3 + b) * T_TILE + col] = fe;
+          /* bf16 chains: (e sin, e cos) of every (j, b) once more as a bf16 pair in tile rows 128.. (free until P4): the
+           * density-normal VJP needs exactly these as d feature / d mean (ipe_vjp_accum_lds) */
+          if constexpr (BFC) reinterpret_cast<unsigned short *>(X)[((BNECK + j * 3 + b) * T_TILE + col) * 2 + h] = (unsigned short)cvt_pk_bf16(fe, fe);
           if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, act_pitch, ACT_IPE + 48 * h + j * 3 + b, gsx, fe); }
         }
     }
@@ -797,7 +824,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 
     SampleHeads sh;
     RN_STAMP(A, 5);
-    if constexpr (BFC) density_normals_bf16(rs, lane, h, wave, reinterpret_cast<char *>(smem) + A.ring_off, out, pk, M, lm, lv, sh.normals);
+    if constexpr (BFC) density_normals_bf16(rs, lane, h, wave, reinterpret_cast<char *>(smem) + A.ring_off, out, pk, M, X, col, sh.normals);
     else if constexpr (TRAIN) density_normals(rs, lane, h, in, out, M, lm, lv, xl, sh.normals);
 
     RN_STAMP(A, 6);
