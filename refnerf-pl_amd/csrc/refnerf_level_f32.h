@@ -738,7 +738,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       for (int j = 0; j < 16; ++j)
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-          const float fe = ipe_feature(lm[b], lv[b], j, h);
+          const float fe = ipe_feature<BFC>(lm[b], lv[b], j, h);   /* bf16 chains: hardware sin / exp2, as the bf16 eval kernel (the MLP rounds its inputs to 8 bits) */
           X[(48 * h + j * 3 + b) * T_TILE + col] = fe;
           /* bf16 chains: (e sin, e cos) of every (j, b) once more as a bf16 pair in tile rows 128.. (free until P4): the
            * density-normal VJP needs exactly these as d feature / d mean (ipe_vjp_accum_lds) */
