@@ -38,7 +38,8 @@ enum {
 /* arithmetic of the MLP contractions */
 enum {
   REFNERF_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains (parity mode) */
-  REFNERF_PREC_BF16 = 1  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate                   */
+  REFNERF_PREC_BF16 = 1  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate (training forward / backward in
+                            this mode: n_samples <= 294, REFNERF_EINVAL beyond -- LDS budget)  */
 };
 
 /* arithmetic of the weight-gradient GEMM of refnerf_level_backward (dW = DELTA x ACT^T over the samples) */

@@ -958,3 +958,24 @@ def test_bf16_chain_training_step(hip, n_rays, n_prop, n_nerf):
                                                 ["Config.hip_bwd_precision = 'fp8'"])
         m = models.construct_model(utils.dummy_rays(), configs.Config()).to(DEV).train()
         m(rays, 1.0, False)
+
+def test_bf16_chain_training_sample_limit(hip):
+    """The bf16-chain training forward keeps a 24 KB weight-stream ring in LDS on top of the level's tiles: it takes
+    n_samples <= 294 (f32: 561) and says so instead of running something else."""
+    import os
+    from refnerf_pl_amd import configs, models, synthetic, utils
+    rays = utils.rays_from_dict(synthetic.blender_rays(8, seed=2, center_frac=0.4), DEV)
+    for mode, ok in (("f32", True), ("bf16", False)):
+        configs.clear_config()
+        configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                                ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 320",
+                                                 f"Config.hip_train_precision = '{mode}'", f"Config.hip_bwd_precision = '{mode}'"])
+        model = models.construct_model(utils.dummy_rays(), configs.Config()).to(DEV).train()
+        model.nerf_mlp.load_flat_params(synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0))
+        if ok:
+            rend, _ = model(rays, 1.0, True)
+            assert bool(torch.isfinite(rend[1]["rgb"]).all())
+        else:
+            with pytest.raises(ValueError, match="LDS budget"):
+                model(rays, 1.0, True)
+    configs.clear_config()
