@@ -399,13 +399,20 @@ __device__ __forceinline__ void gemm_chain_bf16_shared(__amdgpu_buffer_rsrc_t rs
   rendezvous();
 }
 
+/* x where bit `bit` of `mk` is set, else +0: v_bfe_i32 (0 / all ones) + v_and -- VALU only.  As `bit ? x : 0.0f` the
+ * compiler produced 128 v_cmp results in SGPR pairs first, spilled them through v_writelane (+ s_nop hazards) and
+ * selected afterwards: ~6 instructions per element instead of 2. */
+__device__ __forceinline__ float keep_if_bit(float x, unsigned mk, int bit) {
+  const int m = __builtin_amdgcn_sbfe((int)mk, bit, 1);
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & (unsigned)m);
+}
 /* delta through a ReLU (recorded mask) and straight into the next GEMM's packed B fragments */
 __device__ __forceinline__ void mask_pack(const v16f (&out)[8], const unsigned (&mk)[4], v4uu (&pk)[16]) {
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) {
     float v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = ((mk[ob >> 1] >> (16 * (ob & 1) + r)) & 1u) ? out[ob][r] : 0.0f;
+    for (int r = 0; r < 16; ++r) v[r] = keep_if_bit(out[ob][r], mk[ob >> 1], 16 * (ob & 1) + r);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       pk[2 * ob][e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
@@ -539,7 +546,7 @@ __device__ __forceinline__ void masked_into(const v16f (&out)[8], v16f (&in)[8],
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) in[ob][r] = ((mk[ob >> 1] >> (16 * (ob & 1) + r)) & 1u) ? out[ob][r] : 0.0f;
+    for (int r = 0; r < 16; ++r) in[ob][r] = keep_if_bit(out[ob][r], mk[ob >> 1], 16 * (ob & 1) + r);
 }
 
 /* Contribution of this lane's 48 IPE-gradient rows to d(raw_density)/d(lifted
