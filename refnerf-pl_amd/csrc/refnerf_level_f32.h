@@ -399,6 +399,15 @@ __device__ __forceinline__ void gemm_chain_bf16_shared(__amdgpu_buffer_rsrc_t rs
   rendezvous();
 }
 
+/* ReLU and its sign bit without a compare: as integers, x > 0 <=> max_i32(x, 0) != 0 (negative floats and -0 are
+ * negative integers), so relu(x) = max_i32(x, 0) and the mask bit = min_u32(relu(x), 1) -- VALU only (see keep_if_bit),
+ * bit-identical to `x > 0 ? x : 0` for every non-NaN x. */
+__device__ __forceinline__ float relu_bit(float x, unsigned &mk, int bit) {
+  const int xi = __builtin_bit_cast(int, x);
+  const unsigned v = (unsigned)(xi > 0 ? xi : 0);
+  mk |= (v < 1u ? v : 1u) << bit;
+  return __builtin_bit_cast(float, v);
+}
 /* x where bit `bit` of `mk` is set, else +0: v_bfe_i32 (0 / all ones) + v_and -- VALU only.  As `bit ? x : 0.0f` the
  * compiler produced 128 v_cmp results in SGPR pairs first, spilled them through v_writelane (+ s_nop hazards) and
  * selected afterwards: ~6 instructions per element instead of 2. */
@@ -435,9 +444,7 @@ __device__ __forceinline__ void relu_mask_pack(const v16f (&out)[8], unsigned (&
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const bool p = out[ob][r] > 0.0f;
-      v[r] = p ? out[ob][r] : 0.0f;
-      mk[ob >> 1] |= p ? (1u << (16 * (ob & 1) + r)) : 0u;
+      v[r] = relu_bit(out[ob][r], mk[ob >> 1], 16 * (ob & 1) + r);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -536,9 +543,7 @@ __device__ __forceinline__ void relu_mask_into(const v16f (&out)[8], v16f (&in)[
   for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const bool p = out[ob][r] > 0.0f;          /* relu'(0) = 0, as torch */
-      in[ob][r] = p ? out[ob][r] : 0.0f;
-      mk[ob >> 1] |= p ? (1u << (16 * (ob & 1) + r)) : 0u;
+      in[ob][r] = relu_bit(out[ob][r], mk[ob >> 1], 16 * (ob & 1) + r);          /* relu'(0) = 0, as torch */
     }
 }
 /* in = out where the recorded ReLU was active, else 0 (delta through a ReLU). */
