@@ -213,7 +213,7 @@ __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, in
  * The head / rgb recompute and everything per sample stay fp32.
  * ------------------------------------------------------------------------------------------------ */
 #ifndef REFNERF_PF16
-#define REFNERF_PF16 2
+#define REFNERF_PF16 4
 #endif
 constexpr int PF16 = REFNERF_PF16;
 template <int NOB>
