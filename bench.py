@@ -1,32 +1,62 @@
 #!/usr/bin/env python3
 """bench.py -- Ref-NeRF rendering inner loop on MI355X.
 
-One "step" = one ``Model.__call__`` (eval forward, compute_extras=True) over a
-synthetic Blender-style batch of 4096 rays x 128 samples x 2 levels
-(BASELINE.json configs[1]) through the fused HIP path.  Prints ONE JSON line.
+One "step" = one pass of the hot path over one synthetic batch through the fused HIP kernels:
+``Model.__call__`` (eval forward, compute_extras=True, full ray_history) for the rendering
+configurations, a full training step (training forward + losses + backward + gradient all-reduce +
+Adam) for C5.  Prints ONE JSON line.
 
-  python bench.py [--gpus N --steps K --warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N --steps K --warmup W] [--config C2|C3|C4|C5]
 
-Multi-GPU: rays shard by rank (each rank renders its own 4096-ray tile, weights
-replicated, no data-path collective) -> weak scaling; RCCL is used only for the
-timing barrier / max-over-ranks.
+  --config C2 (default, the headline): blender_refnerf.gin, 4096 rays x 128 samples x 2 levels per GPU (weak scaling)
+  --config C3: the "shiny" network (raw_roughness.bias = -6), 8192 rays x 192 samples x 2 levels per GPU (weak)
+  --config C4: llff_refnerf.gin rays, 4096 rays x 128 samples over ALL ranks (strong scaling: 4096/N rays per rank;
+               below 1024 rays per rank the level loop is replayed from a HIP graph)
+  --config C5: llff_refnerf_geometry_losses.gin, 16384 rays x 256 samples over ALL ranks (strong: 16384/N per rank),
+               full training step with the nine-term loss set and ONE RCCL all-reduce of the 4.44 MB gradient blob
+
+Multi-GPU: `--gpus N` with N > 1 starts N processes itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in their environment) BEFORE anything touches a GPU, unless it is already running under torchrun
+(RANK set), in which case it is one of the ranks.  Rays shard by rank, weights are replicated, no data-path
+collective; RCCL carries the timing barrier and, for C5, the gradient all-reduce.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 FLOP_PER_SAMPLE = 2211840            # MLP contractions only
+NORMALS_VJP_FLOP = 1016320           # density-normal VJP of the training forward
 TRAIN_FLOP_PER_SAMPLE = 7651840      # fwd + density-normal VJP + backward
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+CONFIGS = {
+    # name: rays (per GPU when weak, total when strong), samples, gin file, ray family, mode, scaling, weight recipe
+    "C2": dict(rays=4096, samples=128, gin="refnerf_blender.gin", family="blender", mode="eval", scaling="weak",
+               params=dict(seed=0, bias_scale=0.05, sharpen=20.0),
+               workload="blender_refnerf.gin, 4096 rays x 128 samples, 2-level, Model.__call__ eval forward with "
+                        "compute_extras + full ray_history"),
+    "C3": dict(rays=8192, samples=192, gin="refnerf_blender.gin", family="blender", mode="eval", scaling="weak",
+               params=dict(seed=0, bias_scale=0.05, sharpen=20.0, roughness_bias=-6.0),
+               workload="blender_refnerf.gin shiny network (roughness ~1e-3), 8192 rays x 192 samples, 2-level, "
+                        "Model.__call__ eval forward with compute_extras + full ray_history"),
+    "C4": dict(rays=4096, samples=128, gin="refnerf_llff.gin", family="llff", mode="eval", scaling="strong",
+               params=dict(seed=0, bias_scale=0.05, sharpen=20.0),
+               workload="llff_refnerf.gin forward-facing NDC rays, 4096 rays x 128 samples over all ranks, 2-level, "
+                        "Model.__call__ eval forward with compute_extras + full ray_history"),
+    "C5": dict(rays=16384, samples=256, gin="refnerf_llff_geometry_losses.gin", family="llff", mode="train",
+               scaling="strong", params=dict(seed=0, bias_scale=0.05, sharpen=20.0),
+               workload="llff_refnerf_geometry_losses.gin, 16384 rays (+ noisy rays) x 256 samples over all ranks, "
+                        "2-level, full training step: clean + noisy pass, nine loss terms, fused backward, gradient "
+                        "all-reduce, Adam"),
+}
 
 
 def parse():
@@ -34,106 +64,169 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rays", type=int, default=4096)
-    ap.add_argument("--samples", type=int, default=128)
-    ap.add_argument("--precision", default="bf16", choices=["f32", "bf16"],
-                    help="arithmetic of the MLP contractions for the headline value; the other mode is reported alongside")
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--rays", type=int, default=None, help="override the configuration's ray count")
+    ap.add_argument("--samples", type=int, default=None, help="override the configuration's samples per level")
+    ap.add_argument("--precision", default="bf16", choices=["f32", "bf16", "f16"],
+                    help="arithmetic of the MLP contractions for the headline value; the other modes are reported alongside")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-image", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-graph", action="store_true", help="never replay the level loop from a HIP graph")
     return ap.parse_args()
 
 
-def build_model(args, dev):
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args) -> int:
+    """Parent of `--gpus N` (N > 1) outside torchrun: start one fresh child per GPU and relay rank 0's JSON line.
+    Nothing here initialises a GPU (torch.cuda.device_count() only counts devices)."""
+    import torch
+    n = args.gpus
+    share = os.environ.get("REFNERF_BENCH_SHARE_GPU") == "1"
+    visible = torch.cuda.device_count()
+    if visible < n and not share:
+        print(f"bench.py: --gpus {n} but only {visible} device(s) visible "
+              "(REFNERF_BENCH_SHARE_GPU=1 lets the ranks share device 0 for a smoke run)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        sys.stderr.write(out0)
+        return 1
+    sys.stdout.write(out0)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ workload
+def build_model(args, spec, dev):
     import refnerf_pl_amd  # noqa: F401
     from refnerf_pl_amd import configs, models, synthetic
     configs.clear_config()
-    configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", "refnerf_blender.gin")], [
-        f"Model.num_prop_samples = {args.samples}", f"Model.num_nerf_samples = {args.samples}",
-        f"Config.batch_size = {args.rays}", f"Config.hip_precision = '{args.precision}'"])
+    configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", spec["gin"])], [
+        f"Model.num_prop_samples = {spec['samples']}", f"Model.num_nerf_samples = {spec['samples']}",
+        f"Config.batch_size = {spec['rays']}", f"Config.hip_precision = '{args.precision}'"])
     cfg = configs.Config()
     model = models.construct_model(None, cfg).to(dev)
     model.eval()
-    blob = synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0)
+    blob = synthetic.make_params(**spec["params"])
     model.nerf_mlp.load_flat_params(blob)
     return model, cfg, blob
 
 
-def cpu_baseline(blob, args, target_seconds):
-    """Time the CPU oracle (a from-scratch C port, OpenMP over rays, all host
-    cores) on a bounded sample of the same workload."""
-    from oracle import oracle as O
+def make_rays(spec, n_rays, seed):
     from refnerf_pl_amd import synthetic
+    if spec["family"] == "llff":
+        return synthetic.llff_rays(n_rays, seed=seed)
+    return synthetic.blender_rays(n_rays, seed=seed, center_frac=0.5)
+
+
+def cpu_sample_size(spec, cores):
+    """FIXED size of the CPU-baseline sample (no calibration runs: the figure used to drift by 40 % with them): the
+    first n rays of rank 0's own batch -- the whole batch on a many-core host (~10-20 s), 512 rays otherwise."""
+    return min(spec["rays"], 4096 if cores >= 64 else 512)
+
+
+def cpu_baseline_and_parity(blob, spec, rays_np, hip_outputs):
+    """(a) cpu_baseline: the CPU oracle (a from-scratch C port of the reference's algorithm, OpenMP over rays, all
+    host cores) timed on a fixed prefix of the batch the GPU just rendered; (b) its outputs double as the checker
+    of the GPU results of both arithmetic modes on exactly those rays (`parity`)."""
+    import numpy as np
+    from oracle import oracle as O
     cores = os.cpu_count() or 1
-    # two calibration rounds (64 rays, then ~2 s worth) so that the timed sample lands in the 10-30 s window
-    # whatever the core count: the first call also pays for thread start-up and page faults
-    n_probe, rate = 64, None
-    for _ in range(3):
-        probe = synthetic.blender_rays(n_probe, seed=1, center_frac=0.5)
-        t0 = time.time()
-        O.model_forward(blob, probe, num_prop_samples=args.samples, num_nerf_samples=args.samples, n_threads=cores, history=True)
-        rate = n_probe * args.samples * 2 / max(time.time() - t0, 1e-6)
-        n_probe = max(64, min(4096, int(rate * 2.0 / (args.samples * 2)) // 64 * 64))
-    n_rays = int(min(16 * args.rays, max(64, rate * target_seconds / (args.samples * 2))))
-    n_rays = max(64, (n_rays // 64) * 64)
-    rays = synthetic.blender_rays(n_rays, seed=1, center_frac=0.5)
+    N = spec["samples"]
+    n = cpu_sample_size(spec, cores)
+    sub = {k: v[:n] for k, v in rays_np.items()}
+    O.model_forward(blob, {k: v[:64] for k, v in rays_np.items()}, num_prop_samples=N, num_nerf_samples=N, n_threads=cores)  # thread start-up, page faults
     t0 = time.time()
-    O.model_forward(blob, rays, num_prop_samples=args.samples, num_nerf_samples=args.samples, n_threads=cores, history=True)
+    ref = O.model_forward(blob, sub, num_prop_samples=N, num_nerf_samples=N, n_threads=cores, history=True)
     dt = time.time() - t0
-    return {"value": n_rays * args.samples * 2 / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n_rays} rays (same generator as the {args.rays}-ray batch) x {args.samples} samples x 2 levels, "
-                      f"eval forward, fp32, {dt:.1f} s"}
+    base = {"value": n * N * 2 / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} rays of the timed batch x {N} samples x 2 levels, eval forward with full history, "
+                      f"fp32, OpenMP over rays, {dt:.1f} s"}
+    parity = {"rays_checked": n, "checker": "oracle/refnerf_oracle.c (pinned by tests/golden, captured from the reference)"}
+    for tag, out in hip_outputs.items():
+        rgb = out[0][-1]["rgb"][:n].float().cpu().numpy()
+        err = np.abs(rgb - ref[-1]["r_rgb"])
+        mse = float(np.mean((rgb.astype(np.float64) - ref[-1]["r_rgb"]) ** 2))
+        w_hip = out[1][-1]["weights"][:n].cpu().numpy()
+        parity[tag] = {"rgb_linf_vs_oracle": float(err.max()), "psnr_vs_oracle_db": float(-10 * np.log10(max(mse, 1e-20))),
+                       "weights_linf_vs_oracle": float(np.abs(w_hip - ref[-1]["weights"]).max()),
+                       "sdist_identical_frac": float(np.mean(out[1][-1]["sdist"][:n].cpu().numpy() == ref[-1]["sdist"]))}
+    return base, parity
 
 
-def train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync, chains="f32"):
-    """Secondary figure: one full training step (training forward with density-gradient
-    normals + saved layer inputs, the three Ref-NeRF losses, HIP backward + weight-gradient GEMM, gradient
-    all-reduce over the ranks, Adam step) on the same batch; fp32 MFMA chains, the weight-gradient GEMM on
-    split-bf16 MFMA at fp32 accuracy (Config.hip_wgrad_mode)."""
-    from refnerf_pl_amd import distributed, synthetic, train_utils, utils
-    model.train()
-    cfg.hip_train_precision = cfg.hip_bwd_precision = chains      # 'f32' (parity mode) | 'bf16' (bf16 MFMA chains)
-    gt = synthetic.target_rgb(args.rays, seed=7 + rank)
-    batch = utils.Batch(rays=rays, rgb=gt)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+def trained_like_parity(model, cfg, dev, spec, modes):
+    """The same check on the "trained-like" weights (tests/golden/trained_blob.npz: what the REFERENCE reached after 400
+    of its own Adam steps on an analytic shiny sphere): 256 Blender rays x this configuration's sample counts, every
+    arithmetic mode against the CPU oracle.  Random-init weights flatter 16-bit arithmetic; these do not."""
+    import numpy as np
+    import torch
+    from oracle import oracle as O
+    from refnerf_pl_amd import synthetic, utils
+    path = os.path.join(ROOT, "tests", "golden", "trained_blob.npz")
+    if not os.path.exists(path):
+        return None
+    blob = np.load(path)["blob_f16"].astype(np.float32)
+    N = spec["samples"]
+    rays_np = synthetic.blender_rays(256, seed=3, center_frac=0.8)
+    ref = O.model_forward(blob, rays_np, num_prop_samples=N, num_nerf_samples=N, n_threads=os.cpu_count() or 1)
+    keep = model.nerf_mlp.flat_params().clone()
+    model.nerf_mlp.load_flat_params(blob)
+    rays = utils.rays_from_dict(rays_np, dev)
+    res = {"rays_checked": 256, "weights": "tests/golden/trained_blob.npz"}
+    prev = cfg.hip_precision
+    for m in modes:
+        cfg.hip_precision = m
+        with torch.no_grad():
+            out = model(rays, 1.0, True)
+        rgb = out[0][-1]["rgb"].cpu().numpy()
+        mse = float(np.mean((rgb.astype(np.float64) - ref[-1]["r_rgb"]) ** 2))
+        res[m] = {"rgb_linf_vs_oracle": float(np.abs(rgb - ref[-1]["r_rgb"]).max()),
+                  "psnr_vs_oracle_db": float(-10 * np.log10(max(mse, 1e-20)))}
+    cfg.hip_precision = prev
+    model.nerf_mlp.load_flat_params(keep)
+    return res
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        renderings, history = model(rays, 1.0, False)
-        total, terms, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
-        total.backward()
-        distributed.allreduce_gradients(model)
-        opt.step()
-        return total
 
-    n = max(2, min(10, args.steps // 3))
-    step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        loss = step()
-    sync()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    model.eval()
-    cfg.hip_train_precision = cfg.hip_bwd_precision = "f32"
-    assert torch.isfinite(loss.detach()).all()
-    rate = world * args.rays * args.samples * 2 * n / el
-    tf = rate / world * TRAIN_FLOP_PER_SAMPLE / 1e12
-    return {"value": rate, "unit": "ray-samples/s (fwd+bwd+Adam)", "ms_per_step": 1e3 * el / n, "steps": n,
-            "dtype": chains, "wgrad": getattr(cfg, "hip_wgrad_mode", "bf16x3"), "loss": float(loss.detach()),
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[chains], "unit": "TFLOP/s",
-                         "frac": tf / PEAK_TFLOPS[chains],
-                         "note": "whole step incl. losses, optimiser and weight re-pack; algorithmic 7,651,840 FLOP/ray-sample; "
-                                 "the weight-gradient GEMM runs on split-bf16 MFMA in both modes and is HBM-bound"}}
+def torch_cpu_baseline(spec):
+    """Second CPU baseline: the build's own UNFUSED PyTorch restatement of the path (oracle/torch_path.py,
+    plain ATen ops on the host cores -- how the reference itself evaluates the path), at C1's shape and at this
+    configuration's shape on a bounded sample.  Runs in a child process (its own OpenMP runtime: the C oracle's
+    spinning worker threads otherwise fight torch's) and keeps the fastest of two intra-op thread counts."""
+    out = []
+    n2 = min(spec["rays"], 1024)
+    for tag, n_rays, N, levels in ((f"C1 shape: 1024 rays x 64 samples x 1 level", 1024, 64, 1),
+                                   (f"this configuration's samples: {n2} rays x {spec['samples']} samples x 2 levels", n2, spec["samples"], 2)):
+        try:
+            r = subprocess.run([sys.executable, "-m", "oracle.torch_path", spec["family"], str(n_rays), str(N), str(levels),
+                                json.dumps(spec["params"])], cwd=ROOT, capture_output=True, text=True, timeout=150)
+            res = json.loads(r.stdout.strip().splitlines()[-1])
+            out.append({"value": res["rate"], "unit": "ray-samples/s", "cores": res["threads"], "kind": "port",
+                        "sample": f"unfused PyTorch CPU path, {tag}, eval forward, fp32, {res['seconds']:.2f} s per pass "
+                                  f"(best of {res['tried']} intra-op thread counts on {os.cpu_count()} cores)"})
+        except (subprocess.TimeoutExpired, ValueError, IndexError, KeyError) as e:
+            out.append({"value": None, "unit": "ray-samples/s", "cores": None, "kind": "port",
+                        "sample": f"unfused PyTorch CPU path, {tag}: not measured ({type(e).__name__})"})
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,125 +246,273 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    n_ranks_seen = dist.get_world_size() if dist is not None else 1
+    assert n_ranks_seen == world
 
-    from refnerf_pl_amd import _hip, synthetic, utils
+    spec = dict(CONFIGS[args.config])
+    if args.rays:
+        spec["rays"] = args.rays
+    if args.samples:
+        spec["samples"] = args.samples
+    strong = spec["scaling"] == "strong"
+    rays_per_rank = spec["rays"] // world if strong else spec["rays"]
+    total_rays = rays_per_rank * world
+    N = spec["samples"]
+
+    from refnerf_pl_amd import _hip, utils
     _hip.require_device()
-    model, cfg, blob = build_model(args, dev)
-    # ray-tile data parallel: rank r renders its own tile of the (virtual) image
-    rays = utils.rays_from_dict(synthetic.blender_rays(args.rays, seed=1 + rank, center_frac=0.5), dev)
-
-    def step():
-        with torch.no_grad():
-            return model(rays, 1.0, True)
+    model, cfg, blob = build_model(args, spec, dev)
+    # ray-tile data parallel: rank r works on its own tile of the (virtual) image / batch
+    rays_np = make_rays(spec, rays_per_rank, seed=1 + rank)
+    rays = utils.rays_from_dict(rays_np, dev)
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n_steps, n_warm):
-        """n_warm untimed steps, then exactly n_steps bracketed by barrier + synchronize on
-        both sides; returns (elapsed s [max over ranks], kernel ms total, launches, last output)."""
-        for _ in range(n_warm):
-            step()
-        sync()
-        _hip.set_timing(True)      # HIP event pairs on the kernel's own stream, inside the library
-        t0 = time.perf_counter()
-        for _ in range(n_steps):
-            out = step()
-        sync()
-        el = time.perf_counter() - t0
-        kern_ms, launches = _hip.get_timing()
-        _hip.set_timing(False)
-        if dist is not None:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, kern_ms, launches, out
+    def max_over_ranks(el):
+        if dist is None:
+            return el
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    def roofline(prec, kern_ms, launches):
-        avg_ms = kern_ms / launches
-        flop_per_launch = args.rays * args.samples * FLOP_PER_SAMPLE
-        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
-        kernel = "rn::level_fwd_f32" if prec == "f32" else "rn::level_fwd_bf16"
-        traffic = None
-        try:   # PMC numbers cannot be collected inside this process: taken from the committed rocprofv3 passes
-            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
-            if args.rays == 4096 and args.samples == 128:
-                traffic = prof["bytes_per_launch"]
+    line = {"metric": None, "value": None, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": spec["scaling"],
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": spec["workload"], "name": args.config, "rays_per_gpu": rays_per_rank,
+                       "total_rays": total_rays, "samples_per_level": N, "parallelism": f"ray-tile dp{world}",
+                       "n_ranks_seen": n_ranks_seen}}
+
+    def traffic_of(kernel):
+        """PMC numbers cannot be collected inside this process: copied from the committed rocprofv3 --pmc passes
+        (profiles/traffic.json), only for the workload they were measured on."""
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            entry = prof[f"{kernel}@{args.config}"] if f"{kernel}@{args.config}" in prof else (prof[kernel] if args.config == "C2" else None)
+            if entry and rays_per_rank == CONFIGS[args.config]["rays"] and N == CONFIGS[args.config]["samples"]:
+                return entry["bytes_per_launch"], f"profiles/traffic.json@{entry.get('round', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not measured in this run)"
         except (OSError, KeyError, ValueError):
             pass
+        return None, None
+
+    def mfma_roofline(prec, kernel, kern_ms, launches, flop_per_launch):
+        avg_ms = kern_ms / launches
+        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+        traffic, src = traffic_of(kernel)
         return {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
-                "frac": achieved / PEAK_TFLOPS[prec], "traffic": traffic, "kernel": kernel,
-                "avg_launch_ms": avg_ms, "launches": launches, "flop_per_launch": flop_per_launch}
+                "frac": achieved / PEAK_TFLOPS[prec], "traffic": traffic, "traffic_source": src, "kernel": kernel,
+                "avg_launch_ms": avg_ms, "launches": launches, "flop_per_launch": flop_per_launch,
+                "timing": "HIP event pairs on the launch stream, inside the timed region"}
 
-    elapsed, kern_ms, launches, out = timed(args.steps, args.warmup)
-    rgb = out[0][-1]["rgb"]
-    assert torch.isfinite(rgb).all()
+    if spec["mode"] == "eval":
+        graphed = None
+        use_graph = rays_per_rank < 1024 and not args.no_graph
 
-    samples_per_step = args.rays * args.samples * 2
-    value = world * samples_per_step * args.steps / elapsed
-    line = {
-        "metric": "ray-samples/s (4096 rays x 128 samples x 2 levels, Ref-NeRF Blender, eval forward)",
-        "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"blender_refnerf.gin, {args.rays} rays x {args.samples} samples, 2-level, "
-                               "Model.__call__ eval forward with compute_extras + full ray_history",
-                   "rays_per_gpu": args.rays, "parallelism": f"ray-tile dp{world}"},
-    }
-    if launches:
-        line["roofline"] = roofline(args.precision, kern_ms, launches)
-    if rank == 0 and world == 1:
-        # the other arithmetic mode on the same batch (f32 = exact-fp32 MFMA, the strict parity mode)
-        other = "f32" if args.precision == "bf16" else "bf16"
-        cfg.hip_precision = other
-        n2 = max(3, args.steps // 5)
-        el2, k2, l2, out2 = timed(n2, 1)
-        line[other + "_mode"] = {"value": samples_per_step * n2 / el2, "unit": "ray-samples/s",
-                                 "ms_per_step": 1e3 * el2 / n2, "dtype": other, "roofline": roofline(other, k2, l2)}
-        line["mode_agreement"] = {"rgb_linf_bf16_vs_f32": float((out[0][-1]["rgb"] - out2[0][-1]["rgb"]).abs().max()),
-                                  "note": "rendered RGB of the two modes on this batch; parity of each mode vs the "
-                                          "reference's golden vectors is asserted in tests/test_hip_parity.py"}
-        cfg.hip_precision = args.precision
-    if rank == 0 and world == 1 and not args.no_image:
-        # full-image render ms: 800x800 Blender view, 157 chunks of 4096 rays (models.render_image)
-        from refnerf_pl_amd import models
-        # rays of the whole view are cast on the device (refnerf_pixels_to_rays), inside the timed region
-        from refnerf_pl_amd import camera_utils
-        c2w, focal = synthetic.blender_camera(seed=1)
-        # two renders: the first one also pays for the one-off growth of torch's caching allocator (157 chunks of
-        # outputs) and the first launch of the ray-casting kernel; the headline is the steady state
-        for tag in ("full_image_render_first_ms", "full_image_render_ms"):
+        def eager_step():
+            with torch.no_grad():
+                return model(rays, 1.0, True)
+
+        def make_step():
+            nonlocal graphed
+            if use_graph:
+                from refnerf_pl_amd import graphs
+                graphed = graphs.GraphedForward(model, rays, 1.0, True)
+                return lambda: graphed(rays)
+            return eager_step
+
+        def timed(step, n_steps, n_warm, with_events):
+            """n_warm untimed steps, then exactly n_steps bracketed by barrier + synchronize on both sides;
+            returns (elapsed s [max over ranks], kernel ms total, launches, last output)."""
+            for _ in range(n_warm):
+                step()
+            sync()
+            if with_events:
+                _hip.set_timing(True)      # HIP event pairs on the kernel's own stream, inside the library
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                out = step()
+            sync()
+            el = time.perf_counter() - t0
+            kern_ms, launches = _hip.get_timing() if with_events else (0.0, 0)
+            _hip.set_timing(False)
+            return max_over_ranks(el), kern_ms, launches, out
+
+        def kernel_name(prec):
+            return {"f32": "rn::level_fwd_f32", "bf16": "rn::level_fwd_bf16", "f16": "rn::level_fwd_f16"}[prec]
+
+        step = make_step()
+        elapsed, kern_ms, launches, out = timed(step, args.steps, args.warmup, with_events=not use_graph)
+        if use_graph:   # events cannot be recorded inside a graph replay: kernel durations from a short eager pass
+            _, kern_ms, launches, _ = timed(eager_step, max(5, args.steps // 10), 2, True)
+        rgb = out[0][-1]["rgb"]
+        assert torch.isfinite(rgb).all()
+        samples_per_step = total_rays * N * 2
+        line["metric"] = (f"ray-samples/s ({spec['rays']} rays x {N} samples x 2 levels, Ref-NeRF "
+                          f"{'Blender' if spec['family'] == 'blender' else 'LLFF'}, eval forward)")
+        line["value"] = samples_per_step * args.steps / elapsed
+        line["ms_per_step"] = 1e3 * elapsed / args.steps
+        line["config"]["hip_graph_replay"] = bool(use_graph)
+        flop_per_launch = rays_per_rank * N * FLOP_PER_SAMPLE
+        if launches:
+            line["roofline"] = mfma_roofline(args.precision, kernel_name(args.precision), kern_ms, launches, flop_per_launch)
+        hip_outputs = {args.precision: out}
+        if rank == 0 and world == 1:
+            # the other arithmetic modes on the same batch (f32 = exact-fp32 MFMA, the strict parity mode; bf16 / f16 =
+            # the two 16-bit MFMA throughput modes)
+            def fp64_psnr(x, y):
+                return float(-10 * torch.log10(torch.clamp(((x.double() - y.double()) ** 2).mean(), min=1e-20)))
+            for other in [m for m in ("f32", "bf16", "f16") if m != args.precision]:
+                cfg.hip_precision = other
+                n2 = max(3, args.steps // 5)
+                el2, k2, l2, out2 = timed(eager_step, n2, 1, True)
+                line[other + "_mode"] = {"value": samples_per_step * n2 / el2, "unit": "ray-samples/s",
+                                         "ms_per_step": 1e3 * el2 / n2, "dtype": other,
+                                         "roofline": mfma_roofline(other, kernel_name(other), k2, l2, flop_per_launch)}
+                hip_outputs[other] = out2
+            cfg.hip_precision = args.precision
+            ref32 = hip_outputs["f32"]
+            line["mode_agreement"] = {
+                m: {"rgb_linf_vs_f32": float((o[0][-1]["rgb"] - ref32[0][-1]["rgb"]).abs().max()),
+                    "psnr_vs_f32_db": fp64_psnr(o[0][-1]["rgb"], ref32[0][-1]["rgb"]),
+                    "sdist_identical_frac": float((o[1][-1]["sdist"] == ref32[1][-1]["sdist"]).double().mean())}
+                for m, o in hip_outputs.items() if m != "f32"}
+        if rank == 0 and world == 1 and not args.no_image and args.config == "C2":
+            from refnerf_pl_amd import camera_utils, models, synthetic
+            # full-image render ms: 800x800 Blender view, 157 chunks of 4096 rays (models.render_image); the rays of
+            # the whole view are cast on the device (refnerf_pixels_to_rays), inside the timed region
+            c2w, focal = synthetic.blender_camera(seed=1)
+            # two renders: the first one also pays for the one-off growth of torch's caching allocator (157 chunks of
+            # outputs) and the first launch of the ray-casting kernel; the headline is the steady state
+            for tag in ("full_image_render_first_ms", "full_image_render_ms"):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    img = camera_utils.cast_pinhole_rays(c2w.astype(np.float32), 800, 800, focal, 2.0, 6.0, device=dev)
+                    rendering = models.render_image(lambda r: model(r, 1.0, True), img, cfg, verbose=False, device=dev)
+                torch.cuda.synchronize()
+                line[tag] = 1e3 * (time.perf_counter() - t0)
+            assert rendering["rgb"].shape == (800, 800, 3)
+            # 1008x756 LLFF-style view (NDC rays, near 0 / far 1), same chunked loop
+            del img, rendering
+            lr = synthetic.llff_rays(0, seed=1, full_image=True)
+            img = utils.rays_from_dict({k: v.reshape(756, 1008, -1) for k, v in lr.items()}, dev)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             with torch.no_grad():
-                img = camera_utils.cast_pinhole_rays(c2w.astype(np.float32), 800, 800, focal, 2.0, 6.0, device=dev)
                 rendering = models.render_image(lambda r: model(r, 1.0, True), img, cfg, verbose=False, device=dev)
             torch.cuda.synchronize()
-            line[tag] = 1e3 * (time.perf_counter() - t0)
-        assert rendering["rgb"].shape == (800, 800, 3)
-        # 1008x756 LLFF-style view (NDC rays, near 0 / far 1), same chunked loop
-        del img, rendering
-        lr = synthetic.llff_rays(0, seed=1, full_image=True)
-        img = utils.rays_from_dict({k: v.reshape(756, 1008, -1) for k, v in lr.items()}, dev)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            rendering = models.render_image(lambda r: model(r, 1.0, True), img, cfg, verbose=False, device=dev)
-        torch.cuda.synchronize()
-        line["llff_image_render_ms"] = 1e3 * (time.perf_counter() - t0)
-        assert rendering["rgb"].shape == (756, 1008, 3)
-    if not args.no_train:
-        line["train_step"] = train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync, "f32")
-        line["train_step_bf16"] = train_step_bench(args, model, cfg, rays, rank, world, dev, dist, sync, "bf16")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(blob, args, args.cpu_seconds)
+            line["llff_image_render_ms"] = 1e3 * (time.perf_counter() - t0)
+            assert rendering["rgb"].shape == (756, 1008, 3)
+            del img, rendering
+        if not args.no_train and args.config == "C2":
+            line["train_step"] = train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync, max_over_ranks, "f32")
+            line["train_step_bf16"] = train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync, max_over_ranks, "bf16")
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(blob, spec, rays_np, hip_outputs)
+            line["parity"]["trained_like_weights"] = trained_like_parity(model, cfg, dev, spec, sorted(hip_outputs))
+            if args.config == "C2":
+                line["cpu_baseline_torch"] = torch_cpu_baseline(spec)
+    else:
+        res = train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync, max_over_ranks,
+                               args.precision, n_steps=args.steps, n_warm=args.warmup, geometry=True)
+        line["metric"] = (f"ray-samples/s ({spec['rays']} rays x {N} samples x 2 levels, Ref-NeRF LLFF geometry losses, "
+                          "training step fwd+bwd+all-reduce+Adam)")
+        line["value"] = res["value"]
+        line["ms_per_step"] = res["ms_per_step"]
+        line["roofline"] = res.pop("roofline")
+        line["train_step"] = res
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync, max_over_ranks, chains="f32",
+                     n_steps=None, n_warm=1, geometry=False):
+    """One full training step on the batch: training forward (density-gradient normals + saved layer inputs),
+    losses (the three Ref-NeRF terms, or with `geometry` the nine-term set of llff_refnerf_geometry_losses.gin incl.
+    the noisy-ray second pass), HIP backward + weight-gradient GEMM, ONE all-reduce of the gradient blob over the
+    ranks, Adam step.  `chains` = arithmetic of the MLP chains of the training kernels ('f32' parity mode | 'bf16');
+    the weight-gradient GEMM runs on split-bf16 MFMA at fp32 accuracy in both (Config.hip_wgrad_mode)."""
+    import torch
+    from refnerf_pl_amd import _hip, distributed, synthetic, train_utils, utils
+    model.train()
+    cfg.hip_train_precision = cfg.hip_bwd_precision = chains
+    R = rays.origins.shape[0]
+    N = spec["samples"]
+    gt = synthetic.target_rgb(R, seed=7 + rank)
+    batch = utils.Batch(rays=rays, rgb=gt)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    extra_rays = cfg.sample_noise_size * cfg.sample_noise_angles if geometry else 0
+    it = [0]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        if geometry:
+            total, _, _, _ = train_utils.training_losses(model, batch, rays, cfg, global_step=200000 + it[0])
+        else:
+            renderings, history = model(rays, 1.0, False)
+            total, _, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+        total.backward()
+        distributed.allreduce_gradients(model)
+        opt.step()
+        it[0] += 1
+        return total
+
+    n = n_steps if n_steps is not None else max(2, min(10, args.steps // 3))
+    for _ in range(max(1, n_warm)):
+        step()
+    sync()
+    _hip.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = step()
+    sync()
+    el = max_over_ranks(time.perf_counter() - t0)
+    fam = {k: _hip.get_timing(f) for k, f in (("fwd", _hip.TIMER_FORWARD), ("bwd", _hip.TIMER_BACKWARD), ("wgrad", _hip.TIMER_WGRAD))}
+    _hip.set_timing(False)
+    model.eval()
+    cfg.hip_train_precision = cfg.hip_bwd_precision = "f32"
+    assert torch.isfinite(loss.detach()).all()
+    rate = world * (R + extra_rays) * N * 2 * n / el
+    # per-kernel rooflines from the event pairs of the timed steps (a level = one launch of each family; the noisy
+    # pass of the geometry config launches the same kernels on fewer rays: averages are per launch over both)
+    passes = 2 if geometry else 1           # clean + noisy pass: two launches of each family per level and step
+    samples_per_launch = (R + extra_rays) * N / passes
+    kernels = {}
+    names = {"fwd": "rn::level_fwd_train_" + ("bf16c" if chains == "bf16" else "f32"),
+             "bwd": "rn::level_bwd_" + ("bf16c" if chains == "bf16" else "f32"), "wgrad": "rn::wgrad_bf16x3_kernel"}
+    for k, (ms, cnt) in fam.items():
+        if not cnt:
+            continue
+        avg = ms / cnt
+        if k == "wgrad":
+            # algorithmic bytes: both operand matrices read once -- ACT (4396 rows) + DELTA (4244 rows) per sample,
+            # fp32 rows in the f32 mode, bf16 rows with the bf16 chains
+            bytes_per_launch = samples_per_launch * (4396 + 4244) * (2 if chains == "bf16" else 4)
+            ach = bytes_per_launch / (avg * 1e-3) / 1e9
+            kernels[k] = {"kernel": names[k], "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": ach / PEAK_HBM_GBS, "avg_launch_ms": avg, "launches": cnt, "bytes_per_launch": bytes_per_launch}
+        else:
+            # forward: MLP + density-normal VJP; backward kernel: the transposed chains dX = W^T delta (one pass over
+            # the MLP's contractions -- the other half of the backward FLOPs, dW, is the wgrad GEMM's)
+            flop = samples_per_launch * ((FLOP_PER_SAMPLE + NORMALS_VJP_FLOP) if k == "fwd" else FLOP_PER_SAMPLE)
+            ach = flop / (avg * 1e-3) / 1e12
+            kernels[k] = {"kernel": names[k], "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[chains], "unit": "TFLOP/s",
+                          "frac": ach / PEAK_TFLOPS[chains], "avg_launch_ms": avg, "launches": cnt, "flop_per_launch": flop}
+    out = {"value": rate, "unit": "ray-samples/s (fwd+bwd+Adam)", "ms_per_step": 1e3 * el / n, "steps": n,
+           "dtype": chains, "wgrad": getattr(cfg, "hip_wgrad_mode", "bf16x3"), "loss": float(loss.detach()),
+           "kernels": kernels,
+           "whole_step_mfma_frac": rate / world * TRAIN_FLOP_PER_SAMPLE / 1e12 / PEAK_TFLOPS[chains],
+           "note": "whole_step_mfma_frac = wall-clock step (incl. losses, all-reduce, optimiser, weight re-pack) priced at "
+                   "7,651,840 FLOP/ray-sample; `kernels` holds the per-kernel rooflines from HIP event pairs"}
+    if "fwd" in kernels:
+        out["roofline"] = dict(kernels["fwd"], traffic=None, traffic_source=None,
+                               timing="HIP event pairs on the launch stream, inside the timed region")
+    return out
 
 
 if __name__ == "__main__":

@@ -5,8 +5,12 @@
  * sizes only; every `d_*` pointer is DEVICE memory owned by the caller; every
  * call is asynchronous on `stream` (a hipStream_t passed as void*, NULL = the
  * default stream) and returns 0 or a negative REFNERF_E* code (message via
- * refnerf_last_error()).  No global state besides the per-thread error string;
- * re-entrant.
+ * refnerf_last_error()).  Level / stage calls keep no state between calls and
+ * may be issued concurrently from several host threads (each on its own
+ * stream); the error string is per thread.  The only process-wide state is the
+ * opt-in kernel timer of refnerf_set_timing / refnerf_get_timing (mutex-guarded)
+ * and two debug knobs read once from the environment (REFNERF_PROF,
+ * REFNERF_LDS_PAD).
  *
  * The upstream reference (minfenli/refnerf-pl) has no FFI: its boundary is the
  * Python call surface of internal/models.py.  Each entry point below names the
@@ -24,7 +28,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 4   /* v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
+#define REFNERF_ABI_VERSION 5   /* v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {
@@ -38,8 +42,11 @@ enum {
 /* arithmetic of the MLP contractions */
 enum {
   REFNERF_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains (parity mode) */
-  REFNERF_PREC_BF16 = 1  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate (training forward / backward in
+  REFNERF_PREC_BF16 = 1, /* v_mfma_f32_32x32x16_bf16, fp32 accumulate (training forward / backward in
                             this mode: n_samples <= 294, REFNERF_EINVAL beyond -- LDS budget)  */
+  REFNERF_PREC_F16 = 2   /* v_mfma_f32_32x32x16_f16 (IEEE half operands, fp32 accumulate): the bf16 inference kernel
+                            with 11 instead of 8 significand bits -- 8-10x closer to REFNERF_PREC_F32 at ~3 % lower
+                            throughput; hidden activations must stay below 65504.  refnerf_level_forward only. */
 };
 
 /* arithmetic of the weight-gradient GEMM of refnerf_level_backward (dW = DELTA x ACT^T over the samples) */
@@ -258,11 +265,26 @@ int refnerf_integrated_pos_enc(const float *d_lmean, const float *d_lvar, int32_
 int refnerf_integrated_dir_enc(const float *d_xyz, const float *d_kappa_inv, int32_t n,
                                float *d_ide, void *stream);
 
+/* render.compute_alpha_weights (render.py:132-149) + render.volumetric_rendering (render.py:152-254, all five
+ * render-time `srgb_mapping` modes :186-216, float64 percentiles via stepfun.py:294-307 / math.py:114-142) on
+ * caller-supplied per-sample values -- the compositing phase of the fused level kernel behind its own entry.
+ * d_density / d_roughness [R,N]; d_tdist [R,N+1]; d_directions [R,3]; d_far [R]; the [R,N,3] inputs may be NULL
+ * (zero).  Reads cfg->n_samples (<= 1024), opaque_background, render_srgb_mode, compute_extras, bg_rgb; writes
+ * out->d_weights and the d_r_* fields (d_r_normals only when d_normals is given). */
+int refnerf_render_rays(const refnerf_level_cfg *cfg, int32_t R, const float *d_density, const float *d_tdist,
+                        const float *d_directions, const float *d_far, const float *d_rgb, const float *d_diffuse,
+                        const float *d_specular, const float *d_normals, const float *d_normals_pred,
+                        const float *d_roughness, const float *d_tint, const refnerf_level_out *out, void *stream);
+
 /* Total duration (ms) and count of the `refnerf_level_forward` kernels launched
  * since refnerf_set_timing(1), from HIP event pairs on the launch stream.
  * Used by bench.py for the roofline line. */
+enum { REFNERF_TIMER_FORWARD = 0,   /* the level kernel of refnerf_level_forward / _forward_train           */
+       REFNERF_TIMER_BACKWARD = 1,  /* the per-sample backward kernel of refnerf_level_backward              */
+       REFNERF_TIMER_WGRAD = 2 };   /* its weight-gradient GEMM                                              */
 int refnerf_set_timing(int enable);
-int refnerf_get_timing(double *total_ms, int64_t *launches);
+int refnerf_get_timing(double *total_ms, int64_t *launches);                         /* REFNERF_TIMER_FORWARD */
+int refnerf_get_timing_family(int family, double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus
 }

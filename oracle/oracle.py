@@ -212,6 +212,42 @@ def alpha_weights(density, tdist, dirs, opaque_background=False):
     return out
 
 
+def render_rays(density, tdist, dirs, far, rgb=None, diffuse=None, specular=None, normals=None, normals_pred=None,
+                roughness=None, tint=None, **cfg_kw):
+    """rn_render_rays: compute_alpha_weights + volumetric_rendering (render.py:132-254) on caller-supplied
+    per-sample values -> dict(weights, r_rgb, r_diffuse, r_specular, r_distance, r_acc, extras, r_percentiles)."""
+    lib().rn_render_rays.restype = C.c_int
+    dn, dnp = _f(density)
+    R, N = dn.shape
+    td, tdp = _f(np.asarray(tdist).reshape(R, N + 1))
+    d, dp = _f(np.asarray(dirs).reshape(R, 3))
+    fr, frp = _f(np.asarray(far).reshape(R))
+    opt, keep = [], []
+    for a, last in ((rgb, 3), (diffuse, 3), (specular, 3), (normals, 3), (normals_pred, 3), (roughness, 1), (tint, 3)):
+        if a is None:
+            opt.append(None)
+        else:
+            arr, ap = _f(np.asarray(a).reshape(R, N, last))
+            keep.append(arr)
+            opt.append(ap)
+    cfg = default_cfg(n_samples=N, training=int(normals is not None), **cfg_kw)
+    out = LevelOut()
+    res = {"weights": np.zeros((R, N), np.float32), "r_rgb": np.zeros((R, 3), np.float32),
+           "r_diffuse": np.zeros((R, 3), np.float32), "r_specular": np.zeros((R, 3), np.float32),
+           "r_distance": np.zeros(R, np.float32), "r_acc": np.zeros(R, np.float32),
+           "r_normals": np.zeros((R, 3), np.float32), "r_normals_pred": np.zeros((R, 3), np.float32),
+           "r_tint": np.zeros((R, 3), np.float32), "r_roughness": np.zeros(R, np.float32),
+           "r_distance_mean": np.zeros(R, np.float32)}
+    for k, a in res.items():
+        setattr(out, k, a.ctypes.data_as(_FP))
+    res["r_percentiles"] = np.zeros((R, 3), np.float64)
+    out.r_percentiles = res["r_percentiles"].ctypes.data_as(C.POINTER(C.c_double))
+    rc = lib().rn_render_rays(C.byref(cfg), C.c_int(R), dnp, tdp, dp, frp, *opt, C.byref(out))
+    if rc != 0:
+        raise ValueError(f"rn_render_rays failed with code {rc}")
+    return res
+
+
 def _rays_struct(rays: dict):
     keep = {}
     rs = Rays()

@@ -634,6 +634,80 @@ static void percentiles(const float *tdist, const float *w, int N, float bg_w, f
   free(xp);
 }
 
+/* render.py:152-254 (volumetric_rendering) for one ray: per-sample outputs `so`, weights `wts`, tdist `td`. */
+static void composite_ray(const rn_level_cfg *cfg, const rn_sample_out *so, const float *wts, const float *td,
+                          float far, int r, rn_level_out *out) {
+  const int N = cfg->n_samples;
+  float acc = 0.0f, rgb[3] = {0, 0, 0}, dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
+  float dist = 0.0f, nrm[3] = {0, 0, 0}, nrp[3] = {0, 0, 0}, tnt[3] = {0, 0, 0}, rgh = 0.0f, logd = 0.0f;
+  for (int i = 0; i < N; ++i) {
+    float w = wts[i];
+    acc += w;
+    float tmid = 0.5f * (td[i] + td[i + 1]);
+    dist += w * tmid;
+    logd += w * logf(tmid);
+    rgh += w * so[i].roughness;
+    for (int c = 0; c < 3; ++c) {
+      rgb[c] += w * so[i].rgb[c]; dif[c] += w * so[i].diffuse[c]; spc[c] += w * so[i].specular[c];
+      nrm[c] += w * so[i].normals[c]; nrp[c] += w * so[i].normals_pred[c]; tnt[c] += w * so[i].tint[c];
+    }
+  }
+  float bg_w = fmaxf(0.0f, 1.0f - acc);
+  for (int c = 0; c < 3; ++c) { rgb[c] += bg_w * cfg->bg_rgb; dif[c] += bg_w * cfg->bg_rgb; spc[c] += bg_w * cfg->bg_rgb; }
+  render_map(cfg->render_srgb_mode, rgb, dif, spc);
+  if (out->r_rgb) memcpy(out->r_rgb + 3 * (size_t)r, rgb, 12);
+  if (out->r_diffuse) memcpy(out->r_diffuse + 3 * (size_t)r, dif, 12);
+  if (out->r_specular) memcpy(out->r_specular + 3 * (size_t)r, spc, 12);
+  if (out->r_distance) out->r_distance[r] = dist;
+  if (out->r_acc) out->r_acc[r] = acc;
+  if (cfg->compute_extras) {
+    if (out->r_normals && cfg->training) memcpy(out->r_normals + 3 * (size_t)r, nrm, 12);
+    if (out->r_normals_pred) memcpy(out->r_normals_pred + 3 * (size_t)r, nrp, 12);
+    if (out->r_tint) memcpy(out->r_tint + 3 * (size_t)r, tnt, 12);
+    if (out->r_roughness) out->r_roughness[r] = rgh;
+    if (out->r_distance_mean) {
+      float e = expf(logd / fmaxf(EPS32, acc));
+      if (isnan(e)) e = INFINITY;              /* nan_to_num(x, inf) */
+      if (isinf(e)) e = e > 0 ? FLT_MAX : -FLT_MAX;
+      out->r_distance_mean[r] = fminf(fmaxf(e, td[0]), td[N]);
+    }
+    if (out->r_percentiles) percentiles(td, wts, N, bg_w, far, out->r_percentiles + 3 * (size_t)r);
+  }
+}
+
+/* Stage entry: compute_alpha_weights (render.py:132-149) + volumetric_rendering (render.py:152-254) on
+ * caller-supplied per-sample values.  density / roughness [R,N]; tdist [R,N+1]; dirs [R,3]; far [R]; the
+ * [R,N,3] tensors may be NULL (treated as zero).  cfg: n_samples, opaque_background, render_srgb_mode,
+ * compute_extras, training (-> r_normals), bg_rgb.  Writes out->weights and the r_* fields. */
+int rn_render_rays(const rn_level_cfg *cfg, int R, const float *density, const float *tdist, const float *dirs,
+                   const float *far, const float *rgb, const float *diffuse, const float *specular,
+                   const float *normals, const float *normals_pred, const float *roughness, const float *tint,
+                   rn_level_out *out) {
+  const int N = cfg->n_samples;
+  if (N < 1) return -1;
+  rn_sample_out *so = (rn_sample_out *)calloc((size_t)N, sizeof(rn_sample_out));
+  float *wts = (float *)malloc(sizeof(float) * (size_t)N);
+  for (int r = 0; r < R; ++r) {
+    rn_alpha_weights(density + (size_t)r * N, tdist + (size_t)r * (N + 1), dirs + 3 * (size_t)r, N, cfg->opaque_background, wts);
+    for (int i = 0; i < N; ++i) {
+      size_t e = (size_t)r * N + i;
+      so[i].roughness = roughness ? roughness[e] : 0.0f;
+      for (int c = 0; c < 3; ++c) {
+        so[i].rgb[c] = rgb ? rgb[3 * e + c] : 0.0f;
+        so[i].diffuse[c] = diffuse ? diffuse[3 * e + c] : 0.0f;
+        so[i].specular[c] = specular ? specular[3 * e + c] : 0.0f;
+        so[i].normals[c] = normals ? normals[3 * e + c] : 0.0f;
+        so[i].normals_pred[c] = normals_pred ? normals_pred[3 * e + c] : 0.0f;
+        so[i].tint[c] = tint ? tint[3 * e + c] : 0.0f;
+      }
+    }
+    if (out->weights) memcpy(out->weights + (size_t)r * N, wts, sizeof(float) * (size_t)N);
+    composite_ray(cfg, so, wts, tdist + (size_t)r * (N + 1), far[r], r, out);
+  }
+  free(so); free(wts);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* one level                                                          */
 /* ------------------------------------------------------------------ */
@@ -690,41 +764,7 @@ int rn_level_forward(const float *params, const rn_level_cfg *cfg, const rn_rays
         ST3(out->specular, r, i, N, so[i].specular);
       }
       /* ---- render.py:152-254 ---- */
-      float acc = 0.0f, rgb[3] = {0, 0, 0}, dif[3] = {0, 0, 0}, spc[3] = {0, 0, 0};
-      float dist = 0.0f, nrm[3] = {0, 0, 0}, nrp[3] = {0, 0, 0}, tnt[3] = {0, 0, 0}, rgh = 0.0f, logd = 0.0f;
-      for (int i = 0; i < N; ++i) {
-        float w = wts[i];
-        acc += w;
-        float tmid = 0.5f * (td[i] + td[i + 1]);
-        dist += w * tmid;
-        logd += w * logf(tmid);
-        rgh += w * so[i].roughness;
-        for (int c = 0; c < 3; ++c) {
-          rgb[c] += w * so[i].rgb[c]; dif[c] += w * so[i].diffuse[c]; spc[c] += w * so[i].specular[c];
-          nrm[c] += w * so[i].normals[c]; nrp[c] += w * so[i].normals_pred[c]; tnt[c] += w * so[i].tint[c];
-        }
-      }
-      float bg_w = fmaxf(0.0f, 1.0f - acc);
-      for (int c = 0; c < 3; ++c) { rgb[c] += bg_w * cfg->bg_rgb; dif[c] += bg_w * cfg->bg_rgb; spc[c] += bg_w * cfg->bg_rgb; }
-      render_map(cfg->render_srgb_mode, rgb, dif, spc);
-      if (out->r_rgb) memcpy(out->r_rgb + 3 * (size_t)r, rgb, 12);
-      if (out->r_diffuse) memcpy(out->r_diffuse + 3 * (size_t)r, dif, 12);
-      if (out->r_specular) memcpy(out->r_specular + 3 * (size_t)r, spc, 12);
-      if (out->r_distance) out->r_distance[r] = dist;
-      if (out->r_acc) out->r_acc[r] = acc;
-      if (cfg->compute_extras) {
-        if (out->r_normals && cfg->training) memcpy(out->r_normals + 3 * (size_t)r, nrm, 12);
-        if (out->r_normals_pred) memcpy(out->r_normals_pred + 3 * (size_t)r, nrp, 12);
-        if (out->r_tint) memcpy(out->r_tint + 3 * (size_t)r, tnt, 12);
-        if (out->r_roughness) out->r_roughness[r] = rgh;
-        if (out->r_distance_mean) {
-          float e = expf(logd / fmaxf(EPS32, acc));
-          if (isnan(e)) e = INFINITY;              /* nan_to_num(x, inf) */
-          if (isinf(e)) e = e > 0 ? FLT_MAX : -FLT_MAX;
-          out->r_distance_mean[r] = fminf(fmaxf(e, td[0]), td[N]);
-        }
-        if (out->r_percentiles) percentiles(td, wts, N, bg_w, far, out->r_percentiles + 3 * (size_t)r);
-      }
+      composite_ray(cfg, so, wts, td, far, r, out);
     }
     free(logits); free(so); free(bidx);
   }

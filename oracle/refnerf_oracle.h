@@ -164,6 +164,14 @@ void rn_mlp_sample(const float *params, const rn_level_cfg *cfg,
 void rn_alpha_weights(const float *density, const float *tdist, const float *dir,
                       int N, int opaque_background, float *weights);
 
+/* compute_alpha_weights (render.py:132-149) + volumetric_rendering (render.py:152-254, all five srgb_mapping
+ * modes :186-216, float64 percentiles) on caller-supplied per-sample values; pinned by tests/golden/render.npz.
+ * density / roughness [R,N]; tdist [R,N+1]; dirs [R,3]; far [R]; [R,N,3] tensors (NULL = zero). */
+int rn_render_rays(const rn_level_cfg *cfg, int R, const float *density, const float *tdist, const float *dirs,
+                   const float *far, const float *rgb, const float *diffuse, const float *specular,
+                   const float *normals, const float *normals_pred, const float *roughness, const float *tint,
+                   rn_level_out *out);
+
 /* One level of Model.__call__ (models.py:162-306) for R rays.
  * sdist_in[R,M+1], weights_in[R,M]. Returns 0 or a negative error code. */
 int rn_level_forward(const float *params, const rn_level_cfg *cfg,

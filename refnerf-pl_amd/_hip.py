@@ -14,8 +14,8 @@ import torch
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
 
-PREC_F32, PREC_BF16 = 0, 1
-ABI_VERSION = 4   # REFNERF_ABI_VERSION
+PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
+ABI_VERSION = 5   # REFNERF_ABI_VERSION
 WGRAD_F32, WGRAD_BF16X3 = 0, 1
 SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 4}
 
@@ -102,7 +102,9 @@ def lib():
                                                _FP, _FP, _FP]
         L.refnerf_integrated_pos_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
         L.refnerf_integrated_dir_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
+        L.refnerf_render_rays.argtypes = [C.POINTER(LevelCfg), C.c_int32] + [_FP] * 11 + [C.POINTER(LevelOut), _FP]
         L.refnerf_get_timing.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.refnerf_get_timing_family.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         if L.refnerf_abi_version() != ABI_VERSION:
             raise HipLibraryError("librefnerf_hip.so ABI version mismatch")
         _lib = L
@@ -319,6 +321,43 @@ def level_backward(packed, cfg: LevelCfg, rays: dict, saved: dict, g_r_rgb, g_we
     return param_grads
 
 
+def render_rays(cfg: LevelCfg, density, tdist, directions, far, rgb=None, diffuse=None, specular=None, normals=None,
+                normals_pred=None, roughness=None, tint=None):
+    """render.compute_alpha_weights + render.volumetric_rendering (render.py:132-254) on caller-supplied per-sample
+    device tensors: density / roughness [R,N], tdist [R,N+1], directions [R,3], far [R], the others [R,N,3] or None.
+    cfg.n_samples is taken from `density`.  Returns dict(weights, r_rgb, ..., r_percentiles)."""
+    require_device()
+    dev = density.device
+    R, N = density.shape
+    cfg.n_samples = N
+    f32 = dict(dtype=torch.float32, device=dev)
+    keep = []
+
+    def prep(t, shape):
+        if t is None:
+            return None
+        t = t.to(torch.float32).reshape(shape).contiguous()
+        keep.append(t)
+        return C.c_void_p(t.data_ptr())
+    args = [prep(density, (R, N)), prep(tdist, (R, N + 1)), prep(directions, (R, 3)), prep(far, (R,)),
+            prep(rgb, (R, N, 3)), prep(diffuse, (R, N, 3)), prep(specular, (R, N, 3)), prep(normals, (R, N, 3)),
+            prep(normals_pred, (R, N, 3)), prep(roughness, (R, N)), prep(tint, (R, N, 3))]
+    res = {"weights": torch.empty((R, N), **f32), "r_rgb": torch.empty((R, 3), **f32),
+           "r_diffuse": torch.empty((R, 3), **f32), "r_specular": torch.empty((R, 3), **f32),
+           "r_distance": torch.empty((R,), **f32), "r_acc": torch.empty((R,), **f32)}
+    if cfg.compute_extras:
+        res.update({"r_normals_pred": torch.empty((R, 3), **f32), "r_tint": torch.empty((R, 3), **f32),
+                    "r_roughness": torch.empty((R,), **f32), "r_distance_mean": torch.empty((R,), **f32),
+                    "r_percentiles": torch.empty((R, 3), dtype=torch.float64, device=dev)})
+        if normals is not None:
+            res["r_normals"] = torch.empty((R, 3), **f32)
+    out = LevelOut()
+    for k, t in res.items():
+        setattr(out, "d_" + k, t.data_ptr())
+    check(lib().refnerf_render_rays(C.byref(cfg), R, *args, C.byref(out), stream_ptr()))
+    return res
+
+
 def sample_intervals(t, logits, n, smin=0.0, smax=1.0):
     require_device()
     R, M = logits.shape
@@ -350,7 +389,11 @@ def set_timing(enable: bool):
     lib().refnerf_set_timing(int(enable))
 
 
-def get_timing():
+TIMER_FORWARD, TIMER_BACKWARD, TIMER_WGRAD = 0, 1, 2
+
+
+def get_timing(family: int = TIMER_FORWARD):
+    """(total ms, launches) of the kernels of one family launched since set_timing(True)."""
     ms, n = C.c_double(0), C.c_int64(0)
-    lib().refnerf_get_timing(C.byref(ms), C.byref(n))
+    check(lib().refnerf_get_timing_family(family, C.byref(ms), C.byref(n)))
     return ms.value, n.value

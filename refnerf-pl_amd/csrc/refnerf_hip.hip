@@ -189,7 +189,8 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
 
 /* bf16 image: one block per (op, ob) slice, uniform 17 KB chunks in execution
  * order; see refnerf_layout.h. */
-__global__ void pack_weights_bf16(const float *__restrict__ P, char *__restrict__ out) {
+template <typename E>   /* E = __bf16 (REFNERF_PREC_BF16) or _Float16 (REFNERF_PREC_F16): same image layout */
+__global__ void pack_weights_16(const float *__restrict__ P, char *__restrict__ out) {
   const int op = blockIdx.y, ob = blockIdx.x;
   const BfOp o = BFPACKED.op[op];
   if (ob >= o.nob) return;
@@ -225,7 +226,7 @@ __global__ void pack_weights_bf16(const float *__restrict__ P, char *__restrict_
         else if (kp == IDE_TERMS) v = canon_w(P, op, row, base + BNECK + IDE_DIM);
         else if (kp >= 40 && kp < 40 + IDE_TERMS) v = canon_w(P, op, row, base + BNECK + IDE_TERMS + (kp - 40));
       }
-      reinterpret_cast<__bf16 *>(chunk + 1024)[idx] = (__bf16)v;
+      reinterpret_cast<E *>(chunk + 1024)[idx] = (E)v;
     }
   }
 }
@@ -269,6 +270,52 @@ __global__ void ide_kernel(const float *xyz, const float *kappa_inv, int n, floa
              [&](int q, float val) { o[part * IDE_TERMS + q] = val; });
 }
 
+/* compute_alpha_weights + volumetric_rendering (render.py:132-254) on caller-supplied per-sample values: the P7
+ * device code of the level kernels (composite_phase) behind its own entry.  One wave per ray, rpw rays per workgroup. */
+struct RenderArgs {
+  refnerf_level_cfg cfg;
+  int R, rpw;
+  const float *density, *tdist, *dirs, *far, *rgb, *dif, *spc, *nrm, *npred, *rough, *tint;
+  refnerf_level_out out;
+};
+__global__ __launch_bounds__(256) void render_rays_kernel(RenderArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = ra.cfg.n_samples, rpw = ra.rpw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *TD = smem, *XP = TD + rpw * (N + 1), *PS = XP + rpw * (N + 1), *wscr = PS + (size_t)rpw * N * NPS_TRAIN;
+  const int ray0 = blockIdx.x * rpw;
+  for (int e = threadIdx.x; e < rpw * (N + 1); e += NTHREADS) {
+    const int rl = e / (N + 1), ray = ray0 + rl;
+    if (ray < ra.R) TD[e] = ra.tdist[(size_t)ray * (N + 1) + (e - rl * (N + 1))];
+  }
+  for (int e = threadIdx.x; e < rpw * N; e += NTHREADS) {
+    const int rl = e / N, ray = ray0 + rl;
+    if (ray >= ra.R) continue;
+    const size_t g = (size_t)ray * N + (e - rl * N);
+    float *ps = PS + (size_t)e * NPS_TRAIN;
+    ps[PS_DENSITY] = ra.density[g];
+    ps[PS_ROUGH] = ra.rough ? ra.rough[g] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ps[PS_RGB + c] = ra.rgb ? ra.rgb[3 * g + c] : 0.0f;
+      ps[PS_DIF + c] = ra.dif ? ra.dif[3 * g + c] : 0.0f;
+      ps[PS_SPC + c] = ra.spc ? ra.spc[3 * g + c] : 0.0f;
+      ps[PS_NPRED + c] = ra.npred ? ra.npred[3 * g + c] : 0.0f;
+      ps[PS_TINT + c] = ra.tint ? ra.tint[3 * g + c] : 0.0f;
+      ps[PS_NORMALS + c] = ra.nrm ? ra.nrm[3 * g + c] : 0.0f;
+    }
+  }
+  __syncthreads();
+  LevelArgs A{};
+  A.cfg = ra.cfg;
+  A.R = ra.R;
+  A.rpw = rpw;
+  A.rays.d_directions = ra.dirs;
+  A.rays.d_far = ra.far;
+  A.out = ra.out;
+  composite_phase<4, false, NPS_TRAIN>(A, TD, XP, PS, rpw * N, ray0, wave, lane, wscr, nullptr);
+}
+
 }  // namespace rn
 
 /* ================================================================== */
@@ -287,13 +334,77 @@ int fail(int code, const char *fmt, const char *detail = "") {
     if (e_ != hipSuccess) return fail(REFNERF_EHIP, #expr ": %s", hipGetErrorString(e_)); \
   } while (0)
 
-int ensure_tables() { return 0; }   /* IDE tables are compile-time literals now */
-
-/* kernel timing: event pairs recorded on the launch stream, resolved lazily in
- * refnerf_get_timing() so the timed region is not serialised by event syncs */
-bool g_timing = false;
-std::vector<std::pair<hipEvent_t, hipEvent_t>> g_events;
-size_t g_events_used = 0;
+/* The library's only process-wide state (everything else lives in caller-owned buffers):
+ *  - the opt-in kernel timer of refnerf_set_timing / refnerf_get_timing: event pairs recorded on the launch stream and
+ *    resolved lazily in refnerf_get_timing(), so the timed region is not serialised by event syncs; guarded by `mu`, so
+ *    level calls from several host threads stay safe while it is on;
+ *  - two debug knobs read from the environment ONCE (REFNERF_PROF: per-phase cycle stamps, REFNERF_LDS_PAD: force one
+ *    workgroup per CU) and the 2 KB device buffer of the stamps, allocated on first use and kept for the process. */
+struct Runtime {
+  std::mutex mu;
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<int> family;       /* REFNERF_TIMER_* of each recorded pair */
+  size_t events_used = 0;
+  bool prof = false;
+  int lds_pad = 0;
+  long long *d_prof = nullptr;
+  Runtime() {
+    prof = getenv("REFNERF_PROF") != nullptr;
+    if (const char *pad = getenv("REFNERF_LDS_PAD")) lds_pad = atoi(pad);
+  }
+};
+Runtime &rt() {
+  static Runtime r;
+  return r;
+}
+/* cycle-stamp buffer of the REFNERF_PROF debug mode (8 waves x 32 slots) */
+int prof_buffer(long long **out) {
+  Runtime &r = rt();
+  std::lock_guard<std::mutex> lk(r.mu);
+  if (!r.d_prof) HIP_TRY(hipMalloc(&r.d_prof, 8 * 32 * sizeof(long long)));
+  *out = r.d_prof;
+  return REFNERF_OK;
+}
+/* begin / end of a timed launch on stream `st`; `slot` < 0 = timer off */
+int timer_begin(hipStream_t st, long *slot, int fam = REFNERF_TIMER_FORWARD) {
+  Runtime &r = rt();
+  *slot = -1;
+  std::lock_guard<std::mutex> lk(r.mu);
+  if (!r.timing || r.events_used >= 65536) return REFNERF_OK;
+  if (r.events_used == r.events.size()) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    r.events.emplace_back(e0, e1);
+    r.family.push_back(fam);
+  }
+  *slot = (long)r.events_used++;
+  r.family[*slot] = fam;
+  HIP_TRY(hipEventRecord(r.events[*slot].first, st));
+  return REFNERF_OK;
+}
+int timer_end(hipStream_t st, long slot) {
+  if (slot < 0) return REFNERF_OK;
+  Runtime &r = rt();
+  std::lock_guard<std::mutex> lk(r.mu);
+  HIP_TRY(hipEventRecord(r.events[slot].second, st));
+  return REFNERF_OK;
+}
+/* opt a kernel into the 160 KiB dynamic-LDS limit; the first failure is remembered and reported by every later call */
+template <typename K>
+hipError_t lds_attr(K kernel, int bytes = 160 * 1024) {
+  return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+#define LDS_ATTR_ONCE(...)                                                                         \
+  do {                                                                                             \
+    static hipError_t attr_err_ = [] {                                                             \
+      hipError_t es_[] = {__VA_ARGS__};                                                            \
+      for (hipError_t e_ : es_) if (e_ != hipSuccess) return e_;                                   \
+      return hipSuccess;                                                                           \
+    }();                                                                                           \
+    if (attr_err_ != hipSuccess) return fail(REFNERF_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(attr_err_)); \
+  } while (0)
 
 }  // namespace
 
@@ -325,7 +436,7 @@ int refnerf_device_ok(void) {
 
 size_t refnerf_packed_weights_bytes(int precision) {
   if (precision == REFNERF_PREC_F32) return (size_t)rn::PACKED.total * sizeof(float);
-  if (precision == REFNERF_PREC_BF16) return ((size_t)rn::BFPACKED.chunks_per_pass + 2) * rn::BF_CHUNK_BYTES;
+  if (precision == REFNERF_PREC_BF16 || precision == REFNERF_PREC_F16) return ((size_t)rn::BFPACKED.chunks_per_pass + 2) * rn::BF_CHUNK_BYTES;
   return 0;
 }
 
@@ -336,7 +447,10 @@ int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, v
     hipLaunchKernelGGL(rn::pack_weights_f32, grid, dim3(256), 0, (hipStream_t)stream, d_params, (float *)d_packed);
   } else if (precision == REFNERF_PREC_BF16) {
     dim3 grid(8, rn::NUM_OPS);
-    hipLaunchKernelGGL(rn::pack_weights_bf16, grid, dim3(256), 0, (hipStream_t)stream, d_params, (char *)d_packed);
+    hipLaunchKernelGGL(rn::pack_weights_16<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, d_params, (char *)d_packed);
+  } else if (precision == REFNERF_PREC_F16) {
+    dim3 grid(8, rn::NUM_OPS);
+    hipLaunchKernelGGL(rn::pack_weights_16<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, d_params, (char *)d_packed);
   } else {
     return fail(REFNERF_EINVAL, "refnerf_pack_weights: unknown precision%s");
   }
@@ -383,17 +497,17 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   /* render.py:126 */
   if (cfg->ray_shape != 0 && cfg->ray_shape != 1) return fail(REFNERF_EINVAL, "ray_shape must be 'cone' or 'cylinder'%s");
   if (cfg->n_in < 1 || cfg->n_in > 512) return fail(REFNERF_EINVAL, "n_in must be in [1,512]%s");
-  if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16)
+  if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16 && cfg->precision != REFNERF_PREC_F16)
     return fail(REFNERF_EINVAL, "unknown precision mode%s");
+  if (cfg->training && cfg->precision == REFNERF_PREC_F16)
+    return fail(REFNERF_EUNSUPPORTED, "REFNERF_PREC_F16 is an inference mode (training levels: REFNERF_PREC_F32 or REFNERF_PREC_BF16)%s");
   /* training + BF16: the fp32-structure kernel with its MLP chains on bf16 MFMA (level_fwd_train_bf16c); d_packed is
    * the REFNERF_PREC_F32 image in that case (it carries the bf16 copies of the ops) */
   const bool train_bf = cfg->training && cfg->precision == REFNERF_PREC_BF16;
   if (!rays->d_origins || !rays->d_directions || !rays->d_viewdirs || !rays->d_radii || !rays->d_near || !rays->d_far)
     return fail(REFNERF_EINVAL, "refnerf_level_forward: null ray field%s");
-  int rc = ensure_tables();
-  if (rc) return rc;
   const int N = cfg->n_samples;
-  const bool bf = cfg->precision == REFNERF_PREC_BF16 && !train_bf;     /* the LDS-ring bf16 eval kernel */
+  const bool bf = (cfg->precision == REFNERF_PREC_BF16 && !train_bf) || cfg->precision == REFNERF_PREC_F16;     /* the LDS-ring 16-bit eval kernel */
   int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
   auto lds_bytes = [&](int rays) -> size_t {
     const int np = bf ? rn::NPS_EVAL : rn::NPS_TRAIN, tile = bf ? rn::BT : rn::T_TILE;
@@ -420,15 +534,10 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   while (train_bf && rpw > 1 && (lds + 15) / 16 * 16 + rn::RING_BYTES > 160 * 1024) { rpw /= 2; lds = lds_bytes(rpw); }
   const size_t ring_off = (lds + 15) / 16 * 16;
   if (train_bf) lds = ring_off + rn::RING_BYTES;
-  if (const char *padenv = getenv("REFNERF_LDS_PAD")) lds += (size_t)atoi(padenv);   /* debug: force 1 workgroup/CU */
+  lds += (size_t)rt().lds_pad;   /* debug (REFNERF_LDS_PAD): force 1 workgroup/CU */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget of this precision mode%s");
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute((const void *)rn::level_fwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)rn::level_fwd_train_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)rn::level_fwd_train_bf16c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)rn::level_fwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
+  LDS_ATTR_ONCE(lds_attr(rn::level_fwd_f32), lds_attr(rn::level_fwd_train_f32), lds_attr(rn::level_fwd_train_bf16c),
+                lds_attr(rn::level_fwd_bf16), lds_attr(rn::level_fwd_f16));
   rn::LevelArgs a;
   a.packed = d_packed;
   a.cfg = *cfg;
@@ -442,33 +551,28 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   a.g_means = nullptr; a.g_covs = nullptr; a.cov_full = 0;
   a.act = d_act; a.act_pitch = act_pitch;
   a.ring_off = (int)ring_off;
-  if (getenv("REFNERF_PROF")) {
-    static long long *d_prof = nullptr;
-    if (!d_prof) { HIP_TRY(hipMalloc(&d_prof, 8 * 32 * sizeof(long long))); }
-    a.prof = d_prof;
+  if (rt().prof) {
+    int prc = prof_buffer(&a.prof);
+    if (prc) return prc;
   }
   int grid = (R + rpw - 1) / rpw;
   hipStream_t st = (hipStream_t)stream;
-  const bool timed = g_timing && g_events_used < 65536;
-  if (timed) {
-    if (g_events_used == g_events.size()) {
-      hipEvent_t e0, e1;
-      HIP_TRY(hipEventCreate(&e0));
-      HIP_TRY(hipEventCreate(&e1));
-      g_events.emplace_back(e0, e1);
-    }
-    HIP_TRY(hipEventRecord(g_events[g_events_used].first, st));
+  long tslot = -1;
+  {
+    int trc = timer_begin(st, &tslot);
+    if (trc) return trc;
   }
-  if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  if (bf && cfg->precision == REFNERF_PREC_F16) hipLaunchKernelGGL(rn::level_fwd_f16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  else if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else if (train_bf) hipLaunchKernelGGL(rn::level_fwd_train_bf16c, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (cfg->training) hipLaunchKernelGGL(rn::level_fwd_train_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else hipLaunchKernelGGL(rn::level_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());
-  if (timed) {
-    HIP_TRY(hipEventRecord(g_events[g_events_used].second, st));
-    g_events_used += 1;
+  {
+    int trc = timer_end(st, tslot);
+    if (trc) return trc;
   }
-  if (a.prof) {   /* debug aid (REFNERF_PROF=1): per-phase cycle stamps of workgroup 0 */
+  if (a.prof) {   /* debug aid (REFNERF_PROF=1): per-phase cycle stamps of a mid-grid workgroup */
     long long hbuf[8 * 32];
     HIP_TRY(hipMemcpy(hbuf, a.prof, sizeof(hbuf), hipMemcpyDeviceToHost));
     const int nw = bf ? 8 : 4;
@@ -527,18 +631,12 @@ int refnerf_mlp_forward(const void *d_packed, const refnerf_level_cfg *cfg, cons
   if (R <= 0 || N <= 0) return fail(REFNERF_EINVAL, "refnerf_mlp_forward: R and N must be positive%s");
   if (cfg->precision != REFNERF_PREC_F32)
     return fail(REFNERF_EUNSUPPORTED, "refnerf_mlp_forward runs in the f32 precision mode only%s");
-  int rc = ensure_tables();
-  if (rc) return rc;
   int rpw = rays_per_wg(N, rn::T_TILE);
   if (rpw * N > 640) return fail(REFNERF_EINVAL, "n too large for the LDS budget (rays_per_wg*N must be <= 640)%s");
   const size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + 2 * rpw * (N + 1) +
                                               rn::NPS_TRAIN * rpw * N + 3 * rn::T_TILE + 8);
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n too large for the 160 KiB LDS budget%s");
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute((const void *)rn::mlp_fwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)rn::mlp_fwd_train_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
+  LDS_ATTR_ONCE(lds_attr(rn::mlp_fwd_f32), lds_attr(rn::mlp_fwd_train_f32));
   rn::LevelArgs a{};
   a.packed = d_packed;
   a.cfg = *cfg;
@@ -587,8 +685,6 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     return fail(REFNERF_EINVAL, "refnerf_level_backward: the level was not run through refnerf_level_forward_train (no saved activations)%s");
   if (!rays->d_origins || !rays->d_directions || !rays->d_viewdirs || !rays->d_radii || !rays->d_near || !rays->d_far)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: null ray field%s");
-  int rc = ensure_tables();
-  if (rc) return rc;
   const int N = cfg->n_samples;
   const BwdPlan plan = bwd_plan(R, N);
   if (workspace_bytes < plan.total) return fail(REFNERF_EINVAL, "refnerf_level_backward: workspace too small (see refnerf_backward_workspace_bytes)%s");
@@ -597,16 +693,12 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   const size_t ring_off = (lds + 15) / 16 * 16;
   if (cfg->precision == REFNERF_PREC_BF16) lds = ring_off + rn::RING_BYTES;       /* the chains' shared weight-stream ring */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget%s");
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute((const void *)rn::level_bwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)rn::level_bwd_bf16c, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)rn::wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4);
-    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::wb_lds(false, false));
-    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::wb_lds(false, true));
-    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::wb_lds(true, false));
-    (void)hipFuncSetAttribute((const void *)rn::wgrad_bf16x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rn::wb_lds(true, true));
-  });
+  LDS_ATTR_ONCE(lds_attr(rn::level_bwd_f32), lds_attr(rn::level_bwd_bf16c),
+                lds_attr(rn::wgrad_kernel, (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4),
+                lds_attr(rn::wgrad_bf16x3_kernel<false, false>, rn::wb_lds(false, false)),
+                lds_attr(rn::wgrad_bf16x3_kernel<false, true>, rn::wb_lds(false, true)),
+                lds_attr(rn::wgrad_bf16x3_kernel<true, false>, rn::wb_lds(true, false)),
+                lds_attr(rn::wgrad_bf16x3_kernel<true, true>, rn::wb_lds(true, true)));
   char *ws = (char *)d_workspace;
   rn::BwdArgs a;
   a.packed = d_packed;
@@ -631,21 +723,23 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   a.act16 = act16 ? 1 : 0;
   a.ring_off = (int)ring_off;
   a.prof = nullptr;
-  if (getenv("REFNERF_PROF")) {
-    static long long *d_prof = nullptr;
-    if (!d_prof) { HIP_TRY(hipMalloc(&d_prof, 8 * 32 * sizeof(long long))); }
-    HIP_TRY(hipMemset(d_prof, 0, 8 * 32 * sizeof(long long)));
-    a.prof = d_prof;
+  if (rt().prof) {
+    int prc = prof_buffer(&a.prof);
+    if (prc) return prc;
+    HIP_TRY(hipMemset(a.prof, 0, 8 * 32 * sizeof(long long)));
   }
   hipStream_t st = (hipStream_t)stream;
   /* per-ray seeds first (one wave per ray), then the per-sample backward */
   hipLaunchKernelGGL(rn::bwd_seed_kernel, dim3((R + 3) / 4), dim3(rn::NTHREADS), sizeof(float) * 4 * (size_t)(N + 1), st, a);
   /* d_packed is the f32 image in both modes (it carries the bf16 transposed ops behind the fp32 ones) */
+  long tslot = -1;
+  { int trc = timer_begin(st, &tslot, REFNERF_TIMER_BACKWARD); if (trc) return trc; }
   if (cfg->precision == REFNERF_PREC_BF16)
     hipLaunchKernelGGL(rn::level_bwd_bf16c, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
   else
     hipLaunchKernelGGL(rn::level_bwd_f32, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());
+  { int trc = timer_end(st, tslot); if (trc) return trc; }
   if (a.prof) {   /* debug aid (REFNERF_PROF=1): cycle stamps of workgroup 0: prologue | heads recompute | rgb recompute + colour head | seed | dir chain | IDE / heads | spatial chain */
     long long hbuf[8 * 32];
     HIP_TRY(hipMemcpy(hbuf, a.prof, sizeof(hbuf), hipMemcpyDeviceToHost));
@@ -665,6 +759,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   w.act = a.act; w.delta = a.delta; w.pitch = plan.pitch; w.S = plan.S; w.k_per_slice = plan.k_per_slice;
   w.part = (float *)(ws + plan.part_off);
   const int slices = (int)((plan.S + plan.k_per_slice - 1) / plan.k_per_slice);
+  { int trc = timer_begin(st, &tslot, REFNERF_TIMER_WGRAD); if (trc) return trc; }
   if (cfg->wgrad_mode == REFNERF_WGRAD_BF16X3)
   {
     const dim3 wg_grid(8 * ((slices + 7) / 8) * rn::WJOBS.tiles);
@@ -676,6 +771,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   else
     hipLaunchKernelGGL(rn::wgrad_kernel, dim3(rn::WJOBS.tiles, slices), dim3(256), (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4, st, w);
   HIP_TRY(hipGetLastError());
+  { int trc = timer_end(st, tslot); if (trc) return trc; }
   hipLaunchKernelGGL(rn::wgrad_reduce, dim3(1024), dim3(256), 0, st, w.part, slices, d_param_grads);
   HIP_TRY(hipGetLastError());
   return REFNERF_OK;
@@ -688,10 +784,7 @@ int refnerf_sample_intervals(const float *d_t, const float *d_logits, int32_t R,
   if (M < 1 || M > 2048 || N > 2048 || R <= 0) return fail(REFNERF_EINVAL, "refnerf_sample_intervals: size out of range%s");
   size_t lds = sizeof(float) * 4 * (size_t)((M + 1) + M + (M + 1) + N + (N + 1) + 8);
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "refnerf_sample_intervals: M,N too large%s");
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute((const void *)rn::sample_intervals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
+  LDS_ATTR_ONCE(lds_attr(rn::sample_intervals_kernel));
   hipLaunchKernelGGL(rn::sample_intervals_kernel, dim3((R + 3) / 4), dim3(256), lds, (hipStream_t)stream,
                      d_t, d_logits, R, M, N, s_min, s_max, d_sdist, d_bin_idx);
   HIP_TRY(hipGetLastError());
@@ -707,29 +800,61 @@ int refnerf_integrated_pos_enc(const float *d_lmean, const float *d_lvar, int32_
 
 int refnerf_integrated_dir_enc(const float *d_xyz, const float *d_kappa_inv, int32_t n, float *d_ide, void *stream) {
   if (!d_xyz || !d_kappa_inv || !d_ide || n <= 0) return fail(REFNERF_EINVAL, "refnerf_integrated_dir_enc: bad argument%s");
-  int rc = ensure_tables();
-  if (rc) return rc;
   hipLaunchKernelGGL(rn::ide_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_xyz, d_kappa_inv, n, d_ide);
   HIP_TRY(hipGetLastError());
   return REFNERF_OK;
 }
 
+int refnerf_render_rays(const refnerf_level_cfg *cfg, int32_t R, const float *d_density, const float *d_tdist,
+                        const float *d_directions, const float *d_far, const float *d_rgb, const float *d_diffuse,
+                        const float *d_specular, const float *d_normals, const float *d_normals_pred,
+                        const float *d_roughness, const float *d_tint, const refnerf_level_out *out, void *stream) {
+  if (!cfg || !d_density || !d_tdist || !d_directions || !d_far || !out)
+    return fail(REFNERF_EINVAL, "refnerf_render_rays: null pointer%s");
+  const int N = cfg->n_samples;
+  if (R <= 0 || N < 1 || N > 1024) return fail(REFNERF_EINVAL, "refnerf_render_rays: R must be positive and n_samples in [1,1024]%s");
+  rn::RenderArgs a;
+  a.cfg = *cfg;
+  a.cfg.training = d_normals != nullptr;
+  a.R = R;
+  a.rpw = N <= 256 ? 4 : 1;
+  a.density = d_density; a.tdist = d_tdist; a.dirs = d_directions; a.far = d_far;
+  a.rgb = d_rgb; a.dif = d_diffuse; a.spc = d_specular; a.nrm = d_normals; a.npred = d_normals_pred;
+  a.rough = d_roughness; a.tint = d_tint;
+  a.out = *out;
+  const size_t lds = sizeof(float) * ((size_t)a.rpw * (2 * (N + 1) + rn::NPS_TRAIN * N) + 4 * 22 * rn::WSUM_PITCH);
+  LDS_ATTR_ONCE(lds_attr(rn::render_rays_kernel));
+  hipLaunchKernelGGL(rn::render_rays_kernel, dim3((R + a.rpw - 1) / a.rpw), dim3(rn::NTHREADS), lds, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return REFNERF_OK;
+}
+
 int refnerf_set_timing(int enable) {
-  g_timing = enable != 0;
-  g_events_used = 0;
+  Runtime &r = rt();
+  std::lock_guard<std::mutex> lk(r.mu);
+  r.timing = enable != 0;
+  r.events_used = 0;
+  return REFNERF_OK;
+}
+int refnerf_get_timing_family(int family, double *total_ms, int64_t *launches) {
+  Runtime &r = rt();
+  std::lock_guard<std::mutex> lk(r.mu);
+  double tot = 0.0;
+  int64_t n = 0;
+  for (size_t i = 0; i < r.events_used; ++i) {
+    if (r.family[i] != family) continue;
+    HIP_TRY(hipEventSynchronize(r.events[i].second));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, r.events[i].first, r.events[i].second));
+    tot += ms;
+    n += 1;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = n;
   return REFNERF_OK;
 }
 int refnerf_get_timing(double *total_ms, int64_t *launches) {
-  double tot = 0.0;
-  for (size_t i = 0; i < g_events_used; ++i) {
-    HIP_TRY(hipEventSynchronize(g_events[i].second));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, g_events[i].first, g_events[i].second));
-    tot += ms;
-  }
-  if (total_ms) *total_ms = tot;
-  if (launches) *launches = (int64_t)g_events_used;
-  return REFNERF_OK;
+  return refnerf_get_timing_family(REFNERF_TIMER_FORWARD, total_ms, launches);
 }
 
 }  /* extern "C" */

@@ -36,6 +36,35 @@ namespace rn {
 
 typedef short v2s __attribute__((ext_vector_type(2)));
 
+/* Element type of the MFMA operands: the kernel is a template over it.
+ *   MmBf16: v_mfma_f32_32x32x16_bf16 (8 significand bits, fp32 range)            -- REFNERF_PREC_BF16
+ *   MmF16 : v_mfma_f32_32x32x16_f16  (IEEE half: 11 significand bits, |x| <= 65504) -- REFNERF_PREC_F16
+ * Same MFMA rate, same packed layouts (two 16-bit values per dword), fp32 accumulation in both.  f16 is 8-10x closer
+ * to the fp32 parity mode (measured); it needs the hidden activations to stay below 65504 (they are O(1)..O(100)
+ * in a NeRF MLP; the head outputs -- densities, colours -- never pass through the 16-bit type). */
+struct MmBf16 {
+  typedef __bf16 t;
+  typedef t v8 __attribute__((ext_vector_type(8)));
+  typedef t v2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ v16f mfma(v8 a, v8 b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+struct MmF16 {
+  typedef _Float16 t;
+  typedef t v8 __attribute__((ext_vector_type(8)));
+  typedef t v2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ v16f mfma(v8 a, v8 b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <typename MM>
+__device__ __forceinline__ unsigned cvt_pk_mm(float lo, float hi) {
+  typename MM::v2 r = __builtin_convertvector((v2f){lo, hi}, typename MM::v2);
+  return __builtin_bit_cast(unsigned, r);
+}
+#ifdef REFNERF_EVAL_EXACT_ENC
+constexpr bool ENC_FAST = false;     /* experiment: libm-accurate encodings / head activations in this kernel */
+#else
+constexpr bool ENC_FAST = true;
+#endif
+
 constexpr int BT = 256;                               /* samples per pass: 8 waves x 32 */
 constexpr int BF_NW = 8;                              /* waves per workgroup */
 constexpr int BF_NTHREADS = 64 * BF_NW;
@@ -80,7 +109,8 @@ __device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off) {
   }
 }
 
-__device__ __forceinline__ v8bf lds_frag(const char *q) { return *reinterpret_cast<const v8bf *>(q); }
+template <typename MM>
+__device__ __forceinline__ typename MM::v8 lds_frag(const char *q) { return *reinterpret_cast<const typename MM::v8 *>(q); }
 
 __device__ __forceinline__ v16f bias16(const char *w, int h) {
   const v4f *bp = reinterpret_cast<const v4f *>(w + h * 64);
@@ -89,9 +119,9 @@ __device__ __forceinline__ v16f bias16(const char *w, int h) {
                 b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
 }
 
-template <bool RELU>
+template <typename MM, bool RELU>
 __device__ __forceinline__ unsigned pack_pair(float lo, float hi) {
-  unsigned w = cvt_pk_bf16(lo, hi);
+  unsigned w = cvt_pk_mm<MM>(lo, hi);
   if (RELU) {
     v2s s = __builtin_bit_cast(v2s, w);
     s = __builtin_elementwise_max(s, (v2s){0, 0});
@@ -101,21 +131,21 @@ __device__ __forceinline__ unsigned pack_pair(float lo, float hi) {
 }
 
 /* acc (one 32x32 fp32 tile) -> two packed bf16 B fragments of the next layer */
-template <bool RELU>
+template <typename MM, bool RELU>
 __device__ __forceinline__ void pack_acc(const v16f &a, v4uu &f0, v4uu &f1) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    f0[e] = pack_pair<RELU>(a[2 * e], a[2 * e + 1]);
-    f1[e] = pack_pair<RELU>(a[8 + 2 * e], a[8 + 2 * e + 1]);
+    f0[e] = pack_pair<MM, RELU>(a[2 * e], a[2 * e + 1]);
+    f1[e] = pack_pair<MM, RELU>(a[8 + 2 * e], a[8 + 2 * e + 1]);
   }
 }
 
 /* B fragment (LDS encodings) of LDS k-step kl; REAL steps hold data, the
  * zero-weight pad steps re-read early groups (any finite value). */
-template <int REAL>
-__device__ __forceinline__ v8bf lds_b(const Pipe &p, int kl) {
+template <typename MM, int REAL>
+__device__ __forceinline__ typename MM::v8 lds_b(const Pipe &p, int kl) {
   const int kk = (kl < REAL) ? kl : kl - REAL;
-  return lds_frag(p.xp + (2 * kk) * BT * 16);
+  return lds_frag<MM>(p.xp + (2 * kk) * BT * 16);
 }
 
 /* One chunk.  KIND: BF_REG (16 steps over `in`), BF_LDS8 (8 steps over LDS,
@@ -123,30 +153,31 @@ __device__ __forceinline__ v8bf lds_b(const Pipe &p, int kl) {
  * FIRST: the chunk opens a slice (accumulator starts from the bias piece).
  * `a` is the A-fragment ring; on entry it holds fragments 0..AF-1 of this chunk,
  * on exit those of the next one. */
-template <int KIND, int REAL_L, bool FIRST>
-__device__ __forceinline__ void bf_chunk(Pipe &p, v8bf (&a)[AF], const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
+template <typename MM, int KIND, int REAL_L, bool FIRST>
+__device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
+  typedef typename MM::v8 v8mm;
   constexpr int KS = (KIND == BF_LDS8) ? 8 : 16;
   constexpr int L0 = (KIND == BF_BNLDS) ? 8 : 0;      /* first LDS step (for the LDS kinds) */
   const char *w = p.wbuf + p.cur_off;
   const char *cur = w + 1024 + p.lane * 16;
   const char *nxt = p.wbuf + p.nxt_off + 1024 + p.lane * 16;
-  v8bf xr[2];
-  if (KIND == BF_LDS8) { xr[0] = lds_b<REAL_L>(p, 0); xr[1] = lds_b<REAL_L>(p, 1); }
+  v8mm xr[2];
+  if (KIND == BF_LDS8) { xr[0] = lds_b<MM, REAL_L>(p, 0); xr[1] = lds_b<MM, REAL_L>(p, 1); }
   if (FIRST) acc = bias16(w, p.h);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
-    v8bf b;
+    v8mm b;
     const bool lds_step = (KIND == BF_LDS8) || (KIND == BF_BNLDS && k >= 8);
     if (lds_step) b = xr[(k - L0) & 1];
-    else if (KIND == BF_REG) b = __builtin_bit_cast(v8bf, in[k]);
-    else b = __builtin_bit_cast(v8bf, bn[k & 7]);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k % AF], b, acc, 0, 0, 0);
+    else if (KIND == BF_REG) b = __builtin_bit_cast(v8mm, in[k]);
+    else b = __builtin_bit_cast(v8mm, bn[k & 7]);
+    acc = MM::mfma(a[k % AF], b, acc);
     /* A ring: fragment k+AF of this chunk, or the head of the next chunk (landed: k >= KS/2) */
-    a[k % AF] = (k + AF < KS) ? lds_frag(cur + (k + AF) * 1024) : lds_frag(nxt + (k + AF - KS) * 1024);
+    a[k % AF] = (k + AF < KS) ? lds_frag<MM>(cur + (k + AF) * 1024) : lds_frag<MM>(nxt + (k + AF - KS) * 1024);
     if (KIND != BF_REG) {
       const int kl2 = k + 2 - L0;                       /* LDS step to fetch now */
-      if (kl2 >= 0 && kl2 < 8 && !(KIND == BF_LDS8 && kl2 < 2)) xr[kl2 & 1] = lds_b<REAL_L>(p, kl2);
+      if (kl2 >= 0 && kl2 < 8 && !(KIND == BF_LDS8 && kl2 < 2)) xr[kl2 & 1] = lds_b<MM, REAL_L>(p, kl2);
     }
 #ifndef REFNERF_BF_RDV
 #define REFNERF_BF_RDV (KS / 2 - 1)
@@ -178,12 +209,12 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, v8bf (&a)[AF], const v4uu (&in
 /* One slice (32 output rows): first chunk of kind KIND0 plus, for the skip
  * layers, a run-time selected second chunk (1: IPE from LDS, 2: bottleneck +
  * dir encodings). */
-template <int KIND0, int REAL0>
-__device__ __forceinline__ void bf_slice(Pipe &p, v8bf (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
-  bf_chunk<KIND0, REAL0, true>(p, a, in, bn, acc);
+template <typename MM, int KIND0, int REAL0>
+__device__ __forceinline__ void bf_slice(Pipe &p, typename MM::v8 (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
+  bf_chunk<MM, KIND0, REAL0, true>(p, a, in, bn, acc);
   if constexpr (KIND0 == BF_REG) {
-    if (second == 1) bf_chunk<BF_LDS8, BF_IPE_REAL_KS, false>(p, a, in, bn, acc);
-    else if (second == 2) bf_chunk<BF_BNLDS, BF_DIR_REAL_KS, false>(p, a, in, bn, acc);
+    if (second == 1) bf_chunk<MM, BF_LDS8, BF_IPE_REAL_KS, false>(p, a, in, bn, acc);
+    else if (second == 2) bf_chunk<MM, BF_BNLDS, BF_DIR_REAL_KS, false>(p, a, in, bn, acc);
   }
 }
 
@@ -194,21 +225,22 @@ __device__ __forceinline__ void bf_slice(Pipe &p, v8bf (&a)[AF], int second, con
  * destination registers dynamically, so `out` works as a shift register: the
  * new fragments enter at [12..15] and everything moves down four places per
  * slice pair; after the 8 slices fragment pair ob sits at [2ob],[2ob+1]. */
-template <int KIND0, int REAL0>
-__device__ __forceinline__ void bf_layer(Pipe &p, v8bf (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16]) {
+template <typename MM, int KIND0, int REAL0>
+__device__ __forceinline__ void bf_layer(Pipe &p, typename MM::v8 (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16]) {
   /* fully unrolled: slice ob packs straight into out[2ob], out[2ob+1] (no register-queue moves) */
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) {
     v16f acc;
-    bf_slice<KIND0, REAL0>(p, a, second, in, bn, acc);
-    pack_acc<true>(acc, out[2 * ob], out[2 * ob + 1]);
+    bf_slice<MM, KIND0, REAL0>(p, a, second, in, bn, acc);
+    pack_acc<MM, true>(acc, out[2 * ob], out[2 * ob + 1]);
     __builtin_amdgcn_sched_barrier(0);   /* pack now: do not keep the fp32 tile alive */
   }
 }
 
-__device__ __forceinline__ void st_bf16(char *q, float v) { *reinterpret_cast<__bf16 *>(q) = (__bf16)v; }
-
-__global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A) {
+template <typename MM>
+__device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
+  typedef typename MM::v8 v8mm;
+  typedef typename MM::t mm_t;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples;
@@ -257,9 +289,9 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   if (wave >= BF_NW / 2) __builtin_amdgcn_s_setprio(1);
 #endif
   v4uu R0[16], R1[16], bn[8];
-  v8bf ar[AF];
+  v8mm ar[AF];
 #pragma unroll
-  for (int d = 0; d < AF; ++d) ar[d] = lds_frag(WB + 1024 + lane * 16 + d * 1024);
+  for (int d = 0; d < AF; ++d) ar[d] = lds_frag<MM>(WB + 1024 + lane * 16 + d * 1024);
 
   for (int pass0 = 0; pass0 < n_tot; pass0 += BT) {
     /* opaque copies: keep hipcc from hoisting ~100 registers of per-lane address
@@ -282,7 +314,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         raw_dif[i] = HD[(5 + i) * BT + col];
         raw_tint[i] = HD[(8 + i) * BT + col];
       }
-      sample_heads<true>(cfg, HD[0 * BT + col], gp, HD[4 * BT + col], raw_dif, raw_tint, v, sh);
+      sample_heads<ENC_FAST>(cfg, HD[0 * BT + col], gp, HD[4 * BT + col], raw_dif, raw_tint, v, sh);
     };
 
 #pragma unroll 1
@@ -314,13 +346,13 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         for (int qq = 0; qq < 2; ++qq) {
 #pragma unroll
           for (int q = 0; q < 3; ++q) {
-            v8bf pk;
+            v8mm pk;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const int kk = q * 8 + e;                  /* 3 * (j - 8qq) + b */
-              pk[e] = (__bf16)ipe_feature<true>(lm[kk % 3], lv[kk % 3], 8 * qq + kk / 3, h);
+              pk[e] = (mm_t)ipe_feature<ENC_FAST>(lm[kk % 3], lv[kk % 3], 8 * qq + kk / 3, h);
             }
-            *reinterpret_cast<v8bf *>(xs + (6 * h + 3 * qq + q) * BT * 16) = pk;
+            *reinterpret_cast<v8mm *>(xs + (6 * h + 3 * qq + q) * BT * 16) = pk;
           }
         }
         RN_STAMP(A, 18);
@@ -332,29 +364,29 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         float ide[40];
 #pragma unroll
         for (int q = 36; q < 40; ++q) ide[q] = 0.0f;
-        ide_eval<true>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { ide[q] = val; });
+        ide_eval<ENC_FAST>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { ide[q] = val; });
         if (h == 0) ide[36] = sh.dot;
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-          v8bf pk;
+          v8mm pk;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) pk[e] = (__bf16)ide[q * 8 + e];
-          *reinterpret_cast<v8bf *>(xs + (5 * h + q) * BT * 16) = pk;
+          for (int e = 0; e < 8; ++e) pk[e] = (mm_t)ide[q * 8 + e];
+          *reinterpret_cast<v8mm *>(xs + (5 * h + q) * BT * 16) = pk;
         }
       }
       wave_sync();
       RN_STAMP(A, 3 + phase * 8);
 
       /* layer 0 of the trunk: inputs from LDS (+ bottleneck registers for the dir MLP) -> R0 */
-      if (phase == 0) bf_layer<BF_LDS8, BF_IPE_REAL_KS>(p, ar, 0, R0, bn, R0);
-      else bf_layer<BF_BNLDS, BF_DIR_REAL_KS>(p, ar, 0, R0, bn, R0);
+      if (phase == 0) bf_layer<MM, BF_LDS8, BF_IPE_REAL_KS>(p, ar, 0, R0, bn, R0);
+      else bf_layer<MM, BF_BNLDS, BF_DIR_REAL_KS>(p, ar, 0, R0, bn, R0);
       RN_STAMP(A, 4 + phase * 8);
       /* layers 1..7: A (R0->R1), B (R1->R0); the third A carries the skip input */
 #pragma unroll 1
       for (int it = 0; it < 4; ++it) {
         const int second = (it == 2) ? (phase ? 2 : 1) : 0;
-        bf_layer<BF_REG, 0>(p, ar, second, R0, bn, R1);
-        if (it < 3) bf_layer<BF_REG, 0>(p, ar, 0, R1, bn, R0);
+        bf_layer<MM, BF_REG, 0>(p, ar, second, R0, bn, R1);
+        if (it < 3) bf_layer<MM, BF_REG, 0>(p, ar, 0, R1, bn, R0);
       }
       RN_STAMP(A, 5 + phase * 8);
       if (phase == 0) {
@@ -362,8 +394,8 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
 #pragma unroll
         for (int ob = 0; ob < 5; ++ob) {
           v16f acc;
-          bf_slice<BF_REG, 0>(p, ar, 0, R1, bn, acc);
-          if (ob < 4) pack_acc<false>(acc, bn[2 * ob], bn[2 * ob + 1]);
+          bf_slice<MM, BF_REG, 0>(p, ar, 0, R1, bn, acc);
+          if (ob < 4) pack_acc<MM, false>(acc, bn[2 * ob], bn[2 * ob + 1]);
           else {
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
@@ -377,7 +409,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
       } else {
         /* rgb: one slice */
         v16f acc;
-        bf_slice<BF_REG, 0>(p, ar, 0, R1, bn, acc);
+        bf_slice<MM, BF_REG, 0>(p, ar, 0, R1, bn, acc);
         float raw_rgb[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n, 64);
@@ -388,7 +420,7 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
         if (valid && h == 0) {                                                            /* P6 */
           SampleHeads sh;
           load_heads(sh);
-          colour_store<true, NPS_EVAL>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
+          colour_store<ENC_FAST, NPS_EVAL>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
         }
         wave_sync();
         history_flush<NPS_EVAL>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);
@@ -407,6 +439,9 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A)
   composite_phase<BF_NW, true, NPS_EVAL>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB), NRM);   /* P7 */
   RN_STAMP(A, 16);
 }
+
+__global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A) { level_fwd_mm<MmBf16>(A); }
+__global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16(const LevelArgs A) { level_fwd_mm<MmF16>(A); }
 
 /* ---------------- bf16 weight image ---------------- */
 __device__ __forceinline__ int ipe_col_of_kprime(int kp) { return kp; }   /* LDS order = canonical IPE order */

@@ -377,7 +377,7 @@ class PropMLP(MLP):
     pass
 
 
-_PREC = {"f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16}
+_PREC = {"f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16, "f16": _hip.PREC_F16}
 
 
 class _Lean(threading.local):

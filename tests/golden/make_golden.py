@@ -580,7 +580,136 @@ def golden_dilation():
     save("model_dilation_anneal_eval", **res)
 
 
+def analytic_target(rays):
+    """Ground-truth colours of a synthetic shiny scene for the rays of synthetic.blender_rays: a unit sphere at the
+    origin with a normal-dependent albedo and a Phong highlight, white background (own code; gives the reference
+    something with real geometry to fit)."""
+    o, d = rays["origins"].astype(np.float64), rays["viewdirs"].astype(np.float64)
+    b = (o * d).sum(-1)
+    c = (o * o).sum(-1) - 1.0
+    disc = b * b - c
+    hit = disc > 0
+    t = -b - np.sqrt(np.where(hit, disc, 0.0))
+    p = o + t[:, None] * d
+    n = p / np.maximum(np.linalg.norm(p, axis=-1, keepdims=True), 1e-9)
+    light = np.array([0.5, 0.6, 0.62])
+    light /= np.linalg.norm(light)
+    refl = d - 2.0 * (d * n).sum(-1, keepdims=True) * n
+    spec = np.maximum(0.0, refl @ light) ** 24 * 0.8
+    col = (0.5 + 0.4 * n) * np.maximum(0.15, n @ light)[:, None] + spec[:, None]
+    return np.where(hit[:, None], np.clip(col, 0.0, 1.0), 1.0).astype(np.float32)
+
+
+TRAINED_BLOB = os.path.join(HERE, "trained_blob.npz")
+
+
+def golden_trained(steps=400, n_rays=512, n_samples=32, lr=5e-4):
+    """"Trained-like" weights: the REFERENCE takes `steps` Adam steps (its own forward, its three Ref-NeRF losses,
+    its autograd) on the analytic shiny sphere above, starting from the seeded init.  The resulting blob is stored
+    rounded to float16 (trained_blob.npz, 2.2 MB) and that rounded blob DEFINES the fixture weights: the reference
+    outputs below are computed after loading the rounded blob back into the reference model."""
+    pk = dict(seed=0, bias_scale=0.0)
+    model, cfg = build_model([f"Model.num_prop_samples = {n_samples}", f"Model.num_nerf_samples = {n_samples}"], pk)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=lr, eps=1e-6)
+    import time
+    t0 = time.time()
+    hist_loss = []
+    for it in range(steps):
+        rays = synthetic.blender_rays(n_rays, seed=1000 + it, center_frac=0.85)
+        gt = analytic_target(rays)
+        r = to_rays(rays)
+        opt.zero_grad()
+        rend, hist = model(r, 1.0, False)
+        batch = utils.Batch(rays=r, rgb=gt)
+        data_loss, stats = train_utils.compute_data_loss(batch, rend, r, cfg)
+        loss = data_loss + train_utils.orientation_loss(r, model, hist, cfg) + train_utils.predicted_normal_loss(model, hist, cfg)
+        loss.backward()
+        opt.step()
+        hist_loss.append(float(data_loss))
+        if it % 20 == 0:
+            print(f"step {it}: data loss {float(data_loss):.5f}  ({time.time() - t0:.0f} s)", flush=True)
+    blob = np.zeros(layout.NUM_PARAMS, np.float32)
+    sd = model.nerf_mlp.state_dict()
+    for spec in layout.PARAM_SPECS:
+        blob[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = sd[spec.name + ".weight"].numpy().reshape(-1)
+        blob[spec.b_off:spec.b_off + spec.out_dim] = sd[spec.name + ".bias"].numpy()
+    blob16 = blob.astype(np.float16)
+    assert np.isfinite(blob16.astype(np.float32)).all()
+    np.savez_compressed(TRAINED_BLOB, blob_f16=blob16, data_loss_curve=np.array(hist_loss, np.float32),
+                        recipe=np.array([steps, n_rays, n_samples, lr]))
+    print("wrote", TRAINED_BLOB, os.path.getsize(TRAINED_BLOB) // 1024, "KiB; final data loss", hist_loss[-1])
+    golden_trained_models()
+
+
+def _load_trained_blob():
+    return np.load(TRAINED_BLOB)["blob_f16"].astype(np.float32)
+
+
+def build_model_blob(bindings, blob):
+    gin.clear_config()
+    gin.parse_config_files_and_bindings([REF_CFG], list(bindings))
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg)
+    _set_mlp_params(model.nerf_mlp, blob)
+    return model, cfg
+
+
+def golden_trained_models():
+    """Reference outputs on the trained-like weights (trained_blob.npz): eval at C2's sample counts and one
+    training step (losses + autograd gradients)."""
+    blob = _load_trained_blob()
+    cases = {
+        "model_trained_eval": ([], synthetic.blender_rays(32, seed=31, center_frac=0.8), False),
+        "model_trained_train": (["Model.num_prop_samples = 64", "Model.num_nerf_samples = 96"],
+                                synthetic.blender_rays(16, seed=32, center_frac=0.8), True),
+    }
+    for name, (bindings, rays, train) in cases.items():
+        model, cfg = build_model_blob(bindings, blob)
+        gt = analytic_target(rays)
+        res = run_model(model, cfg, rays, train, gt)
+        if train:   # a usable fixture exercises every tensor: no dead branch (e.g. a saturated specular sigmoid)
+            g = res["grads"]
+            dead = [s.name for s in layout.PARAM_SPECS if not np.any(g[s.w_off:s.w_off + s.out_dim * s.in_dim])]
+            assert not dead, f"trained blob has dead tensors: {dead}"
+        print(name, "specular max", float(res["L1_h_specular"].max()), "tint range", float(res["L1_h_tint"].min()), float(res["L1_h_tint"].max()))
+        _finish_model_fixture(name, res, bindings, rays, gt, param_kw=np.array([-1.0, 0.0, 1.0, 0.0]))
+
+
+def _finish_model_fixture(name, res, bindings, rays, gt, param_kw):
+    res["bindings"] = np.array(bindings if bindings else [""])
+    res["param_kw"] = param_kw          # seed -1: weights = trained_blob.npz (float16 -> float32)
+    for k, v in rays.items():
+        res["rays_" + k] = v
+    res["gt_rgb"] = gt
+    if "grads" in res:
+        g = res.pop("grads")
+        res["grads_sub"] = g[::97].copy()
+        res["grads_tensor_l2"] = np.array([[np.linalg.norm(g[s.w_off:s.w_off + s.out_dim * s.in_dim]),
+                                            np.linalg.norm(g[s.b_off:s.b_off + s.out_dim])] for s in layout.PARAM_SPECS])
+    save(name, **res)
+
+
+def golden_shiny():
+    """BASELINE configs[2] (C3): the "shiny" network -- raw_roughness.bias = -6, roughness ~ 1e-3, so the degree-8 /
+    degree-16 IDE terms are barely attenuated (ref_utils.py:98-161, models.py:637-665) -- at 192 + 192 samples."""
+    b = ["Model.num_prop_samples = 192", "Model.num_nerf_samples = 192"]
+    pk = dict(seed=0, bias_scale=0.05, sharpen=20.0, roughness_bias=-6.0)
+    cases = {
+        "model_shiny_eval": (b, synthetic.blender_rays(16, seed=41, center_frac=0.4), False),
+        "model_shiny_train": (b, synthetic.blender_rays(10, seed=42, center_frac=0.4), True),
+    }
+    for name, (bindings, rays, train) in cases.items():
+        model, cfg = build_model(bindings, pk)
+        gt = synthetic.target_rgb(rays["origins"].shape[0], seed=2)
+        res = run_model(model, cfg, rays, train, gt)
+        assert res["L1_h_roughness"].max() < 5e-3, res["L1_h_roughness"].max()
+        _finish_model_fixture(name, res, bindings, rays, gt,
+                              param_kw=np.array([pk["seed"], pk["bias_scale"], pk["sharpen"], pk["roughness_bias"]]))
+
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models"]
     for w in which:
         globals()["golden_" + w]()

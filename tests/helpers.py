@@ -13,8 +13,17 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
+def trained_blob():
+    """The "trained-like" weights: the blob the REFERENCE reached after 300 of its own Adam steps on an analytic
+    shiny sphere (tests/golden/make_golden.py::golden_trained), stored as float16; the float16 -> float32 upcast is
+    the fixture's weight set (the reference outputs were computed from exactly these values)."""
+    return np.load(os.path.join(GOLDEN, "trained_blob.npz"))["blob_f16"].astype(np.float32)
+
+
 def params_from_golden(g):
     pk = g["param_kw"]
+    if int(pk[0]) < 0:
+        return trained_blob()
     return synthetic.make_params(int(pk[0]), float(pk[1]), float(pk[2]), float(pk[3]))
 
 
@@ -39,7 +48,10 @@ def cfg_from_bindings(bindings):
 
 
 MODEL_CASES = ["model_blender_eval", "model_blender_sharp_eval", "model_c1_eval",
-               "model_llff_linear_eval", "model_blender_sharp_train", "model_llff_linear_train"]
+               "model_llff_linear_eval", "model_blender_sharp_train", "model_llff_linear_train",
+               "model_shiny_eval", "model_shiny_train", "model_trained_eval", "model_trained_train"]
+EVAL_CASES = [n for n in MODEL_CASES if n.endswith("eval")]
+TRAIN_CASES = [n for n in MODEL_CASES if n.endswith("train")]
 
 HIST_KEYS = ("sdist", "weights", "density", "rgb", "normals_pred", "roughness", "diffuse", "specular", "tint")
 REND_KEYS = ("rgb", "diffuse", "specular", "distance", "acc", "normals_pred", "tint", "roughness", "distance_mean")

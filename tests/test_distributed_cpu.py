@@ -100,3 +100,27 @@ def test_single_process_noop():
     configs.clear_config()
     distributed.allreduce_gradients(model)        # not initialised: no-op
     distributed.broadcast_parameters(model)
+
+
+def test_bench_launcher_starts_ranks_and_fails_loudly_without_gpus():
+    """`bench.py --gpus N` (N > 1, outside torchrun) is a PARENT that starts N rank processes before touching a GPU.
+    On this CPU-only box: (a) it refuses N ranks on fewer devices (exit 2, nothing started); (b) with the share-GPU
+    smoke override it does start the two ranks, each of which fails loudly for lack of a device (no CPU fallback),
+    and the parent reports a non-zero exit."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a box with fewer than two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "REFNERF_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "only" in r.stderr and r.stdout == ""
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, REFNERF_BENCH_SHARE_GPU="1", REFNERF_BENCH_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "rank exit codes" in r.stderr and r.stdout == ""

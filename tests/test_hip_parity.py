@@ -4,8 +4,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (HIST_KEYS, REND_KEYS, cfg_from_bindings, load_golden, params_from_golden,
-                     rays_from_golden)
+from helpers import (EVAL_CASES, HIST_KEYS, REND_KEYS, TRAIN_CASES, cfg_from_bindings, load_golden,
+                     params_from_golden, rays_from_golden)
 
 pytestmark = pytest.mark.gpu
 
@@ -109,7 +109,46 @@ def test_ide_stage_gated_by_fp64(hip, O):
 
 
 # ---------------------------------------------------------------- end to end
-EVAL_CASES = ["model_blender_eval", "model_blender_sharp_eval", "model_c1_eval", "model_llff_linear_eval"]
+STRICT_INDEX_CASES = ("model_blender_eval", "model_blender_sharp_eval", "model_c1_eval", "model_llff_linear_eval",
+                      "model_blender_sharp_train", "model_llff_linear_train")
+WIDE_RANGE_CASES = ("model_trained_eval", "model_trained_train", "model_shiny_eval", "model_shiny_train")
+
+
+def hist_tol(name, L, k):
+    """(rtol, atol) of the per-sample comparison HIP f32 mode <-> oracle / reference.  Random-init fixtures: round-off.
+    Shiny (un-attenuated degree-16 IDE terms in a K = 457 GEMM) and trained-like weights (pre-activations of 20-30):
+    summation-order noise reaches 1e-5 per sample at level 0; at level 1 the sample POSITIONS already differ by an ulp
+    (sdist ~1e-7) and the trained network turns that into <= 5e-3 per sample -- the rendered
+    quantities, compared separately, stay at 1e-5."""
+    tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 5e-6)
+    if name not in WIDE_RANGE_CASES:
+        return 0.0, tol
+    if k in ("sdist", "weights"):
+        return 0.0, (1e-5 if L == 0 else 5e-5)
+    if L == 0:
+        return 2e-5, max(tol, 1e-5)
+    return 2e-4, max(tol, 5e-3 if name.startswith("model_trained") else 5e-5)
+def test_render_rays_all_render_time_modes(hip):
+    """refnerf_render_rays = compute_alpha_weights + volumetric_rendering (render.py:132-254): the five render-time
+    srgb_mapping modes (:186-216), extras and float64 percentiles against the REFERENCE's outputs on the same
+    per-sample inputs (tests/golden/render.npz) -- the same checker the oracle passes on CPU."""
+    from test_oracle_golden import check_render_modes
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=DEV)
+
+    def fn(mode, g):
+        cfg = hip.default_cfg(render_srgb_mode=mode)
+        res = hip.render_rays(cfg, t(g["density"]), t(g["tdist"]), t(g["dirs"]), t(g["far"]), t(g["rgbs"]), t(g["dif"]),
+                              t(g["spc"]), t(g["normals"]), t(g["normals_pred"]), t(g["roughness"]), t(g["tint"]))
+        return {k: v.cpu().numpy() for k, v in res.items()}
+    worst = check_render_modes(fn)
+    print("render_rays vs reference, worst abs error per output over the five modes:", worst)
+    # opaque background (render.py:139-143) through the same entry
+    g = load_golden("render")
+    res = hip.render_rays(hip.default_cfg(opaque_background=1), t(g["density"]), t(g["tdist"]), t(g["dirs"]), t(g["far"]))
+    np.testing.assert_allclose(res["weights"].cpu().numpy(), g["weights_opaque1"], rtol=0, atol=2e-7)
+    with pytest.raises(ValueError):
+        hip.render_rays(hip.default_cfg(), torch.zeros((2, 2000), device=DEV), torch.zeros((2, 2001), device=DEV),
+                        torch.zeros((2, 3), device=DEV), torch.zeros(2, device=DEV))
 
 
 @pytest.mark.parametrize("name", EVAL_CASES)
@@ -120,26 +159,41 @@ def test_level_forward_vs_oracle_and_reference(hip, O, name):
     kw, lv = cfg_from_bindings(g["bindings"])
     ref = O.model_forward(P, rays, **lv, **kw)
     outs = run_hip_model(hip, P, rays, kw, lv)
+    ok = np.ones(rays["origins"].shape[0], bool)
     for L, (res, orc) in enumerate(zip(outs, ref)):
         if L == 0:
             assert np.array_equal(res["sdist"], orc["sdist"])
-        # sample indices: identical to the oracle on this fixture (fp32 mode)
-        assert np.mean(res["bin_idx"] == orc["bin_idx"]) == 1.0
+        # sample indices: identical to the oracle on the random-init fixtures (fp32 mode); on the shiny / trained-like
+        # ones a level-1 quantile within an ulp of a CDF knot may take the neighbouring bin: bounded,
+        # and the per-sample comparison continues on the rays whose indices agree
+        same = res["bin_idx"] == orc["bin_idx"]
+        assert np.mean(same) == 1.0 if name in STRICT_INDEX_CASES else np.mean(same) >= 0.999, (L, np.mean(same))
+        ok &= same.all(-1)
+        assert ok.mean() >= 0.9
         for k in HIST_KEYS:
-            tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 5e-6)
-            np.testing.assert_allclose(res[k], orc[k].reshape(res[k].shape), rtol=0, atol=tol, err_msg=f"L{L} {k}")
-            np.testing.assert_allclose(res[k], g[f"L{L}_h_{k}"].reshape(res[k].shape), rtol=0, atol=max(tol, 2e-5), err_msg=f"golden L{L} {k}")
+            rtol, tol = hist_tol(name, L, k)
+            a, b, c = res[k][ok], orc[k].reshape(res[k].shape)[ok], g[f"L{L}_h_{k}"].reshape(res[k].shape)[ok]
+            np.testing.assert_allclose(a, b, rtol=rtol, atol=tol, err_msg=f"L{L} {k}")
+            np.testing.assert_allclose(a, c, rtol=rtol, atol=max(tol, 2e-5), err_msg=f"golden L{L} {k}")
         for k in REND_KEYS:
-            np.testing.assert_allclose(res["r_" + k], orc["r_" + k], rtol=0, atol=1e-5, err_msg=f"L{L} r_{k}")
-            np.testing.assert_allclose(res["r_" + k], g[f"L{L}_r_{k}"].reshape(res["r_" + k].shape), rtol=0, atol=1e-5)
-        # headline bar: RGB L-inf <= 1e-4 vs the reference CPU path
-        assert np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max() <= 1e-4
+            rtol_r = 2e-5 if name in WIDE_RANGE_CASES else 1e-5
+            if k == "distance_mean":     # exp(sum(w log t) / acc): round-off scales with 1 / acc (rays that miss everything)
+                rtol_r = rtol_r + 1e-6 / np.maximum(orc["r_acc"][ok], 1e-6)
+            for want in (orc["r_" + k][ok], g[f"L{L}_r_{k}"].reshape(res["r_" + k].shape)[ok]):
+                diff = np.abs(res["r_" + k][ok] - want)
+                lim = rtol_r if np.ndim(rtol_r) == 0 or diff.ndim == 1 else rtol_r[:, None]
+                assert np.all(diff <= lim), (L, k, float(diff.max()))
+        # headline bar: RGB L-inf <= 1e-4 vs the reference CPU path (ALL rays, whatever their indices did)
+        err = np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max()
+        print(f"{name} f32 L{L}: RGB L-inf vs reference {err:.2e}, identical bin indices {np.mean(same):.5f}")
+        assert err <= 1e-4
         pc = np.stack([g[f"L{L}_r_distance_percentile_5"], g[f"L{L}_r_distance_median"], g[f"L{L}_r_distance_percentile_95"]], -1)
         assert res["r_percentiles"].dtype == np.float64
-        np.testing.assert_allclose(res["r_percentiles"], pc, rtol=0, atol=2e-5)
-
-
-TRAIN_CASES = ["model_blender_sharp_train", "model_llff_linear_train"]
+        perr = np.abs(res["r_percentiles"][ok] - pc[ok])
+        if name in WIDE_RANGE_CASES:   # float64 interpolation inside a near-empty CDF bin: bulk tight, worst case bounded
+            assert np.mean(perr <= 2e-5) >= 0.95 and perr.max() <= 5e-4, (np.mean(perr <= 2e-5), perr.max())
+        else:
+            assert perr.max() <= 2e-5
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
@@ -152,18 +206,22 @@ def test_training_forward_density_normals(hip, O, name):
     kw, lv = cfg_from_bindings(g["bindings"])
     ref = O.model_forward(P, rays, training=1, **lv, **kw)
     outs = run_hip_model(hip, P, rays, dict(kw, training=1), lv)
+    ok = np.ones(rays["origins"].shape[0], bool)
     for L, (res, orc) in enumerate(zip(outs, ref)):
-        assert np.mean(res["bin_idx"] == orc["bin_idx"]) == 1.0
+        same = res["bin_idx"] == orc["bin_idx"]
+        assert np.mean(same) == 1.0 if name in STRICT_INDEX_CASES else np.mean(same) >= 0.999, (L, np.mean(same))
+        ok &= same.all(-1)
+        assert ok.mean() >= 0.9
         for k in HIST_KEYS:
-            tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 5e-6)
-            np.testing.assert_allclose(res[k], orc[k].reshape(res[k].shape), rtol=0, atol=tol, err_msg=f"L{L} {k}")
+            rtol, tol = hist_tol(name, L, k)
+            np.testing.assert_allclose(res[k][ok], orc[k].reshape(res[k].shape)[ok], rtol=rtol, atol=tol, err_msg=f"L{L} {k}")
         assert np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max() <= 1e-4
         for refn, bulk, tail in ((orc["normals"], 2e-5, 0.99), (g[f"L{L}_h_normals"], 1e-4, 0.97)):
-            err = np.abs(res["normals"] - refn.reshape(res["normals"].shape)).max(-1)
+            err = np.abs(res["normals"] - refn.reshape(res["normals"].shape)).max(-1)[ok]
             # ill-conditioned where the density gradient is tiny: bulk tight, tail loose
             assert np.median(err) < bulk and np.mean(err < 1e-3) > tail, (L, np.median(err), np.mean(err < 1e-3))
-        np.testing.assert_allclose(res["r_normals"], g[f"L{L}_r_normals"], rtol=0, atol=2e-3)
-        np.testing.assert_allclose(res["r_normals"], orc["r_normals"], rtol=0, atol=5e-4)
+        np.testing.assert_allclose(res["r_normals"][ok], g[f"L{L}_r_normals"][ok], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(res["r_normals"][ok], orc["r_normals"][ok], rtol=0, atol=5e-4)
 
 
 def _hip_train_step(hip, P, rays, gt_rgb, lossmult, kw, lv, mults):
@@ -214,20 +272,26 @@ def test_training_step_gradients(hip, O, name):
     for k in ("data", "orientation", "normal"):
         assert losses[k] == pytest.approx(o_losses[k], rel=2e-4), k
     assert losses["data"] == pytest.approx(float(g["loss_data"]), rel=1e-5)
+    wide = name.startswith("model_trained")   # level-1 sample positions differ by an ulp, amplified ~5e3 x by this network
     rel = np.linalg.norm(grads - o_grads) / np.linalg.norm(o_grads)
-    assert rel < 2e-4, rel      # fp32 summation order over the sample axis differs (split-K MFMA vs sequential)
+    print(f"{name}: gradient rel-L2 vs oracle {rel:.2e}")
+    assert rel < (1e-3 if wide else 2e-4), rel      # fp32 summation order over the sample axis differs (split-K MFMA vs sequential)
     ref = g["grads_sub"]
-    assert np.linalg.norm(grads[::97] - ref) / np.linalg.norm(ref) < 2e-4
+    assert np.linalg.norm(grads[::97] - ref) / np.linalg.norm(ref) < (1e-3 if wide else 2e-4)
     norms = g["grads_tensor_l2"]
     for i, s in enumerate(layout.PARAM_SPECS):       # all 46 tensors receive their gradient
         nw = s.out_dim * s.in_dim
-        assert np.linalg.norm(grads[s.w_off:s.w_off + nw]) == pytest.approx(norms[i, 0], rel=2e-3), s.name
-        assert np.linalg.norm(grads[s.b_off:s.b_off + s.out_dim]) == pytest.approx(norms[i, 1], rel=2e-3), s.name
+        trel = 3e-2 if wide else 2e-3
+        assert np.linalg.norm(grads[s.w_off:s.w_off + nw]) == pytest.approx(norms[i, 0], rel=trel), s.name
+        assert np.linalg.norm(grads[s.b_off:s.b_off + s.out_dim]) == pytest.approx(norms[i, 1], rel=trel), s.name
         ow, ob = o_grads[s.w_off:s.w_off + nw], o_grads[s.b_off:s.b_off + s.out_dim]
         # per tensor: round-off level (~6e-7) except where a pre-activation within 1 ulp of 0 takes the
         # other side of the ReLU than in the oracle's summation order (isolated flips, <= ~2e-3 of a tensor)
-        assert np.linalg.norm(grads[s.w_off:s.w_off + nw] - ow) <= 5e-3 * np.linalg.norm(ow) + 1e-12, s.name
-        assert np.linalg.norm(grads[s.b_off:s.b_off + s.out_dim] - ob) <= 5e-3 * np.linalg.norm(ob) + 1e-12, s.name
+        # (trained-like fixture: the directional tensors carry gradients of norm ~1e-6 of the whole -- a nearly saturated
+        # specular branch -- so their own norm is no yardstick: bound them against the whole gradient as well)
+        tb, floor = (5e-2, 1e-4 * np.linalg.norm(o_grads)) if wide else (5e-3, 1e-12)
+        assert np.linalg.norm(grads[s.w_off:s.w_off + nw] - ow) <= tb * np.linalg.norm(ow) + floor, s.name
+        assert np.linalg.norm(grads[s.b_off:s.b_off + s.out_dim] - ob) <= tb * np.linalg.norm(ob) + floor, s.name
 
 
 def test_model_api_matches_reference_contract(hip):
@@ -674,20 +738,21 @@ def test_full_size_properties(hip):
 
 
 # ---------------------------------------------------------------- bf16 mode
-@pytest.mark.parametrize("name", EVAL_CASES)
-def test_bf16_mode_tolerance(hip, name):
-    """bf16 MFMA mode (bf16 weights/activations, fp32 accumulate, hardware
-    transcendentals) against the reference golden vectors: rendered RGB L-inf
-    <= 1e-4 (the north-star bar; measured 1e-5 .. 9e-5 on these fixtures, and
-    deterministic), per-sample colour 2e-3, >= 99% identical CDF bin indices."""
+@pytest.mark.parametrize("precision", [1, 2], ids=["bf16", "f16"])
+@pytest.mark.parametrize("name", [n for n in EVAL_CASES if n in STRICT_INDEX_CASES])
+def test_bf16_mode_tolerance(hip, name, precision):
+    """The 16-bit MFMA modes (bf16 / f16 weights and activations, fp32 accumulate, hardware
+    transcendentals) against the reference golden vectors on the random-init fixtures: rendered RGB L-inf
+    <= 1e-4 (the north-star bar; measured 1e-5 .. 9e-5 in bf16 and <= 1e-5 in f16, deterministic),
+    per-sample colour 2e-3, >= 99% identical CDF bin indices."""
     g = load_golden(name)
     P = params_from_golden(g)
     rays = rays_from_golden(g)
     kw, lv = cfg_from_bindings(g["bindings"])
-    outs = run_hip_model(hip, P, rays, kw, lv, precision=1)
+    outs = run_hip_model(hip, P, rays, kw, lv, precision=precision)
     f32 = run_hip_model(hip, P, rays, kw, lv, precision=0)
     for L, res in enumerate(outs):
-        assert np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max() <= 1e-4
+        assert np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max() <= (1e-4 if precision == 1 else 2e-5)
         assert np.abs(res["rgb"] - g[f"L{L}_h_rgb"].reshape(res["rgb"].shape)).max() <= 2e-3
         np.testing.assert_allclose(res["weights"], g[f"L{L}_h_weights"], rtol=0, atol=1e-3)
         np.testing.assert_allclose(res["r_acc"], g[f"L{L}_r_acc"], rtol=0, atol=2e-3)
@@ -720,6 +785,118 @@ def test_bf16_full_size_properties(hip):
         y = run_hip_model(hip, P, rr, {}, dict(num_prop_samples=n0, num_nerf_samples=n1), precision=0)
         for L in range(2):
             assert np.abs(x[L]["r_rgb"] - y[L]["r_rgb"]).max() <= 2e-3, (R, n0, n1, L)
+
+
+# ---------------------------------------------------------------- full-size batches against the oracle
+def _psnr(a, b):
+    return float(-10.0 * np.log10(max(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2), 1e-20)))
+
+
+def _record(name, payload):
+    """Measured parity numbers of this run -> gpurun_out/parity_full_size.json (copied into profiles/ by the builder)."""
+    import json
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "parity_full_size.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[name] = payload
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print(name, payload)
+
+
+FULL_SIZE = {
+    # name: (R, N, param recipe, ray recipe, oracle rays, f32 bound, bf16 bound) -- bounds on rendered RGB L-inf
+    "C2_bench_batch": (4096, 128, dict(seed=0, bias_scale=0.05, sharpen=20.0), dict(seed=1, center_frac=0.5), 512, 1e-5, 1e-4),
+    "C3_shiny": (8192, 192, dict(seed=0, bias_scale=0.05, sharpen=20.0, roughness_bias=-6.0), dict(seed=1, center_frac=0.5), 512, 1e-5, 1e-4),
+    "C2_trained_like": (4096, 128, "trained", dict(seed=3, center_frac=0.8), 512, 3e-5, None),
+}
+
+
+@pytest.mark.parametrize("case", list(FULL_SIZE))
+def test_full_size_batches_vs_oracle(hip, O, case):
+    """The batches bench.py times (C2, C3) and a C2-sized batch on the trained-like weights, at FULL size on the HIP
+    path in both arithmetic modes; the first 512 rays of each also through the CPU oracle (rays are independent, so
+    a prefix of the batch is the same computation).  f32 mode: rendered RGB L-inf <= 1e-5 (3e-5 on the trained-like
+    network, whose level-1 outputs amplify the ulp-level differences of the level-1 sample positions) and >= 99.9 %
+    identical CDF bin indices; bf16 / f16 modes: the north-star bar 1e-4 on the random-init networks, and whatever
+    they measure on the trained-like one (recorded; the f32 mode is the parity mode of record there)."""
+    from helpers import trained_blob
+    from refnerf_pl_amd import synthetic
+    R, N, pk, rk, n_or, tol32, tol16 = FULL_SIZE[case]
+    P = trained_blob() if pk == "trained" else synthetic.make_params(**pk)
+    rays = synthetic.blender_rays(R, **rk)
+    lv = dict(num_prop_samples=N, num_nerf_samples=N)
+    f32 = run_hip_model(hip, P, rays, {}, lv, precision=0)
+    bf = run_hip_model(hip, P, rays, {}, lv, precision=1)
+    hf = run_hip_model(hip, P, rays, {}, lv, precision=2)
+    sub = {k: v[:n_or] for k, v in rays.items()}
+    ref = O.model_forward(P, sub, **lv)
+    rec = {"rays": R, "samples": N, "oracle_rays": n_or}
+    for L in range(2):
+        for tag, out in (("f32", f32), ("bf16", bf), ("f16", hf)):
+            a = out[L]
+            # size-independent properties on the whole batch
+            w, sd = a["weights"], a["sdist"]
+            assert np.isfinite(a["r_rgb"]).all()
+            assert w.min() >= 0 and np.all(w.sum(-1) <= 1 + 1e-5)
+            assert np.all(np.diff(sd, axis=-1) >= 0) and sd.min() >= 0 and sd.max() <= 1
+            bg = np.maximum(0, 1 - a["r_acc"])[:, None]
+            np.testing.assert_allclose(a["r_rgb"], (w[..., None] * a["rgb"]).sum(1) + bg, rtol=0, atol=3e-5)
+            # against the oracle on the prefix
+            err = float(np.abs(a["r_rgb"][:n_or] - ref[L]["r_rgb"]).max())
+            same = float(np.mean(a["bin_idx"][:n_or] == ref[L]["bin_idx"]))
+            rec[f"L{L}_{tag}_rgb_linf_vs_oracle"] = err
+            rec[f"L{L}_{tag}_bin_idx_agreement"] = same
+            rec[f"L{L}_{tag}_psnr_vs_oracle_db"] = _psnr(a["r_rgb"][:n_or], ref[L]["r_rgb"])
+        for tag, out in (("bf16", bf), ("f16", hf)):
+            rec[f"L{L}_{tag}_rgb_linf_vs_f32_full_batch"] = float(np.abs(out[L]["r_rgb"] - f32[L]["r_rgb"]).max())
+            rec[f"L{L}_{tag}_psnr_vs_f32_db"] = _psnr(out[L]["r_rgb"], f32[L]["r_rgb"])
+        rec[f"L{L}_density_max"] = float(f32[L]["density"].max())
+    _record(case, rec)
+    for L in range(2):
+        assert rec[f"L{L}_f32_rgb_linf_vs_oracle"] <= tol32, rec
+        assert rec[f"L{L}_f32_bin_idx_agreement"] >= 0.999, rec
+        if tol16 is not None:
+            assert rec[f"L{L}_bf16_rgb_linf_vs_oracle"] <= tol16, rec
+            assert rec[f"L{L}_f16_rgb_linf_vs_oracle"] <= tol16 / 5, rec
+        else:
+            # trained-like weights: the 16-bit modes do NOT meet the 1e-4 bar (measured: bf16 6e-3 / 5e-2 at level 0 / 1,
+            # f16 5e-4 / 1.2e-2; PSNR vs the f32 mode 52-66 dB and 68-85 dB) -- f32 is the parity mode of record; the
+            # bounds below only catch regressions of these figures
+            assert rec[f"L{L}_bf16_rgb_linf_vs_oracle"] <= 0.1 and rec[f"L{L}_bf16_psnr_vs_f32_db"] >= 48.0, rec
+            assert rec[f"L{L}_f16_rgb_linf_vs_oracle"] <= 0.03 and rec[f"L{L}_f16_psnr_vs_f32_db"] >= 64.0, rec
+        assert rec[f"L{L}_bf16_bin_idx_agreement"] >= 0.98, rec
+
+
+@pytest.mark.parametrize("name", ["model_shiny_eval", "model_trained_eval"])
+def test_bf16_mode_on_shiny_and_trained_fixtures(hip, name):
+    """bf16 mode against the REFERENCE's outputs on the two hard fixtures: the shiny network (roughness ~ 1e-3: the
+    degree-16 IDE terms reach the bf16 GEMM unattenuated, through hardware sin/cos) at 192 samples, and the
+    trained-like weights, in all three arithmetic modes.  Measured values are recorded; on the shiny network the 16-bit
+    modes meet the north-star 1e-4, on the trained-like weights only the f32 mode does (bf16 ~3e-3, f16 ~4e-4 on this
+    fixture: 16-bit products in pre-activations of magnitude 20-30) -- the bounds there only catch regressions."""
+    g = load_golden(name)
+    P = params_from_golden(g)
+    rays = rays_from_golden(g)
+    kw, lv = cfg_from_bindings(g["bindings"])
+    outs = {tag: run_hip_model(hip, P, rays, kw, lv, precision=prec) for tag, prec in (("f32", 0), ("bf16", 1), ("f16", 2))}
+    rec = {}
+    for L in range(2):
+        for tag, out in outs.items():
+            res = out[L]
+            rec[f"L{L}_{tag}_rgb_linf_vs_reference"] = float(np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max())
+            rec[f"L{L}_{tag}_sample_rgb_linf"] = float(np.abs(res["rgb"] - g[f"L{L}_h_rgb"].reshape(res["rgb"].shape)).max())
+            rec[f"L{L}_{tag}_bin_idx_vs_f32"] = float(np.mean(res["bin_idx"] == outs["f32"][L]["bin_idx"]))
+            assert np.all(np.isfinite(res["r_percentiles"]))
+    _record("fixture_" + name, rec)
+    for L in range(2):
+        assert rec[f"L{L}_f32_rgb_linf_vs_reference"] <= 1e-5, rec
+        assert rec[f"L{L}_bf16_rgb_linf_vs_reference"] <= (1e-4 if "shiny" in name else 2e-2), rec
+        assert rec[f"L{L}_f16_rgb_linf_vs_reference"] <= (2e-5 if "shiny" in name else 5e-3), rec
 
 
 def test_render_image_lean_history_is_invisible(hip):
@@ -905,15 +1082,20 @@ def test_bf16_chain_training_forward(hip, O, name):
     ref = O.model_forward(P, rays, training=1, **lv, **kw)
     outs = run_hip_model(hip, P, rays, dict(kw, training=1), lv, precision=1)
     assert np.mean(outs[0]["bin_idx"] == ref[0]["bin_idx"]) == 1.0
+    # trained-like weights: bf16 products in pre-activations of magnitude 20-30 -- the bf16 chains measure 4e-3 there
+    # (the same as the bf16 eval mode, see test_full_size_batches_vs_oracle); the f32 chains are the parity mode
+    rgb_tol, w_tol = (2e-2, 5e-2) if name.startswith("model_trained") else (1e-4, 2e-3)
     for L, (res, orc) in enumerate(zip(outs, ref)):
-        assert np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max() <= 1e-4
+        err = np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max()
+        print(f"{name} bf16 chains L{L}: RGB L-inf vs reference {err:.2e}")
+        assert err <= rgb_tol
         # level 1 resamples from level-0 weights that carry bf16 noise: a quantile next to a CDF knot may take the
         # neighbouring bin (the same happens in the bf16 eval mode); per-sample quantities are compared on the other rays
         assert np.mean(res["bin_idx"] == orc["bin_idx"]) > 0.97
         same = (res["bin_idx"] == orc["bin_idx"]).all(-1)
         assert same.any()
-        assert np.abs(res["r_rgb"][same] - orc["r_rgb"][same]).max() <= 1e-4
-        assert np.abs(res["weights"][same] - orc["weights"][same]).max() <= 2e-3
+        assert np.abs(res["r_rgb"][same] - orc["r_rgb"][same]).max() <= rgb_tol
+        assert np.abs(res["weights"][same] - orc["weights"][same]).max() <= w_tol
         nrm = res["normals"][same]
         assert np.abs(np.linalg.norm(nrm, axis=-1) - 1.0).max() < 1e-3
         cos = (nrm * orc["normals"].reshape(res["normals"].shape)[same]).sum(-1)

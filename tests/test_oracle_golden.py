@@ -3,9 +3,11 @@ the upstream reference (tests/golden/make_golden.py).  SURVEY.md 8c."""
 import numpy as np
 import pytest
 
-from helpers import (HIST_KEYS, MODEL_CASES, REND_KEYS, cfg_from_bindings, load_golden,
+from helpers import (HIST_KEYS, MODEL_CASES, REND_KEYS, TRAIN_CASES, cfg_from_bindings, load_golden,
                      params_from_golden, rays_from_golden)
 from oracle import oracle as O
+
+WIDE_RANGE_CASES = ("model_trained_eval", "model_trained_train", "model_shiny_eval", "model_shiny_train")
 
 
 def test_param_layout_matches_c():
@@ -123,6 +125,39 @@ def test_alpha_weights_and_compositing():
         assert np.all(w >= 0) and np.all(w.sum(-1) <= 1 + 1e-6)
 
 
+RENDER_MODES = ("none", "linear", "norm_linear", "srgb", "norm_srgb")
+
+
+def check_render_modes(render_fn):
+    """render.volumetric_rendering (render.py:152-254) in all five `srgb_mapping` modes (:186-216) against the
+    reference's outputs on the same per-sample inputs (tests/golden/render.npz).  `render_fn(mode, g)` -> dict with
+    the r_* names of the level outputs.  Shared by the oracle (CPU) and the HIP stage entry (GPU)."""
+    g = load_golden("render")
+    worst = {}
+    for mode in RENDER_MODES:
+        res = render_fn(mode, g)
+        np.testing.assert_allclose(res["weights"], g["weights_opaque0"], rtol=0, atol=2e-7)
+        for k in ("rgb", "diffuse", "specular", "distance", "acc", "normals", "normals_pred", "roughness", "tint",
+                  "distance_mean"):
+            ref = g[f"{mode}_{k}"]
+            mine = np.asarray(res["r_" + k]).reshape(ref.shape)
+            # distance sums t ~ 2..6 weights: 1 ulp there is 5e-7
+            tol = 2e-6 if k in ("distance", "distance_mean") else 1e-6
+            np.testing.assert_allclose(mine, ref, rtol=0, atol=tol, err_msg=f"{mode} {k}")
+            worst[k] = max(worst.get(k, 0.0), float(np.abs(mine - ref).max()))
+        pc = np.stack([g[f"{mode}_distance_percentile_5"], g[f"{mode}_distance_median"], g[f"{mode}_distance_percentile_95"]], -1)
+        assert res["r_percentiles"].dtype == np.float64
+        np.testing.assert_allclose(res["r_percentiles"], pc, rtol=0, atol=1e-5, err_msg=mode)
+    return worst
+
+
+def test_volumetric_rendering_all_render_time_modes():
+    def fn(mode, g):
+        return O.render_rays(g["density"], g["tdist"], g["dirs"], g["far"], g["rgbs"], g["dif"], g["spc"], g["normals"],
+                             g["normals_pred"], g["roughness"], g["tint"], render_srgb_mode=mode)
+    check_render_modes(fn)
+
+
 @pytest.mark.parametrize("name", MODEL_CASES)
 def test_model_end_to_end(name):
     g = load_golden(name)
@@ -135,16 +170,39 @@ def test_model_end_to_end(name):
         for k in HIST_KEYS:
             a = g[f"L{L}_h_{k}"].reshape(res[k].shape)
             tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 2e-6)
-            np.testing.assert_allclose(res[k], a, rtol=0, atol=tol, err_msg=f"L{L} {k}")
+            rtol = 0
+            if name in WIDE_RANGE_CASES:
+                # shiny (un-attenuated degree-16 IDE terms in a K = 457 GEMM) / trained-like weights (densities ~30,
+                # weights up to 0.26): summation-order noise is 3.5e-6 per sample at level 0; at level 1 the sample
+                # POSITIONS already differ by an ulp (sdist ~1e-7) and the trained network
+                # turns that into <= 1.4e-3 per sample (measured) -- the renderings below stay at the 1e-5 level
+                wide, rtol = (5e-6, 2e-5) if L == 0 else (5e-3 if name.startswith("model_trained") else 5e-5, 2e-4)
+                tol = max(tol, wide)
+                if k in ("sdist", "weights"):
+                    tol = 2e-6 if L == 0 else 5e-5
+            np.testing.assert_allclose(res[k], a, rtol=rtol, atol=tol, err_msg=f"L{L} {k}")
         for k in REND_KEYS:
             a = g[f"L{L}_r_{k}"].reshape(res["r_" + k].shape)
-            np.testing.assert_allclose(res["r_" + k], a, rtol=0, atol=5e-6, err_msg=f"L{L} r_{k}")
+            tol = 2e-5 if name in WIDE_RANGE_CASES else 5e-6
+            if k == "distance_mean":
+                # exp(sum(w log t) / acc): a ratio of two sums that are both ~acc -- round-off scales with 1 / acc
+                # (rays that miss the trained sphere have acc ~1e-4)
+                tol = tol + 1e-6 / np.maximum(res["r_acc"], 1e-6)
+                assert np.all(np.abs(res["r_" + k] - a) <= tol), (L, k, np.abs(res["r_" + k] - a).max())
+                continue
+            np.testing.assert_allclose(res["r_" + k], a, rtol=0, atol=tol, err_msg=f"L{L} r_{k}")
         # the headline parity bar: RGB L-inf <= 1e-4 vs the reference CPU path
         assert np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max() <= 1e-4
         pc = np.stack([g[f"L{L}_r_distance_percentile_5"], g[f"L{L}_r_distance_median"],
                        g[f"L{L}_r_distance_percentile_95"]], -1)
         assert res["r_percentiles"].dtype == np.float64
-        np.testing.assert_allclose(res["r_percentiles"], pc, rtol=0, atol=2e-5)
+        if name in WIDE_RANGE_CASES:
+            # the float64 interpolation divides by the CDF step of one bin: round-off of the weights (1e-7) over a
+            # near-empty bin moves the percentile inside that bin -- bulk tight, worst case bounded by the bin width
+            perr = np.abs(res["r_percentiles"] - pc)
+            assert np.mean(perr <= 2e-5) >= 0.95 and perr.max() <= 5e-4, (np.mean(perr <= 2e-5), perr.max())
+        else:
+            np.testing.assert_allclose(res["r_percentiles"], pc, rtol=0, atol=2e-5)
         if train:
             n_ref = g[f"L{L}_h_normals"].reshape(res["normals"].shape)
             err = np.abs(res["normals"] - n_ref).max(-1)
@@ -154,7 +212,7 @@ def test_model_end_to_end(name):
             np.testing.assert_allclose(res["r_normals"], g[f"L{L}_r_normals"], rtol=0, atol=2e-3)
 
 
-@pytest.mark.parametrize("name", ["model_blender_sharp_train", "model_llff_linear_train"])
+@pytest.mark.parametrize("name", TRAIN_CASES)
 def test_training_step_losses_and_gradients(name):
     """rn_level_train (forward + data / orientation / predicted-normal losses +
     backward) against the reference's autograd: loss values and
@@ -164,19 +222,26 @@ def test_training_step_losses_and_gradients(name):
     P = params_from_golden(g)
     kw, lv = cfg_from_bindings(g["bindings"])
     losses, grads, _ = O.model_train(P, rays_from_golden(g), g["gt_rgb"], **lv, **kw)
-    assert losses["data"] == pytest.approx(float(g["loss_data"]), rel=2e-6)
+    # trained-like weights: the data loss is ~9e-3, i.e. fp32 round-off of the renderings (1e-7) is 1e-5 of it
+    lrel = 5e-5 if name in WIDE_RANGE_CASES else 2e-6
+    assert losses["data"] == pytest.approx(float(g["loss_data"]), rel=lrel)
     assert losses["orientation"] == pytest.approx(float(g["loss_orientation"]), rel=2e-4)
     assert losses["normal"] == pytest.approx(float(g["loss_normal"]), rel=2e-4)
-    assert losses["total"] == pytest.approx(float(g["loss_total"]), rel=2e-6)
+    assert losses["total"] == pytest.approx(float(g["loss_total"]), rel=lrel)
     ref = g["grads_sub"]
     mine = grads[::97]
-    assert np.linalg.norm(mine - ref) / np.linalg.norm(ref) < 1e-4
-    np.testing.assert_allclose(mine, ref, rtol=0, atol=1e-6 * max(1.0, np.abs(ref).max() / 1e-3))
+    # trained-like weights: the level-1 sample positions differ from the reference's by an ulp (see above) and the
+    # trained network is ~5e3 x more sensitive to them than the random-init one: gradient rel-L2 1.6e-4 (measured)
+    wide = name.startswith("model_trained")
+    rel = np.linalg.norm(mine - ref) / np.linalg.norm(ref)
+    assert rel < (5e-4 if wide else 1e-4), rel
+    np.testing.assert_allclose(mine, ref, rtol=0, atol=(2e-5 if wide else 1e-6) * max(1.0, np.abs(ref).max() / 1e-3))
     norms = g["grads_tensor_l2"]
     for i, s in enumerate(layout.PARAM_SPECS):      # all 46 tensors receive their gradient (A10)
         n = s.out_dim * s.in_dim
-        assert np.linalg.norm(grads[s.w_off:s.w_off + n]) == pytest.approx(norms[i, 0], rel=2e-3), s.name
-        assert np.linalg.norm(grads[s.b_off:s.b_off + s.out_dim]) == pytest.approx(norms[i, 1], rel=2e-3), s.name
+        trel = 1e-2 if wide else 2e-3
+        assert np.linalg.norm(grads[s.w_off:s.w_off + n]) == pytest.approx(norms[i, 0], rel=trel), s.name
+        assert np.linalg.norm(grads[s.b_off:s.b_off + s.out_dim]) == pytest.approx(norms[i, 1], rel=trel), s.name
         assert norms[i, 0] > 0
 
 
@@ -220,3 +285,25 @@ def test_dilation_and_anneal_vs_reference():
     ok = np.abs(lvl1["sdist"] - g["L1_h_sdist"]).max(-1) < 2e-6
     np.testing.assert_allclose(lvl1["r_rgb"][ok], g["L1_r_rgb"][ok], atol=5e-6)
     np.testing.assert_allclose(lvl1["weights"][ok], g["L1_h_weights"][ok], atol=5e-6)
+
+
+@pytest.mark.parametrize("fam", ["blender", "llff_linear"])
+def test_unfused_torch_path_matches_oracle(fam):
+    """oracle/torch_path.py (the unfused PyTorch-CPU restatement bench.py times as the second cpu_baseline) against the
+    C oracle in its reference-order IDE mode: identical CDF bin indices, renderings to 5e-6."""
+    from oracle import torch_path as T
+    from refnerf_pl_amd import synthetic
+    P = synthetic.make_params(0, 0.05, 20.0)
+    if fam == "blender":
+        rays, okw, tkw = synthetic.blender_rays(40, seed=1, center_frac=0.5), {}, {}
+    else:
+        rays = synthetic.llff_rays(24, seed=1)
+        okw = dict(srgb_mapping=0, render_srgb_mode="norm_linear")
+        tkw = dict(srgb_mapping=False, render_srgb_mode="norm_linear")
+    a = O.model_forward(P, rays, num_prop_samples=64, num_nerf_samples=96, ide_mode=1, **okw)
+    b = T.model_forward(P, rays, num_prop_samples=64, num_nerf_samples=96, **tkw)
+    for L in range(2):
+        assert np.array_equal(a[L]["bin_idx"], b[L]["bin_idx"])
+        for k in ("sdist", "weights", "rgb", "r_rgb", "r_diffuse", "r_specular", "r_acc", "r_distance", "r_distance_mean",
+                  "r_roughness", "r_tint", "r_normals_pred", "r_percentiles"):
+            np.testing.assert_allclose(b[L][k].reshape(a[L][k].shape), a[L][k], rtol=2e-6, atol=5e-6, err_msg=f"L{L} {k}")
