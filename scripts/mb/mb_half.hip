@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(512) void mlp_loop(const char *img, float *out, lon
   for (int d = 0; d < AFD; ++d) { a[d] = *reinterpret_cast<const v8bf *>(faddr(fnext)); ++fnext; }
   v4u bfrag[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) bfrag[i] = (v4u){0x3f803f80u + lane + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  for (int i = 0; i < 16; ++i) bfrag[i] = (v4u){0x3f803f80u + ((lane * 7 + i * 3) & 0x7f), 0x3f803f80u, 0x3f003f80u + i, 0x3f803f80u};
   v16f acc0 = {0};
   float sink = 0.f;
   auto half = [&](int k0) {      // 8 k-steps k0..k0+7 of the current slice
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(512) void mlp_loop(const char *img, float *out, lon
     issue();
   };
   long long t0 = __builtin_readcyclecounter();
+  long long r0 = __builtin_amdgcn_s_memrealtime();
   if (grpB) {
     half(0);                                        // first half of chunk 0, un-synchronised
 #pragma unroll 1
@@ -109,6 +111,8 @@ __global__ __launch_bounds__(512) void mlp_loop(const char *img, float *out, lon
     for (int c = 0; c < NCH; ++c) { half(0); rendezvous(); half(8); epilogue(); }
   }
   long long t1 = __builtin_readcyclecounter();
+  long long r1 = __builtin_amdgcn_s_memrealtime();
+  if (wave == 0 && lane == 0) { cyc[8 + 2 * blockIdx.x] = t1 - t0; cyc[9 + 2 * blockIdx.x] = r1 - r0; }
   if (sink == 12345.678f) out[tid] = sink;
   if (blockIdx.x == 0 && lane == 0) cyc[wave] = t1 - t0;
 }
@@ -116,8 +120,15 @@ __global__ __launch_bounds__(512) void mlp_loop(const char *img, float *out, lon
 int main(int argc, char **argv) {
   int grid = argc > 1 ? atoi(argv[1]) : 2048;
   char *img; float *out; long long *cyc;
-  hipMalloc(&img, (size_t)140 * 17 * 1024); hipMemset(img, 0x3c, (size_t)140 * 17 * 1024);
-  hipMalloc(&out, 4096); hipMalloc(&cyc, 64);
+  hipMalloc(&img, (size_t)140 * 17 * 1024);
+#ifdef RANDIMG
+  { std::vector<unsigned short> hh((size_t)140 * 17 * 512); unsigned sd = 12345;
+    for (auto &v : hh) { sd = sd * 1664525u + 1013904223u; v = 0x3c00 + ((sd >> 16) & 0x1ff); }
+    hipMemcpy(img, hh.data(), hh.size() * 2, hipMemcpyHostToDevice); }
+#else
+  hipMemset(img, 0x3c, (size_t)140 * 17 * 1024);
+#endif
+  hipMalloc(&out, 4096); hipMalloc(&cyc, 64 + 16 * (size_t)grid);
   size_t lds = 4 * CHUNK + 70000;
   hipFuncSetAttribute((const void *)mlp_loop, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -128,6 +139,9 @@ int main(int argc, char **argv) {
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   long long h[8]; hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
+  { std::vector<long long> pb(2 * (size_t)grid); hipMemcpy(pb.data(), cyc + 8, 16 * (size_t)grid, hipMemcpyDeviceToHost);
+    double sc = 0, sr = 0; for (int i = 0; i < grid; ++i) { sc += pb[2 * i]; sr += pb[2 * i + 1]; }
+    printf("[all blocks: loop %.0f cycles/chunk, %.3f us/chunk, clock %.2f GHz, loops sum/CU %.3f ms] ", sc / grid / NCH, sr / grid / NCH / 100.0, sc / sr / 10.0, sr / 100.0 / 256 / 1000.0); }
   double flop = (double)grid * 8 * NCH * 16 * 32768.0;
   printf("%s grid %d: %.3f ms  %.1f TFLOP/s (%.1f%% of 2500)  cycles/chunk wave0 %.0f wave4 %.0f  err=%s\n", VARIANT, grid, ms,
          flop / ms / 1e9, flop / ms / 1e9 / 25.0, (double)h[0] / NCH, (double)h[4] / NCH, hipGetErrorString(hipGetLastError()));

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "$(dirname "$0")"
-for b in bin/m0_nolds bin/m1_deadlds bin/m2_oneacc_nolds; do timeout 60 ./$b 2048; done
+for b in bin/a0_rand bin/b7_rand bin/hp6 bin/hb_check bin/hb bin/hb_noprio bin/hb_lockstep bin/hb_epi60 bin/a3_rand_epi60; do timeout 60 ./$b 2048; done
