@@ -441,11 +441,13 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     from refnerf_pl_amd import _hip, distributed, synthetic, train_utils, utils
     model.train()
     cfg.hip_train_precision = cfg.hip_bwd_precision = chains
+    cfg.hip_fused_losses = True          # data + orientation + predicted-normal terms through the fused loss kernels
+    cfg.hip_flat_grads = True            # gradient, all-reduce and Adam on ONE flat tensor per MLP
     R = rays.origins.shape[0]
     N = spec["samples"]
-    gt = synthetic.target_rgb(R, seed=7 + rank)
+    gt = torch.as_tensor(synthetic.target_rgb(R, seed=7 + rank), device=dev)     # resident like the rays: no per-step H2D copy
     batch = utils.Batch(rays=rays, rgb=gt)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    opt = torch.optim.Adam([m.flat_parameter() for m in {id(x): x for x in (model.nerf_mlp, model.prop_mlp)}.values()], lr=1e-4, fused=True)
     extra_rays = cfg.sample_noise_size * cfg.sample_noise_angles if geometry else 0
     it = [0]
 
@@ -476,6 +478,7 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     _hip.set_timing(False)
     model.eval()
     cfg.hip_train_precision = cfg.hip_bwd_precision = "f32"
+    cfg.hip_flat_grads = cfg.hip_fused_losses = False
     assert torch.isfinite(loss.detach()).all()
     rate = world * (R + extra_rays) * N * 2 * n / el
     # per-kernel rooflines from the event pairs of the timed steps (a level = one launch of each family; the noisy
@@ -504,7 +507,8 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
             kernels[k] = {"kernel": names[k], "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[chains], "unit": "TFLOP/s",
                           "frac": ach / PEAK_TFLOPS[chains], "avg_launch_ms": avg, "launches": cnt, "flop_per_launch": flop}
     out = {"value": rate, "unit": "ray-samples/s (fwd+bwd+Adam)", "ms_per_step": 1e3 * el / n, "steps": n,
-           "dtype": chains, "wgrad": getattr(cfg, "hip_wgrad_mode", "bf16x3"), "loss": float(loss.detach()),
+           "dtype": chains, "wgrad": getattr(cfg, "hip_wgrad_mode", "bf16x3"), "losses": "fused kernels (Config.hip_fused_losses)", "gradients": "one flat tensor per MLP (Config.hip_flat_grads)",
+           "loss": float(loss.detach()),
            "kernels": kernels,
            "whole_step_mfma_frac": rate / world * TRAIN_FLOP_PER_SAMPLE / 1e12 / PEAK_TFLOPS[chains],
            "note": "whole_step_mfma_frac = wall-clock step (incl. losses, all-reduce, optimiser, weight re-pack) priced at "

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 5   /* v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
+#define REFNERF_ABI_VERSION 5   /* v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {
@@ -275,6 +275,27 @@ int refnerf_render_rays(const refnerf_level_cfg *cfg, int32_t R, const float *d_
                         const float *d_directions, const float *d_far, const float *d_rgb, const float *d_diffuse,
                         const float *d_specular, const float *d_normals, const float *d_normals_pred,
                         const float *d_roughness, const float *d_tint, const refnerf_level_out *out, void *stream);
+
+/* The three Ref-NeRF losses of one level, fused (internal/train_utils.py:33-88 compute_data_loss with
+ * data_loss_type 'mse', :165-183 orientation_loss, :186-204 predicted_normal_loss): ONE pass over the level's outputs
+ * instead of ~25 elementwise ATen ops and their autograd graph.
+ * refnerf_losses_forward writes per-ray terms d_terms [R,3] = { sum_c lossmult (rgb_c - gt_c)^2,
+ * sum_i w_i min(0, n_i . (-viewdir))^2, sum_i w_i (1 - n_i . n_pred,i) }; the caller sums them over the rays and applies
+ * the normalisers (sum of the broadcast lossmult; ray count) and Config's coarse / fine multipliers.
+ * d_orientation_normals = ray_history[Config.orientation_loss_target] (NULL: term off); d_normals = the density normals
+ * (NULL: predicted-normal term off).  refnerf_losses_backward produces what autograd would hand to the level's
+ * backward: dL/d renderings['rgb'] [R,3], dL/d ray_history['weights'] [R,N], dL/d ray_history['normals_pred'] [R,N,3],
+ * given g_* = d(term)/d(term sum) (multiplier / normaliser included) times d_upstream[0..2] = dL/d(data, orientation,
+ * predicted-normal term) (device float[3], NULL = 1: on the device so that autograd's grad_output needs no host sync); the density normals are detached as in the reference
+ * (models.py:609), so an orientation target other than normals_pred only reaches the weights. */
+int refnerf_losses_forward(int32_t R, int32_t N, const float *d_r_rgb, const float *d_gt_rgb, const float *d_lossmult,
+                           const float *d_weights, const float *d_orientation_normals, const float *d_normals,
+                           const float *d_normals_pred, const float *d_viewdirs, float *d_terms, void *stream);
+int refnerf_losses_backward(int32_t R, int32_t N, const float *d_r_rgb, const float *d_gt_rgb, const float *d_lossmult,
+                            const float *d_weights, const float *d_orientation_normals, int32_t orientation_on_pred,
+                            const float *d_normals, const float *d_normals_pred, const float *d_viewdirs,
+                            float g_data, float g_orientation, float g_normal, const float *d_upstream,
+                            float *d_g_r_rgb, float *d_g_weights, float *d_g_normals_pred, void *stream);
 
 /* Total duration (ms) and count of the `refnerf_level_forward` kernels launched
  * since refnerf_set_timing(1), from HIP event pairs on the launch stream.

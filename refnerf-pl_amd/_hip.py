@@ -103,6 +103,8 @@ def lib():
         L.refnerf_integrated_pos_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
         L.refnerf_integrated_dir_enc.argtypes = [_FP, _FP, C.c_int32, _FP, _FP]
         L.refnerf_render_rays.argtypes = [C.POINTER(LevelCfg), C.c_int32] + [_FP] * 11 + [C.POINTER(LevelOut), _FP]
+        L.refnerf_losses_forward.argtypes = [C.c_int32, C.c_int32] + [_FP] * 9 + [_FP]
+        L.refnerf_losses_backward.argtypes = [C.c_int32, C.c_int32] + [_FP] * 5 + [C.c_int32] + [_FP] * 3 + [C.c_float] * 3 + [_FP] * 4 + [_FP]
         L.refnerf_get_timing.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.refnerf_get_timing_family.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         if L.refnerf_abi_version() != ABI_VERSION:
@@ -356,6 +358,31 @@ def render_rays(cfg: LevelCfg, density, tdist, directions, far, rgb=None, diffus
         setattr(out, "d_" + k, t.data_ptr())
     check(lib().refnerf_render_rays(C.byref(cfg), R, *args, C.byref(out), stream_ptr()))
     return res
+
+
+def losses_forward(r_rgb, gt_rgb, lossmult, weights, orientation_normals, normals, normals_pred, viewdirs):
+    """refnerf_losses_forward: per-ray terms [R,3] of the three Ref-NeRF losses of one level (device tensors; the
+    normals arguments may be None = term off)."""
+    require_device()
+    R, N = weights.shape
+    terms = torch.empty((R, 3), dtype=torch.float32, device=weights.device)
+    check(lib().refnerf_losses_forward(R, N, ptr(r_rgb), ptr(gt_rgb), ptr(lossmult), ptr(weights), ptr(orientation_normals),
+                                       ptr(normals), ptr(normals_pred), ptr(viewdirs), ptr(terms), stream_ptr()))
+    return terms
+
+
+def losses_backward(r_rgb, gt_rgb, lossmult, weights, orientation_normals, orientation_on_pred, normals, normals_pred,
+                    viewdirs, g_data, g_orientation, g_normal, upstream=None):
+    """refnerf_losses_backward -> (g_r_rgb [R,3], g_weights [R,N], g_normals_pred [R,N,3])."""
+    require_device()
+    R, N = weights.shape
+    f32 = dict(dtype=torch.float32, device=weights.device)
+    g_rgb, g_w, g_np = torch.empty((R, 3), **f32), torch.empty((R, N), **f32), torch.empty((R, N, 3), **f32)
+    check(lib().refnerf_losses_backward(R, N, ptr(r_rgb), ptr(gt_rgb), ptr(lossmult), ptr(weights), ptr(orientation_normals),
+                                        int(orientation_on_pred), ptr(normals), ptr(normals_pred), ptr(viewdirs),
+                                        float(g_data), float(g_orientation), float(g_normal), ptr(upstream),
+                                        ptr(g_rgb), ptr(g_w), ptr(g_np), stream_ptr()))
+    return g_rgb, g_w, g_np
 
 
 def sample_intervals(t, logits, n, smin=0.0, smax=1.0):

@@ -221,6 +221,8 @@ class Config:
     hip_precision: str = 'f32'
     hip_train_precision: str = 'f32'  # MLP chains of the training forward: 'f32' (parity) | 'bf16' (bf16 MFMA, activations rounded per layer)
     hip_bwd_precision: str = 'f32'  # transposed GEMM chains of the backward: 'f32' (parity) | 'bf16' (bf16 MFMA, gradients at bf16 accuracy)
+    hip_fused_losses: bool = False  # data (mse) + orientation + predicted-normal losses of a level as ONE fused kernel each way (train_utils.fused_refnerf_losses)
+    hip_flat_grads: bool = False  # route the backward's gradient to MLP.flat_parameter().grad (one tensor) instead of the 46 nn.Parameters
     hip_wgrad_mode: str = 'bf16x3'  # weight-gradient GEMM of the backward: 'bf16x3' (split-bf16 MFMA, fp32-level accuracy) | 'f32'
 
 

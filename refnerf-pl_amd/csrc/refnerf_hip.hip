@@ -316,6 +316,81 @@ __global__ __launch_bounds__(256) void render_rays_kernel(RenderArgs ra) {
   composite_phase<4, false, NPS_TRAIN>(A, TD, XP, PS, rpw * N, ray0, wave, lane, wscr, nullptr);
 }
 
+/* The three Ref-NeRF losses of one level as ONE pass over the level's outputs (train_utils.py:33-88 mse data term,
+ * :165-183 orientation, :186-204 predicted normals), one wave per ray:
+ *   terms[ray] = { sum_c lossmult (rgb_c - gt_c)^2,  sum_i w_i min(0, n_i . (-v))^2,  sum_i w_i (1 - n_i . npred_i) }
+ * with n = `normals_o` (the orientation target: normals_pred or the density normals) / `normals` (density normals,
+ * detached in the reference).  The host sums over the rays and applies multipliers and normalisers. */
+struct LossArgs {
+  int R, N;
+  const float *rgb, *gt, *lossmult, *weights, *normals_o, *normals, *normals_pred, *viewdirs;
+  float *terms;                 /* forward: [R,3] */
+  /* backward: upstream scalars (already multiplied by multiplier / normaliser) and the gradient tensors */
+  float g_data, g_orient, g_normal;
+  const float *upstream;        /* device float[3]: dL/d(data, orientation, normal term) multiplying g_*, or NULL (= 1) */
+  int orient_on_pred;           /* the orientation target IS normals_pred (its gradient then reaches g_npred) */
+  float *g_rgb, *g_weights, *g_npred;
+};
+__global__ __launch_bounds__(256) void refnerf_losses_fwd_kernel(LossArgs a) {
+  const int lane = threadIdx.x & 63, ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.R) return;
+  const float v0 = -a.viewdirs[ray * 3], v1 = -a.viewdirs[ray * 3 + 1], v2 = -a.viewdirs[ray * 3 + 2];
+  float s_o = 0.0f, s_n = 0.0f;
+  for (int i = lane; i < a.N; i += 64) {
+    const size_t e = (size_t)ray * a.N + i;
+    const float w = a.weights[e];
+    if (a.normals_o) {
+      const float ndv = (a.normals_o[3 * e] * v0 + a.normals_o[3 * e + 1] * v1) + a.normals_o[3 * e + 2] * v2;
+      const float m = fminf(ndv, 0.0f);
+      s_o += w * (m * m);
+    }
+    if (a.normals) {
+      const float d = (a.normals[3 * e] * a.normals_pred[3 * e] + a.normals[3 * e + 1] * a.normals_pred[3 * e + 1]) +
+                      a.normals[3 * e + 2] * a.normals_pred[3 * e + 2];
+      s_n += w * (1.0f - d);
+    }
+  }
+  s_o = wave_sum(s_o);
+  s_n = wave_sum(s_n);
+  if (lane == 0) {
+    float d = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float r = a.rgb[ray * 3 + c] - a.gt[ray * 3 + c]; d += a.lossmult[ray] * (r * r); }
+    a.terms[ray * 3] = d; a.terms[ray * 3 + 1] = s_o; a.terms[ray * 3 + 2] = s_n;
+  }
+}
+__global__ __launch_bounds__(256) void refnerf_losses_bwd_kernel(LossArgs a) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)a.R * a.N) return;
+  const int ray = (int)(e / a.N);
+  const float g_data = a.g_data * (a.upstream ? a.upstream[0] : 1.0f), g_orient = a.g_orient * (a.upstream ? a.upstream[1] : 1.0f),
+              g_normal = a.g_normal * (a.upstream ? a.upstream[2] : 1.0f);
+  const float v0 = -a.viewdirs[ray * 3], v1 = -a.viewdirs[ray * 3 + 1], v2 = -a.viewdirs[ray * 3 + 2];
+  const float w = a.weights[e];
+  float gw = 0.0f, gn[3] = {0.0f, 0.0f, 0.0f};
+  if (a.normals_o) {
+    const float ndv = (a.normals_o[3 * e] * v0 + a.normals_o[3 * e + 1] * v1) + a.normals_o[3 * e + 2] * v2;
+    const float m = fminf(ndv, 0.0f);
+    gw += g_orient * (m * m);
+    if (a.orient_on_pred) { const float k = g_orient * w * 2.0f * m; gn[0] += k * v0; gn[1] += k * v1; gn[2] += k * v2; }
+  }
+  if (a.normals) {
+    const float d = (a.normals[3 * e] * a.normals_pred[3 * e] + a.normals[3 * e + 1] * a.normals_pred[3 * e + 1]) +
+                    a.normals[3 * e + 2] * a.normals_pred[3 * e + 2];
+    gw += g_normal * (1.0f - d);
+    const float k = -g_normal * w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gn[c] += k * a.normals[3 * e + c];
+  }
+  a.g_weights[e] = gw;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a.g_npred[3 * e + c] = gn[c];
+  if (e < (size_t)a.R * 3) {      /* the first 3R threads also write the rendering gradient: d/d rgb of the mse term */
+    const int r = (int)(e / 3);
+    a.g_rgb[e] = g_data * a.lossmult[r] * 2.0f * (a.rgb[e] - a.gt[e]);
+  }
+}
+
 }  // namespace rn
 
 /* ================================================================== */
@@ -825,6 +900,42 @@ int refnerf_render_rays(const refnerf_level_cfg *cfg, int32_t R, const float *d_
   const size_t lds = sizeof(float) * ((size_t)a.rpw * (2 * (N + 1) + rn::NPS_TRAIN * N) + 4 * 22 * rn::WSUM_PITCH);
   LDS_ATTR_ONCE(lds_attr(rn::render_rays_kernel));
   hipLaunchKernelGGL(rn::render_rays_kernel, dim3((R + a.rpw - 1) / a.rpw), dim3(rn::NTHREADS), lds, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return REFNERF_OK;
+}
+
+int refnerf_losses_forward(int32_t R, int32_t N, const float *d_r_rgb, const float *d_gt_rgb, const float *d_lossmult,
+                           const float *d_weights, const float *d_orientation_normals, const float *d_normals,
+                           const float *d_normals_pred, const float *d_viewdirs, float *d_terms, void *stream) {
+  if (!d_r_rgb || !d_gt_rgb || !d_lossmult || !d_weights || !d_viewdirs || !d_terms || (d_normals && !d_normals_pred))
+    return fail(REFNERF_EINVAL, "refnerf_losses_forward: null pointer%s");
+  if (R <= 0 || N <= 0) return fail(REFNERF_EINVAL, "refnerf_losses_forward: R and N must be positive%s");
+  rn::LossArgs a{};
+  a.R = R; a.N = N; a.rgb = d_r_rgb; a.gt = d_gt_rgb; a.lossmult = d_lossmult; a.weights = d_weights;
+  a.normals_o = d_orientation_normals; a.normals = d_normals; a.normals_pred = d_normals_pred; a.viewdirs = d_viewdirs;
+  a.terms = d_terms;
+  hipLaunchKernelGGL(rn::refnerf_losses_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return REFNERF_OK;
+}
+
+int refnerf_losses_backward(int32_t R, int32_t N, const float *d_r_rgb, const float *d_gt_rgb, const float *d_lossmult,
+                            const float *d_weights, const float *d_orientation_normals, int32_t orientation_on_pred,
+                            const float *d_normals, const float *d_normals_pred, const float *d_viewdirs,
+                            float g_data, float g_orientation, float g_normal, const float *d_upstream,
+                            float *d_g_r_rgb, float *d_g_weights, float *d_g_normals_pred, void *stream) {
+  if (!d_r_rgb || !d_gt_rgb || !d_lossmult || !d_weights || !d_viewdirs || !d_g_r_rgb || !d_g_weights || !d_g_normals_pred ||
+      (d_normals && !d_normals_pred))
+    return fail(REFNERF_EINVAL, "refnerf_losses_backward: null pointer%s");
+  if (R <= 0 || N < 3) return fail(REFNERF_EINVAL, "refnerf_losses_backward: R must be positive and N >= 3%s");
+  rn::LossArgs a{};
+  a.R = R; a.N = N; a.rgb = d_r_rgb; a.gt = d_gt_rgb; a.lossmult = d_lossmult; a.weights = d_weights;
+  a.normals_o = d_orientation_normals; a.orient_on_pred = orientation_on_pred; a.normals = d_normals;
+  a.normals_pred = d_normals_pred; a.viewdirs = d_viewdirs;
+  a.g_data = g_data; a.g_orient = g_orientation; a.g_normal = g_normal; a.upstream = d_upstream;
+  a.g_rgb = d_g_r_rgb; a.g_weights = d_g_weights; a.g_npred = d_g_normals_pred;
+  const size_t n = (size_t)R * N;
+  hipLaunchKernelGGL(rn::refnerf_losses_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return REFNERF_OK;
 }

@@ -61,6 +61,23 @@ def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = Tru
     all-reduce of the flattened blob.  Parameters without a gradient contribute zeros."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    # Config.hip_flat_grads: the gradient already is one tensor per MLP (MLP.flat_parameter().grad): reduce it in place
+    flat_done = False
+    for m in module.modules():
+        blob = getattr(m, "_flat", None)
+        if blob is not None and blob.requires_grad and blob.grad is not None:
+            g = blob.grad
+            if _host_staged(g, group):
+                host = g.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                g.copy_(host)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                g /= dist.get_world_size(group)
+            flat_done = True
+    if flat_done:
+        return
     params = [p for p in module.parameters() if p.requires_grad]
     if not params:
         return

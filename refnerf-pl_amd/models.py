@@ -166,6 +166,16 @@ class MLP(nn.Module):
             self._packed_key = None
         return self._flat
 
+    def flat_parameter(self) -> torch.Tensor:
+        """The canonical blob as ONE differentiable leaf (Config.hip_flat_grads): Model.__call__ then routes the level
+        backward's gradient to `flat_parameter().grad` (one tensor, one accumulation per backward) instead of to the 46
+        nn.Parameters -- whose autograd accumulation is ~180 small kernels per step -- and an optimiser built on
+        `[mlp.flat_parameter()]` updates all of them in place (they are views of this blob)."""
+        flat = self.flat_params()
+        if not flat.requires_grad:
+            flat.requires_grad_(True)
+        return flat
+
     def load_flat_params(self, blob):
         """Copy a canonical blob (numpy / tensor) into the parameters."""
         flat = self.flat_params()
@@ -326,7 +336,9 @@ class _LevelFunction(torch.autograd.Function):
         res = _hip.level_forward(packed, cfg, rays, sdist_in, weights_in, history=True, save_activations=True)
         ctx.mlp, ctx.cfg, ctx.rays, ctx.packed = mlp, cfg, rays, packed
         ctx.packed_key = mlp._packed_key
+        ctx.set_materialize_grads(False)           # outputs without an upstream gradient arrive as None, not as zero tensors
         ctx.bwd_precision = holder.get("bwd_precision", _hip.PREC_F32)
+        ctx.flat_mode = bool(holder.get("flat_mode", False))
         ctx.saved = {k: res.pop(k) if k in ("activations", "activations_format") else res[k]
                      for k in ("sdist", "density", "rgb", "weights", "activations", "activations_format", "diffuse",
                                "specular", "tint", "roughness", "normals", "normals_pred")}
@@ -352,6 +364,7 @@ class _LevelFunction(torch.autograd.Function):
         if g_rgb is None:
             g_rgb = torch.zeros_like(ctx.saved["sdist"][:, :3])
         g_weights, g_npred, seeds = _fold_ray_seeds(ctx.cfg, ctx.saved, g, g.get("weights"), g.get("normals_pred"))
+        flat_mode = ctx.flat_mode
         cfg = ctx.cfg
         if ctx.bwd_precision != cfg.precision:
             cfg = type(cfg).from_buffer_copy(cfg)      # same level, bf16 chains in the backward kernel
@@ -359,6 +372,8 @@ class _LevelFunction(torch.autograd.Function):
         _hip.level_backward(ctx.packed, cfg, ctx.rays, ctx.saved, g_rgb, g_weights, g_npred, grads,
                             g_r_acc=g.get("r_acc"), g_r_distance=g.get("r_distance"), sample_seeds=seeds)
         ctx.saved = None                           # release the 17.6 KB/sample activation buffer
+        if flat_mode:                              # Config.hip_flat_grads: the blob itself is the differentiable input
+            return (None, None, None, None, None, None, grads)
         out = []
         for spec in layout.PARAM_SPECS:            # same order as MLP.ordered_parameters()
             n = spec.out_dim * spec.in_dim
@@ -527,9 +542,10 @@ class Model(nn.Module):
                 bwd_prec = getattr(self.config, "hip_bwd_precision", "f32")
                 if bwd_prec not in _PREC:
                     raise ValueError("Config.hip_bwd_precision must be 'f32' or 'bf16'")
-                holder = {"bwd_precision": _PREC[bwd_prec]}
-                outs = _LevelFunction.apply(mlp, cfg, r, holder, sdist.detach(), weights.detach(),
-                                            *mlp.ordered_parameters())
+                flat_mode = bool(getattr(self.config, "hip_flat_grads", False))
+                holder = {"bwd_precision": _PREC[bwd_prec], "flat_mode": flat_mode}
+                diff_inputs = (mlp.flat_parameter(),) if flat_mode else tuple(mlp.ordered_parameters())
+                outs = _LevelFunction.apply(mlp, cfg, r, holder, sdist.detach(), weights.detach(), *diff_inputs)
                 res = dict(zip(holder["keys"], outs))
             else:
                 lean = _LEAN.depth > 0 and not self.training
@@ -567,7 +583,7 @@ class Model(nn.Module):
                            "grad_pred": hist("grad_pred", N, 3), "tint": hist("tint", N, 3),
                            "diffuse": hist("diffuse", N, 3), "specular": hist("specular", N, 3),
                            "roughness": hist("roughness", N, 1),
-                           "sdist": rs(sdist, N + 1).clone(), "weights": rs(weights, N).clone()}
+                           "sdist": rs(sdist, N + 1), "weights": rs(weights, N)}      # (read-only for the next level: no copies)
             ray_history.append(ray_results)
 
         if compute_extras:                                                       # models.py:308-319

@@ -92,6 +92,94 @@ def predicted_normal_loss(model, ray_history, config):
     return total_loss
 
 
+class _FusedRefNerfLosses(torch.autograd.Function):
+    """data (mse) + orientation + predicted-normal loss of ONE level as a single autograd node on the fused kernels
+    refnerf_losses_forward / refnerf_losses_backward (Config.hip_fused_losses): what compute_data_loss,
+    orientation_loss and predicted_normal_loss compute with ~25 elementwise ATen ops per level, in one pass each way."""
+
+    @staticmethod
+    def forward(ctx, rgb, weights, normals_pred, aux):
+        from . import _hip
+        rgb_c, w_c, np_c = rgb.detach().contiguous(), weights.detach().contiguous(), normals_pred.detach().contiguous()
+        terms = _hip.losses_forward(rgb_c, aux["gt"], aux["lossmult"], w_c, aux["orient_n"], aux["normals"], np_c, aux["viewdirs"])
+        sums = terms.sum(dim=0)
+        ctx.set_materialize_grads(False)
+        ctx.aux, ctx.t = aux, (rgb_c, w_c, np_c)
+        per_term = sums * aux["scales"]
+        ctx.mark_non_differentiable(sums)
+        return per_term.sum(), per_term, sums
+
+    @staticmethod
+    def backward(ctx, g_total, g_terms, _g_sums):
+        from . import _hip
+        aux = ctx.aux
+        rgb_c, w_c, np_c = ctx.t
+        # upstream gradient of the three terms, on the device (no host sync): the total's plus each term's own
+        if g_total is None and g_terms is None:
+            return None, None, None, None
+        if g_terms is None:
+            up3 = g_total.to(torch.float32).expand(3)
+        elif g_total is None:
+            up3 = g_terms.to(torch.float32)
+        else:
+            up3 = g_terms.to(torch.float32) + g_total.to(torch.float32)
+        g_rgb, g_w, g_np = _hip.losses_backward(rgb_c, aux["gt"], aux["lossmult"], w_c, aux["orient_n"], aux["orient_on_pred"],
+                                                aux["normals"], np_c, aux["viewdirs"], 1.0, 1.0, 1.0,
+                                                upstream=(up3 * aux["scales"]).contiguous())
+        return g_rgb, g_w, g_np, None
+
+
+def fused_losses_supported(config):
+    """The fused path covers the loss set of the shipped refnerf configs: mse data term on the rendered rgb, orientation
+    and predicted-normal regularisers."""
+    return (config.data_loss_type == 'mse' and not config.supervised_by_linear_rgb and not config.compute_disp_metrics)
+
+
+def fused_refnerf_losses(model, batch, rays, renderings, ray_history, config):
+    """compute_data_loss + orientation_loss + predicted_normal_loss (train_utils.py:33-88,165-204) through the fused
+    kernels: returns (data_loss, stats, orientation_loss, predicted_normal_loss) with the same values (fp32 summation
+    order aside) and the same gradients into renderings['rgb'], ray_history['weights'], ray_history['normals_pred']."""
+    dev = renderings[0]['rgb'].device
+    f32 = dict(dtype=torch.float32, device=dev)
+    gt = torch.as_tensor(batch.rgb, **f32)[..., :3].reshape(-1, 3).contiguous()
+    lossmult = torch.as_tensor(rays.lossmult, **f32).reshape(-1).contiguous()
+    if config.disable_multiscale_loss:
+        lossmult = torch.ones_like(lossmult)
+    denom = 3.0 * lossmult.sum()                      # sum of the lossmult broadcast to [R, 3]
+    viewdirs = torch.as_tensor(rays.viewdirs, **f32).reshape(-1, 3).contiguous()
+    R = gt.shape[0]
+    inv_denom = 1.0 / denom                           # stays on the device: no host synchronisation in the step
+    want_o = _any_positive(config, 'orientation_coarse_loss_mult', 'orientation_loss_mult')
+    want_n = _any_positive(config, 'predicted_normal_coarse_loss_mult', 'predicted_normal_loss_mult')
+    data, orient, normal, mses = [], [], [], []
+    for i, (rendering, hist) in enumerate(zip(renderings, ray_history)):
+        N = hist['weights'].shape[-1]
+        fine = i == model.num_levels - 1
+        orient_n = None
+        if want_o:
+            orient_n = hist[config.orientation_loss_target]
+            if orient_n is None:
+                raise ValueError('Normals cannot be None if orientation loss is on.')
+            orient_n = orient_n.detach().reshape(R, N, 3).contiguous()
+        normals = None
+        if want_n:
+            if hist['normals'] is None or hist['normals_pred'] is None:
+                raise ValueError('Predicted normals and gradient normals cannot be None if predicted normal loss is on.')
+            normals = hist['normals'].detach().reshape(R, N, 3).contiguous()
+        scales = torch.stack([(config.data_loss_mult if fine else config.data_coarse_loss_mult) * inv_denom,
+                              torch.full_like(inv_denom, (config.orientation_loss_mult if fine else config.orientation_coarse_loss_mult) / R),
+                              torch.full_like(inv_denom, (config.predicted_normal_loss_mult if fine else config.predicted_normal_coarse_loss_mult) / R)])
+        aux = dict(gt=gt, lossmult=lossmult, viewdirs=viewdirs, orient_n=orient_n, normals=normals, scales=scales,
+                   orient_on_pred=config.orientation_loss_target == 'normals_pred')
+        _, per_term, sums = _FusedRefNerfLosses.apply(rendering['rgb'].reshape(R, 3), hist['weights'].reshape(R, N),
+                                                      hist['normals_pred'].reshape(R, N, 3), aux)
+        data.append(per_term[0]); orient.append(per_term[1]); normal.append(per_term[2])
+        mses.append(sums[0] * inv_denom)
+    stats = {'mses': torch.stack([m.detach() for m in mses])}
+    return (torch.stack(data).sum(), stats, torch.stack(orient).sum() if want_o else None,
+            torch.stack(normal).sum() if want_n else None)
+
+
 def interlevel_loss(ray_history, config):
     """Interlevel (proposal) loss of mip-NeRF 360 (train_utils.py:150-162): the proposal levels' weights must
     envelope the final level's; the final level is detached, so only the proposal MLP is trained by it."""
@@ -270,14 +358,18 @@ def compute_losses(model, batch, rays, renderings, ray_history, config, renderin
     """The loss assembly of NeRFSystem.training_step (nerf_system.py:118-180) on already computed
     renderings: returns (total, dict of terms, stats)."""
     losses = {}
-    data_loss, stats = compute_data_loss(batch, renderings, rays, config)
+    fused = getattr(config, 'hip_fused_losses', False) and fused_losses_supported(config) and renderings[0]['rgb'].is_cuda
+    if fused:      # opt-in: the three Ref-NeRF terms of every level through refnerf_losses_forward / _backward
+        data_loss, stats, o_loss, n_loss = fused_refnerf_losses(model, batch, rays, renderings, ray_history, config)
+    else:
+        data_loss, stats = compute_data_loss(batch, renderings, rays, config)
     losses['data'] = data_loss
     if config.interlevel_loss_mult > 0:
         losses['interlevel'] = interlevel_loss(ray_history, config)
     if _any_positive(config, 'orientation_coarse_loss_mult', 'orientation_loss_mult'):
-        losses['orientation'] = orientation_loss(rays, model, ray_history, config)
+        losses['orientation'] = o_loss if fused else orientation_loss(rays, model, ray_history, config)
     if _any_positive(config, 'predicted_normal_coarse_loss_mult', 'predicted_normal_loss_mult'):
-        losses['predicted_normals'] = predicted_normal_loss(model, ray_history, config)
+        losses['predicted_normals'] = n_loss if fused else predicted_normal_loss(model, ray_history, config)
     if config.patch_size > 1 and _any_positive(config, 'depth_smoothness_coarse_loss_mult', 'depth_smoothness_loss_mult'):
         losses['smoothness'] = compute_depth_smoothness_loss(renderings, config)
     if wants_noisy_pass(config):

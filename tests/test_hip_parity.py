@@ -631,6 +631,95 @@ def test_model_training_step_autograd(hip):
     assert h3[0]["normals"] is None
 
 
+@pytest.mark.parametrize("name,extra", [("model_blender_sharp_train", []),
+                                        ("model_llff_linear_train", ["Config.orientation_loss_target = 'normals'"]),
+                                        ("model_trained_train", ["Config.predicted_normal_loss_mult = 0.", "Config.predicted_normal_coarse_loss_mult = 0."])])
+def test_fused_refnerf_losses_match_train_utils(hip, name, extra):
+    """Config.hip_fused_losses: data + orientation + predicted-normal losses of a level through refnerf_losses_forward /
+    _backward (one pass each way) against the train_utils path (ATen ops + autograd) on the same forward: loss terms to
+    1e-6, parameter gradients to fp32 round-off, and the reference's golden loss values.  Also with the orientation
+    target on the (detached) density normals and with a term switched off."""
+    import os
+    from refnerf_pl_amd import configs, layout, models, train_utils, utils
+    g = load_golden(name)
+    bindings = [str(b) for b in g["bindings"] if str(b)] + list(extra)
+    res = {}
+    for fused in (False, True):
+        configs.clear_config()
+        configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                                bindings + [f"Config.hip_fused_losses = {fused}"])
+        cfg = configs.Config()
+        model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
+        model.nerf_mlp.load_flat_params(params_from_golden(g))
+        rays = utils.rays_from_dict(rays_from_golden(g), DEV)
+        batch = utils.Batch(rays=rays, rgb=np.asarray(g["gt_rgb"], np.float32))
+        renderings, history = model(rays, 1.0, False)
+        total, terms, stats = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+        total.backward()
+        flat = torch.zeros(layout.NUM_PARAMS)
+        for spec, lin in model.nerf_mlp._named_linears():
+            flat[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = lin.weight.grad.reshape(-1).cpu()
+            flat[spec.b_off:spec.b_off + spec.out_dim] = lin.bias.grad.cpu()
+        res[fused] = (float(total.detach()), {k: float(v.detach()) for k, v in terms.items()}, stats["mses"].cpu().numpy(), flat.numpy())
+    (t0, terms0, mses0, g0), (t1, terms1, mses1, g1) = res[False], res[True]
+    assert set(terms0) == set(terms1)
+    assert t1 == pytest.approx(t0, rel=2e-6)
+    for k in terms0:
+        assert terms1[k] == pytest.approx(terms0[k], rel=2e-6, abs=1e-12), k
+    np.testing.assert_allclose(mses1, mses0, rtol=2e-6)
+    rel = np.linalg.norm(g1 - g0) / np.linalg.norm(g0)
+    print(f"{name}: fused vs unfused losses: total {t1:.8f} / {t0:.8f}, gradient rel-L2 {rel:.2e}")
+    assert rel < 2e-6, rel
+    if not extra:
+        assert terms1["data"] == pytest.approx(float(g["loss_data"]), rel=1e-5)
+        assert terms1["orientation"] == pytest.approx(float(g["loss_orientation"]), rel=2e-4)
+        assert terms1["predicted_normals"] == pytest.approx(float(g["loss_normal"]), rel=2e-4)
+
+
+def test_flat_gradient_mode(hip):
+    """Config.hip_flat_grads: the level backward's gradient goes to MLP.flat_parameter().grad (ONE tensor) instead of the
+    46 nn.Parameters: bit-identical values, and an Adam step on the flat parameter moves the 46 parameters (views of
+    the blob) exactly as an Adam step on the parameters themselves does."""
+    import os
+    from refnerf_pl_amd import configs, layout, models, train_utils, utils
+    g = load_golden("model_blender_sharp_train")
+    out = {}
+    for flat_mode in (False, True):
+        configs.clear_config()
+        configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                                [f"Config.hip_flat_grads = {flat_mode}"])
+        cfg = configs.Config()
+        model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
+        model.nerf_mlp.load_flat_params(params_from_golden(g))
+        rays = utils.rays_from_dict(rays_from_golden(g), DEV)
+        batch = utils.Batch(rays=rays, rgb=np.asarray(g["gt_rgb"], np.float32))
+        params = [model.nerf_mlp.flat_parameter()] if flat_mode else list(model.parameters())
+        opt = torch.optim.Adam(params, lr=1e-3)
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            renderings, history = model(rays, 1.0, False)
+            total, _, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+            total.backward()
+            if flat_mode:
+                grad = model.nerf_mlp.flat_parameter().grad.detach().cpu().numpy().copy()
+                assert all(p.grad is None for p in model.parameters())
+            else:
+                grad = np.zeros(layout.NUM_PARAMS, np.float32)
+                for spec, lin in model.nerf_mlp._named_linears():
+                    grad[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = lin.weight.grad.reshape(-1).cpu().numpy()
+                    grad[spec.b_off:spec.b_off + spec.out_dim] = lin.bias.grad.cpu().numpy()
+            opt.step()
+        # after two steps: blob, state_dict view of it, last gradient, last loss
+        sd = model.state_dict()
+        out[flat_mode] = (model.nerf_mlp.flat_params().detach().cpu().numpy().copy(), sd["nerf_mlp.rgb.weight"].cpu().numpy().copy(),
+                          grad, float(total.detach()))
+    assert np.array_equal(out[True][2], out[False][2]), "flat-mode gradient must be bit-identical"
+    assert out[True][3] == out[False][3]
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=0, atol=1e-7)      # Adam: foreach over 92 tensors vs one tensor
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=0, atol=1e-7)
+    assert np.abs(out[True][0] - params_from_golden(g)).max() > 1e-4                 # the steps did move the weights
+
+
 def test_edge_shapes_and_errors(hip, O):
     """Ragged / edge sizes: R not a multiple of the workgroup tile, N in {2, 33,
     64, 192, 256}, a single ray; and the reference's error cases."""
