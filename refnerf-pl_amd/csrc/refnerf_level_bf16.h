@@ -206,6 +206,23 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], cons
   p.fil_off = t;
 }
 
+/* A wave whose 32 samples of this pass are all past the end (the partly filled last pass of a workgroup: N = 192 puts 384
+ * samples into 2 x 256) takes no part in the MLP, but keeps the weight stream going: it joins every rendezvous of the pass
+ * and issues its DMA pieces.  The matrix pipe of its SIMD then belongs to the one active wave -- a half-filled pass costs
+ * about two thirds of a full one instead of all of it. */
+__device__ __forceinline__ void idle_pass(Pipe &p) {
+#pragma unroll 1
+  for (int c = 0; c < BFPACKED.chunks_per_pass; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue_chunk(p, p.fil_off);
+    const int t = p.cur_off;
+    p.cur_off = p.nxt_off;
+    p.nxt_off = p.fil_off;
+    p.fil_off = t;
+  }
+}
+
 /* One slice (32 output rows): first chunk of kind KIND0 plus, for the skip
  * layers, a run-time selected second chunk (1: IPE from LDS, 2: bottleneck +
  * dir encodings). */
@@ -303,6 +320,11 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
     const int ray = ray0 + rl;
     const bool valid = (g < n_tot) && (ray < A.R);
     const int rayc = valid ? ray : (A.R - 1);
+    {
+      /* validity is monotone in the sample index: the wave is idle iff its first sample is past the end */
+      const int g0 = pass0 + wave * 32;
+      if (g0 >= n_tot || ray0 + g0 / N >= A.R) { idle_pass(p); continue; }
+    }
     /* head scalars of this sample live in LDS (HD); P4 and P6 both rebuild the
      * activations from them instead of keeping ~20 VGPRs alive across the dir MLP */
     auto load_heads = [&](SampleHeads &sh) {
