@@ -4,7 +4,8 @@ per-round summaries committed under profiles/<round>/:
   kernel_stats.csv        -- rocprofv3 --kernel-trace --stats table of the rn:: kernels
   pmc_<kernel>.csv        -- per-dispatch mean/min/max of every counter collected (separate --pmc passes)
 and refresh profiles/traffic.json (HBM-side bytes per launch, gfx950 FETCH_SIZE x2 correction).
-usage: summarize_prof.py gpurun_out/prof_r01b profiles/r01"""
+usage: summarize_prof.py gpurun_out/prof_r02 profiles/r02 [C2|C3|...]   (the bench.py --config the passes ran with;
+entries of configurations other than C2 are keyed "kernel@config" in traffic.json and their files get a _<config> suffix)"""
 import csv
 import glob
 import json
@@ -13,16 +14,22 @@ import sys
 from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
+cfg = sys.argv[3] if len(sys.argv) > 3 else "C2"
+sfx = "" if cfg == "C2" else "_" + cfg
+WORKLOAD = {"C2": "4096 rays x 128 samples, one level per launch", "C3": "8192 rays x 192 samples (shiny network), one level per launch",
+            "C4": "4096 LLFF rays x 128 samples, one level per launch", "C5": "16384 (+512 noisy) LLFF rays x 256 samples, one level per launch"}[cfg]
+bench_args = "" if cfg == "C2" else f" --config {cfg}"
 os.makedirs(dst, exist_ok=True)
 KERNELS = {"level_fwd_bf16": "rn::level_fwd_bf16", "level_fwd_f32": "rn::level_fwd_f32",
            "level_fwd_train_f32": "rn::level_fwd_train_f32", "level_bwd_f32": "rn::level_bwd_f32",
            "wgrad_kernel": "rn::wgrad_kernel", "wgrad_bf16x3_kernel": "rn::wgrad_bf16x3_kernel", "level_bwd_bf16c": "rn::level_bwd_bf16c",
-           "level_fwd_train_bf16c": "rn::level_fwd_train_bf16c"}
+           "level_fwd_train_bf16c": "rn::level_fwd_train_bf16c", "level_fwd_f16": "rn::level_fwd_f16",
+           "bwd_seed_kernel": "rn::bwd_seed_kernel", "wgrad_reduce": "rn::wgrad_reduce"}
 
 rows = list(csv.reader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
-with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as f:
+with open(os.path.join(dst, f"kernel_stats{sfx}.csv"), "w", newline="") as f:
     w = csv.writer(f)
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-image\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-image{bench_args}\n")
     w.writerow(rows[0])
     for r in rows[1:]:
         if r and (r[0].startswith("rn::") or r[0].startswith("void rn::")):
@@ -38,9 +45,9 @@ for path in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
                 stats[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta[short] = (r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"])
 for short, counters in stats.items():
-    with open(os.path.join(dst, f"pmc_{short}.csv"), "w") as f:
+    with open(os.path.join(dst, f"pmc_{short}{sfx}.csv"), "w") as f:
         g = meta[short]
-        f.write(f"# rocprofv3 --pmc passes (separate runs) of: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-image\n")
+        f.write(f"# rocprofv3 --pmc passes (separate runs) of: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-image{bench_args}\n")
         f.write(f"# kernel {KERNELS[short]}, grid {g[0]}, wg {g[1]}, VGPR {g[2]}, AGPR {g[3]}, SGPR {g[4]}, scratch {g[5]}\n")
         f.write("counter,dispatches,mean_per_dispatch,min,max\n")
         for c in sorted(counters):
@@ -53,10 +60,11 @@ for short, counters in stats.items():
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
         fs = sum(counters["FETCH_SIZE"]) / len(counters["FETCH_SIZE"])
         ws = sum(counters["WRITE_SIZE"]) / len(counters["WRITE_SIZE"])
-        e = traffic.get(KERNELS[short], {})
-        e.update({"round": os.path.basename(dst.rstrip("/")), "workload": "4096 rays x 128 samples, one level per launch",
+        key = KERNELS[short] if cfg == "C2" else f"{KERNELS[short]}@{cfg}"
+        e = traffic.get(key, {})
+        e.update({"round": os.path.basename(dst.rstrip("/")), "workload": WORKLOAD,
                   "FETCH_SIZE_KB": round(fs, 1), "WRITE_SIZE_KB": round(ws, 1),
                   "bytes_per_launch": int((2 * fs + ws) * 1024)})
-        traffic[KERNELS[short]] = e
+        traffic[key] = e
 json.dump(traffic, open(tj, "w"), indent=2)
 print("wrote", sorted(os.listdir(dst)))
