@@ -193,17 +193,24 @@ class MLP(nn.Module):
     def _param_version(self):
         return tuple(p._version for p in self.parameters())
 
-    def packed_weights(self, precision: int) -> torch.Tensor:
-        """MFMA operand image of the current parameters for a precision mode
-        (one cached buffer per mode, re-packed in place when the parameters changed)."""
+    def packed_weights(self, precision: int, force: bool = False) -> torch.Tensor:
+        """MFMA operand image of the current parameters for a precision mode (one cached buffer per mode, re-packed in
+        place when the parameters changed).  Change detection = the tensors' version counters, plus: `force` (a training
+        forward: an optimiser step follows it, and fused optimisers do not bump version counters), after which the
+        first inference use of EVERY mode re-packs as well."""
         flat = self.flat_params()
         key = (precision, flat.data_ptr(), self._param_version(), flat._version)
         if self._packed is None:
             self._packed = {}
-        buf, have = self._packed.get(precision, (None, None))
-        if have != key or self._packed_key is None:
+        if force:
+            self._train_gen = getattr(self, "_train_gen", 0) + 1
+        gen = getattr(self, "_train_gen", 0)
+        buf, have, have_gen = self._packed.get(precision, (None, None, -1))
+        if force or have != key or have_gen != gen or self._packed_key is None:
             buf = _hip.pack_weights(flat, buf, precision)
-            self._packed[precision] = (buf, key)
+            # an image packed by a training forward is stale after the optimiser step: gen - 1 makes the next
+            # inference call of this mode re-pack once more
+            self._packed[precision] = (buf, key, gen - 1 if force else gen)
         self._packed_key = key
         return buf
 
@@ -332,7 +339,10 @@ class _LevelFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mlp, cfg, rays, holder, sdist_in, weights_in, *params):
-        packed = mlp.packed_weights(_hip.PREC_F32)       # training kernels read the f32 image (it carries the bf16 chain ops)
+        # training kernels read the f32 image (it carries the bf16 chain ops); a training forward re-packs
+        # unconditionally -- an optimiser step always changes the weights, but not every optimiser bumps the tensors'
+        # version counters (fused Adam does not), and the pack is 16 us
+        packed = mlp.packed_weights(_hip.PREC_F32, force=True)
         res = _hip.level_forward(packed, cfg, rays, sdist_in, weights_in, history=True, save_activations=True)
         ctx.mlp, ctx.cfg, ctx.rays, ctx.packed = mlp, cfg, rays, packed
         ctx.packed_key = mlp._packed_key

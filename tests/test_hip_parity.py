@@ -718,6 +718,30 @@ def test_flat_gradient_mode(hip):
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=0, atol=1e-7)      # Adam: foreach over 92 tensors vs one tensor
     np.testing.assert_allclose(out[True][1], out[False][1], rtol=0, atol=1e-7)
     assert np.abs(out[True][0] - params_from_golden(g)).max() > 1e-4                 # the steps did move the weights
+    # regression: a FUSED optimiser does not bump the tensors' version counters -- the kernels must still see its update
+    # (training forwards re-pack unconditionally; so does the first inference call after them)
+    opt = torch.optim.Adam([model.nerf_mlp.flat_parameter()], lr=1e-3, fused=True)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        renderings, history = model(rays, 1.0, False)
+        total, _, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+        total.backward()
+        opt.step()
+        losses.append(float(total.detach()))
+    assert len(set(losses)) == 3, losses
+    model.eval()
+    with torch.no_grad():
+        e1 = model(rays, 1.0, False)[0][-1]["rgb"].clone()
+    model.train()
+    opt.zero_grad(set_to_none=True)
+    renderings, history = model(rays, 1.0, False)
+    train_utils.compute_losses(model, batch, rays, renderings, history, cfg)[0].backward()
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        e2 = model(rays, 1.0, False)[0][-1]["rgb"]
+    assert (e1 - e2).abs().max() > 0
 
 
 def test_edge_shapes_and_errors(hip, O):
