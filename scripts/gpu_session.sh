@@ -14,4 +14,4 @@ python bench.py --config C5 --steps 4 --warmup 1 > $OUT/bench_C5.json 2> $OUT/be
 bash scripts/smoke_two_ranks.sh --config C4; cp gpurun_out/n2.log $OUT/n2_C4.log
 bash scripts/smoke_two_ranks.sh --config C5 --rays 1024 --steps 3; cp gpurun_out/n2.log $OUT/n2_C5.log
 for f in $OUT/bench_*.json; do echo "== $f"; cut -c1-600 $f; done
-tail -3 $OUT/bench_*.err
+for f in $OUT/bench_*.err; do tail -n 2 $f; done

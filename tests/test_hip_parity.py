@@ -744,6 +744,35 @@ def test_flat_gradient_mode(hip):
     assert (e1 - e2).abs().max() > 0
 
 
+def test_train_ray_batcher_on_device(hip):
+    """datasets.TrainRayBatcher.next(): the rays of a random batch are what camera_utils.cast_ray_batch gives for the
+    drawn pixels (itself pinned by tests/golden/camera.npz), colours gathered on the device, and the batch feeds
+    Model.__call__ directly."""
+    from refnerf_pl_amd import camera_utils, datasets, synthetic, utils
+    rng = np.random.default_rng(0)
+    n, H, W = 3, 40, 60
+    imgs = rng.random((n, H, W, 3)).astype(np.float32)
+    p2c = np.tile(camera_utils.get_pixtocam(80.0, W, H)[None], (n, 1, 1))
+    c2w = np.stack([np.concatenate([synthetic._rot(i), (synthetic._rot(i) @ np.array([0., 0., 4.]))[:, None]], 1) for i in range(n)]).astype(np.float32)
+    b = datasets.TrainRayBatcher(imgs, (p2c, c2w, None, None), 2., 6., 256, device=DEV, seed=5)
+    batch = b.next()
+    r = batch.rays
+    assert r.origins.shape == (256, 1, 1, 3) and r.origins.is_cuda and batch.rgb.is_cuda
+    cam = r.cam_idx[..., 0].long().cpu().numpy()
+    # recover the pixels from the image plane and compare with a host-side cast of the same pixels
+    pix = utils.Pixels(pix_x_int=None, pix_y_int=None, lossmult=r.lossmult, near=r.near, far=r.far, cam_idx=r.cam_idx)
+    ip = r.imageplane.cpu().numpy()
+    px = np.rint(ip[..., 0] * 80.0 + W / 2 - 0.5).astype(np.int32)
+    py = np.rint(-ip[..., 1] * 80.0 + H / 2 - 0.5).astype(np.int32)
+    np.testing.assert_allclose(batch.rgb.cpu().numpy(), imgs[cam, py, px])
+    for i in range(0, 256, 37):
+        c = int(cam[i, 0, 0])
+        o, d, v, rad, _ = synthetic._pixels_to_rays(px[i].reshape(-1), py[i].reshape(-1), 80.0, W, H, c2w[c].astype(np.float64))
+        np.testing.assert_allclose(r.origins[i].reshape(-1, 3).cpu().numpy(), o, atol=1e-6)
+        np.testing.assert_allclose(r.directions[i].reshape(-1, 3).cpu().numpy(), d, atol=2e-6)
+        np.testing.assert_allclose(r.radii[i].reshape(-1).cpu().numpy(), rad.reshape(-1), rtol=1e-4)
+
+
 def test_edge_shapes_and_errors(hip, O):
     """Ragged / edge sizes: R not a multiple of the workgroup tile, N in {2, 33,
     64, 192, 256}, a single ray; and the reference's error cases."""

@@ -230,3 +230,35 @@ def test_reference_checkpoint_round_trip(tmp_path):
         assert torch.equal(v, sd[k]), k
     with pytest.raises(RuntimeError):
         utils.load_reference_checkpoint(model, {"state_dict": {"model.nerf_mlp.nope.weight": torch.zeros(1)}})
+
+
+def test_train_ray_batcher_sampling_logic():
+    """datasets.TrainRayBatcher (mirror of Dataset._next_train / _make_ray_batch, datasets.py:395-485) on CPU tensors,
+    without casting rays: patch structure, pixel ranges, colour gather, per-rank streams, single-image batching."""
+    from refnerf_pl_amd import camera_utils, datasets
+    rng = np.random.default_rng(0)
+    imgs = rng.random((4, 20, 30, 3)).astype(np.float32)
+    p2c = np.tile(camera_utils.get_pixtocam(40.0, 30, 20)[None], (4, 1, 1))
+    c2w = np.tile(np.eye(4, dtype=np.float32)[:3][None], (4, 1, 1))
+
+    def make(**kw):
+        return datasets.TrainRayBatcher(imgs, (p2c, c2w, None, None), 2., 6., 64, device="cpu", **kw)
+    b = make(patch_size=2, seed=1)
+    batch = b.next(cast_rays=False)
+    px, py, cam = batch.rays.pix_x_int, batch.rays.pix_y_int, batch.rays.cam_idx[..., 0]
+    assert px.shape == (16, 2, 2) and batch.rgb.shape == (16, 2, 2, 3)
+    assert int(px.min()) >= 0 and int(px.max()) <= 29 and int(py.min()) >= 0 and int(py.max()) <= 19
+    assert (px[:, :, 1] - px[:, :, 0] == 1).all() and (py[:, 1, :] - py[:, 0, :] == 1).all()      # patches are contiguous pixels
+    assert (cam[:, 0, 0][:, None, None] == cam).all() and len(cam.unique()) > 1                      # one camera per patch
+    assert np.array_equal(batch.rgb.numpy(), imgs[cam.numpy(), py.numpy(), px.numpy()])
+    assert float(batch.rays.near.min()) == 2. and float(batch.rays.far.max()) == 6. and float(batch.rays.lossmult.min()) == 1.
+    # same seed -> same stream; another rank -> another stream (the reference's ranks share one numpy stream: quirk B17)
+    assert torch.equal(make(patch_size=2, seed=1).next(cast_rays=False).rays.pix_x_int, px)
+    assert not torch.equal(make(patch_size=2, seed=1, rank=1).next(cast_rays=False).rays.pix_x_int, px)
+    # single_image batching: one camera for the whole batch; debug mode: raster order from pixel (0, 0) of camera 0
+    s = make(batching="single_image", seed=3).next(cast_rays=False)
+    assert len(s.rays.cam_idx.unique()) == 1 and s.rays.pix_x_int.shape == (64, 1, 1)
+    d = make(debug_mode=True).next(cast_rays=False)
+    assert d.rays.pix_x_int.reshape(-1)[:3].tolist() == [0, 1, 2] and int(d.rays.cam_idx.max()) == 0
+    with pytest.raises(ValueError):
+        make(batching="per_pixel")
