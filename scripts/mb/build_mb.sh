@@ -29,3 +29,16 @@ build d1_bar2_epi60    mb_mlp.hip -DPRIO -DBAR2 -DEPI=60 -DLDSPAD=80000 &
 build d2_bar2_nodma    mb_mlp.hip -DPRIO -DBAR2 -DNODMA -DLDSPAD=80000 &
 wait
 ls bin
+# round 2: two independent 4-wave workgroups per CU (bin4/)
+mkdir -p bin4
+b4() { n=$1; shift; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVARIANT="\"$n\"" "$@" -o bin4/$n || exit 1; }
+b4 g0_a0_8w mb_mlp.hip -DPRIO -DRANDIMG -DLDSPAD=90000 &
+b4 g0_b7_half mb_half.hip -DPRIO -DDMAHI -DRANDIMG &
+b4 g1_ring3 mb_wg4.hip -DRING3 -DRANDIMG -DLDSPAD=28000 &
+b4 g2_ring2 mb_wg4.hip -DRANDIMG -DLDSPAD=45000 &
+wait
+b4 g4_ring2_epi60 mb_wg4.hip -DRANDIMG -DEPI=60 -DLDSPAD=45000 &
+b4 g5_a3_epi60_8w mb_mlp.hip -DPRIO -DRANDIMG -DEPI=60 -DLDSPAD=90000 &
+b4 g6_ring2_nodma_nobar mb_wg4.hip -DRANDIMG -DNODMA -DNOBAR -DLDSPAD=45000 &
+b4 g8_ring3_epi60 mb_wg4.hip -DRING3 -DRANDIMG -DEPI=60 -DLDSPAD=28000 &
+wait
