@@ -552,9 +552,9 @@ BwdPlan bwd_plan(int R, int N) {
   p.slices = (int)(sl < 1 ? 1 : (sl > 32 ? 32 : sl));
   long long per = (p.S + p.slices - 1) / p.slices;
   p.k_per_slice = (int)((per + rn::WG_KT - 1) / rn::WG_KT * rn::WG_KT);
-  p.act_bytes = sizeof(float) * (size_t)rn::ACT_ROWS_TOTAL * p.pitch;
+  p.act_bytes = sizeof(float) * (size_t)rn::ACT_ALLOC_ROWS * p.pitch;
   p.delta_off = 0;
-  p.part_off = p.delta_off + sizeof(float) * (size_t)rn::DEL_ROWS * p.pitch;
+  p.part_off = p.delta_off + sizeof(float) * (size_t)rn::DEL_ALLOC_ROWS * p.pitch;
   p.seed_off = p.part_off + sizeof(float) * (size_t)p.slices * rn::NUM_PARAMS;
   p.total = p.seed_off + sizeof(float) * (size_t)rn::NGS * p.pitch;
   return p;
@@ -825,13 +825,11 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     }
   }
   if (plan.pitch > plan.S) {   /* pad columns of both operand matrices must read as zero in the wgrad GEMM */
-    if (act16) hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(a.act), rn::ACT_ROWS / 2, plan.pitch, plan.S);   /* pair-rows of dwords */
-    else hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(a.act), rn::ACT_ROWS, plan.pitch, plan.S);
-    if (del16) hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, rn::DEL_ROWS / 2, plan.pitch, plan.S);
-    else hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, rn::DEL_ROWS, plan.pitch, plan.S);
+    hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(a.act), act16 ? rn::ACT_ROWS / 2 : rn::ACT_ROWS, rn::act_units(act16), plan.pitch, plan.S);
+    hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, del16 ? rn::DEL_ROWS / 2 : rn::DEL_ROWS, rn::del_units(del16), plan.pitch, plan.S);
   }
   rn::WgradArgs w;
-  w.act = a.act; w.delta = a.delta; w.pitch = plan.pitch; w.S = plan.S; w.k_per_slice = plan.k_per_slice;
+  w.act = a.act; w.delta = a.delta; w.a_units = rn::act_units(act16); w.d_units = rn::del_units(del16); w.pitch = plan.pitch; w.S = plan.S; w.k_per_slice = plan.k_per_slice;
   w.part = (float *)(ws + plan.part_off);
   const int slices = (int)((plan.S + plan.k_per_slice - 1) / plan.k_per_slice);
   { int trc = timer_begin(st, &tslot, REFNERF_TIMER_WGRAD); if (trc) return trc; }

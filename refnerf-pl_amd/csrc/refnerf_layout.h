@@ -183,13 +183,33 @@ constexpr int ACT_ROWS_TOTAL = ACT_MASK + 16 * 8;  /* 4524 */
  * contiguous 1 KB.  Row-wise reads of those 320 rows (each row 2 MB from the next: a page and a DRAM row per 128 B)
  * were 0.15 of the backward.  The mask rows stay unused in this format. */
 constexpr int SMB_SLOTS = 48, SMB_X7 = 0, SMB_V7 = 16, SMB_MASK = 32;
-constexpr int SMB_ROW0 = ACT_ROWS / 2 + 2;         /* first float-row of the block: 2200 */
+constexpr int SMB_ROW0 = ACT_ROWS / 2 + 3;         /* first float-row of the block: 2201 (odd: it is also the block stride of the bf16 rows) */
 static_assert((long long)(ACT_MASK - SMB_ROW0) * 4 >= SMB_SLOTS * 2 * 16 + 64, "sample-major block must fit in front of the mask rows");
+/* Storage order of both matrices: BLOCKS OF 64 SAMPLES, [block][unit][64 samples] with one dword per unit and sample
+ * (unit = an fp32 row, or a pair-row of the bf16 format): element (unit u, sample s) is dword
+ *     (s >> 6) * units * 64 + u * 64 + (s & 63)
+ * i.e. the row-major expression `u * pitch + col` with pitch = RB and col = rb_col(s, units).  What the weight-gradient GEMM
+ * reads per k-step -- 64 samples of 128 rows -- is then ONE contiguous 32 KB (16 KB in the bf16 format) instead of 128
+ * segments of 256 B each 2 MB from the next (a DRAM row and a page per segment: 3.7 TB/s; blocked: 4.8 TB/s), and what a
+ * workgroup of the chain kernels writes per layer is contiguous as well.  `units` is the unit count of the whole matrix
+ * (the block stride); sizes are unchanged (rows x pitch dwords, pitch a multiple of 128). */
+constexpr int RB = 64;
+__host__ __device__ inline long long rb_col(long long s, int units) { return (s >> 6) * ((long long)units * RB) + (s & (RB - 1)); }
 constexpr int DEL_SP = 0;                          /* 8 x 256: spatial layer deltas         */
 constexpr int DEL_HEADS = DEL_SP + 8 * WIDTH;      /* 144: head rows (HROW_* order), 139 used */
 constexpr int DEL_VD = DEL_HEADS + 144;            /* 8 x 256: directional layer deltas     */
 constexpr int DEL_RGB = DEL_VD + 8 * WIDTH;        /* 4: rgb layer (3 used)                 */
 constexpr int DEL_ROWS = DEL_RGB + 4;              /* 4244 */
+/* unit counts (block strides) of the two matrices in the two formats; the bf16 ACT block region ends where the
+ * sample-major block begins */
+/* (ODD counts: the block stride is then an odd number of 256-B lines and the same unit of successive blocks -- what
+ * all workgroups of a chain kernel write at the same moment -- rotates through the memory channels; the matrices are
+ * allocated one row larger for it: ACT_ALLOC_ROWS / DEL_ALLOC_ROWS) */
+constexpr int ACT_UNITS_F32 = ACT_ROWS_TOTAL + 1, ACT_UNITS_H16 = SMB_ROW0, DEL_UNITS_F32 = DEL_ROWS + 1, DEL_UNITS_H16 = DEL_ROWS / 2 + 1;
+constexpr int ACT_ALLOC_ROWS = ACT_ROWS_TOTAL + 1, DEL_ALLOC_ROWS = DEL_ROWS + 1;
+static_assert((ACT_UNITS_F32 & ACT_UNITS_H16 & DEL_UNITS_F32 & DEL_UNITS_H16 & 1) == 1, "odd block strides");
+constexpr int act_units(bool h16) { return h16 ? ACT_UNITS_H16 : ACT_UNITS_F32; }
+constexpr int del_units(bool h16) { return h16 ? DEL_UNITS_H16 : DEL_UNITS_F32; }
 
 /* ---------------- bf16 MFMA operand image ----------------
  * Same 18 ops on v_mfma_f32_32x32x16_bf16 (K = 16 per step), two 32-sample

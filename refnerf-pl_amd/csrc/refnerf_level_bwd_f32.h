@@ -181,7 +181,7 @@ __device__ __forceinline__ void heads_scalar_block_f32(__amdgpu_buffer_rsrc_t rs
 }
 
 /* the saved ReLU sign patterns of the 8 layers of one trunk (ACT_MASK rows 8*layer0 ...): 4 dwords per layer */
-__device__ __forceinline__ void load_masks(const float *act, long long pitch, int layer0, size_t gs, int h, unsigned (&M)[8][4], bool act16) {
+__device__ __forceinline__ void load_masks(const float *act, long long pitch, long long rpitch, int layer0, size_t gs, size_t acol, int h, unsigned (&M)[8][4], bool act16) {
   if (act16) {                                   /* bf16 format: one 16-B slot per layer in the sample-major block */
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
@@ -191,12 +191,12 @@ __device__ __forceinline__ void load_masks(const float *act, long long pitch, in
     }
     return;
   }
-  const long long e0 = (long long)(ACT_MASK + 8 * layer0 + 4 * h) * pitch + (long long)gs;   /* one origin, compile-time row offsets */
+  const long long e0 = (long long)(ACT_MASK + 8 * layer0 + 4 * h) * rpitch + (long long)acol;   /* one origin, compile-time row offsets */
 #pragma unroll
   for (int l = 0; l < 8; ++l)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      M[l][q] = __builtin_bit_cast(unsigned, act[e0 + (long long)(8 * l + q) * pitch]);
+      M[l][q] = __builtin_bit_cast(unsigned, act[e0 + (long long)(8 * l + q) * rpitch]);
 }
 
 
@@ -247,6 +247,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     const void *packed_l = A.packed;
     long long pitch = A.pitch;                     /* same for the row pitch: ~140 hoisted 64-bit row origins, all spilled */
     asm volatile("" : "+s"(packed_l), "+s"(pitch));
+    constexpr long long rpitch = RB;               /* unit pitch of the blocked ACT / DELTA rows (refnerf_layout.h) */
     int hdb = DIR_PAD * T_TILE + col;                /* the HD tile (beyond the 64 KB immediate range) through one laundered base */
     asm volatile("" : "+v"(hdb));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)packed_l, 0, PACKED.total * 4, 0x00020000);
@@ -257,6 +258,9 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     const bool valid = (g < n_tot) && (ray < A.R);
     const int rayc = valid ? ray : (A.R - 1);
     const size_t gs = valid ? (size_t)ray * N + si : 0;
+    /* this sample's column in the blocked rows of DELTA and (fp32 format) ACT; the sample-major block and the seed
+     * rows keep (pitch, gs) */
+    const size_t dcol = (size_t)rb_col((long long)gs, del_units(D16)), acol = (size_t)rb_col((long long)gs, ACT_UNITS_F32);
     float v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
@@ -278,7 +282,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
       }
       if (!done) {
         if (A.act16) smb_load_rows(A.act, pitch, gs, h, SMB_X7, in);                  /* x7: input of the heads */
-        else load_rows<8>(A.act, pitch, ACT_SP + 7 * WIDTH, gs, h, in);
+        else load_rows<8>(A.act, rpitch, ACT_SP + 7 * WIDTH, acol, h, in);
         heads_scalar_block_f32(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd4[0]);
       }
 #pragma unroll
@@ -301,7 +305,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     }
     if (!rgb_bf) {
       if (A.act16) smb_load_rows(A.act, pitch, gs, h, SMB_V7, in);                  /* v7: input of the rgb layer */
-      else load_rows<8>(A.act, pitch, ACT_VD + 7 * WIDTH, gs, h, in);
+      else load_rows<8>(A.act, rpitch, ACT_VD + 7 * WIDTH, acol, h, in);
     }
     wave_sync();
     SampleHeads sh;
@@ -325,7 +329,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
       for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(rgbv[0][i], sl, 64);
     }
     RN_STAMP(A, 3);
-    load_masks(A.act, pitch, 8, gs, h, M, A.act16);                                    /* directional trunk */
+    load_masks(A.act, pitch, rpitch, 8, gs, acol, h, M, A.act16);                                    /* directional trunk */
 
     /* ================= backward ================= */
     float gsv[NGS];
@@ -373,7 +377,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     }
     if (valid && h == 0) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) store_row1<D16>(A.delta, pitch, DEL_RGB + i, gs, g_raw_rgb[i]);
+      for (int i = 0; i < 3; ++i) store_row1<D16>(A.delta, rpitch, DEL_RGB + i, dcol, g_raw_rgb[i]);
     }
     /* ---- seed of the directional chain: W_rgb^T g_raw_rgb through the last ReLU ---- */
 #pragma unroll
@@ -407,7 +411,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     for (int i = 7; i >= 0; --i) {
       /* delta_i leaves through the store hook of the GEMM that consumes it (one row per k-step) */
       if constexpr (BF) {
-        std::conditional_t<D16, PairStoreHook, RowStoreHook> sh_(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid);
+        std::conditional_t<D16, PairStoreHook, RowStoreHook> sh_(A.delta, rpitch, DEL_VD + i * WIDTH, dcol, h, valid);
         auto hook = [&](int t) {
           if constexpr (D16) {
 #pragma unroll
@@ -430,13 +434,13 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
       } else {
         if (i == 5 || i == 0) {
           if (i == 0) gemm_op<DIN_BLOCKS, 8, true, false>(rs, PACKED.top[TOP_VD0].a_off, 0, lane, h, in, gd, xl, 0,
-                                                          RowStoreHook(A.delta, pitch, DEL_VD, gs, h, valid));
+                                                          RowStoreHook(A.delta, rpitch, DEL_VD, dcol, h, valid));
           else gemm_op<DIN_BLOCKS, 8, true, false>(rs, PACKED.top[TOP_VD5_DIN].a_off, 0, lane, h, in, gd, xl, 0);
           park_din(i);
         }
         if (i > 0) {
           gemm_op<8, 8, true, false, RowStoreHook, PF_BWD>(rs, PACKED.top[TOP_VD1 + i - 1].a_off, 0, lane, h, in, out, xl, 0,
-                                     RowStoreHook(A.delta, pitch, DEL_VD + i * WIDTH, gs, h, valid));
+                                     RowStoreHook(A.delta, rpitch, DEL_VD + i * WIDTH, dcol, h, valid));
           shift_masks(M);                                                     /* M[7] <- mask of layer i-1 */
           masked_into(out, in, M[7]);
         }
@@ -444,7 +448,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     }
     RN_STAMP(A, 5);
     /* X rows 0..127: dL/d bottleneck (= head rows 0..127), rows 128..200: dL/d (IDE, n.v) */
-    store_rows<4, D16>(A.delta, pitch, DEL_HEADS, gs, h, valid, gd);
+    store_rows<4, D16>(A.delta, rpitch, DEL_HEADS, dcol, h, valid, gd);
     wave_sync();
     /* ---- IDE, reflection, predicted normal, head activations (models.py:611-686) ---- */
     {
@@ -482,7 +486,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
 #pragma unroll
         for (int i = 0; i < 11; ++i) {
           X[tile_idx(HROW_DENSITY + i, col, xhi)] = hrow[i];
-          if (valid) store_row1<D16>(A.delta, pitch, DEL_HEADS + HROW_DENSITY + i, gs, hrow[i]);
+          if (valid) store_row1<D16>(A.delta, rpitch, DEL_HEADS + HROW_DENSITY + i, dcol, hrow[i]);
         }
       } else {
 #pragma unroll
@@ -492,14 +496,14 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     wave_sync();
     /* ---- heads^T, then the spatial MLP, layers 7..0 ---- */
     RN_STAMP(A, 6);
-    load_masks(A.act, pitch, 0, gs, h, M, A.act16);                                    /* spatial trunk */
+    load_masks(A.act, pitch, rpitch, 0, gs, acol, h, M, A.act16);                                    /* spatial trunk */
     if constexpr (BF) {
       gemm_op_bf16<8, 0, BT_HEADS_STEPS, false>(rs, PACKED.bt_off[TOP_HEADS], 0, lane, h, pk, out, X + col);
       mask_pack(out, M[7], pk);
 #pragma unroll 1
       for (int i = 7; i >= 0; --i) {
         if (i > 0) {
-          std::conditional_t<D16, PairStoreHook, RowStoreHook> sh_(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid);
+          std::conditional_t<D16, PairStoreHook, RowStoreHook> sh_(A.delta, rpitch, DEL_SP + i * WIDTH, dcol, h, valid);
           gemm_chain_bf16_shared<false>(rs, PACKED.bt_off[i - 1], 0, lane, h, wave, pk, out, ring, [&](int t) {
             if constexpr (D16) {
 #pragma unroll
@@ -516,7 +520,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
           for (int blk = 0; blk < 8; ++blk)
 #pragma unroll
             for (int r = 0; r < 16; ++r) in[blk][r] = pk_elem(pk, blk, r);
-          store_rows<8, D16>(A.delta, pitch, DEL_SP, gs, h, valid, in);
+          store_rows<8, D16>(A.delta, rpitch, DEL_SP, dcol, h, valid, in);
         }
       }
     } else {
@@ -526,10 +530,10 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
       for (int i = 7; i >= 0; --i) {
         if (i > 0) {
           gemm_op<8, 8, true, false, RowStoreHook, PF_BWD>(rs, PACKED.top[i - 1].a_off, 0, lane, h, in, out, xl, 0,
-                                     RowStoreHook(A.delta, pitch, DEL_SP + i * WIDTH, gs, h, valid));
+                                     RowStoreHook(A.delta, rpitch, DEL_SP + i * WIDTH, dcol, h, valid));
           shift_masks(M);                                                     /* M[7] <- mask of layer i-1 */
           masked_into(out, in, M[7]);
-        } else store_rows<8>(A.delta, pitch, DEL_SP, gs, h, valid, in);      /* no GEMM consumes delta_0 */
+        } else store_rows<8>(A.delta, rpitch, DEL_SP, dcol, h, valid, in);      /* no GEMM consumes delta_0 */
       }
     }
     RN_STAMP(A, 7);

@@ -88,6 +88,11 @@ struct NoStepHook {
  * cycles of wait per layer in the backward.  Spread over the GEMM the stores ride under the MFMAs.
  * Rows follow the accumulator layout: row(r) = (r&3) + 8*(r>>2) (+4h in `voff`), i.e. +1,+1,+1,+5 rows
  * per step; the buffer descriptor is re-based every 32 rows so that 32-bit offsets suffice for any pitch. */
+/* the value of lane 0 (all lanes of the chain kernels are active) */
+__device__ __forceinline__ long long uniform64(long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
 /* H16: the matrix holds bf16 rows (the bf16-chain kernels: the values are bf16-exact, the stream is half as large) */
 template <bool H16 = false>
 struct RowStoreHookT {
@@ -99,9 +104,12 @@ struct RowStoreHookT {
   __amdgpu_buffer_rsrc_t rs;
   static constexpr int ESZ = H16 ? 2 : 4;
   __device__ __forceinline__ RowStoreHookT(float *matrix, long long pitch, int row0, size_t col, int h, bool store) {
-    base = reinterpret_cast<char *>(matrix) + (long long)row0 * pitch * ESZ;
+    /* the column of the wave's first lane goes into the 64-bit base: a blocked column (rb_col) does not fit 32 bits,
+     * the distance to it inside a wave (at most two 64-sample blocks) does */
+    const long long c0 = uniform64((long long)col);
+    base = reinterpret_cast<char *>(matrix) + ((long long)row0 * pitch + c0) * ESZ;
     blk_bytes = (unsigned long long)pitch * 32ull * ESZ;
-    voff = store ? (unsigned)(((long long)(4 * h) * pitch + (long long)col) * ESZ) : 0xfffffff0u;
+    voff = store ? (unsigned)(((long long)(4 * h) * pitch + ((long long)col - c0)) * ESZ) : 0xfffffff0u;
     p1 = (unsigned)(pitch * ESZ);
     p5 = 5u * p1;
     soff = 0;
@@ -130,9 +138,10 @@ struct PairStoreHook {
   unsigned voff, p1, p3, soff;
   __amdgpu_buffer_rsrc_t rs;
   __device__ __forceinline__ PairStoreHook(float *matrix, long long pitch, int row0, size_t col, int h, bool store) {
-    base = reinterpret_cast<char *>(matrix) + (long long)(row0 >> 1) * pitch * 4;
+    const long long c0 = uniform64((long long)col);
+    base = reinterpret_cast<char *>(matrix) + ((long long)(row0 >> 1) * pitch + c0) * 4;
     blk_bytes = (unsigned long long)pitch * 64ull;
-    voff = store ? (unsigned)(((long long)(2 * h) * pitch + (long long)col) * 4) : 0xfffffff0u;
+    voff = store ? (unsigned)(((long long)(2 * h) * pitch + ((long long)col - c0)) * 4) : 0xfffffff0u;
     p1 = (unsigned)(pitch * 4);
     p3 = 3u * p1;
     soff = 0;
@@ -710,6 +719,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     const void *packed_l = A.packed;
     long long act_pitch = A.act_pitch;             /* same for the row pitch of ACT: hoisted 64-bit row origins, all spilled */
     asm volatile("" : "+s"(packed_l), "+s"(act_pitch));
+    constexpr long long rpitch = RB;               /* unit pitch of the blocked ACT / DELTA rows (refnerf_layout.h) */
     int hdb = DIR_PAD * T_TILE + col;                /* the HD tile (beyond the 64 KB immediate range) through one laundered base */
     asm volatile("" : "+v"(hdb));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)packed_l, 0, PACKED.total * 4, 0x00020000);
@@ -720,6 +730,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     const int rayc = valid ? ray : (A.R - 1);
     const bool save = TRAIN && !STAGE && A.act != nullptr && valid;   /* keep the layer inputs for the backward */
     const size_t gsx = valid ? (size_t)ray * N + si : 0;
+    const size_t rcol = (size_t)rb_col((long long)gsx, act_units(BFC));   /* this sample's column in the blocked ACT rows */
     float o[3] = {0.0f, 0.0f, 0.0f}, d[3] = {0.0f, 0.0f, 0.0f}, v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -755,7 +766,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
           /* bf16 chains: (e sin, e cos) of every (j, b) once more as a bf16 pair in tile rows 128.. (free until P4): the
            * density-normal VJP needs exactly these as d feature / d mean (ipe_vjp_accum_lds) */
           if constexpr (BFC) reinterpret_cast<unsigned short *>(X)[((BNECK + j * 3 + b) * T_TILE + col) * 2 + h] = (unsigned short)cvt_pk_bf16(fe, fe);
-          if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, act_pitch, ACT_IPE + 48 * h + j * 3 + b, gsx, fe); }
+          if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, rpitch, ACT_IPE + 48 * h + j * 3 + b, rcol, fe); }
         }
     }
     wave_sync();
@@ -764,7 +775,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     /* P2: spatial MLP (models.py:576-580) */
     unsigned M[TRAIN ? 8 : 1][4];                /* ReLU masks of the spatial layers (training) */
     auto act_hook = [&](int row0) {              /* bf16 chains: the packed layer input leaves for ACT, 8 rows per k-step */
-      return [&, hk = PairStoreHook(A.act, act_pitch, row0, gsx, h, save)](int t) mutable {
+      return [&, hk = PairStoreHook(A.act, rpitch, row0, rcol, h, save)](int t) mutable {
 #pragma unroll
         for (int e = 0; e < 4; ++e) hk(4 * t + e, pk[t][e]);       /* the k-step's B fragment as it is */
       };
@@ -781,7 +792,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         if (save) smb_store(A.act, act_pitch, gsx, h, SMB_MASK + layer, (v4u){mk[0], mk[1], mk[2], mk[3]});
       } else if (save) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) store_row1(A.act, act_pitch, ACT_MASK + 8 * layer + 4 * h + q, gsx, __builtin_bit_cast(float, mk[q]));
+        for (int q = 0; q < 4; ++q) store_row1(A.act, rpitch, ACT_MASK + 8 * layer + 4 * h + q, rcol, __builtin_bit_cast(float, mk[q]));
       }
     };
     if constexpr (TRAIN && !STAGE) { if (A.act) save_mask(0, M[7]); }
@@ -795,7 +806,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
                                           reinterpret_cast<char *>(smem) + A.ring_off, act_hook(ACT_SP + (op - 1) * WIDTH));
       } else if constexpr (TRAIN && !STAGE)
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
-                            RowStoreHook(A.act, act_pitch, ACT_SP + (op - 1) * WIDTH, gsx, h, save));
+                            RowStoreHook(A.act, rpitch, ACT_SP + (op - 1) * WIDTH, rcol, h, save));
       else
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
       if constexpr (TRAIN) {
@@ -817,7 +828,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
                                      act_hook(ACT_SP + 7 * WIDTH));
       else if constexpr (TRAIN && !STAGE)
         gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0,
-                            RowStoreHook(A.act, act_pitch, ACT_SP + 7 * WIDTH, gsx, h, save));
+                            RowStoreHook(A.act, rpitch, ACT_SP + 7 * WIDTH, rcol, h, save));
       else
         gemm_op<5, 8, true>(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd, xl, 0);
       __builtin_amdgcn_wave_barrier();          /* all IPE reads of this wave are done */
@@ -830,7 +841,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < HD_ROWS) X[hdb + row * T_TILE] = hd[4][r];
       }
-      if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<4, BFC>(A.act, act_pitch, ACT_DIN, gsx, h, save, hd); }
+      if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<4, BFC>(A.act, rpitch, ACT_DIN, rcol, h, save, hd); }
     }
     wave_sync();
 
@@ -854,11 +865,11 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       float *xi = X + xhi + IDE_TERMS * h * T_TILE;   /* row BNECK (= 128) + 36 h */
       ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) {
         xi[q * T_TILE] = val;
-        if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, act_pitch, ACT_DIN + BNECK + IDE_TERMS * h + q, gsx, val); }
+        if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, rpitch, ACT_DIN + BNECK + IDE_TERMS * h + q, rcol, val); }
       });
       if (h == 0) {
         X[tile_idx(BNECK + IDE_DIM, col, xhi)] = sh.dot;
-        if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, act_pitch, ACT_DIN + BNECK + IDE_DIM, gsx, sh.dot); }
+        if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, rpitch, ACT_DIN + BNECK + IDE_DIM, rcol, sh.dot); }
       } else {
 #pragma unroll
         for (int q = DIR_IN; q < DIR_PAD; ++q) X[tile_idx(q, col, xhi)] = 0.0f;
@@ -890,7 +901,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
                                           reinterpret_cast<char *>(smem) + A.ring_off, act_hook(ACT_VD + (op - 10) * WIDTH));
       } else if constexpr (TRAIN && !STAGE)
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
-                            RowStoreHook(A.act, act_pitch, ACT_VD + (op - 10) * WIDTH, gsx, h, save));
+                            RowStoreHook(A.act, rpitch, ACT_VD + (op - 10) * WIDTH, rcol, h, save));
       else
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
       if constexpr (TRAIN && !STAGE) {
@@ -906,7 +917,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       gemm_op_bf16<1, 16, 0, true>(rs, PACKED.bf_off[OP_RGB], PACKED.op[OP_RGB].b_off, lane, h, pk, rgbv, xc, act_hook(ACT_VD + 7 * WIDTH));
     else if constexpr (TRAIN && !STAGE)
       gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0,
-                          RowStoreHook(A.act, act_pitch, ACT_VD + 7 * WIDTH, gsx, h, save));
+                          RowStoreHook(A.act, rpitch, ACT_VD + 7 * WIDTH, rcol, h, save));
     else
       gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0);
     /* rows 0..2 live in half 0, regs 0..2; hand them to half 1 as well */

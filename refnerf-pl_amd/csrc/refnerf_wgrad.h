@@ -84,7 +84,8 @@ __device__ __forceinline__ size_t wjob_row_off(const WJob &J, int orow) {
 __device__ __forceinline__ int wjob_bias_off(const WJob &J, int orow) { return J.ld ? J.b_off + orow : HEAD_ROWS.b[orow]; }
 
 struct WgradArgs {
-  const float *act, *delta;
+  const float *act, *delta;   /* blocked rows (refnerf_layout.h: [64-sample block][unit][64]) */
+  int a_units, d_units;       /* unit counts of the two matrices in their formats = block strides / 64 */
   long long pitch;
   long long S;            /* valid samples (columns) */
   int k_per_slice;        /* samples per split-K slice, multiple of WG_KT */
@@ -124,9 +125,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int orow = tm * WG_TM + lrow + 16 * p, irow = tn * WG_TN + lrow + 16 * p;
-    dp[p] = (orow < J.n_out) ? A.delta + (long long)(J.d_row + orow) * A.pitch + lc4 : nullptr;
-    ap[p] = (irow < J.n_in) ? A.act + (long long)(J.a_row + irow) * A.pitch + lc4 : nullptr;
+    dp[p] = (orow < J.n_out) ? A.delta + (long long)(J.d_row + orow) * RB + lc4 : nullptr;
+    ap[p] = (irow < J.n_in) ? A.act + (long long)(J.a_row + irow) * RB + lc4 : nullptr;
   }
+  static_assert(WG_KT == RB, "one k-step = one 64-sample block of the operand matrices");
+  const long long dstep = (long long)A.d_units, astep = (long long)A.a_units;   /* floats per sample of k0: block k0/64 starts at k0 * units */
   v4f dv[8], av[8];
   /* plain loads, nothing consumes them before the next rendezvous (a tail mask on the loaded values
    * would put an s_waitcnt right behind every load): the columns [S, pitch) of both matrices are
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       v4f x = {0.0f, 0.0f, 0.0f, 0.0f}, y = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (dp[p]) x = *reinterpret_cast<const v4f *>(dp[p] + k0);
-      if (ap[p]) y = *reinterpret_cast<const v4f *>(ap[p] + k0);
+      if (dp[p]) x = *reinterpret_cast<const v4f *>(dp[p] + k0 * dstep);
+      if (ap[p]) y = *reinterpret_cast<const v4f *>(ap[p] + k0 * astep);
       dv[p] = x; av[p] = y;
     }
   };
@@ -193,12 +196,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
   }
 }
 
-/* zero the pad columns [S, pitch) of a [rows][pitch] matrix */
-__global__ void wgrad_zero_tail(float *m, int rows, long long pitch, long long S) {
+/* zero the pad samples [S, pitch) of the first `rows` units of a blocked matrix of `units` units */
+__global__ void wgrad_zero_tail(float *m, int rows, int units, long long pitch, long long S) {
   const int tail = (int)(pitch - S);
   const long long n = (long long)rows * tail;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    m[(i / tail) * pitch + S + (i % tail)] = 0.0f;
+    m[(i / tail) * RB + rb_col(S + (i % tail), units)] = 0.0f;
 }
 
 /* grads[i] += sum over slices (fixed order) of PART[slice][i] */

@@ -82,11 +82,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
   for (int p = 0; p < 8; ++p) {
     const int orow = tm * WG_TM + tile_row(p, D16), irow = tn * WG_TN + tile_row(p, A16);
     /* (all row origins of the job table are even, so a tile's row pairs are the matrices' row pairs) */
-    if constexpr (D16) dp[p] = (orow < J.n_out) ? reinterpret_cast<const char *>(A.delta) + ((long long)((J.d_row + orow) >> 1) * A.pitch + lc4) * 4 : nullptr;
-    else dp[p] = (orow < J.n_out) ? reinterpret_cast<const char *>(A.delta) + ((long long)(J.d_row + orow) * A.pitch + lc4) * 4 : nullptr;
-    if constexpr (A16) ap[p] = (irow < J.n_in) ? reinterpret_cast<const char *>(A.act) + ((long long)((J.a_row + irow) >> 1) * A.pitch + lc4) * 4 : nullptr;
-    else ap[p] = (irow < J.n_in) ? reinterpret_cast<const char *>(A.act) + ((long long)(J.a_row + irow) * A.pitch + lc4) * 4 : nullptr;
+    /* blocked rows: unit u of the 64-sample block that starts at sample k0 is at dword k0 * units + u * 64 */
+    if constexpr (D16) dp[p] = (orow < J.n_out) ? reinterpret_cast<const char *>(A.delta) + ((long long)((J.d_row + orow) >> 1) * RB + lc4) * 4 : nullptr;
+    else dp[p] = (orow < J.n_out) ? reinterpret_cast<const char *>(A.delta) + ((long long)(J.d_row + orow) * RB + lc4) * 4 : nullptr;
+    if constexpr (A16) ap[p] = (irow < J.n_in) ? reinterpret_cast<const char *>(A.act) + ((long long)((J.a_row + irow) >> 1) * RB + lc4) * 4 : nullptr;
+    else ap[p] = (irow < J.n_in) ? reinterpret_cast<const char *>(A.act) + ((long long)(J.a_row + irow) * RB + lc4) * 4 : nullptr;
   }
+  static_assert(WB_KT == RB, "one k-step = one 64-sample block of the operand matrices");
+  const long long dstep = (long long)A.d_units * 4, astep = (long long)A.a_units * 4;   /* bytes per sample of k0 */
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
   /* 4 samples as raw dwords: of one fp32 row, or of a PAIR of bf16 rows (dword = {row 2j | row 2j+1 << 16}; held in the
    * even slot, the odd slot stays unused).  Kept as integers: a packed bf16 pair is not a well-formed float (it may
@@ -97,12 +100,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
     for (int p = 0; p < 8; ++p) {
       if (!(D16 && (p & 1))) {
         v4u x = {0u, 0u, 0u, 0u};
-        if (dp[p]) x = *reinterpret_cast<const v4u *>(dp[p] + k0 * 4);
+        if (dp[p]) x = *reinterpret_cast<const v4u *>(dp[p] + k0 * dstep);
         dv[p] = x;
       }
       if (!(A16 && (p & 1))) {
         v4u y = {0u, 0u, 0u, 0u};
-        if (ap[p]) y = *reinterpret_cast<const v4u *>(ap[p] + k0 * 4);
+        if (ap[p]) y = *reinterpret_cast<const v4u *>(ap[p] + k0 * astep);
         av[p] = y;
       }
     }

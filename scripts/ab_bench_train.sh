@@ -6,7 +6,7 @@ cp $LIB /tmp/lib_keep.so
 for rep in 1 2; do
 for so in "$@"; do
   cp $so $LIB
-  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-image > /tmp/ab_bt.json 2>/dev/null
+  REFNERF_BENCH_PROBE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-image > /tmp/ab_bt.json 2>/dev/null
   python - "$so" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab_bt.json"))
