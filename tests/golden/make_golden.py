@@ -709,7 +709,55 @@ def golden_shiny():
 
 
 
+def golden_variants():
+    """Which of the reference's shipped configs construct and run at all.
+
+    The mip-NeRF configs switch `use_diffuse_color` off; `Model.__call__` reads `ray_results['diffuse']` unconditionally
+    (internal/models.py:272), so `construct_model` -- which runs the model once -- raises for them.  Recorded as data: the
+    exception each config ends in (or 'ok'), plus, for a Ref-NeRF config with single flags flipped, whether the reference
+    still runs.  tests/test_host_cpu.py::test_variant_gate_matches_reference_status replays it against this build's gate.
+    """
+    import json
+    import traceback
+    cfg_dir = os.path.join(_ref_harness.REFERENCE_ROOT, "configs")
+    status = {}
+    for name in sorted(os.listdir(cfg_dir)):
+        gin.clear_config()
+        try:
+            gin.parse_config_files_and_bindings([os.path.join(cfg_dir, name)], [])
+            cfg = configs.Config()
+            m = models.construct_model(utils.dummy_rays(), cfg)
+            m.eval()
+            m(utils.dummy_rays(), 1.0, True)
+            status[name] = "ok"
+        except Exception as e:   # noqa: BLE001
+            tb = traceback.extract_tb(e.__traceback__)[-1]
+            status[name] = f"{type(e).__name__}: {e} (internal/{os.path.basename(tb.filename)}:{tb.lineno})"
+    flags = {}
+    for flag in ["NerfMLP.use_diffuse_color = False", "NerfMLP.use_directional_enc = False", "NerfMLP.use_reflections = False",
+                 "NerfMLP.enable_pred_roughness = False", "NerfMLP.use_specular_tint = False", "NerfMLP.use_n_dot_v = False",
+                 "NerfMLP.net_width_viewdirs = 128", "NerfMLP.basis_shape = 'icosahedron'", "NerfMLP.disable_density_normals = True",
+                 "NerfMLP.enable_pred_normals = False"]:
+        gin.clear_config()
+        try:
+            gin.parse_config_files_and_bindings([REF_CFG], [flag])
+            cfg = configs.Config()
+            m = models.construct_model(utils.dummy_rays(), cfg)
+            m.eval()
+            m(utils.dummy_rays(), 1.0, True)
+            flags[flag] = "ok"
+        except Exception as e:   # noqa: BLE001
+            tb = traceback.extract_tb(e.__traceback__)[-1]
+            flags[flag] = f"{type(e).__name__}: {e} (internal/{os.path.basename(tb.filename)}:{tb.lineno})"
+    path = os.path.join(HERE, "variants_status.json")
+    with open(path, "w") as f:
+        json.dump({"configs": status, "refnerf_with_flag": flags}, f, indent=1, sort_keys=True)
+    print("wrote", path)
+    for k, v in {**status, **flags}.items():
+        print(f"  {k}: {v}")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants"]
     for w in which:
         globals()["golden_" + w]()
