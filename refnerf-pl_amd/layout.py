@@ -52,3 +52,58 @@ PARAM_SPECS: List[ParamSpec] = _build()
 NUM_PARAMS: int = PARAM_SPECS[-1].b_off + PARAM_SPECS[-1].out_dim
 assert NUM_PARAMS == 1110158
 SPEC_BY_NAME = {s.name: s for s in PARAM_SPECS}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Variants of the NerfMLP that run in the reference and still fit the fused kernels' topology (SURVEY section 8 row f4;
+# tests/golden/variants_status.json records which flag settings the reference itself survives).  They are served by
+# EMBEDDING their parameters into the canonical blob above -- the kernels and the C ABI see the Ref-NeRF network:
+#   net_width_viewdirs = Wv <= 256   rows / hidden columns >= Wv of the directional layers are zero (dead units)
+#   use_n_dot_v = False              the n.v column of the two layers that read the dir input is zero
+#   use_specular_tint = False        raw_tint absent: zero weights and bias -> tint = sigmoid(0) = 0.5 exactly, i.e.
+#                                    specular = 0.5 rgb (internal/models.py:708-709)
+#   enable_pred_roughness = False    raw_roughness absent: zero weights, and the level runs with roughness_bias = -inf-ish
+#                                    (ROUGHNESS_OFF_BIAS): softplus -> exactly 0, the IDE at zero roughness (models.py:636-641)
+# The module keeps the reference's parameter names and TRUE shapes (checkpoints load unchanged); `variant_layout` gives the
+# true-shape spec list and, for every true parameter element, its position in the canonical blob.
+ROUGHNESS_OFF_BIAS = -1.0e30
+
+
+def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint=True, enable_pred_roughness=True):
+    """-> (specs, index): `specs` = ParamSpec list of the variant (true shapes, offsets into ITS flat blob, state_dict
+    order), `index` = int64 numpy array, index[i] = canonical-blob position of element i of the variant's flat blob; or
+    (PARAM_SPECS, None) for the Ref-NeRF network itself."""
+    import numpy as np
+    wv = int(net_width_viewdirs)
+    if not 1 <= wv <= WIDTH:
+        raise ValueError(f"net_width_viewdirs must be in [1, {WIDTH}] for the fused kernels, got {wv}")
+    if wv == WIDTH and use_n_dot_v and use_specular_tint and enable_pred_roughness:
+        return PARAM_SPECS, None
+    din_cols = list(range(BNECK + IDE_DIM)) + ([BNECK + IDE_DIM] if use_n_dot_v else [])
+    specs, idx, p = [], [], 0
+    for c in PARAM_SPECS:
+        if c.name == "raw_tint" and not use_specular_tint:
+            continue
+        if c.name == "raw_roughness" and not enable_pred_roughness:
+            continue
+        rows = list(range(c.out_dim))
+        cols = list(range(c.in_dim))
+        if c.name.startswith("viewdir_mlp."):
+            i = int(c.name.split(".")[1])
+            rows = list(range(wv))
+            if i == 0:
+                cols = din_cols
+            elif i == SKIP + 1:
+                cols = list(range(wv)) + [WIDTH + k for k in din_cols]
+            else:
+                cols = list(range(wv))
+        elif c.name == "rgb":
+            cols = list(range(wv))
+        out_dim, in_dim = len(rows), len(cols)
+        specs.append(ParamSpec(c.name, out_dim, in_dim, p, p + out_dim * in_dim))
+        p += out_dim * in_dim + out_dim
+        r = np.asarray(rows, np.int64)[:, None]
+        k = np.asarray(cols, np.int64)[None, :]
+        idx.append((c.w_off + r * c.in_dim + k).reshape(-1))
+        idx.append(c.b_off + np.asarray(rows, np.int64))
+    return specs, np.concatenate(idx)

@@ -99,34 +99,59 @@ class MLP(nn.Module):
         self.spatial_net = nn.ModuleList([_linear(sp_in[i], W) for i in range(self.net_depth)])
         self.raw_density = _linear(W, 1)
         self.grad_pred = _linear(W, 3)
-        self.raw_roughness = _linear(W, 1)
+        # the variants the reference runs and the fused kernels serve by embedding (layout.variant_layout): same module
+        # names and TRUE shapes as the reference gives them (models.py:509-531)
+        self.specs, idx = layout.variant_layout(self.net_width_viewdirs, self.use_n_dot_v, self.use_specular_tint,
+                                                self.enable_pred_roughness)
+        self.num_params = self.specs[-1].b_off + self.specs[-1].out_dim
+        self._embed_index_np = idx                 # None: the parameters ARE the canonical blob
+        self._embed_index = None
+        self._canon = None
+        if self.enable_pred_roughness:
+            self.raw_roughness = _linear(W, 1)
         self.raw_rgb_diffuse = _linear(W, self.num_rgb_channels)
-        self.raw_tint = _linear(W, 3)
+        if self.use_specular_tint:
+            self.raw_tint = _linear(W, 3)
         self.bottleneck = _linear(W, self.bottleneck_width)
-        vd_in = [layout.DIR_IN if i == 0 else (W + layout.DIR_IN if i == self.skip_layer + 1 else W)
+        Wv = self.net_width_viewdirs
+        din = layout.BNECK + layout.IDE_DIM + (1 if self.use_n_dot_v else 0)
+        vd_in = [din if i == 0 else (Wv + din if i == self.skip_layer + 1 else Wv)
                  for i in range(self.net_depth_viewdirs)]
-        self.viewdir_mlp = nn.ModuleList([_linear(vd_in[i], self.net_width_viewdirs)
-                                          for i in range(self.net_depth_viewdirs)])
-        self.rgb = _linear(self.net_width_viewdirs, self.num_rgb_channels)
+        self.viewdir_mlp = nn.ModuleList([_linear(vd_in[i], Wv) for i in range(self.net_depth_viewdirs)])
+        self.rgb = _linear(Wv, self.num_rgb_channels)
 
-        self._flat = None          # canonical blob the parameters alias
+        self._flat = None          # flat blob (state_dict order, true shapes) the parameters alias
         self._packed = None        # MFMA operand image
         self._packed_key = None
 
     # ---- supported-configuration gate ------------------------------------
     def _check_supported(self):
+        # Flag settings the REFERENCE does not survive (tests/golden/variants_status.json, captured from it): its
+        # Model.__call__ reads ray_results['diffuse'] unconditionally (models.py:272), reflect() needs predicted normals
+        # in eval mode (ref_utils.py:37), and the un-reflected encoding is broadcast with one dimension too many
+        # (models.py:671).  That includes both shipped mip-NeRF configs; the same settings raise here.
+        dead = {}
+        if not self.use_diffuse_color:
+            dead["use_diffuse_color"] = "False: KeyError 'diffuse' at internal/models.py:272 in the reference"
+        if not self.use_reflections:
+            dead["use_reflections"] = "False: RuntimeError in torch.broadcast_to at internal/models.py:671 in the reference"
+        if not self.enable_pred_normals:
+            dead["enable_pred_normals"] = "False: TypeError in ref_utils.reflect at internal/ref_utils.py:37 in the reference"
+        if dead:
+            raise ValueError(f"MLP flags the reference itself cannot run (so there is nothing to match): {dead}")
         want = dict(net_depth=8, net_width=256, bottleneck_width=128, net_depth_viewdirs=8,
-                    net_width_viewdirs=256, min_deg_point=0, max_deg_point=16, skip_layer=4,
-                    num_rgb_channels=3, deg_view=5, use_reflections=True, use_directional_enc=True,
-                    enable_pred_roughness=True, use_diffuse_color=True, use_specular_tint=True,
-                    use_n_dot_v=True, enable_pred_specular_density=False, bottleneck_noise=0.0,
-                    density_noise=0., enable_pred_normals=True, disable_density_normals=False,
-                    disable_rgb=False, warp_fn=None, basis_shape='octahedron', basis_subdivisions=1)
+                    min_deg_point=0, max_deg_point=16, skip_layer=4,
+                    num_rgb_channels=3, deg_view=5, use_directional_enc=True,
+                    enable_pred_specular_density=False, bottleneck_noise=0.0,
+                    density_noise=0., disable_rgb=False, warp_fn=None, basis_shape='octahedron', basis_subdivisions=1)
         bad = {k: getattr(self, k) for k, v in want.items() if getattr(self, k) != v}
+        if not 1 <= int(self.net_width_viewdirs) <= layout.WIDTH:
+            bad["net_width_viewdirs"] = self.net_width_viewdirs
         if bad:
             raise ValueError(
-                "MLP configuration outside the fused Ref-NeRF family (configs/*refnerf*.gin): "
-                f"{bad}; expected {({k: want[k] for k in bad})}")
+                "MLP configuration outside the fused Ref-NeRF family (configs/*refnerf*.gin; served variants: "
+                "net_width_viewdirs <= 256, use_n_dot_v / use_specular_tint / enable_pred_roughness / "
+                f"disable_density_normals either way): {bad}; expected {({k: want.get(k, '<= 256') for k in bad})}")
         if self.net_activation is not torch.nn.functional.relu:
             raise ValueError("net_activation must be relu")
         if self.density_activation is not torch.nn.functional.softplus or \
@@ -136,7 +161,7 @@ class MLP(nn.Module):
 
     # ---- flat canonical blob ----------------------------------------------
     def _named_linears(self):
-        for spec in layout.PARAM_SPECS:
+        for spec in self.specs:
             mod = self
             for part in spec.name.split("."):
                 mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
@@ -154,7 +179,7 @@ class MLP(nn.Module):
                     ok = False
                     break
         if not ok:
-            flat = torch.empty(layout.NUM_PARAMS, dtype=torch.float32, device=first.device)
+            flat = torch.empty(self.num_params, dtype=torch.float32, device=first.device)
             with torch.no_grad():
                 for spec, lin in self._named_linears():
                     n = spec.out_dim * spec.in_dim
@@ -177,11 +202,40 @@ class MLP(nn.Module):
         return flat
 
     def load_flat_params(self, blob):
-        """Copy a canonical blob (numpy / tensor) into the parameters."""
+        """Copy a flat blob (numpy / tensor) into the parameters: this module's own blob (`num_params` elements,
+        state_dict order) or, for a variant, also a CANONICAL blob -- its embedded elements are taken, the rest ignored."""
         flat = self.flat_params()
+        blob = torch.as_tensor(blob, dtype=torch.float32).to(flat.device).reshape(-1)
+        if blob.numel() == layout.NUM_PARAMS and self._embed_index_np is not None:
+            blob = blob[self.embed_index()]
         with torch.no_grad():
-            flat.copy_(torch.as_tensor(blob, dtype=torch.float32).to(flat.device))
+            flat.copy_(blob)
         self._packed_key = None
+
+    def embed_index(self):
+        """Variant only: LongTensor, position of every element of this module's blob in the canonical blob."""
+        flat = self.flat_params()
+        if self._embed_index is None or self._embed_index.device != flat.device:
+            self._embed_index = torch.as_tensor(self._embed_index_np, device=flat.device)
+        return self._embed_index
+
+    def canonical_blob(self) -> torch.Tensor:
+        """The parameters as the canonical Ref-NeRF blob the kernels and the C ABI take (layout.PARAM_SPECS): the module's
+        own blob, or for a variant its embedding (absent heads / columns / dead units are zeros; one index_copy)."""
+        flat = self.flat_params()
+        if self._embed_index_np is None:
+            return flat
+        if self._canon is None or self._canon.device != flat.device:
+            self._canon = torch.zeros(layout.NUM_PARAMS, dtype=torch.float32, device=flat.device)
+        with torch.no_grad():
+            self._canon.index_copy_(0, self.embed_index(), flat.detach())
+        return self._canon
+
+    @property
+    def kernel_roughness_bias(self) -> float:
+        """roughness_bias the level runs with: without a roughness head the raw value is 0 and this bias drives the
+        softplus to exactly 0 (internal/models.py:636: roughness = 0)."""
+        return float(self.roughness_bias) if self.enable_pred_roughness else layout.ROUGHNESS_OFF_BIAS
 
     def ordered_parameters(self):
         """[w0, b0, w1, b1, ...] in canonical (state_dict) order."""
@@ -207,7 +261,7 @@ class MLP(nn.Module):
         gen = getattr(self, "_train_gen", 0)
         buf, have, have_gen = self._packed.get(precision, (None, None, -1))
         if force or have != key or have_gen != gen or self._packed_key is None:
-            buf = _hip.pack_weights(flat, buf, precision)
+            buf = _hip.pack_weights(self.canonical_blob(), buf, precision)
             # an image packed by a training forward is stale after the optimiser step: gen - 1 makes the next
             # inference call of this mode re-pack once more
             self._packed[precision] = (buf, key, gen - 1 if force else gen)
@@ -242,7 +296,7 @@ class MLP(nn.Module):
         cfg = _hip.default_cfg(
             n_samples=int(n), n_in=1, training=int(self.training), compute_extras=0,
             srgb_mapping=int(self.srgb_mapping), srgb_mapping_normalization=int(self.srgb_mapping_normalization),
-            precision=_PREC["f32"], density_bias=float(self.density_bias), roughness_bias=float(self.roughness_bias),
+            precision=_PREC["f32"], density_bias=float(self.density_bias), roughness_bias=self.kernel_roughness_bias,
             rgb_premultiplier=float(self.rgb_premultiplier), rgb_bias=float(self.rgb_bias),
             rgb_padding=float(self.rgb_padding))
         res = _hip.mlp_forward(self.packed_weights(cfg.precision), cfg, m, c, v)
@@ -250,13 +304,16 @@ class MLP(nn.Module):
         def rs(x, *tail):
             return x.reshape(batch + (n,) + tuple(tail))
         ray_results = dict(density=rs(res["density"]), rgb=rs(res["rgb"], 3))
-        ray_results["normals"] = rs(res["normals"], 3) if self.training else None
+        if not self.disable_density_normals:                   # models.py:735-748: keys follow the flags
+            ray_results["normals"] = rs(res["normals"], 3) if self.training else None
         ray_results["normals_pred"] = rs(res["normals_pred"], 3)
         ray_results["grad_pred"] = rs(res["grad_pred"], 3)
-        ray_results["tint"] = rs(res["tint"], 3)
+        if self.use_specular_tint:
+            ray_results["tint"] = rs(res["tint"], 3)
         ray_results["diffuse"] = rs(res["diffuse"], 3)
         ray_results["specular"] = rs(res["specular"], 3)
-        ray_results["roughness"] = rs(res["roughness"], 1)
+        if self.enable_pred_roughness:
+            ray_results["roughness"] = rs(res["roughness"], 1)
         return ray_results
 
 
@@ -382,10 +439,12 @@ class _LevelFunction(torch.autograd.Function):
         _hip.level_backward(ctx.packed, cfg, ctx.rays, ctx.saved, g_rgb, g_weights, g_npred, grads,
                             g_r_acc=g.get("r_acc"), g_r_distance=g.get("r_distance"), sample_seeds=seeds)
         ctx.saved = None                           # release the 17.6 KB/sample activation buffer
+        if mlp._embed_index_np is not None:        # a variant: its parameters' elements of the canonical gradient
+            grads = grads.index_select(0, mlp.embed_index())
         if flat_mode:                              # Config.hip_flat_grads: the blob itself is the differentiable input
             return (None, None, None, None, None, None, grads)
         out = []
-        for spec in layout.PARAM_SPECS:            # same order as MLP.ordered_parameters()
+        for spec in mlp.specs:                     # same order as MLP.ordered_parameters()
             n = spec.out_dim * spec.in_dim
             out.append(grads[spec.w_off:spec.w_off + n].view(spec.out_dim, spec.in_dim))
             out.append(grads[spec.b_off:spec.b_off + spec.out_dim])
@@ -500,7 +559,7 @@ class Model(nn.Module):
             opaque_background=int(self.opaque_background), ray_shape=0 if self.ray_shape == 'cone' else 1,
             precision=_PREC[getattr(cfg, "hip_train_precision", "f32")] if self.training else _PREC[prec], wgrad_mode=wgrad, anneal=float(anneal), resample_padding=float(self.resample_padding),
             s_near=float(self.init_s_near), s_far=float(self.init_s_far), density_bias=float(mlp.density_bias),
-            roughness_bias=float(mlp.roughness_bias), rgb_premultiplier=float(mlp.rgb_premultiplier),
+            roughness_bias=mlp.kernel_roughness_bias, rgb_premultiplier=float(mlp.rgb_premultiplier),
             rgb_bias=float(mlp.rgb_bias), rgb_padding=float(mlp.rgb_padding), bg_rgb=float(bg))
 
     def __call__(self, rays, train_frac, compute_extras):
@@ -570,11 +629,14 @@ class Model(nn.Module):
                          "specular": rs(res["r_specular"], 3), "distance": rs(res["r_distance"], 1),
                          "acc": rs(res["r_acc"])}
             if compute_extras:                                                   # render.py:227-254
-                if self.training:
+                # extras = the ray_results keys that start with 'normals' or are 'roughness' / 'tint' (models.py:280-284)
+                if self.training and not mlp.disable_density_normals:
                     rendering["normals"] = rs(res["r_normals"], 3)
                 rendering["normals_pred"] = rs(res["r_normals_pred"], 3)
-                rendering["tint"] = rs(res["r_tint"], 3)
-                rendering["roughness"] = rs(res["r_roughness"], 1)
+                if mlp.use_specular_tint:
+                    rendering["tint"] = rs(res["r_tint"], 3)
+                if mlp.enable_pred_roughness:
+                    rendering["roughness"] = rs(res["r_roughness"], 1)
                 rendering["distance_mean"] = rs(res["r_distance_mean"])
                 pct = res["r_percentiles"]
                 rendering["distance_percentile_5"] = rs(pct[:, 0].contiguous())
@@ -594,6 +656,13 @@ class Model(nn.Module):
                            "diffuse": hist("diffuse", N, 3), "specular": hist("specular", N, 3),
                            "roughness": hist("roughness", N, 1),
                            "sdist": rs(sdist, N + 1), "weights": rs(weights, N)}      # (read-only for the next level: no copies)
+            # the reference's dict only has the keys its flags produce (models.py:735-748)
+            if mlp.disable_density_normals:
+                del ray_results["normals"]
+            if not mlp.use_specular_tint:
+                del ray_results["tint"]
+            if not mlp.enable_pred_roughness:
+                del ray_results["roughness"]
             ray_history.append(ray_results)
 
         if compute_extras:                                                       # models.py:308-319

@@ -709,6 +709,85 @@ def golden_shiny():
 
 
 
+VARIANT_FLAGS = ["NerfMLP.net_width_viewdirs = 128", "NerfMLP.use_n_dot_v = False", "NerfMLP.use_specular_tint = False",
+                 "NerfMLP.enable_pred_roughness = False"]
+
+
+def golden_variant_models():
+    """The NerfMLP variants this build serves by embedding (layout.variant_layout): reference outputs with the four
+    flags of VARIANT_FLAGS at once (eval; one training step with losses and autograd gradients, stored in the VARIANT's
+    own flat order), and a training step with disable_density_normals on top (no 'normals' in the history, so no
+    predicted-normal loss).  Weights: the embedded elements of a synthetic canonical blob."""
+    pk = dict(seed=5, bias_scale=0.05, sharpen=20.0)
+    canon = synthetic.make_params(**pk)
+    specs, idx = layout.variant_layout(128, False, False, False)
+    small = ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 96"]
+    cases = {
+        "model_variant_eval": (VARIANT_FLAGS, synthetic.blender_rays(16, seed=51, center_frac=0.4), False, True),
+        "model_variant_train": (VARIANT_FLAGS + small, synthetic.blender_rays(12, seed=52, center_frac=0.4), True, True),
+        "model_variant_nonormals_train": (VARIANT_FLAGS + small + ["NerfMLP.disable_density_normals = True"],
+                                          synthetic.blender_rays(12, seed=53, center_frac=0.4), True, False),
+    }
+    for name, (bindings, rays, train, with_normal_loss) in cases.items():
+        gin.clear_config()
+        gin.parse_config_files_and_bindings([REF_CFG], list(bindings))
+        cfg = configs.Config()
+        model = models.construct_model(utils.dummy_rays(), cfg)
+        sd = model.nerf_mlp.state_dict()
+        assert len(sd) == 2 * len(specs), (len(sd), len(specs))
+        true = canon[idx]
+        for sp in specs:
+            w = true[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim].reshape(sp.out_dim, sp.in_dim)
+            assert tuple(sd[sp.name + ".weight"].shape) == w.shape, sp
+            sd[sp.name + ".weight"].copy_(torch.tensor(w))
+            sd[sp.name + ".bias"].copy_(torch.tensor(true[sp.b_off:sp.b_off + sp.out_dim]))
+        r = to_rays(rays)
+        gt = synthetic.target_rgb(rays["origins"].shape[0], seed=2)
+        res = {}
+        if not train:
+            model.eval()
+            with torch.no_grad():
+                rend, hist = model(r, 1.0, True)
+        else:
+            model.train()
+            model.zero_grad()
+            rend, hist = model(r, 1.0, True)
+            batch = utils.Batch(rays=r, rgb=gt)
+            data_loss, _ = train_utils.compute_data_loss(batch, rend, r, cfg)
+            o_loss = train_utils.orientation_loss(r, model, hist, cfg)
+            loss = data_loss + o_loss
+            res["loss_data"], res["loss_orientation"] = data_loss.item(), o_loss.item()
+            if with_normal_loss:
+                n_loss = train_utils.predicted_normal_loss(model, hist, cfg)
+                loss = loss + n_loss
+                res["loss_normal"] = n_loss.item()
+            loss.backward()
+            res["loss_total"] = loss.item()
+            named = dict(model.nerf_mlp.named_parameters())
+            g = np.zeros(len(idx), np.float32)
+            for sp in specs:
+                g[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim] = named[sp.name + ".weight"].grad.numpy().reshape(-1)
+                g[sp.b_off:sp.b_off + sp.out_dim] = named[sp.name + ".bias"].grad.numpy()
+            res["grads_sub"] = g[::61].copy()
+            res["grads_tensor_l2"] = np.array([[np.linalg.norm(g[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim]),
+                                                np.linalg.norm(g[sp.b_off:sp.b_off + sp.out_dim])] for sp in specs])
+        for lvl, (rd, hs) in enumerate(zip(rend, hist)):
+            for k, v in rd.items():
+                res[f"L{lvl}_r_{k}"] = v.detach().numpy()
+            for k, v in hs.items():
+                if v is not None:
+                    res[f"L{lvl}_h_{k}"] = v.detach().numpy()
+        res["history_keys"] = np.array(sorted(k for k, v in hist[-1].items()))
+        res["rendering_keys"] = np.array(sorted(rend[-1].keys()))
+        res["bindings"] = np.array(bindings)
+        res["param_kw"] = np.array([pk["seed"], pk["bias_scale"], pk["sharpen"], 0.0])
+        for k, v in rays.items():
+            res["rays_" + k] = v
+        res["gt_rgb"] = gt
+        save(name, **res)
+        print(name, "history keys", list(res["history_keys"]), "rendering keys", list(res["rendering_keys"]))
+
+
 def golden_variants():
     """Which of the reference's shipped configs construct and run at all.
 
@@ -758,6 +837,6 @@ def golden_variants():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models"]
     for w in which:
         globals()["golden_" + w]()

@@ -55,3 +55,21 @@ TRAIN_CASES = [n for n in MODEL_CASES if n.endswith("train")]
 
 HIST_KEYS = ("sdist", "weights", "density", "rgb", "normals_pred", "roughness", "diffuse", "specular", "tint")
 REND_KEYS = ("rgb", "diffuse", "specular", "distance", "acc", "normals_pred", "tint", "roughness", "distance_mean")
+
+
+# ---- NerfMLP variants served by embedding (refnerf_pl_amd.layout.variant_layout) ------------------------------------
+VARIANT_CASES = ["model_variant_eval", "model_variant_train", "model_variant_nonormals_train"]
+VARIANT_KW = dict(net_width_viewdirs=128, use_n_dot_v=False, use_specular_tint=False, enable_pred_roughness=False)
+VARIANT_HIST_KEYS = ("sdist", "weights", "density", "rgb", "normals_pred", "diffuse", "specular")
+VARIANT_REND_KEYS = ("rgb", "diffuse", "specular", "distance", "acc", "normals_pred", "distance_mean")
+
+
+def variant_params(g):
+    """(canonical blob with the variant embedded, the variant's own flat blob, index): the fixture's weights are the
+    embedded elements of the synthetic canonical blob its param_kw names."""
+    from refnerf_pl_amd import layout
+    full = params_from_golden(g)
+    _, idx = layout.variant_layout(**VARIANT_KW)
+    canon = np.zeros_like(full)
+    canon[idx] = full[idx]
+    return canon, full[idx].copy(), idx

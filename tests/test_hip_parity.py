@@ -631,6 +631,84 @@ def test_model_training_step_autograd(hip):
     assert h3[0]["normals"] is None
 
 
+@pytest.mark.parametrize("name", ["model_variant_eval", "model_variant_train", "model_variant_nonormals_train"])
+@pytest.mark.parametrize("flat", [False, True])
+def test_nerfmlp_variants_vs_reference(hip, name, flat):
+    """the NerfMLP variants the reference runs and this build serves by embedding (net_width_viewdirs = 128,
+    no n.v input, no tint head, no roughness head; disable_density_normals) -- Model.__call__ with the reference's gin
+    bindings against the reference's own outputs, dict keys, losses and autograd gradients (tests/golden/model_variant_*)."""
+    import os
+    from helpers import VARIANT_HIST_KEYS, VARIANT_REND_KEYS, variant_params
+    from refnerf_pl_amd import configs, layout, models, train_utils, utils
+    g = load_golden(name)
+    train = name.endswith("train")
+    if flat and not train:
+        pytest.skip("flat gradients: training only")
+    _, true_blob, idx = variant_params(g)
+    bindings = [str(b) for b in g["bindings"]]
+    if "loss_normal" not in g.files:
+        bindings += ["Config.predicted_normal_loss_mult = 0.", "Config.predicted_normal_coarse_loss_mult = 0."]
+    if flat:
+        bindings += ["Config.hip_flat_grads = True"]
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")], bindings)
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV)
+    mlp = model.nerf_mlp
+    assert sorted(n for n, _ in mlp.named_parameters()) == sorted(
+        x for s in layout.variant_layout(128, False, False, False)[0] for x in (s.name + ".weight", s.name + ".bias"))
+    mlp.load_flat_params(true_blob)
+    rays = utils.rays_from_dict(rays_from_golden(g), DEV)
+    model.train(train)
+    with torch.set_grad_enabled(train):
+        renderings, history = model(rays, 1.0, True)
+    # the dicts carry exactly the reference's keys for these flags (models.py:735-748, 280-284)
+    assert sorted(history[-1].keys()) == [str(k) for k in g["history_keys"]]
+    assert sorted(renderings[-1].keys()) == [str(k) for k in g["rendering_keys"]]
+    for L in range(2):
+        for k in VARIANT_HIST_KEYS:
+            a = g[f"L{L}_h_{k}"]
+            tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 2e-6)
+            if L > 0 and k not in ("sdist", "weights"):
+                tol = max(tol, 5e-5)                   # level-1 sample positions differ by an ulp (DESIGN.md section 2)
+            np.testing.assert_allclose(history[L][k].detach().cpu().numpy().reshape(a.shape), a, rtol=0, atol=tol, err_msg=f"L{L} {k}")
+        for k in VARIANT_REND_KEYS:
+            a = g[f"L{L}_r_{k}"]
+            x = renderings[L][k].detach().cpu().numpy().reshape(a.shape)
+            tol = 5e-6 + (1e-6 / np.maximum(g[f"L{L}_r_acc"], 1e-6) if k == "distance_mean" else 0.0)
+            assert np.all(np.abs(x - a) <= tol), (L, k, np.abs(x - a).max())
+        assert np.abs(renderings[L]["rgb"].detach().cpu().numpy() - g[f"L{L}_r_rgb"]).max() <= 1e-4
+    if not train:
+        return
+    batch = utils.Batch(rays=rays, rgb=np.asarray(g["gt_rgb"], np.float32))
+    total, terms, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+    assert float(terms["data"].detach()) == pytest.approx(float(g["loss_data"]), rel=1e-5)
+    assert float(terms["orientation"].detach()) == pytest.approx(float(g["loss_orientation"]), rel=2e-4)
+    if "loss_normal" in g.files:
+        assert float(terms["predicted_normals"].detach()) == pytest.approx(float(g["loss_normal"]), rel=2e-4)
+    else:
+        assert "predicted_normals" not in terms and "normals" not in history[0]
+    assert float(total.detach()) == pytest.approx(float(g["loss_total"]), rel=1e-5)
+    total.backward()
+    if flat:
+        grads = mlp.flat_parameter().grad.cpu().numpy()
+    else:
+        grads = np.zeros(mlp.num_params, np.float32)
+        for spec, lin in mlp._named_linears():
+            assert lin.weight.grad is not None and tuple(lin.weight.grad.shape) == (spec.out_dim, spec.in_dim), spec.name
+            grads[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = lin.weight.grad.reshape(-1).cpu().numpy()
+            grads[spec.b_off:spec.b_off + spec.out_dim] = lin.bias.grad.cpu().numpy()
+    assert grads.shape == (len(idx),)
+    ref = g["grads_sub"]
+    assert np.linalg.norm(grads[::61] - ref) / np.linalg.norm(ref) < 2e-4
+    norms = g["grads_tensor_l2"]
+    for i, sp in enumerate(mlp.specs):
+        nw = sp.out_dim * sp.in_dim
+        assert np.linalg.norm(grads[sp.w_off:sp.w_off + nw]) == pytest.approx(norms[i, 0], rel=2e-3), sp.name
+    # the bf16 inference mode takes the same embedded image
+    configs.clear_config()
+
+
 @pytest.mark.parametrize("name,extra", [("model_blender_sharp_train", []),
                                         ("model_llff_linear_train", ["Config.orientation_loss_target = 'normals'"]),
                                         ("model_trained_train", ["Config.predicted_normal_loss_mult = 0.", "Config.predicted_normal_coarse_loss_mult = 0."])])

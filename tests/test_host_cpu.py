@@ -85,8 +85,8 @@ def test_flat_params_alias_and_roundtrip(cfg):
 
 
 def test_unsupported_configurations_raise(cfg):
-    with pytest.raises(ValueError, match="outside the fused Ref-NeRF family"):
-        models.MLP()                                        # reference defaults = mip-NeRF MLP
+    with pytest.raises(ValueError, match="the reference itself cannot run"):
+        models.MLP()                                        # reference defaults = mip-NeRF MLP (dead in the reference too)
     with pytest.raises(ValueError, match="Normals must be computed"):   # models.py:472-475
         models.MLP(use_reflections=True, enable_pred_normals=False, disable_density_normals=True)
     with pytest.raises(ValueError, match="Specular density is useless"):  # models.py:478-480
@@ -94,6 +94,60 @@ def test_unsupported_configurations_raise(cfg):
     with pytest.raises(ValueError, match="outside the fused"):
         models.Model(config=cfg, disable_integration=True)
     assert models.Model(config=cfg, dilation_bias=0.0025).dilation_bias == 0.0025      # built (host dilation)
+
+
+def test_variant_gate_matches_reference_status():
+    """what the reference itself survives (tests/golden/variants_status.json, captured by
+    make_golden.py `variants`) against this build's gate.  Both shipped mip-NeRF configs and the flag settings behind them
+    die inside the reference; of the single flags it does run, all but the two that change an encoding's width are served."""
+    import json
+    st = json.load(open(os.path.join(ROOT, "tests", "golden", "variants_status.json")))
+    assert st["configs"]["blender_mipnerf.gin"].startswith("KeyError: 'diffuse'")
+    assert st["configs"]["llff_mipnerf.gin"].startswith("KeyError: 'diffuse'")
+    assert all(v == "ok" for k, v in st["configs"].items() if "mipnerf" not in k)
+    not_built = {"NerfMLP.use_directional_enc = False", "NerfMLP.basis_shape = 'icosahedron'"}
+    ref_cfg = os.path.join(ROOT, "configs", "refnerf_blender.gin")
+    for flag, status in st["refnerf_with_flag"].items():
+        configs.clear_config()
+        configs.parse_config_files_and_bindings([ref_cfg], [flag])
+        if status != "ok":
+            with pytest.raises(ValueError, match="the reference itself cannot run"):
+                models.NerfMLP()
+        elif flag in not_built:
+            with pytest.raises(ValueError, match="outside the fused Ref-NeRF family"):
+                models.NerfMLP()
+        else:
+            mlp = models.NerfMLP()
+            name, val = flag.split(" = ")
+            assert str(getattr(mlp, name.split(".")[1])) == val
+    configs.clear_config()
+
+
+def test_variant_embedding_layout():
+    """layout.variant_layout: true shapes of the reference's modules, a one-to-one map into the canonical blob, zeros
+    elsewhere; the module exposes exactly the reference's parameter names."""
+    specs, idx = layout.variant_layout(128, False, False, False)
+    shapes = {s.name: (s.out_dim, s.in_dim) for s in specs}
+    assert "raw_tint" not in shapes and "raw_roughness" not in shapes
+    assert shapes["viewdir_mlp.0"] == (128, 200) and shapes["viewdir_mlp.5"] == (128, 328) and shapes["rgb"] == (3, 128)
+    assert shapes["spatial_net.5"] == (256, 352) and shapes["bottleneck"] == (128, 256)
+    assert len(set(idx.tolist())) == len(idx) == specs[-1].b_off + 3 and idx.max() < layout.NUM_PARAMS
+    assert layout.variant_layout()[1] is None
+    mlp = models.MLP(net_depth_viewdirs=8, net_width_viewdirs=128, bottleneck_width=128, max_deg_point=16, deg_view=5,
+                     use_reflections=True, use_directional_enc=True, enable_pred_roughness=False, use_diffuse_color=True,
+                     use_specular_tint=False, use_n_dot_v=False, enable_pred_normals=True, basis_shape="octahedron",
+                     basis_subdivisions=1)
+    names = [n for n, _ in mlp.named_parameters()]
+    assert "raw_tint.weight" not in names and "raw_roughness.weight" not in names
+    assert tuple(mlp.viewdir_mlp[5].weight.shape) == (128, 328)
+    blob = synthetic.make_params(seed=3)
+    mlp.load_flat_params(blob)                               # canonical blob in: the embedded elements are taken
+    canon = mlp.canonical_blob().numpy()
+    assert np.array_equal(canon[idx], blob[idx])
+    rest = np.ones(layout.NUM_PARAMS, bool)
+    rest[idx] = False
+    assert not canon[rest].any()
+    assert mlp.kernel_roughness_bias == layout.ROUGHNESS_OFF_BIAS
 
 
 def test_no_cpu_fallback(cfg):

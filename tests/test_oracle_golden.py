@@ -3,7 +3,8 @@ the upstream reference (tests/golden/make_golden.py).  SURVEY.md 8c."""
 import numpy as np
 import pytest
 
-from helpers import (HIST_KEYS, MODEL_CASES, REND_KEYS, TRAIN_CASES, cfg_from_bindings, load_golden,
+from helpers import (HIST_KEYS, MODEL_CASES, REND_KEYS, TRAIN_CASES, VARIANT_CASES, VARIANT_HIST_KEYS, VARIANT_REND_KEYS,
+                     cfg_from_bindings, load_golden, variant_params,
                      params_from_golden, rays_from_golden)
 from oracle import oracle as O
 
@@ -243,6 +244,66 @@ def test_training_step_losses_and_gradients(name):
         assert np.linalg.norm(grads[s.w_off:s.w_off + n]) == pytest.approx(norms[i, 0], rel=trel), s.name
         assert np.linalg.norm(grads[s.b_off:s.b_off + s.out_dim]) == pytest.approx(norms[i, 1], rel=trel), s.name
         assert norms[i, 0] > 0
+
+
+@pytest.mark.parametrize("name", VARIANT_CASES)
+def test_variant_embedding_matches_reference(name):
+    """a NerfMLP with net_width_viewdirs = 128 and without n.v / tint / roughness heads, as the reference
+    builds it, against the Ref-NeRF network holding the SAME weights embedded in zeros and run with roughness_bias =
+    ROUGHNESS_OFF_BIAS (layout.variant_layout) -- the embedding is what the HIP path ships for these flags, so this pins
+    it to the reference's own outputs, losses and autograd gradients."""
+    from refnerf_pl_amd import layout
+    g = load_golden(name)
+    canon, _, idx = variant_params(g)
+    kw, lv = cfg_from_bindings(g["bindings"])
+    kw["roughness_bias"] = layout.ROUGHNESS_OFF_BIAS
+    train = name.endswith("train")
+    outs = O.model_forward(canon, rays_from_golden(g), training=int(train), **lv, **kw)
+    for L, res in enumerate(outs):
+        assert not res["roughness"].any()                       # softplus(-1e30) = 0 exactly
+        assert np.all(res["tint"] == 0.5)                       # sigmoid(0) exactly: specular = 0.5 rgb
+        for k in VARIANT_HIST_KEYS:
+            a = g[f"L{L}_h_{k}"].reshape(res[k].shape)
+            tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 2e-6)
+            np.testing.assert_allclose(res[k], a, rtol=0, atol=tol, err_msg=f"L{L} {k}")
+        for k in VARIANT_REND_KEYS:
+            a = g[f"L{L}_r_{k}"].reshape(res["r_" + k].shape)
+            if k == "distance_mean":                            # a ratio of two sums ~acc: round-off scales with 1 / acc
+                assert np.all(np.abs(res["r_" + k] - a) <= 5e-6 + 1e-6 / np.maximum(res["r_acc"], 1e-6)), (L, k)
+                continue
+            np.testing.assert_allclose(res["r_" + k], a, rtol=0, atol=5e-6, err_msg=f"L{L} r_{k}")
+        assert np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max() <= 1e-4
+    if not train:
+        return
+    has_normals = "loss_normal" in g.files
+    losses, grads, _ = O.model_train(canon, rays_from_golden(g), g["gt_rgb"], **lv, **kw,
+                                     **({} if has_normals else {"normal_mults": (0.0, 0.0)}))
+    assert losses["data"] == pytest.approx(float(g["loss_data"]), rel=2e-6)
+    assert losses["orientation"] == pytest.approx(float(g["loss_orientation"]), rel=2e-4)
+    if has_normals:
+        assert losses["normal"] == pytest.approx(float(g["loss_normal"]), rel=2e-4)
+    assert losses["total"] == pytest.approx(float(g["loss_total"]), rel=2e-6)
+    mine = grads[idx]                                           # the variant's elements of the canonical gradient
+    ref = g["grads_sub"]
+    rel = np.linalg.norm(mine[::61] - ref) / np.linalg.norm(ref)
+    assert rel < 1e-4, rel
+    specs, _ = layout.variant_layout(net_width_viewdirs=128, use_n_dot_v=False, use_specular_tint=False, enable_pred_roughness=False)
+    norms = g["grads_tensor_l2"]
+    for i, s in enumerate(specs):
+        n = s.out_dim * s.in_dim
+        assert np.linalg.norm(mine[s.w_off:s.w_off + n]) == pytest.approx(norms[i, 0], rel=2e-3), s.name
+        assert np.linalg.norm(mine[s.b_off:s.b_off + s.out_dim]) == pytest.approx(norms[i, 1], rel=2e-3), s.name
+    # what the embedding adds stays inert: the dead units and the absent heads / columns receive exactly zero gradient
+    # except the two head rows whose INPUT is live (raw_tint: d specular / d tint != 0; raw_roughness: sigmoid(-1e30) = 0)
+    rest = np.ones(layout.NUM_PARAMS, bool)
+    rest[idx] = False
+    tint = layout.SPEC_BY_NAME["raw_tint"]
+    rest[tint.w_off:tint.b_off + tint.out_dim] = False
+    vd = [layout.SPEC_BY_NAME[f"viewdir_mlp.{i}"] for i in range(8)]
+    for s in vd:                                               # dead units' OUTGOING columns see zero activations: zero
+        w = grads[s.w_off:s.w_off + s.out_dim * s.in_dim].reshape(s.out_dim, s.in_dim)
+        assert not w[128:, :].any(), s.name                    # dead rows: relu'(0) = 0
+    assert not grads[layout.SPEC_BY_NAME["raw_roughness"].w_off:layout.SPEC_BY_NAME["raw_roughness"].b_off + 1].any()
 
 
 @pytest.mark.parametrize("tag,spec", [("blender", (800, 800, 1111.111, None)), ("llff", (1008, 756, 815.0, 1.0))])
