@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 5   /* v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
+#define REFNERF_ABI_VERSION 6   /* v6: cfg.dir_enc (REFNERF_DIRENC_*); v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {
@@ -62,6 +62,14 @@ enum {
  * mask words are 32-bit in both */
 enum { REFNERF_ACT_F32 = 0, REFNERF_ACT_BF16 = 1 };
 
+/* encoding of the (reflected) direction fed to the directional MLP (internal/models.py:484-492) */
+enum {
+  REFNERF_DIRENC_IDE = 0,    /* MLP.use_directional_enc = True: ref_utils.generate_ide_fn(5), 72 features                 */
+  REFNERF_DIRENC_POSENC = 1  /* False: coord.pos_enc(d, 0, 5, append_identity) (coord.py:136-147), its 33 features in the
+                                slots [x y z | sin(2^j d_i) j-major | 0 x18 || sin(2^j d_i + pi/2) | 0 x21] of the same 72-wide
+                                block (the caller embeds the [.., 33] weight columns there; the roughness is not used)   */
+};
+
 enum { REFNERF_SRGB_NONE = 0, REFNERF_SRGB_LINEAR = 1, REFNERF_SRGB_NORM_LINEAR = 2,
        REFNERF_SRGB_SRGB = 3, REFNERF_SRGB_NORM_SRGB = 4 };
 
@@ -79,6 +87,7 @@ typedef struct refnerf_level_cfg {
   int32_t ray_shape;          /* 0 'cone', 1 'cylinder' (render.py:121-126)                */
   int32_t precision;          /* REFNERF_PREC_*                                            */
   int32_t wgrad_mode;         /* REFNERF_WGRAD_*: arithmetic of the weight-gradient GEMM (backward only) */
+  int32_t dir_enc;            /* REFNERF_DIRENC_*: MLP.use_directional_enc (:484-492)      */
   float anneal;               /* models.py:190-195                                         */
   float resample_padding;     /* Model.resample_padding (:202)                             */
   float s_near, s_far;        /* Model.init_s_near / init_s_far (:213)                     */

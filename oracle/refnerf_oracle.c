@@ -317,6 +317,34 @@ void rn_ide_tables(float *c, float *a, float *b) {
     }
   }
 }
+/* coord.pos_enc(direction, min_deg = 0, max_deg = 5, append_identity = True) (internal/coord.py:136-147, the
+ * `use_directional_enc = False` branch of internal/models.py:487-492) written into the 72 slots of the directional
+ * encoding: [x y z | sin(2^j x_i), j-major (15) | 0 x18 || sin(2^j x_i + pi/2) (15) | 0 x21].  The weight columns of the 33
+ * features are embedded at those slots (refnerf_pl_amd.layout.variant_layout); fewer degrees use a prefix of each block. */
+#define RN_POSENC_DEG 5
+void rn_posenc_slots_f32(const float *xyz, float *out) {
+  for (int q = 0; q < RN_IDE_DIM; ++q) out[q] = 0.0f;
+  const float half_pi = (float)(0.5 * 3.14159265358979323846);
+  for (int i = 0; i < 3; ++i) out[i] = xyz[i];
+  for (int j = 0; j < RN_POSENC_DEG; ++j)
+    for (int i = 0; i < 3; ++i) {
+      float sx = xyz[i] * (float)(1 << j);
+      out[3 + 3 * j + i] = sinf(sx);
+      out[RN_IDE_DIM / 2 + 3 * j + i] = sinf(sx + half_pi);
+    }
+}
+static void posenc_slots_grad(const float *xyz, const float *g_out, float *g_xyz) {
+  const float half_pi = (float)(0.5 * 3.14159265358979323846);
+  for (int i = 0; i < 3; ++i) {
+    float g = g_out[i];
+    for (int j = 0; j < RN_POSENC_DEG; ++j) {
+      float sc = (float)(1 << j), sx = xyz[i] * sc;
+      g += sc * (cosf(sx) * g_out[3 + 3 * j + i] + cosf(sx + half_pi) * g_out[RN_IDE_DIM / 2 + 3 * j + i]);
+    }
+    g_xyz[i] = g;
+  }
+}
+
 static int ide_term_index(int l, int m) { /* position of (l,m) in the 36-list */
   int base = 0;
   for (int li = 0; li < 5; ++li) { if (IDE_L[li] == l) return base + m; base += IDE_L[li] + 1; }
@@ -520,6 +548,7 @@ static void mlp_block(const rn_model *M, const rn_level_cfg *cfg, const float *l
     float *din = x[s] + RN_WIDTH;                 /* [bottleneck | ide | n.v] (:686) */
     memcpy(din, bneck[s], sizeof(bneck[s]));
     if (cfg->ide_mode == 1) rn_ide_ref_f32(refdir, rough, din + RN_BNECK);
+    else if (cfg->ide_mode == 2) rn_posenc_slots_f32(refdir, din + RN_BNECK);    /* :487-492: pos_enc, roughness unused */
     else rn_ide_stable_f32(refdir, rough, din + RN_BNECK);                        /* :665 */
     din[RN_DIR_IN - 1] = (np_[0] * v[0] + np_[1] * v[1]) + np_[2] * v[2];        /* :679-683 */
     /* raw diffuse is parked in `out` until the colour head below */
@@ -865,7 +894,8 @@ static void mlp_forward_cached(const rn_model *M, const rn_level_cfg *cfg, const
   float dot = (c->npred[0] * w[0] + c->npred[1] * w[1]) + c->npred[2] * w[2];
   for (int i = 0; i < 3; ++i) c->refdir[i] = (2.0f * dot) * c->npred[i] - w[i];
   memcpy(c->din, bneck, sizeof(bneck));
-  rn_ide_stable_f32(c->refdir, c->rough, c->din + RN_BNECK);
+  if (cfg->ide_mode == 2) rn_posenc_slots_f32(c->refdir, c->din + RN_BNECK);
+  else rn_ide_stable_f32(c->refdir, c->rough, c->din + RN_BNECK);
   c->din[RN_DIR_IN - 1] = (c->npred[0] * v[0] + c->npred[1] * v[1]) + c->npred[2] * v[2];
   memcpy(x, c->din, sizeof(c->din));
   for (int i = 0; i < RN_DEPTH; ++i) {
@@ -973,7 +1003,8 @@ static void mlp_backward_x(const rn_model *M, const rn_level_cfg *cfg, const rn_
   }
   /* ---- encodings / reflection (models.py:657-686) ---- */
   float g_ref[3], g_rough, g_np[3];
-  ide_stable_grad(c->refdir, c->rough, g_din + RN_BNECK, g_ref, &g_rough);
+  if (cfg->ide_mode == 2) { posenc_slots_grad(c->refdir, g_din + RN_BNECK, g_ref); g_rough = 0.0f; }
+  else ide_stable_grad(c->refdir, c->rough, g_din + RN_BNECK, g_ref, &g_rough);
   float g_dot = g_din[RN_DIR_IN - 1];
   float w[3] = {-v[0], -v[1], -v[2]};
   float ndw = (c->npred[0] * w[0] + c->npred[1] * w[1]) + c->npred[2] * w[2];

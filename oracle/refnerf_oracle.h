@@ -66,7 +66,8 @@ typedef struct rn_level_cfg {
   int32_t render_srgb_mode;   /* RN_SRGB_* (render.py:186-216)                */
   int32_t opaque_background;
   int32_t ray_shape;          /* 0 cone, 1 cylinder (render.py:121-126)       */
-  int32_t ide_mode;           /* 0 stable recurrence, 1 reference-order fp32  */
+  int32_t ide_mode;           /* 0 IDE, stable recurrence; 1 IDE, reference-order fp32; 2 coord.pos_enc of the direction
+                                 (use_directional_enc = False) in the IDE's slots */
   float anneal;               /* models.py:190-195 (1.0 in shipped configs)   */
   float resample_padding;
   float s_near, s_far;        /* Model.init_s_near / init_s_far               */

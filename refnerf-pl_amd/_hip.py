@@ -15,8 +15,9 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
 
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-ABI_VERSION = 5   # REFNERF_ABI_VERSION
+ABI_VERSION = 6   # REFNERF_ABI_VERSION
 WGRAD_F32, WGRAD_BF16X3 = 0, 1
+DIRENC_IDE, DIRENC_POSENC = 0, 1   # REFNERF_DIRENC_*
 SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 4}
 
 _FP = C.c_void_p
@@ -27,7 +28,7 @@ class LevelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_samples", "n_in", "training", "compute_extras", "srgb_mapping",
         "srgb_mapping_normalization", "render_srgb_mode", "opaque_background",
-        "ray_shape", "precision", "wgrad_mode")] + [(n, C.c_float) for n in (
+        "ray_shape", "precision", "wgrad_mode", "dir_enc")] + [(n, C.c_float) for n in (
             "anneal", "resample_padding", "s_near", "s_far", "density_bias",
             "roughness_bias", "rgb_premultiplier", "rgb_bias", "rgb_padding", "bg_rgb")]
 

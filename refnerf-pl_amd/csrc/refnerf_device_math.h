@@ -167,6 +167,42 @@ __device__ __forceinline__ void ide_eval(float x, float y, float z, float kappa_
   }
 }
 
+/* coord.pos_enc(d, 0, 5, append_identity = True) (coord.py:136-147; MLP.use_directional_enc = False, models.py:487-492) with
+ * the calling convention of ide_eval: part 0 emits slots 0..35 = [x y z | sin(2^j d_i), j-major (15) | 0 x18], part 1 slots
+ * 0..35 of the second half = [sin(2^j d_i + pi/2) (15) | 0 x21] (as the reference: a sine of the shifted argument). */
+template <bool FAST = false, typename Emit>
+__device__ __forceinline__ void posenc_eval(float x, float y, float z, int part, Emit emit) {
+  const float d[3] = {x, y, z};
+  const float half_pi = (float)(0.5 * 3.14159265358979323846);
+#pragma unroll
+  for (int q = 0; q < IDE_TERMS; ++q) {
+    float v = 0.0f;
+    if (q < 3 && part == 0) v = d[q];
+    const int k = part ? q : q - 3;                        /* 3 j + i inside the sin / shifted-sin block */
+    if (k >= 0 && k < 15) {
+      const float sx = d[k % 3] * (float)(1 << (k / 3)) + (part ? half_pi : 0.0f);
+      v = FAST ? __builtin_amdgcn_sinf(sx * (float)(0.5 / 3.14159265358979323846)) : sinf(sx);
+    }
+    emit(q, v);
+  }
+}
+/* its gradient w.r.t. d; g(q) = upstream gradient of slot q (0..35 first half, 36..71 second half) */
+template <typename G>
+__device__ __forceinline__ void posenc_grad(float x, float y, float z, G g, float (&gxyz)[3]) {
+  const float d[3] = {x, y, z};
+  const float half_pi = (float)(0.5 * 3.14159265358979323846);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float acc = g(i);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const float sc = (float)(1 << j), sx = d[i] * sc;
+      acc += sc * (cosf(sx) * g(3 + 3 * j + i) + cosf(sx + half_pi) * g(IDE_TERMS + 3 * j + i));
+    }
+    gxyz[i] = acc;
+  }
+}
+
 /* ---- derivatives used by the backward kernel ---- */
 __device__ __forceinline__ float softplus_grad(float x) { return x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x)); }
 /* d linear_to_srgb / du (image.py:51-59) */

@@ -389,7 +389,8 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
         float ide[40];
 #pragma unroll
         for (int q = 36; q < 40; ++q) ide[q] = 0.0f;
-        ide_eval<ENC_FAST>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { ide[q] = val; });
+        if (cfg.dir_enc == REFNERF_DIRENC_POSENC) posenc_eval<ENC_FAST>(sh.refd[0], sh.refd[1], sh.refd[2], h, [&](int q, float val) { ide[q] = val; });
+        else ide_eval<ENC_FAST>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { ide[q] = val; });
         if (h == 0) ide[36] = sh.dot;
 #pragma unroll
         for (int q = 0; q < 5; ++q) {

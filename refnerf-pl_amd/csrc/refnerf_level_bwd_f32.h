@@ -454,7 +454,9 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     {
       float g_ref[3], g_rough;
       const int xhi = tile_hi(col);              /* rows >= 128 of the tile through one laundered base (tile_idx) */
-      ide_grad(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, [&](int q) { return X[tile_idx(BNECK + q, col, xhi)]; }, g_ref, g_rough);
+      auto gq = [&](int q) { return X[tile_idx(BNECK + q, col, xhi)]; };
+      if (cfg.dir_enc == REFNERF_DIRENC_POSENC) { posenc_grad(sh.refd[0], sh.refd[1], sh.refd[2], gq, g_ref); g_rough = 0.0f; }   /* coord.pos_enc: no roughness */
+      else ide_grad(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, gq, g_ref, g_rough);
       const float g_dot = X[tile_idx(BNECK + IDE_DIM, col, xhi)];
       const float w3[3] = {-v[0], -v[1], -v[2]};
       const float ndw = (sh.npred[0] * w3[0] + sh.npred[1] * w3[1]) + sh.npred[2] * w3[2];

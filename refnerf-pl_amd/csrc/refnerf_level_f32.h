@@ -863,10 +863,12 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       sample_heads(cfg, X[hdb + 0 * T_TILE], gp, X[hdb + 4 * T_TILE], raw_dif, raw_tint, v, sh);
       const int xhi = tile_hi(col);
       float *xi = X + xhi + IDE_TERMS * h * T_TILE;   /* row BNECK (= 128) + 36 h */
-      ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) {
+      auto put = [&](int q, float val) {
         xi[q * T_TILE] = val;
         if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, rpitch, ACT_DIN + BNECK + IDE_TERMS * h + q, rcol, val); }
-      });
+      };
+      if (cfg.dir_enc == REFNERF_DIRENC_POSENC) posenc_eval(sh.refd[0], sh.refd[1], sh.refd[2], h, put);   /* models.py:487-492 */
+      else ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, put);
       if (h == 0) {
         X[tile_idx(BNECK + IDE_DIM, col, xhi)] = sh.dot;
         if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, rpitch, ACT_DIN + BNECK + IDE_DIM, rcol, sh.dot); }

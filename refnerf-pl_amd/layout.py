@@ -64,12 +64,28 @@ SPEC_BY_NAME = {s.name: s for s in PARAM_SPECS}
 #                                    specular = 0.5 rgb (internal/models.py:708-709)
 #   enable_pred_roughness = False    raw_roughness absent: zero weights, and the level runs with roughness_bias = -inf-ish
 #                                    (ROUGHNESS_OFF_BIAS): softplus -> exactly 0, the IDE at zero roughness (models.py:636-641)
+#   use_directional_enc = False      coord.pos_enc of the reflected direction (models.py:487-492): the kernels compute it
+#                                    INTO the IDE's 72 slots (cfg.dir_enc = REFNERF_DIRENC_POSENC), its 3 + 6 deg_view weight
+#                                    columns sit at posenc_slots()
 # The module keeps the reference's parameter names and TRUE shapes (checkpoints load unchanged); `variant_layout` gives the
 # true-shape spec list and, for every true parameter element, its position in the canonical blob.
 ROUGHNESS_OFF_BIAS = -1.0e30
 
 
-def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint=True, enable_pred_roughness=True):
+POSENC_MAX_DEG = 5   # degrees of coord.pos_enc the directional slots hold (3 + 15 + 15 features)
+
+
+def posenc_slots(deg_view):
+    """Slot (0..71, relative to the bottleneck's end) of every feature of coord.pos_enc(d, 0, deg_view, append_identity=True)
+    in the kernels' directional encoding block: [x y z | sin(2^j x_i) (j-major) | 0.. || sin(2^j x_i + pi/2) | 0..]."""
+    if not 1 <= int(deg_view) <= POSENC_MAX_DEG:
+        raise ValueError(f"pos_enc view encoding: deg_view must be in [1, {POSENC_MAX_DEG}] for the fused kernels")
+    n = 3 * int(deg_view)
+    return list(range(3)) + [3 + k for k in range(n)] + [IDE_DIM // 2 + k for k in range(n)]
+
+
+def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint=True, enable_pred_roughness=True,
+                   use_directional_enc=True, deg_view=5):
     """-> (specs, index): `specs` = ParamSpec list of the variant (true shapes, offsets into ITS flat blob, state_dict
     order), `index` = int64 numpy array, index[i] = canonical-blob position of element i of the variant's flat blob; or
     (PARAM_SPECS, None) for the Ref-NeRF network itself."""
@@ -77,9 +93,10 @@ def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint
     wv = int(net_width_viewdirs)
     if not 1 <= wv <= WIDTH:
         raise ValueError(f"net_width_viewdirs must be in [1, {WIDTH}] for the fused kernels, got {wv}")
-    if wv == WIDTH and use_n_dot_v and use_specular_tint and enable_pred_roughness:
+    if wv == WIDTH and use_n_dot_v and use_specular_tint and enable_pred_roughness and use_directional_enc:
         return PARAM_SPECS, None
-    din_cols = list(range(BNECK + IDE_DIM)) + ([BNECK + IDE_DIM] if use_n_dot_v else [])
+    enc_cols = list(range(IDE_DIM)) if use_directional_enc else posenc_slots(deg_view)
+    din_cols = list(range(BNECK)) + [BNECK + k for k in enc_cols] + ([BNECK + IDE_DIM] if use_n_dot_v else [])
     specs, idx, p = [], [], 0
     for c in PARAM_SPECS:
         if c.name == "raw_tint" and not use_specular_tint:

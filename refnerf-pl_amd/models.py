@@ -102,7 +102,7 @@ class MLP(nn.Module):
         # the variants the reference runs and the fused kernels serve by embedding (layout.variant_layout): same module
         # names and TRUE shapes as the reference gives them (models.py:509-531)
         self.specs, idx = layout.variant_layout(self.net_width_viewdirs, self.use_n_dot_v, self.use_specular_tint,
-                                                self.enable_pred_roughness)
+                                                self.enable_pred_roughness, self.use_directional_enc, self.deg_view)
         self.num_params = self.specs[-1].b_off + self.specs[-1].out_dim
         self._embed_index_np = idx                 # None: the parameters ARE the canonical blob
         self._embed_index = None
@@ -114,7 +114,8 @@ class MLP(nn.Module):
             self.raw_tint = _linear(W, 3)
         self.bottleneck = _linear(W, self.bottleneck_width)
         Wv = self.net_width_viewdirs
-        din = layout.BNECK + layout.IDE_DIM + (1 if self.use_n_dot_v else 0)
+        enc = layout.IDE_DIM if self.use_directional_enc else 3 + 6 * self.deg_view      # IDE / coord.pos_enc (models.py:484-492)
+        din = layout.BNECK + enc + (1 if self.use_n_dot_v else 0)
         vd_in = [din if i == 0 else (Wv + din if i == self.skip_layer + 1 else Wv)
                  for i in range(self.net_depth_viewdirs)]
         self.viewdir_mlp = nn.ModuleList([_linear(vd_in[i], Wv) for i in range(self.net_depth_viewdirs)])
@@ -141,17 +142,19 @@ class MLP(nn.Module):
             raise ValueError(f"MLP flags the reference itself cannot run (so there is nothing to match): {dead}")
         want = dict(net_depth=8, net_width=256, bottleneck_width=128, net_depth_viewdirs=8,
                     min_deg_point=0, max_deg_point=16, skip_layer=4,
-                    num_rgb_channels=3, deg_view=5, use_directional_enc=True,
+                    num_rgb_channels=3,
                     enable_pred_specular_density=False, bottleneck_noise=0.0,
                     density_noise=0., disable_rgb=False, warp_fn=None, basis_shape='octahedron', basis_subdivisions=1)
         bad = {k: getattr(self, k) for k, v in want.items() if getattr(self, k) != v}
         if not 1 <= int(self.net_width_viewdirs) <= layout.WIDTH:
             bad["net_width_viewdirs"] = self.net_width_viewdirs
+        if (self.use_directional_enc and self.deg_view != 5) or not 1 <= int(self.deg_view) <= layout.POSENC_MAX_DEG:
+            bad["deg_view"] = self.deg_view            # the IDE table is built for degree 5, pos_enc has slots for <= 5
         if bad:
             raise ValueError(
                 "MLP configuration outside the fused Ref-NeRF family (configs/*refnerf*.gin; served variants: "
                 "net_width_viewdirs <= 256, use_n_dot_v / use_specular_tint / enable_pred_roughness / "
-                f"disable_density_normals either way): {bad}; expected {({k: want.get(k, '<= 256') for k in bad})}")
+                f"use_directional_enc / disable_density_normals either way): {bad}; expected {({k: want.get(k, '<= 256') for k in bad})}")
         if self.net_activation is not torch.nn.functional.relu:
             raise ValueError("net_activation must be relu")
         if self.density_activation is not torch.nn.functional.softplus or \
@@ -232,6 +235,10 @@ class MLP(nn.Module):
         return self._canon
 
     @property
+    def kernel_dir_enc(self) -> int:
+        return _hip.DIRENC_IDE if self.use_directional_enc else _hip.DIRENC_POSENC
+
+    @property
     def kernel_roughness_bias(self) -> float:
         """roughness_bias the level runs with: without a roughness head the raw value is 0 and this bias drives the
         softplus to exactly 0 (internal/models.py:636: roughness = 0)."""
@@ -296,7 +303,7 @@ class MLP(nn.Module):
         cfg = _hip.default_cfg(
             n_samples=int(n), n_in=1, training=int(self.training), compute_extras=0,
             srgb_mapping=int(self.srgb_mapping), srgb_mapping_normalization=int(self.srgb_mapping_normalization),
-            precision=_PREC["f32"], density_bias=float(self.density_bias), roughness_bias=self.kernel_roughness_bias,
+            precision=_PREC["f32"], dir_enc=self.kernel_dir_enc, density_bias=float(self.density_bias), roughness_bias=self.kernel_roughness_bias,
             rgb_premultiplier=float(self.rgb_premultiplier), rgb_bias=float(self.rgb_bias),
             rgb_padding=float(self.rgb_padding))
         res = _hip.mlp_forward(self.packed_weights(cfg.precision), cfg, m, c, v)
@@ -559,7 +566,7 @@ class Model(nn.Module):
             opaque_background=int(self.opaque_background), ray_shape=0 if self.ray_shape == 'cone' else 1,
             precision=_PREC[getattr(cfg, "hip_train_precision", "f32")] if self.training else _PREC[prec], wgrad_mode=wgrad, anneal=float(anneal), resample_padding=float(self.resample_padding),
             s_near=float(self.init_s_near), s_far=float(self.init_s_far), density_bias=float(mlp.density_bias),
-            roughness_bias=mlp.kernel_roughness_bias, rgb_premultiplier=float(mlp.rgb_premultiplier),
+            dir_enc=mlp.kernel_dir_enc, roughness_bias=mlp.kernel_roughness_bias, rgb_premultiplier=float(mlp.rgb_premultiplier),
             rgb_bias=float(mlp.rgb_bias), rgb_padding=float(mlp.rgb_padding), bg_rgb=float(bg))
 
     def __call__(self, rays, train_frac, compute_extras):

@@ -788,6 +788,67 @@ def golden_variant_models():
         print(name, "history keys", list(res["history_keys"]), "rendering keys", list(res["rendering_keys"]))
 
 
+def golden_posenc_models():
+    """`NerfMLP.use_directional_enc = False`: coord.pos_enc of the reflected direction instead of the IDE (models.py:487-492),
+    otherwise the Ref-NeRF config -- eval and one training step, gradients in the variant's own flat order."""
+    pk = dict(seed=6, bias_scale=0.05, sharpen=20.0)
+    canon = synthetic.make_params(**pk)
+    flags = ["NerfMLP.use_directional_enc = False"]
+    specs, idx = layout.variant_layout(use_directional_enc=False, deg_view=5)
+    small = ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 96"]
+    cases = {"model_posenc_eval": (flags, synthetic.blender_rays(16, seed=61, center_frac=0.4), False),
+             "model_posenc_train": (flags + small, synthetic.blender_rays(12, seed=62, center_frac=0.4), True)}
+    for name, (bindings, rays, train) in cases.items():
+        gin.clear_config()
+        gin.parse_config_files_and_bindings([REF_CFG], list(bindings))
+        cfg = configs.Config()
+        model = models.construct_model(utils.dummy_rays(), cfg)
+        sd = model.nerf_mlp.state_dict()
+        true = canon[idx]
+        for sp in specs:
+            w = true[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim].reshape(sp.out_dim, sp.in_dim)
+            assert tuple(sd[sp.name + ".weight"].shape) == w.shape, (sp, tuple(sd[sp.name + ".weight"].shape))
+            sd[sp.name + ".weight"].copy_(torch.tensor(w))
+            sd[sp.name + ".bias"].copy_(torch.tensor(true[sp.b_off:sp.b_off + sp.out_dim]))
+        gt = synthetic.target_rgb(rays["origins"].shape[0], seed=2)
+        res = run_model(model, cfg, rays, False, gt) if not train else None
+        if train:
+            r = to_rays(rays)
+            model.train()
+            model.zero_grad()
+            rend, hist = model(r, 1.0, True)
+            batch = utils.Batch(rays=r, rgb=gt)
+            data_loss, _ = train_utils.compute_data_loss(batch, rend, r, cfg)
+            o_loss = train_utils.orientation_loss(r, model, hist, cfg)
+            n_loss = train_utils.predicted_normal_loss(model, hist, cfg)
+            loss = data_loss + o_loss + n_loss
+            loss.backward()
+            res = {"loss_data": data_loss.item(), "loss_orientation": o_loss.item(), "loss_normal": n_loss.item(), "loss_total": loss.item()}
+            named = dict(model.nerf_mlp.named_parameters())
+            g = np.zeros(len(idx), np.float32)
+            for sp in specs:
+                if named[sp.name + ".weight"].grad is None:      # raw_roughness: pos_enc ignores the roughness (no gradient)
+                    assert sp.name == "raw_roughness", sp.name
+                    continue
+                g[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim] = named[sp.name + ".weight"].grad.numpy().reshape(-1)
+                g[sp.b_off:sp.b_off + sp.out_dim] = named[sp.name + ".bias"].grad.numpy()
+            res["grads_sub"] = g[::61].copy()
+            res["grads_tensor_l2"] = np.array([[np.linalg.norm(g[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim]),
+                                                np.linalg.norm(g[sp.b_off:sp.b_off + sp.out_dim])] for sp in specs])
+            for lvl, (rd, hs) in enumerate(zip(rend, hist)):
+                for k, v in rd.items():
+                    res[f"L{lvl}_r_{k}"] = v.detach().numpy()
+                for k, v in hs.items():
+                    if v is not None:
+                        res[f"L{lvl}_h_{k}"] = v.detach().numpy()
+        res["bindings"] = np.array(bindings)
+        res["param_kw"] = np.array([pk["seed"], pk["bias_scale"], pk["sharpen"], 0.0])
+        for k, v in rays.items():
+            res["rays_" + k] = v
+        res["gt_rgb"] = gt
+        save(name, **res)
+
+
 def golden_variants():
     """Which of the reference's shipped configs construct and run at all.
 
@@ -837,6 +898,6 @@ def golden_variants():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models", "posenc_models"]
     for w in which:
         globals()["golden_" + w]()

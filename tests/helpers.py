@@ -73,3 +73,16 @@ def variant_params(g):
     canon = np.zeros_like(full)
     canon[idx] = full[idx]
     return canon, full[idx].copy(), idx
+
+
+POSENC_CASES = ["model_posenc_eval", "model_posenc_train"]
+
+
+def posenc_params(g):
+    """as variant_params, for `use_directional_enc = False` (deg_view 5, everything else Ref-NeRF)"""
+    from refnerf_pl_amd import layout
+    full = params_from_golden(g)
+    _, idx = layout.variant_layout(use_directional_enc=False, deg_view=5)
+    canon = np.zeros_like(full)
+    canon[idx] = full[idx]
+    return canon, full[idx].copy(), idx
