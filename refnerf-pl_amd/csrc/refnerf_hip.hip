@@ -586,18 +586,30 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   const int N = cfg->n_samples;
   const bool bf = (cfg->precision == REFNERF_PREC_BF16 && !train_bf) || cfg->precision == REFNERF_PREC_F16;     /* the LDS-ring 16-bit eval kernel */
   int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
+  /* 16-bit inference, rays that do not tile the 256-sample pass within 640 samples (N = 192: 2 rays = one and a half
+   * passes): take the smallest ray count that does (N = 192: 4 rays = three full passes) with the per-sample records in a
+   * ring (level_fwd_*_ring composites every ray behind the pass that completes it) -- if a ray plus a pass fit the ring,
+   * there are still at least two workgroups per CU, and the per-ray arrays fit */
+  bool ps_ring = false;
+  if (bf && N <= rn::BF_PS_RING - rn::BT && (rpw * N) % rn::BT != 0) {
+    int r = 1;
+    while (r <= rn::BF_NW && (r * N) % rn::BT != 0) ++r;
+    if (r <= rn::BF_NW && r * N > 640 && R / r >= 512) { rpw = r; ps_ring = true; }
+  }
   auto lds_bytes = [&](int rays) -> size_t {
     const int np = bf ? rn::NPS_EVAL : rn::NPS_TRAIN, tile = bf ? rn::BT : rn::T_TILE;
-    const size_t per_wg = sizeof(float) * (size_t)(2 * rays * (N + 1) + np * rays * N + 3 * tile + 8 + 12 * rays);
+    const int ps_rows = ps_ring ? rn::BF_PS_RING : rays * N;
+    const size_t per_wg = sizeof(float) * (size_t)(2 * rays * (N + 1) + np * ps_rows + 3 * tile + 8 + 12 * rays);
     if (bf) return (size_t)rn::BF_RING_BYTES + rn::BF_X_BYTES + sizeof(float) * rn::HD_ROWS * rn::BT + per_wg;
     return sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE) + per_wg;
   };
+  if (ps_ring && lds_bytes(rpw) + (size_t)rt().lds_pad > 160 * 1024) { ps_ring = false; rpw = rays_per_wg(N, rn::BT); }
   /* bf16: the per-ray phases (resample, compositing) occupy one wave per ray, so take as many rays per
    * workgroup as the LDS holds (up to one per wave): the other waves idle for a shorter share of the pass */
-  if (bf) while (2 * rpw <= rn::BF_NW && 2 * rpw * N <= 640 && lds_bytes(2 * rpw) <= 160 * 1024 &&
+  if (bf && !ps_ring) while (2 * rpw <= rn::BF_NW && 2 * rpw * N <= 640 && lds_bytes(2 * rpw) <= 160 * 1024 &&
                  R / (2 * rpw) >= 512)        /* ... but keep at least two workgroups per CU in flight */
     rpw *= 2;
-  if (rpw * N > 640) return fail(REFNERF_EINVAL, "n_samples too large for the LDS budget (rays_per_wg*N must be <= 640)%s");
+  if (rpw * N > 640 && !ps_ring) return fail(REFNERF_EINVAL, "n_samples too large for the LDS budget (rays_per_wg*N must be <= 640)%s");
   size_t lds = lds_bytes(rpw);
   {
     const int nwmax = bf ? rn::BF_NW : 4;
@@ -614,7 +626,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   lds += (size_t)rt().lds_pad;   /* debug (REFNERF_LDS_PAD): force 1 workgroup/CU */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget of this precision mode%s");
   LDS_ATTR_ONCE(lds_attr(rn::level_fwd_f32), lds_attr(rn::level_fwd_train_f32), lds_attr(rn::level_fwd_train_bf16c),
-                lds_attr(rn::level_fwd_bf16), lds_attr(rn::level_fwd_f16));
+                lds_attr(rn::level_fwd_bf16), lds_attr(rn::level_fwd_f16), lds_attr(rn::level_fwd_bf16_ring), lds_attr(rn::level_fwd_f16_ring));
   rn::LevelArgs a;
   a.packed = d_packed;
   a.cfg = *cfg;
@@ -639,7 +651,9 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
     int trc = timer_begin(st, &tslot);
     if (trc) return trc;
   }
-  if (bf && cfg->precision == REFNERF_PREC_F16) hipLaunchKernelGGL(rn::level_fwd_f16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  if (bf && ps_ring && cfg->precision == REFNERF_PREC_F16) hipLaunchKernelGGL(rn::level_fwd_f16_ring, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  else if (bf && ps_ring) hipLaunchKernelGGL(rn::level_fwd_bf16_ring, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  else if (bf && cfg->precision == REFNERF_PREC_F16) hipLaunchKernelGGL(rn::level_fwd_f16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else if (train_bf) hipLaunchKernelGGL(rn::level_fwd_train_bf16c, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (cfg->training) hipLaunchKernelGGL(rn::level_fwd_train_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);

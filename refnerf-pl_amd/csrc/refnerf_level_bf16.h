@@ -257,8 +257,13 @@ __device__ __forceinline__ void bf_layer(Pipe &p, typename MM::v8 (&a)[AF], int 
   }
 }
 
-template <typename MM>
+/* RINGPS: the workgroup owns more samples than per-sample records fit the LDS (rays_per_wg * N > 640: e.g. 4 rays x 192 =
+ * three FULL passes instead of 2 rays = one and a half): the records live in a ring of BF_PS_RING rows and every ray is
+ * composited right behind the pass that brings its last sample (N <= 256: a ray and the pass in flight fit the ring). */
+constexpr int BF_PS_RING = 512;
+template <typename MM, bool RINGPS = false>
 __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
+  constexpr int PSM = RINGPS ? BF_PS_RING - 1 : 0;
   typedef typename MM::v8 v8mm;
   typedef typename MM::t mm_t;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -276,8 +281,8 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
   float *HD = reinterpret_cast<float *>(Xb + BF_X_BYTES);    /* [HD_ROWS][BT]            */
   float *TD = HD + HD_ROWS * BT;                             /* [rpw][N+1]               */
   float *XP = TD + rpw * (N + 1);                            /* [rpw][N+1]               */
-  float *PS = XP + rpw * (N + 1);                            /* [n_tot][NPS_EVAL]        */
-  float *PX = PS + n_tot * NPS_EVAL;                         /* [BT][3] grad_pred of the pass */
+  float *PS = XP + rpw * (N + 1);                            /* [n_tot][NPS_EVAL] (RINGPS: [BF_PS_RING][NPS_EVAL]) */
+  float *PX = PS + (RINGPS ? BF_PS_RING : n_tot) * NPS_EVAL; /* [BT][3] grad_pred of the pass */
   float *NRM = PX + 3 * BT;                                  /* [8] |direction| per ray  */
   const float *RY = NRM + 8;                                 /* [rpw][12] o, d, viewdir, radius per ray */
 
@@ -323,10 +328,18 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
     const int ray = ray0 + rl;
     const bool valid = (g < n_tot) && (ray < A.R);
     const int rayc = valid ? ray : (A.R - 1);
+    /* RINGPS: the rays whose last sample this pass brings are composited behind it (every wave meets the barrier) */
+    auto pass_epilogue = [&]() {
+      if constexpr (RINGPS) {
+        __syncthreads();
+        const int end = (pass0 + BT < n_tot) ? pass0 + BT : n_tot;
+        composite_phase<BF_NW, true, NPS_EVAL, PSM>(A, TD, XP, PS, n_tot, ray0, wave, lane, nullptr, NRM, pass0 / N, end / N);
+      }
+    };
     {
       /* validity is monotone in the sample index: the wave is idle iff its first sample is past the end */
       const int g0 = pass0 + wave * 32;
-      if (g0 >= n_tot || ray0 + g0 / N >= A.R) { idle_pass(p); continue; }
+      if (g0 >= n_tot || ray0 + g0 / N >= A.R) { idle_pass(p); pass_epilogue(); continue; }
     }
     /* head scalars of this sample live in LDS (HD); P4 and P6 both rebuild the
      * activations from them instead of keeping ~20 VGPRs alive across the dir MLP */
@@ -446,14 +459,15 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
         if (valid && h == 0) {                                                            /* P6 */
           SampleHeads sh;
           load_heads(sh);
-          colour_store<ENC_FAST, NPS_EVAL>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
+          colour_store<ENC_FAST, NPS_EVAL, PSM>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
         }
         wave_sync();
-        history_flush<NPS_EVAL>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);
+        history_flush<NPS_EVAL, PSM>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);
         RN_STAMP(A, 14);
       }
     }
     __builtin_amdgcn_wave_barrier();
+    pass_epilogue();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -462,12 +476,15 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
   if (A.prof && blockIdx.x == 0 && lane == 0) { A.prof[wave * 32 + 20] = p.t_vm; A.prof[wave * 32 + 21] = p.t_bar; }
 #endif
 
-  composite_phase<BF_NW, true, NPS_EVAL>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB), NRM);   /* P7 */
+  if constexpr (!RINGPS) composite_phase<BF_NW, true, NPS_EVAL>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB), NRM);   /* P7 */
   RN_STAMP(A, 16);
 }
 
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A) { level_fwd_mm<MmBf16>(A); }
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16(const LevelArgs A) { level_fwd_mm<MmF16>(A); }
+/* the same with the per-sample records in a ring (rays_per_wg * N > 640) */
+__global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16_ring(const LevelArgs A) { level_fwd_mm<MmBf16, true>(A); }
+__global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16_ring(const LevelArgs A) { level_fwd_mm<MmF16, true>(A); }
 
 /* ---------------- bf16 weight image ---------------- */
 __device__ __forceinline__ int ipe_col_of_kprime(int kp) { return kp; }   /* LDS order = canonical IPE order */

@@ -294,9 +294,16 @@ __device__ __forceinline__ void sample_heads(const refnerf_level_cfg &cfg, float
 
 /* P6 (models.py:699-729): colour head; keeps what compositing needs in LDS
  * PS[c][g] (the history is flushed from there by history_flush). */
-template <bool FAST = false, int NP = NPS_TRAIN>
+/* PSM: 0, or (a power of two) - 1: the per-sample records live in a RING of PSM + 1 rows (sample g -> row g & PSM): the
+ * 16-bit inference kernel composites every ray as soon as its last sample is in, so a workgroup can own more samples than
+ * fit the LDS at once (rays_per_wg * N a multiple of the 256-sample pass for N = 192, 96, 160 ...) */
+template <int PSM>
+__device__ __forceinline__ int ps_row(int g) { return PSM ? (g & PSM) : g; }
+
+template <bool FAST = false, int NP = NPS_TRAIN, int PSM = 0>
 __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHeads &s, const float raw_rgb[3],
-                                             float *PS, float *PX, int n_tot, int g, int gcol) {
+                                             float *PS, float *PX, int n_tot, int g_sample, int gcol) {
+  const int g = ps_row<PSM>(g_sample);
   const refnerf_level_cfg &cfg = A.cfg;
   float spec_lin[3], dif_lin[3], rgb[3], dif[3], spc[3];
 #pragma unroll
@@ -356,7 +363,7 @@ __device__ __forceinline__ void hist_store(float *p, float v) {
  * from LDS PS with fully coalesced stores: for the [R,N,3] tensors lane L writes
  * flat element 3*sample + channel = L, L+64.  gw0 = first sample (workgroup
  * index) of the block, gs0 = its global sample index ray*N + i. */
-template <int NP = NPS_TRAIN>
+template <int NP = NPS_TRAIN, int PSM = 0>
 __device__ __forceinline__ void history_flush(const LevelArgs &A, const float *PS, const float *PX, int n_tot, int gw0, int gcol0,
                                               size_t gs0, int lane) {
   const size_t total = (size_t)A.R * A.cfg.n_samples;
@@ -366,11 +373,11 @@ __device__ __forceinline__ void history_flush(const LevelArgs &A, const float *P
     for (int it = 0; it < 2; ++it) {
       const int f = lane + 64 * it;
       const int smp = f / 3, c = f - 3 * smp;
-      if (f < 96 && gw0 + smp < n_tot && gs0 + smp < total) hist_store(dst + gs0 * 3 + f, PS[(gw0 + smp) * NP + slot + c]);
+      if (f < 96 && gw0 + smp < n_tot && gs0 + smp < total) hist_store(dst + gs0 * 3 + f, PS[ps_row<PSM>(gw0 + smp) * NP + slot + c]);
     }
   };
   auto scal = [&](float *dst, int slot) {
-    if (dst && lane < 32 && gw0 + lane < n_tot && gs0 + lane < total) hist_store(dst + gs0 + lane, PS[(gw0 + lane) * NP + slot]);
+    if (dst && lane < 32 && gw0 + lane < n_tot && gs0 + lane < total) hist_store(dst + gs0 + lane, PS[ps_row<PSM>(gw0 + lane) * NP + slot]);
   };
   scal(A.out.d_density, PS_DENSITY);
   scal(A.out.d_roughness, PS_ROUGH);
@@ -391,13 +398,17 @@ __device__ __forceinline__ void history_flush(const LevelArgs &A, const float *P
 }
 
 /* P7: alpha weights + compositing, one wave per ray (render.py:132-149, 152-254). */
-template <int NW = 4, bool FAST = false, int NP = NPS_TRAIN>
+/* rays [rl_begin, rl_end) of the workgroup (default: all of them); PSM: ring of per-sample records (see ps_row), in which
+ * case the cross-lane sums go through shuffles instead of the LDS scratch `wscr` (it is not free while passes are running) */
+template <int NW = 4, bool FAST = false, int NP = NPS_TRAIN, int PSM = 0>
 __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float *TD, float *XP, float *PS, int n_tot,
-                                                int ray0, int wave, int lane, float *wscr, const float *NRM) {
+                                                int ray0, int wave, int lane, float *wscr, const float *NRM,
+                                                int rl_begin = 0, int rl_end = -1) {
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples, rpw = A.rpw;
+  if (rl_end < 0) rl_end = rpw;
   #pragma clang loop unroll(disable)
-  for (int rl = wave; rl < rpw; rl += NW) {
+  for (int rl = rl_begin + wave; rl < rl_end; rl += NW) {
     const int ray = ray0 + rl;
     if (ray >= A.R) break;
     const float *td = TD + rl * (N + 1);
@@ -410,14 +421,16 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
       float dx = A.rays.d_directions[(size_t)ray * 3], dy = A.rays.d_directions[(size_t)ray * 3 + 1], dz = A.rays.d_directions[(size_t)ray * 3 + 2];
       norm = sqrtf((dx * dx + dy * dy) + dz * dz);
     }
-    float *wbuf = PS + base * NP + PS_DENSITY;    /* density (stride NP) is overwritten by the weights */
+    /* density (slot PS_DENSITY of sample i's record) is overwritten by the weights */
+    auto wref = [&](int i) -> float & { return PS[ps_row<PSM>(base + i) * NP + PS_DENSITY]; };
+    auto rec = [&](int i, int slot) { return PS[ps_row<PSM>(base + i) * NP + slot]; };
     /* pass 1: local sums of density*delta */
     double local = 0.0;
     #pragma clang loop unroll(disable)
     for (int q = 0; q < C; ++q) {
       int i = i0 + q;
       if (i < N) {
-        float dd = wbuf[i * NP] * ((td[i + 1] - td[i]) * norm);
+        float dd = wref(i) * ((td[i + 1] - td[i]) * norm);
         /* opaque background (render.py:139-143): the last interval's optical depth is +inf; nothing lies
          * behind it, so it stays out of the prefix sums (inf - inf would poison the exclusive scan) */
         if (!(cfg.opaque_background && i == N - 1)) local += (double)dd;
@@ -434,28 +447,28 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
     for (int q = 0; q < C; ++q) {
       int i = i0 + q;
       if (i < N) {
-        float dd = wbuf[i * NP] * ((td[i + 1] - td[i]) * norm);
+        float dd = wref(i) * ((td[i + 1] - td[i]) * norm);
         if (cfg.opaque_background && i == N - 1) dd = INFINITY;
         float alpha = 1.0f - m_exp<FAST>(-dd);
         float trans = m_exp<FAST>(-(float)cum);
         float w = alpha * trans;
         cum += (double)dd;
-        wbuf[i * NP] = w;
+        wref(i) = w;
         wlocal += (double)w;
         if (A.out.d_weights) A.out.d_weights[(size_t)ray * N + i] = w;
         acc += w;
         float tmid = 0.5f * (td[i] + td[i + 1]);
         s_dist += w * tmid;
         s_logd += w * m_log<FAST>(tmid);
-        s_rgh += w * PS[(base + i) * NP + PS_ROUGH];
+        s_rgh += w * rec(i, PS_ROUGH);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          s_rgb[c] += w * PS[(base + i) * NP + PS_RGB + c];
-          s_dif[c] += w * PS[(base + i) * NP + PS_DIF + c];
-          s_spc[c] += w * PS[(base + i) * NP + PS_SPC + c];
-          s_np[c] += w * PS[(base + i) * NP + PS_NPRED + c];
-          s_tn[c] += w * PS[(base + i) * NP + PS_TINT + c];
-          if (NP > PS_NORMALS) s_nm[c] += w * PS[(base + i) * NP + PS_NORMALS + c];
+          s_rgb[c] += w * rec(i, PS_RGB + c);
+          s_dif[c] += w * rec(i, PS_DIF + c);
+          s_spc[c] += w * rec(i, PS_SPC + c);
+          s_np[c] += w * rec(i, PS_NPRED + c);
+          s_tn[c] += w * rec(i, PS_TINT + c);
+          if (NP > PS_NORMALS) s_nm[c] += w * rec(i, PS_NORMALS + c);
         }
       }
     }
@@ -463,7 +476,10 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
       float red[22] = {acc, s_dist, s_logd, s_rgh, s_rgb[0], s_rgb[1], s_rgb[2], s_dif[0], s_dif[1], s_dif[2],
                        s_spc[0], s_spc[1], s_spc[2], s_np[0], s_np[1], s_np[2], s_tn[0], s_tn[1], s_tn[2],
                        s_nm[0], s_nm[1], s_nm[2]};
-      wave_sum_many<22>(red, wscr + wave * (22 * WSUM_PITCH), lane);
+      if constexpr (PSM != 0) {
+#pragma unroll
+        for (int k = 0; k < 22; ++k) red[k] = wave_sum(red[k]);
+      } else wave_sum_many<22>(red, wscr + wave * (22 * WSUM_PITCH), lane);
       acc = red[0]; s_dist = red[1]; s_logd = red[2]; s_rgh = red[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -522,7 +538,7 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
       #pragma clang loop unroll(disable)
       for (int q = 0; q < C; ++q) {
         int i = i0 + q;
-        if (i < N) { run += (double)wbuf[i * NP]; xp[i + 1] = fminf(1.0f, (float)run); }
+        if (i < N) { run += (double)wref(i); xp[i + 1] = fminf(1.0f, (float)run); }
       }
       if (lane == 0) { xp[0] = 0.0f; }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
