@@ -713,6 +713,47 @@ def test_nerfmlp_variants_vs_reference(hip, name, flat):
     configs.clear_config()
 
 
+@pytest.mark.parametrize("n_rays,n_samples", [(2051, 192), (4099, 96), (2050, 160)])
+def test_record_ring_kernel(hip, n_rays, n_samples):
+    """The 16-bit inference kernel's ring variant (per-sample records in a 512-row ring, rays composited behind the pass
+    that completes them: taken when rays_per_wg * N must exceed 640 records to fill whole 256-sample passes and the grid
+    has >= 512 workgroups -- 4 x 192, 8 x 96, 8 x 160).  Same rays through both variants: a 600-ray prefix alone takes the
+    plain kernel (too few workgroups for the ring), the full ragged batch the ring -- same arithmetic up to the order of the
+    compositing sums; the tail rays (partly filled last workgroup) against the f32 mode."""
+    import os
+    from refnerf_pl_amd import configs, models, synthetic, utils
+    rd = synthetic.blender_rays(n_rays, seed=21, center_frac=0.5)
+    sub = {k: v[:600] for k, v in rd.items()}
+    out = {}
+    for prec in ("f32", "bf16", "f16"):
+        configs.clear_config()
+        configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                                [f"Model.num_prop_samples = {n_samples}", f"Model.num_nerf_samples = {n_samples}",
+                                                 f"Config.hip_precision = '{prec}'"])
+        model = models.construct_model(utils.dummy_rays(), configs.Config()).to(DEV).eval()
+        model.nerf_mlp.load_flat_params(synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0))
+        with torch.no_grad():
+            out[prec] = model(utils.rays_from_dict(rd, DEV), 1.0, True)
+            if prec != "f32":
+                out[prec + "_sub"] = model(utils.rays_from_dict(sub, DEV), 1.0, True)
+    ref_r, _ = out["f32"]
+    for prec in ("bf16", "f16"):
+        (rend, hist), (rend_s, hist_s) = out[prec], out[prec + "_sub"]
+        for L in range(2):
+            for k in ("rgb", "diffuse", "specular", "acc", "distance", "normals_pred", "tint", "roughness", "distance_mean"):
+                err = float((rend[L][k][:600] - rend_s[L][k]).abs().max())
+                assert err <= 2e-6 * (4.0 if "distance" in k else 1.0), (prec, L, k, err)
+            assert bool((hist[L]["sdist"][:600] == hist_s[L]["sdist"]).all())          # same resampling, bit for bit
+            assert float((hist[L]["weights"][:600] - hist_s[L]["weights"]).abs().max()) <= 1e-6
+            for k in ("distance_percentile_5", "distance_median", "distance_percentile_95"):
+                assert rend[L][k].dtype == torch.float64
+                assert float((rend[L][k][:600] - rend_s[L][k]).abs().max()) <= 1e-5, (prec, L, k)
+            # the ragged tail: finite, and the 16-bit distance from the f32 mode that these weights always show
+            assert bool(torch.isfinite(rend[L]["rgb"]).all()) and bool(torch.isfinite(rend[L]["distance_median"]).all())
+            assert float((rend[L]["rgb"][-16:] - ref_r[L]["rgb"][-16:]).abs().max()) <= 1e-4
+    configs.clear_config()
+
+
 @pytest.mark.parametrize("name", ["model_variant_eval", "model_posenc_eval"])
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 def test_nerfmlp_variants_16bit_modes(hip, name, prec):
