@@ -340,7 +340,15 @@ def main():
             return max_over_ranks(el), kern_ms, launches, out
 
         def kernel_name(prec):
-            return {"f32": "rn::level_fwd_f32", "bf16": "rn::level_fwd_bf16", "f16": "rn::level_fwd_f16"}[prec]
+            name = {"f32": "rn::level_fwd_f32", "bf16": "rn::level_fwd_bf16", "f16": "rn::level_fwd_f16"}[prec]
+            # the library's choice (refnerf_hip.hip level_forward_impl): sample counts that do not tile the 256-sample pass
+            # within 640 records take the ring variant of the 16-bit kernel when the grid keeps >= 512 workgroups
+            if prec != "f32" and N <= 256 and 256 % N != 0 and N % 256 != 0:
+                r = next((k for k in range(1, 9) if (k * N) % 256 == 0), None)
+                plain = 2 if (2 * N) % 256 == 0 and 2 * N <= 512 else (4 if (4 * N) % 256 == 0 and 4 * N <= 512 else 1)
+                if r and (plain * N) % 256 != 0 and r * N > 640 and rays_per_rank // r >= 512:
+                    name += "_ring"
+            return name
 
         step = make_step()
         elapsed, kern_ms, launches, out = timed(step, args.steps, args.warmup, with_events=not use_graph)
