@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 6   /* v6: cfg.dir_enc (REFNERF_DIRENC_*); v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
+#define REFNERF_ABI_VERSION 6   /* v6: cfg.dir_enc (REFNERF_DIRENC_*), cfg.raydist (REFNERF_RAYDIST_*), cfg.disable_integration; v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {
@@ -70,6 +70,15 @@ enum {
                                 block (the caller embeds the [.., 33] weight columns there; the roughness is not used)   */
 };
 
+/* Model.raydist_fn: the bijection between normalised and metric ray distance (coord.construct_ray_warps, coord.py:63-99):
+ * t = fn_inv(s * fn(far) + (1 - s) * fn(near)) */
+enum {
+  REFNERF_RAYDIST_NONE = 0,        /* fn = None: linear in t                                   */
+  REFNERF_RAYDIST_PIECEWISE = 1,   /* 'piecewise': x < 1 ? x / 2 : 1 - 1 / (2 x) (allows near = 0) */
+  REFNERF_RAYDIST_RECIPROCAL = 2,  /* torch.reciprocal (linear in disparity)                   */
+  REFNERF_RAYDIST_LOG = 3, REFNERF_RAYDIST_EXP = 4, REFNERF_RAYDIST_SQRT = 5, REFNERF_RAYDIST_SQUARE = 6
+};
+
 enum { REFNERF_SRGB_NONE = 0, REFNERF_SRGB_LINEAR = 1, REFNERF_SRGB_NORM_LINEAR = 2,
        REFNERF_SRGB_SRGB = 3, REFNERF_SRGB_NORM_SRGB = 4 };
 
@@ -88,6 +97,8 @@ typedef struct refnerf_level_cfg {
   int32_t precision;          /* REFNERF_PREC_*                                            */
   int32_t wgrad_mode;         /* REFNERF_WGRAD_*: arithmetic of the weight-gradient GEMM (backward only) */
   int32_t dir_enc;            /* REFNERF_DIRENC_*: MLP.use_directional_enc (:484-492)      */
+  int32_t raydist;            /* REFNERF_RAYDIST_*: Model.raydist_fn (:147, coord.py:63-99) */
+  int32_t disable_integration;/* Model.disable_integration (:228-231): zero covariances -> plain positional encoding */
   float anneal;               /* models.py:190-195                                         */
   float resample_padding;     /* Model.resample_padding (:202)                             */
   float s_near, s_far;        /* Model.init_s_near / init_s_far (:213)                     */

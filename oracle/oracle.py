@@ -32,7 +32,7 @@ class LevelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_samples", "n_in", "training", "compute_extras", "srgb_mapping",
         "srgb_mapping_normalization", "render_srgb_mode", "opaque_background",
-        "ray_shape", "ide_mode")] + [(n, C.c_float) for n in (
+        "ray_shape", "ide_mode", "raydist", "disable_integration")] + [(n, C.c_float) for n in (
             "anneal", "resample_padding", "s_near", "s_far", "density_bias",
             "roughness_bias", "rgb_premultiplier", "rgb_bias", "rgb_padding", "bg_rgb")]
 

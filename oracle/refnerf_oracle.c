@@ -59,7 +59,7 @@ void rn_level_cfg_default(rn_level_cfg *c) {
   c->training = 0; c->compute_extras = 1;
   c->srgb_mapping = 1; c->srgb_mapping_normalization = 1;
   c->render_srgb_mode = RN_SRGB_NONE;
-  c->opaque_background = 0; c->ray_shape = 0; c->ide_mode = 0;
+  c->opaque_background = 0; c->ray_shape = 0; c->ide_mode = 0; c->raydist = 0; c->disable_integration = 0;
   c->anneal = 1.0f; c->resample_padding = 0.01f;
   c->s_near = 0.0f; c->s_far = 1.0f;
   c->density_bias = 0.5f; c->roughness_bias = -1.0f;
@@ -150,6 +150,38 @@ float rn_s_to_t(float s, float near, float far) {
   float a = s * far;
   float b = (1.0f - s) * near;
   return a + b;
+}
+
+/* coord.construct_ray_warps (coord.py:63-99) for the ray-distance functions the reference accepts:
+ * s_to_t(s) = fn_inv(s * fn(far) + (1 - s) * fn(near)) */
+static float raydist_fwd(float x, int m) {
+  switch (m) {
+    case 1: return x < 1.0f ? 0.5f * x : 1.0f - 0.5f / x;
+    case 2: return 1.0f / x;
+    case 3: return logf(x);
+    case 4: return expf(x);
+    case 5: return sqrtf(x);
+    case 6: return x * x;
+    default: return x;
+  }
+}
+static float raydist_inv(float x, int m) {
+  switch (m) {
+    case 1: return x < 0.5f ? 2.0f * x : 0.5f / (1.0f - x);
+    case 2: return 1.0f / x;
+    case 3: return expf(x);
+    case 4: return logf(x);
+    case 5: return x * x;
+    case 6: return sqrtf(x);
+    default: return x;
+  }
+}
+float rn_s_to_t_fn(float s, float near, float far, int raydist) {
+  if (raydist == 0) return rn_s_to_t(s, near, far);
+  float sn = raydist_fwd(near, raydist), sf = raydist_fwd(far, raydist);
+  float a = s * sf;
+  float b = (1.0f - s) * sn;
+  return raydist_inv(a + b, raydist);
 }
 
 /* ------------------------------------------------------------------ */
@@ -767,12 +799,14 @@ int rn_level_forward(const float *params, const rn_level_cfg *cfg, const rn_rays
       /* models.py:200-215 */
       rn_resample_logits(sdist_in + (size_t)r * (M + 1), weights_in + (size_t)r * M, M, cfg->anneal, cfg->resample_padding, logits);
       rn_sample_intervals(sdist_in + (size_t)r * (M + 1), logits, M, N, cfg->s_near, cfg->s_far, sd, bidx);
-      for (int i = 0; i <= N; ++i) td[i] = rn_s_to_t(sd[i], near, far);          /* :218 */
+      for (int i = 0; i <= N; ++i) td[i] = rn_s_to_t_fn(sd[i], near, far, cfg->raydist);          /* :218 */
       for (int i0 = 0; i0 < N; i0 += RN_SB) {                                     /* :221-241 */
         float lm[RN_SB][3], lv[RN_SB][3];
         int S = (N - i0 < RN_SB) ? (N - i0) : RN_SB;
-        for (int s = 0; s < S; ++s)
+        for (int s = 0; s < S; ++s) {
           rn_cast_sample(o, d, radius, td[i0 + s], td[i0 + s + 1], cfg->ray_shape, lm[s], lv[s], NULL);
+          if (cfg->disable_integration) lv[s][0] = lv[s][1] = lv[s][2] = 0.0f;          /* models.py:228-231 */
+        }
         mlp_block(&model, cfg, &lm[0][0], &lv[0][0], v, S, &so[i0]);
         for (int s = 0; s < S; ++s) dens[i0 + s] = so[i0 + s].density;
       }
@@ -1077,10 +1111,11 @@ int rn_level_train(const float *params, const rn_level_cfg *cfg_in, const rn_ray
       float nearv = rays->near[r], farv = rays->far[r], radius = rays->radii[r];
       rn_resample_logits(sdist_in + (size_t)r * (M + 1), weights_in + (size_t)r * M, M, cfg->anneal, cfg->resample_padding, logits);
       rn_sample_intervals(sdist_in + (size_t)r * (M + 1), logits, M, N, cfg->s_near, cfg->s_far, sd, bidx);
-      for (int i = 0; i <= N; ++i) td[i] = rn_s_to_t(sd[i], nearv, farv);
+      for (int i = 0; i <= N; ++i) td[i] = rn_s_to_t_fn(sd[i], nearv, farv, cfg->raydist);
       for (int i = 0; i < N; ++i) {
         float lm[3], lv[3];
         rn_cast_sample(o, d, radius, td[i], td[i + 1], cfg->ray_shape, lm, lv, NULL);
+        if (cfg->disable_integration) lv[0] = lv[1] = lv[2] = 0.0f;
         mlp_block(&model, cfg, lm, lv, v, 1, &so[i]);              /* outputs incl. density normals */
         mlp_forward_cached(&model, cfg, lm, lv, v, &cache[i], NULL);
         dens[i] = so[i].density;
@@ -1235,10 +1270,11 @@ int rn_level_backward(const float *params, const rn_level_cfg *cfg_in, const rn_
       float nearv = rays->near[r], farv = rays->far[r], radius = rays->radii[r];
       rn_resample_logits(sdist_in + (size_t)r * (M + 1), weights_in + (size_t)r * M, M, cfg->anneal, cfg->resample_padding, logits);
       rn_sample_intervals(sdist_in + (size_t)r * (M + 1), logits, M, N, cfg->s_near, cfg->s_far, sd, NULL);
-      for (int i = 0; i <= N; ++i) td[i] = rn_s_to_t(sd[i], nearv, farv);
+      for (int i = 0; i <= N; ++i) td[i] = rn_s_to_t_fn(sd[i], nearv, farv, cfg->raydist);
       for (int i = 0; i < N; ++i) {
         float lm[3], lv[3];
         rn_cast_sample(o, d, radius, td[i], td[i + 1], cfg->ray_shape, lm, lv, NULL);
+        if (cfg->disable_integration) lv[0] = lv[1] = lv[2] = 0.0f;
         mlp_block(&model, cfg, lm, lv, v, 1, &so[i]);
         mlp_forward_cached(&model, cfg, lm, lv, v, &cache[i], NULL);
         dens[i] = so[i].density;

@@ -68,6 +68,8 @@ typedef struct rn_level_cfg {
   int32_t ray_shape;          /* 0 cone, 1 cylinder (render.py:121-126)       */
   int32_t ide_mode;           /* 0 IDE, stable recurrence; 1 IDE, reference-order fp32; 2 coord.pos_enc of the direction
                                  (use_directional_enc = False) in the IDE's slots */
+  int32_t raydist;            /* Model.raydist_fn (coord.py:63-99): 0 None, 1 'piecewise', 2 reciprocal, 3 log, 4 exp, 5 sqrt, 6 square */
+  int32_t disable_integration;/* Model.disable_integration (models.py:228-231): zero covariances            */
   float anneal;               /* models.py:190-195 (1.0 in shipped configs)   */
   float resample_padding;
   float s_near, s_far;        /* Model.init_s_near / init_s_far               */
@@ -130,6 +132,7 @@ void rn_resample_logits(const float *t, const float *w, int M, float anneal,
 
 /* coord.py:96-98 with fn=None. */
 float rn_s_to_t(float s, float near, float far);
+float rn_s_to_t_fn(float s, float near, float far, int raydist);
 
 /* render.py:105-129 + coord.py:129-133 for the octahedron/1 basis:
  * lifted mean[3] and lifted diagonal variance[3] of one interval; also the

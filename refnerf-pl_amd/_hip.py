@@ -18,6 +18,7 @@ PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 ABI_VERSION = 6   # REFNERF_ABI_VERSION
 WGRAD_F32, WGRAD_BF16X3 = 0, 1
 DIRENC_IDE, DIRENC_POSENC = 0, 1   # REFNERF_DIRENC_*
+RAYDIST = {None: 0, "piecewise": 1, "reciprocal": 2, "log": 3, "exp": 4, "sqrt": 5, "square": 6}   # REFNERF_RAYDIST_*
 SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 4}
 
 _FP = C.c_void_p
@@ -28,7 +29,7 @@ class LevelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_samples", "n_in", "training", "compute_extras", "srgb_mapping",
         "srgb_mapping_normalization", "render_srgb_mode", "opaque_background",
-        "ray_shape", "precision", "wgrad_mode", "dir_enc")] + [(n, C.c_float) for n in (
+        "ray_shape", "precision", "wgrad_mode", "dir_enc", "raydist", "disable_integration")] + [(n, C.c_float) for n in (
             "anneal", "resample_padding", "s_near", "s_far", "density_bias",
             "roughness_bias", "rgb_premultiplier", "rgb_bias", "rgb_padding", "bg_rgb")]
 

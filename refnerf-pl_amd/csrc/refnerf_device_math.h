@@ -33,6 +33,37 @@ __device__ __forceinline__ float s_to_t(float s, float nearv, float farv) {
   return a + b;
 }
 
+/* coord.construct_ray_warps for the other ray-distance functions (coord.py:63-99): fn_inv(s fn(far) + (1 - s) fn(near)) */
+__device__ __forceinline__ float raydist_fwd(float x, int m) {
+  switch (m) {
+    case REFNERF_RAYDIST_PIECEWISE: return x < 1.0f ? 0.5f * x : 1.0f - 0.5f / x;
+    case REFNERF_RAYDIST_RECIPROCAL: return 1.0f / x;
+    case REFNERF_RAYDIST_LOG: return logf(x);
+    case REFNERF_RAYDIST_EXP: return expf(x);
+    case REFNERF_RAYDIST_SQRT: return sqrtf(x);
+    case REFNERF_RAYDIST_SQUARE: return x * x;
+    default: return x;
+  }
+}
+__device__ __forceinline__ float raydist_inv(float x, int m) {
+  switch (m) {
+    case REFNERF_RAYDIST_PIECEWISE: return x < 0.5f ? 2.0f * x : 0.5f / (1.0f - x);
+    case REFNERF_RAYDIST_RECIPROCAL: return 1.0f / x;
+    case REFNERF_RAYDIST_LOG: return expf(x);
+    case REFNERF_RAYDIST_EXP: return logf(x);
+    case REFNERF_RAYDIST_SQRT: return x * x;
+    case REFNERF_RAYDIST_SQUARE: return sqrtf(x);
+    default: return x;
+  }
+}
+__device__ __forceinline__ float s_to_t(float s, float nearv, float farv, int raydist) {
+  if (raydist == REFNERF_RAYDIST_NONE) return s_to_t(s, nearv, farv);
+  const float sn = raydist_fwd(nearv, raydist), sf = raydist_fwd(farv, raydist);
+  const float a = s * sf;
+  const float b = (1.0f - s) * sn;
+  return raydist_inv(a + b, raydist);
+}
+
 /* torch.linspace(pad, 1-pad-eps, N)[k] (stepfun.py:199-204; ATen fills
  * symmetrically with fused multiply-adds). */
 __device__ __forceinline__ float linspace_u(int k, int n) {

@@ -492,7 +492,7 @@ void refnerf_level_cfg_default(refnerf_level_cfg *c) {
   memset(c, 0, sizeof(*c));
   c->n_samples = 128; c->n_in = 1; c->training = 0; c->compute_extras = 1;
   c->srgb_mapping = 1; c->srgb_mapping_normalization = 1; c->render_srgb_mode = REFNERF_SRGB_NONE;
-  c->opaque_background = 0; c->ray_shape = 0; c->precision = REFNERF_PREC_F32; c->wgrad_mode = REFNERF_WGRAD_BF16X3; c->dir_enc = REFNERF_DIRENC_IDE;
+  c->opaque_background = 0; c->ray_shape = 0; c->precision = REFNERF_PREC_F32; c->wgrad_mode = REFNERF_WGRAD_BF16X3; c->dir_enc = REFNERF_DIRENC_IDE; c->raydist = REFNERF_RAYDIST_NONE; c->disable_integration = 0;
   c->anneal = 1.0f; c->resample_padding = 0.01f; c->s_near = 0.0f; c->s_far = 1.0f;
   c->density_bias = 0.5f; c->roughness_bias = -1.0f;
   c->rgb_premultiplier = 1.0f; c->rgb_bias = 0.0f; c->rgb_padding = 0.001f; c->bg_rgb = 1.0f;
@@ -574,6 +574,8 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   if (cfg->n_in < 1 || cfg->n_in > 512) return fail(REFNERF_EINVAL, "n_in must be in [1,512]%s");
   if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16 && cfg->precision != REFNERF_PREC_F16)
     return fail(REFNERF_EINVAL, "unknown precision mode%s");
+  if (cfg->raydist < REFNERF_RAYDIST_NONE || cfg->raydist > REFNERF_RAYDIST_SQUARE)
+    return fail(REFNERF_EINVAL, "unknown raydist (REFNERF_RAYDIST_*)%s");
   if (cfg->dir_enc != REFNERF_DIRENC_IDE && cfg->dir_enc != REFNERF_DIRENC_POSENC)
     return fail(REFNERF_EINVAL, "unknown dir_enc (REFNERF_DIRENC_IDE / REFNERF_DIRENC_POSENC)%s");
   if (cfg->training && cfg->precision == REFNERF_PREC_F16)

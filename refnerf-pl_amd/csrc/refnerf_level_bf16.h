@@ -377,6 +377,7 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
         float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
         float lm[3], lv[3];
         cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
+        if (cfg.disable_integration) { lv[0] = 0.0f; lv[1] = 0.0f; lv[2] = 0.0f; }        /* models.py:228-231 */
         /* k' = canonical IPE index: half h owns block h (sin / cos) = k' 48h .. 48h+47 = 6 k-groups;
          * rolled over two halves of 24 features (8 degrees x 3 axes): the (axis, degree) pattern repeats */
         RN_STAMP(A, 17);

@@ -81,7 +81,7 @@ __device__ __forceinline__ void bwd_seed_rays(const BwdArgs &A, float *TD, int r
     if (ray >= A.R) break;
     float *td = TD + rl * (N + 1);
     const float nearv = A.rays.d_near[ray], farv = A.rays.d_far[ray];
-    for (int k = lane; k <= N; k += 64) td[k] = s_to_t(A.sdist[(size_t)ray * (N + 1) + k], nearv, farv);
+    for (int k = lane; k <= N; k += 64) td[k] = s_to_t(A.sdist[(size_t)ray * (N + 1) + k], nearv, farv, A.cfg.raydist);
     wave_sync();
     const float dx = A.rays.d_directions[(size_t)ray * 3], dy = A.rays.d_directions[(size_t)ray * 3 + 1],
                 dz = A.rays.d_directions[(size_t)ray * 3 + 2];
@@ -230,7 +230,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     const int ray = ray0 + rl;
     if (ray >= A.R) break;
     const float nearv = A.rays.d_near[ray], farv = A.rays.d_far[ray];
-    for (int k = lane; k <= N; k += 64) TD[rl * (N + 1) + k] = s_to_t(A.sdist[(size_t)ray * (N + 1) + k], nearv, farv);
+    for (int k = lane; k <= N; k += 64) TD[rl * (N + 1) + k] = s_to_t(A.sdist[(size_t)ray * (N + 1) + k], nearv, farv, A.cfg.raydist);
   }
   __syncthreads();
   RN_STAMP(A, 1);

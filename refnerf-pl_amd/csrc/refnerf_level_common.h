@@ -262,7 +262,7 @@ __device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratc
     for (int k = lane; k <= N; k += 64) {
       float s = sd[k];
       if (A.out.d_sdist) A.out.d_sdist[(size_t)ray * (N + 1) + k] = s;
-      sd[k] = s_to_t(s, nearv, farv);         /* models.py:218 */
+      sd[k] = s_to_t(s, nearv, farv, A.cfg.raydist);         /* models.py:218, coord.py:96-98 */
     }
   }
 }

@@ -756,6 +756,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         const float *td = TD + (valid ? rl : 0) * (N + 1);
         float t0 = td[valid ? si : 0], t1 = td[valid ? si + 1 : 1];
         cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
+        if (cfg.disable_integration) { lv[0] = 0.0f; lv[1] = 0.0f; lv[2] = 0.0f; }        /* models.py:228-231 */
       }
 #pragma unroll 1
       for (int j = 0; j < 16; ++j)

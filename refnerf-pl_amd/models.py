@@ -524,14 +524,25 @@ class Model(nn.Module):
         self.nerf_mlp = NerfMLP()
         self.prop_mlp = self.nerf_mlp if self.single_mlp else PropMLP()
         unsupported = {}
-        if self.raydist_fn is not None:
-            unsupported["raydist_fn"] = self.raydist_fn
-        if self.disable_integration:
-            unsupported["disable_integration"] = True
+        self._raydist_code = self._raydist_enum(self.raydist_fn)      # raises for functions coord.construct_ray_warps rejects too
         if not self.use_viewdirs:
             unsupported["use_viewdirs"] = False
         if unsupported:
             raise ValueError(f"Model options outside the fused Ref-NeRF path: {unsupported}")
+
+    @staticmethod
+    def _raydist_enum(fn):
+        """Model.raydist_fn -> REFNERF_RAYDIST_*: None, 'piecewise', or one of the torch functions coord.construct_ray_warps
+        knows the inverse of (coord.py:84-92: reciprocal, log, exp, sqrt, square) -- as the callable itself or as the gin
+        reference text ('@torch.reciprocal')."""
+        if fn is None:
+            return _hip.RAYDIST[None]
+        name = fn if isinstance(fn, str) else getattr(fn, "__name__", None)
+        if isinstance(name, str):
+            name = name.lstrip("@").split(".")[-1].strip("()")
+        if name not in _hip.RAYDIST:
+            raise KeyError(name)                      # what inv_mapping[fn.__name__] raises in the reference
+        return _hip.RAYDIST[name]
 
     @property
     def device(self):
@@ -566,7 +577,8 @@ class Model(nn.Module):
             opaque_background=int(self.opaque_background), ray_shape=0 if self.ray_shape == 'cone' else 1,
             precision=_PREC[getattr(cfg, "hip_train_precision", "f32")] if self.training else _PREC[prec], wgrad_mode=wgrad, anneal=float(anneal), resample_padding=float(self.resample_padding),
             s_near=float(self.init_s_near), s_far=float(self.init_s_far), density_bias=float(mlp.density_bias),
-            dir_enc=mlp.kernel_dir_enc, roughness_bias=mlp.kernel_roughness_bias, rgb_premultiplier=float(mlp.rgb_premultiplier),
+            dir_enc=mlp.kernel_dir_enc, raydist=self._raydist_enum(self.raydist_fn), disable_integration=int(bool(self.disable_integration)),
+            roughness_bias=mlp.kernel_roughness_bias, rgb_premultiplier=float(mlp.rgb_premultiplier),
             rgb_bias=float(mlp.rgb_bias), rgb_padding=float(mlp.rgb_padding), bg_rgb=float(bg))
 
     def __call__(self, rays, train_frac, compute_extras):

@@ -849,6 +849,39 @@ def golden_posenc_models():
         save(name, **res)
 
 
+RAYDIST_CASES = {
+    # name: (raydist_fn attribute set on the reference Model, disable_integration, rays, train)
+    "model_raydist_reciprocal_eval": ("reciprocal", False, "blender", False),
+    "model_raydist_log_eval": ("log", False, "blender", False),
+    "model_raydist_piecewise_eval": ("piecewise", False, "llff", False),
+    "model_nointegration_eval": (None, True, "blender", False),
+    "model_raydist_nointegration_train": ("reciprocal", True, "blender", True),
+}
+
+
+def golden_raydist_models():
+    """Model.raydist_fn (coord.construct_ray_warps, coord.py:63-99: None / 'piecewise' / torch.reciprocal / log ...) and
+    Model.disable_integration (models.py:228-231): the sample positions along the ray and the zero-covariance IPE -- eval
+    per function, and one training step with both switched on."""
+    fns = {None: None, "piecewise": "piecewise", "reciprocal": torch.reciprocal, "log": torch.log}
+    small = ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 96"]
+    for name, (fn, noint, family, train) in RAYDIST_CASES.items():
+        bindings = list(small) if train else []
+        if family == "llff":
+            bindings += ["Config.near = 0.", "Config.far = 1."]
+        pk = dict(seed=7, bias_scale=0.05, sharpen=20.0)
+        model, cfg = build_model(bindings, pk)
+        model.raydist_fn = fns[fn]                      # read at call time (models.py:147)
+        model.disable_integration = noint
+        rays = (synthetic.llff_rays(12, seed=71) if family == "llff" else
+                synthetic.blender_rays(12 if train else 16, seed=72, center_frac=0.4))
+        gt = synthetic.target_rgb(rays["origins"].shape[0], seed=2)
+        res = run_model(model, cfg, rays, train, gt)
+        res["raydist_fn"] = np.array(fn if fn else "")
+        res["disable_integration"] = np.array(int(noint))
+        _finish_model_fixture(name, res, bindings, rays, gt, param_kw=np.array([pk["seed"], pk["bias_scale"], pk["sharpen"], 0.0]))
+
+
 def golden_variants():
     """Which of the reference's shipped configs construct and run at all.
 
@@ -898,6 +931,6 @@ def golden_variants():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models", "posenc_models"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models", "posenc_models", "raydist_models"]
     for w in which:
         globals()["golden_" + w]()

@@ -86,3 +86,14 @@ def posenc_params(g):
     canon = np.zeros_like(full)
     canon[idx] = full[idx]
     return canon, full[idx].copy(), idx
+
+
+# ---- Model.raydist_fn / Model.disable_integration (coord.py:63-99, models.py:228-231) ------------------------------
+RAYDIST_CASES = ["model_raydist_reciprocal_eval", "model_raydist_log_eval", "model_raydist_piecewise_eval",
+                 "model_nointegration_eval", "model_raydist_nointegration_train"]
+RAYDIST_CODE = {"": 0, "piecewise": 1, "reciprocal": 2, "log": 3, "exp": 4, "sqrt": 5, "square": 6}
+
+
+def raydist_kw(g):
+    """level-cfg kwargs of a raydist fixture"""
+    return dict(raydist=RAYDIST_CODE[str(g["raydist_fn"])], disable_integration=int(g["disable_integration"]))

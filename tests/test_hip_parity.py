@@ -713,6 +713,60 @@ def test_nerfmlp_variants_vs_reference(hip, name, flat):
     configs.clear_config()
 
 
+@pytest.mark.parametrize("name", ["model_raydist_reciprocal_eval", "model_raydist_log_eval", "model_raydist_piecewise_eval",
+                                  "model_nointegration_eval", "model_raydist_nointegration_train"])
+def test_raydist_and_disable_integration_vs_reference(hip, name):
+    """Model.raydist_fn (coord.construct_ray_warps: reciprocal / log / 'piecewise') and Model.disable_integration through
+    cfg.raydist / cfg.disable_integration: Model.__call__ against the reference's outputs, and for the training fixture its
+    losses and autograd gradients.  Tolerances of the un-integrated encoding as in the oracle test (level-1 positions differ by
+    an ulp, sin(2^15 x) is not attenuated)."""
+    import os
+    from refnerf_pl_amd import configs, layout, models, train_utils, utils
+    g = load_golden(name)
+    train = name.endswith("train")
+    noint = bool(int(g["disable_integration"]))
+    fn = {"": None, "piecewise": "piecewise", "reciprocal": torch.reciprocal, "log": "@torch.log"}[str(g["raydist_fn"])]
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                            [str(b) for b in g["bindings"] if str(b)])
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV)
+    model.raydist_fn, model.disable_integration = fn, noint          # read at call time, as in the reference
+    model.nerf_mlp.load_flat_params(params_from_golden(g))
+    rays = utils.rays_from_dict(rays_from_golden(g), DEV)
+    model.train(train)
+    with torch.set_grad_enabled(train):
+        renderings, history = model(rays, 1.0, True)
+    for L in range(2):
+        for k in HIST_KEYS:
+            a = g[f"L{L}_h_{k}"]
+            tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 2e-6)
+            if L > 0 and k not in ("sdist", "weights"):
+                tol = max(tol, 5e-5)
+            if L > 0 and noint:
+                tol = 5e-5 if k == "sdist" else (2e-4 if k == "weights" else (3e-2 if k in ("density", "normals_pred") else 1e-3))
+            np.testing.assert_allclose(history[L][k].detach().cpu().numpy().reshape(a.shape), a, rtol=0, atol=tol, err_msg=f"L{L} {k}")
+        for k in REND_KEYS:
+            a = g[f"L{L}_r_{k}"]
+            x = renderings[L][k].detach().cpu().numpy().reshape(a.shape)
+            base = 2e-4 if (noint and L > 0) else 5e-6
+            tol = (4 * base + 1e-6 / np.maximum(g[f"L{L}_r_acc"], 1e-6)) if k in ("distance", "distance_mean") else base
+            assert np.all(np.abs(x - a) <= tol), (L, k, np.abs(x - a).max())
+        assert np.abs(renderings[L]["rgb"].detach().cpu().numpy() - g[f"L{L}_r_rgb"]).max() <= 1e-4
+    if train:
+        batch = utils.Batch(rays=rays, rgb=np.asarray(g["gt_rgb"], np.float32))
+        total, terms, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+        assert float(terms["data"].detach()) == pytest.approx(float(g["loss_data"]), rel=2e-4)
+        assert float(terms["orientation"].detach()) == pytest.approx(float(g["loss_orientation"]), rel=5e-3)
+        total.backward()
+        grads = torch.cat([p.grad.flatten() for p in model.nerf_mlp.ordered_parameters()]).cpu().numpy()
+        ref = g["grads_sub"]
+        rel = float(np.linalg.norm(grads[::97] - ref) / np.linalg.norm(ref))
+        print(name, "gradient rel-L2 vs reference", rel)
+        assert rel < 2e-2
+    configs.clear_config()
+
+
 @pytest.mark.parametrize("n_rays,n_samples", [(2051, 192), (4099, 96), (2050, 160)])
 def test_record_ring_kernel(hip, n_rays, n_samples):
     """The 16-bit inference kernel's ring variant (per-sample records in a 512-row ring, rays composited behind the pass

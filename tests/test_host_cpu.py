@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     assert _hip.packed_weights_bytes(_hip.PREC_F32) > 4 * layout.NUM_PARAMS
     c = _hip.default_cfg()
     assert (c.n_samples, c.resample_padding, c.density_bias) == (128, pytest.approx(0.01), pytest.approx(0.5))
-    assert C.sizeof(_hip.LevelCfg) == 88 and c.dir_enc == _hip.DIRENC_IDE and c.wgrad_mode == _hip.WGRAD_BF16X3 and C.sizeof(_hip.LevelOut) == 23 * 8
+    assert C.sizeof(_hip.LevelCfg) == 96 and c.dir_enc == _hip.DIRENC_IDE and c.raydist == 0 and c.disable_integration == 0 and c.wgrad_mode == _hip.WGRAD_BF16X3 and C.sizeof(_hip.LevelOut) == 23 * 8
 
 
 def test_gin_loader_syntax(tmp_path):
@@ -92,7 +92,11 @@ def test_unsupported_configurations_raise(cfg):
     with pytest.raises(ValueError, match="Specular density is useless"):  # models.py:478-480
         models.MLP(enable_pred_specular_density=True, use_diffuse_color=False)
     with pytest.raises(ValueError, match="outside the fused"):
-        models.Model(config=cfg, disable_integration=True)
+        models.Model(config=cfg, use_viewdirs=False)
+    with pytest.raises(KeyError):                          # coord.py:92: inv_mapping[fn.__name__]
+        models.Model(config=cfg, raydist_fn=torch.tanh)
+    m = models.Model(config=cfg, raydist_fn="@torch.reciprocal", disable_integration=True)     # built (cfg.raydist, cfg.disable_integration)
+    assert m._raydist_code == _hip.RAYDIST["reciprocal"] and models.Model._raydist_enum(torch.log) == 3 and models.Model._raydist_enum("piecewise") == 1
     assert models.Model(config=cfg, dilation_bias=0.0025).dilation_bias == 0.0025      # built (host dilation)
 
 
