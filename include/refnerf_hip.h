@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 6   /* v6: cfg.dir_enc (REFNERF_DIRENC_*), cfg.raydist (REFNERF_RAYDIST_*), cfg.disable_integration; v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
+#define REFNERF_ABI_VERSION 7   /* v7: REFNERF_PREC_F16X2 (split-operand f16: the parity-grade 16-bit inference mode); v6: cfg.dir_enc (REFNERF_DIRENC_*), cfg.raydist (REFNERF_RAYDIST_*), cfg.disable_integration; v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {
@@ -44,9 +44,15 @@ enum {
   REFNERF_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains (parity mode) */
   REFNERF_PREC_BF16 = 1, /* v_mfma_f32_32x32x16_bf16, fp32 accumulate (training forward / backward in
                             this mode: n_samples <= 294, REFNERF_EINVAL beyond -- LDS budget)  */
-  REFNERF_PREC_F16 = 2   /* v_mfma_f32_32x32x16_f16 (IEEE half operands, fp32 accumulate): the bf16 inference kernel
+  REFNERF_PREC_F16 = 2,  /* v_mfma_f32_32x32x16_f16 (IEEE half operands, fp32 accumulate): the bf16 inference kernel
                             with 11 instead of 8 significand bits -- 8-10x closer to REFNERF_PREC_F32 at ~3 % lower
                             throughput; hidden activations must stay below 65504.  refnerf_level_forward only. */
+  REFNERF_PREC_F16X2 = 3 /* split-operand f16: in the spatial trunk and the density / scalar head block BOTH operands are
+                            hi + lo pairs of IEEE halves (22 significand bits; all four partial products on
+                            v_mfma_f32_32x32x16_f16, fp32 accumulate), the directional trunk is plain f16; resampler,
+                            encodings, activations and compositing are the fp32 parity code.  The 16-bit mode that holds
+                            the reference's fp32 nn.Linear arithmetic (internal/models.py:576-580, 686-700) to 1e-4 RGB
+                            on trained weights; ~2.35x the MFMAs of REFNERF_PREC_F16.  refnerf_level_forward only. */
 };
 
 /* arithmetic of the weight-gradient GEMM of refnerf_level_backward (dW = DELTA x ACT^T over the samples) */

@@ -14,8 +14,8 @@ import torch
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
 
-PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-ABI_VERSION = 6   # REFNERF_ABI_VERSION
+PREC_F32, PREC_BF16, PREC_F16, PREC_F16X2 = 0, 1, 2, 3
+ABI_VERSION = 7   # REFNERF_ABI_VERSION
 WGRAD_F32, WGRAD_BF16X3 = 0, 1
 DIRENC_IDE, DIRENC_POSENC = 0, 1   # REFNERF_DIRENC_*
 RAYDIST = {None: 0, "piecewise": 1, "reciprocal": 2, "log": 3, "exp": 4, "sqrt": 5, "square": 6}   # REFNERF_RAYDIST_*

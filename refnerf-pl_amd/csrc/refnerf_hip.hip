@@ -187,6 +187,41 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
   }
 }
 
+/* One plain 17 KB chunk of the 16-bit images (refnerf_layout.h): bias piece + 16 fragment pieces. */
+template <typename E>
+__device__ void fill_chunk_plain(const float *__restrict__ P, char *__restrict__ chunk, int op, int ob, int kind, bool first, int base) {
+  /* bias piece: fp32 [h][16] (first chunk of the slice), rest of the KB zero */
+  for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+    float v = 0.0f;
+    if (e < 32 && first) {
+      int reg = e & 15, h = e >> 4;
+      v = canon_b(P, op, ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+    }
+    reinterpret_cast<float *>(chunk)[e] = v;
+  }
+  for (int idx = threadIdx.x; idx < 16 * 512; idx += blockDim.x) {
+    int e = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9;
+    int h = lane >> 5, row = ob * 32 + (lane & 31);
+    float v = 0.0f;
+    const bool reg_step = (kind == BF_REG) || (kind == BF_BNLDS && t < 8);
+    if (reg_step) {
+      int r = 8 * (t & 1) + e;
+      int feat = 32 * (t >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+      v = canon_w(P, op, row, (kind == BF_REG) ? feat : base + feat);
+    } else if (kind == BF_LDS8) {
+      int kp = 16 * t + 8 * h + e;
+      if (t < BF_IPE_REAL_KS) v = canon_w(P, op, row, base + ipe_col_of_kprime(kp));
+    } else {
+      int kp = 16 * (t - 8) + 8 * h + e;
+      /* dir k': [Re x36 | n.v | 0 0 0 | Im x36 | 0 0 0 0] */
+      if (kp < IDE_TERMS) v = canon_w(P, op, row, base + BNECK + kp);
+      else if (kp == IDE_TERMS) v = canon_w(P, op, row, base + BNECK + IDE_DIM);
+      else if (kp >= 40 && kp < 40 + IDE_TERMS) v = canon_w(P, op, row, base + BNECK + IDE_TERMS + (kp - 40));
+    }
+    reinterpret_cast<E *>(chunk + 1024)[idx] = (E)v;
+  }
+}
+
 /* bf16 image: one block per (op, ob) slice, uniform 17 KB chunks in execution
  * order; see refnerf_layout.h. */
 template <typename E>   /* E = __bf16 (REFNERF_PREC_BF16) or _Float16 (REFNERF_PREC_F16): same image layout */
@@ -195,38 +230,55 @@ __global__ void pack_weights_16(const float *__restrict__ P, char *__restrict__ 
   const BfOp o = BFPACKED.op[op];
   if (ob >= o.nob) return;
   const int base = (o.nchunk == 2) ? WIDTH : 0;     /* canonical column of the first non-register input */
-  for (int j = 0; j < o.nchunk; ++j) {
-    char *chunk = out + (size_t)(o.chunk0 + ob * o.nchunk + j) * BF_CHUNK_BYTES;
-    const int kind = o.kind[j];
-    /* bias piece: fp32 [h][16] (first chunk of the slice), rest of the KB zero */
-    for (int e = threadIdx.x; e < 256; e += blockDim.x) {
-      float v = 0.0f;
-      if (e < 32 && j == 0) {
-        int reg = e & 15, h = e >> 4;
-        v = canon_b(P, op, ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
-      }
-      reinterpret_cast<float *>(chunk)[e] = v;
+  for (int j = 0; j < o.nchunk; ++j)
+    fill_chunk_plain<E>(P, out + (size_t)(o.chunk0 + ob * o.nchunk + j) * BF_CHUNK_BYTES, op, ob, o.kind[j], j == 0, base);
+}
+
+/* Split-f16 image (REFNERF_PREC_F16X2, refnerf_layout.h): spatial ops + the scalar head block as [hi lo] piece pairs
+ * (w = hi + lo, hi = fl16(w), lo = fl16(w - hi)), bottleneck blocks and the directional ops as plain f16 chunks. */
+__device__ void fill_chunk_split(const float *__restrict__ P, char *__restrict__ chunk, int op, int ob, int kind, bool first, int base) {
+  for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+    float v = 0.0f;
+    if (e < 32 && first) {
+      int reg = e & 15, h = e >> 4;
+      v = canon_b(P, op, ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
     }
-    for (int idx = threadIdx.x; idx < 16 * 512; idx += blockDim.x) {
-      int e = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9;
-      int h = lane >> 5, row = ob * 32 + (lane & 31);
-      float v = 0.0f;
-      const bool reg_step = (kind == BF_REG) || (kind == BF_BNLDS && t < 8);
-      if (reg_step) {
-        int r = 8 * (t & 1) + e;
-        int feat = 32 * (t >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
-        v = canon_w(P, op, row, (kind == BF_REG) ? feat : base + feat);
-      } else if (kind == BF_LDS8) {
-        int kp = 16 * t + 8 * h + e;
-        if (t < BF_IPE_REAL_KS) v = canon_w(P, op, row, base + ipe_col_of_kprime(kp));
-      } else {
-        int kp = 16 * (t - 8) + 8 * h + e;
-        /* dir k': [Re x36 | n.v | 0 0 0 | Im x36 | 0 0 0 0] */
-        if (kp < IDE_TERMS) v = canon_w(P, op, row, base + BNECK + kp);
-        else if (kp == IDE_TERMS) v = canon_w(P, op, row, base + BNECK + IDE_DIM);
-        else if (kp >= 40 && kp < 40 + IDE_TERMS) v = canon_w(P, op, row, base + BNECK + IDE_TERMS + (kp - 40));
-      }
-      reinterpret_cast<E *>(chunk + 1024)[idx] = (E)v;
+    reinterpret_cast<float *>(chunk)[e] = v;      /* floats 32..63 stay zero: the accumulator seed of the lo columns */
+  }
+  for (int idx = threadIdx.x; idx < 16 * 512; idx += blockDim.x) {
+    const int e = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9;
+    const int h = lane >> 5, row = ob * 32 + (lane & 31), part = t & 1;
+    float v = 0.0f;
+    if (kind == BF_SLDS) {
+      const int s = t >> 1;
+      if (s < BF_IPE_REAL_KS) v = canon_w(P, op, row, base + ipe_col_of_kprime(16 * s + 8 * h + e));
+    } else {
+      const int ks = (kind == BF_SREG1 ? 8 : 0) + (t >> 1);
+      const int r = 8 * (ks & 1) + e;
+      v = canon_w(P, op, row, 32 * (ks >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h);
+    }
+    const _Float16 hi = (_Float16)v;
+    reinterpret_cast<_Float16 *>(chunk + 1024)[idx] = part ? (_Float16)(v - (float)hi) : hi;
+  }
+}
+__global__ void pack_weights_split(const float *__restrict__ P, char *__restrict__ out) {
+  const int op = blockIdx.y, ob = blockIdx.x;
+  const int nob = (op == OP_HEADS) ? 5 : (op == OP_RGB ? 1 : 8);
+  if (ob >= nob) return;
+  int c = SPPACKED.chunk0[op];
+  for (int o2 = 0; o2 < ob; ++o2) c += sp_slice_chunks(op, o2);
+  char *chunk = out + (size_t)c * BF_CHUNK_BYTES;
+  if (op > OP_HEADS) {
+    const BfOp o = BFPACKED.op[op];
+    const int base = (o.nchunk == 2) ? WIDTH : 0;
+    for (int j = 0; j < o.nchunk; ++j) fill_chunk_plain<_Float16>(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, o.kind[j], j == 0, base);
+  } else if (op == OP_HEADS && ob < 4) {
+    fill_chunk_plain<_Float16>(P, chunk, op, ob, BF_REG, true, 0);
+  } else {
+    const int n = sp_slice_chunks(op, ob);
+    for (int j = 0; j < n; ++j) {
+      const int kind = (op == 0 || j == 2) ? BF_SLDS : (j == 0 ? BF_SREG0 : BF_SREG1);
+      fill_chunk_split(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, kind, j == 0, op == 5 ? WIDTH : 0);
     }
   }
 }
@@ -512,6 +564,7 @@ int refnerf_device_ok(void) {
 size_t refnerf_packed_weights_bytes(int precision) {
   if (precision == REFNERF_PREC_F32) return (size_t)rn::PACKED.total * sizeof(float);
   if (precision == REFNERF_PREC_BF16 || precision == REFNERF_PREC_F16) return ((size_t)rn::BFPACKED.chunks_per_pass + 2) * rn::BF_CHUNK_BYTES;
+  if (precision == REFNERF_PREC_F16X2) return ((size_t)rn::SPPACKED.total_chunks + 2) * rn::BF_CHUNK_BYTES;
   return 0;
 }
 
@@ -526,6 +579,9 @@ int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, v
   } else if (precision == REFNERF_PREC_F16) {
     dim3 grid(8, rn::NUM_OPS);
     hipLaunchKernelGGL(rn::pack_weights_16<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, d_params, (char *)d_packed);
+  } else if (precision == REFNERF_PREC_F16X2) {
+    dim3 grid(8, rn::NUM_OPS);
+    hipLaunchKernelGGL(rn::pack_weights_split, grid, dim3(256), 0, (hipStream_t)stream, d_params, (char *)d_packed);
   } else {
     return fail(REFNERF_EINVAL, "refnerf_pack_weights: unknown precision%s");
   }
@@ -561,6 +617,12 @@ BwdPlan bwd_plan(int R, int N) {
 }
 }  // namespace
 
+#ifdef REFNERF_SPLIT_DUMP
+/* debug build only (scripts/dbg_split_dump.py): the split kernel dumps what its spatial trunk saw into this buffer */
+static float *g_split_dump = nullptr;
+extern "C" int refnerf_debug_set_dump(float *d_buf) { g_split_dump = d_buf; return 0; }
+#endif
+
 static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays,
                               int32_t R, const float *d_sdist_in, const float *d_weights_in,
                               const refnerf_level_out *out, float *d_act, long long act_pitch, void *stream) {
@@ -572,21 +634,23 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   /* render.py:126 */
   if (cfg->ray_shape != 0 && cfg->ray_shape != 1) return fail(REFNERF_EINVAL, "ray_shape must be 'cone' or 'cylinder'%s");
   if (cfg->n_in < 1 || cfg->n_in > 512) return fail(REFNERF_EINVAL, "n_in must be in [1,512]%s");
-  if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16 && cfg->precision != REFNERF_PREC_F16)
+  if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16 && cfg->precision != REFNERF_PREC_F16 &&
+      cfg->precision != REFNERF_PREC_F16X2)
     return fail(REFNERF_EINVAL, "unknown precision mode%s");
   if (cfg->raydist < REFNERF_RAYDIST_NONE || cfg->raydist > REFNERF_RAYDIST_SQUARE)
     return fail(REFNERF_EINVAL, "unknown raydist (REFNERF_RAYDIST_*)%s");
   if (cfg->dir_enc != REFNERF_DIRENC_IDE && cfg->dir_enc != REFNERF_DIRENC_POSENC)
     return fail(REFNERF_EINVAL, "unknown dir_enc (REFNERF_DIRENC_IDE / REFNERF_DIRENC_POSENC)%s");
-  if (cfg->training && cfg->precision == REFNERF_PREC_F16)
-    return fail(REFNERF_EUNSUPPORTED, "REFNERF_PREC_F16 is an inference mode (training levels: REFNERF_PREC_F32 or REFNERF_PREC_BF16)%s");
+  if (cfg->training && (cfg->precision == REFNERF_PREC_F16 || cfg->precision == REFNERF_PREC_F16X2))
+    return fail(REFNERF_EUNSUPPORTED, "REFNERF_PREC_F16 / REFNERF_PREC_F16X2 are inference modes (training levels: REFNERF_PREC_F32 or REFNERF_PREC_BF16)%s");
   /* training + BF16: the fp32-structure kernel with its MLP chains on bf16 MFMA (level_fwd_train_bf16c); d_packed is
    * the REFNERF_PREC_F32 image in that case (it carries the bf16 copies of the ops) */
   const bool train_bf = cfg->training && cfg->precision == REFNERF_PREC_BF16;
   if (!rays->d_origins || !rays->d_directions || !rays->d_viewdirs || !rays->d_radii || !rays->d_near || !rays->d_far)
     return fail(REFNERF_EINVAL, "refnerf_level_forward: null ray field%s");
   const int N = cfg->n_samples;
-  const bool bf = (cfg->precision == REFNERF_PREC_BF16 && !train_bf) || cfg->precision == REFNERF_PREC_F16;     /* the LDS-ring 16-bit eval kernel */
+  const bool split = cfg->precision == REFNERF_PREC_F16X2;
+  const bool bf = (cfg->precision == REFNERF_PREC_BF16 && !train_bf) || cfg->precision == REFNERF_PREC_F16 || split;     /* the LDS-ring 16-bit eval kernels */
   int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
   /* 16-bit inference, rays that do not tile the 256-sample pass within 640 samples (N = 192: 2 rays = one and a half
    * passes): take the smallest ray count that does (N = 192: 4 rays = three full passes) with the per-sample records in a
@@ -628,7 +692,8 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   lds += (size_t)rt().lds_pad;   /* debug (REFNERF_LDS_PAD): force 1 workgroup/CU */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget of this precision mode%s");
   LDS_ATTR_ONCE(lds_attr(rn::level_fwd_f32), lds_attr(rn::level_fwd_train_f32), lds_attr(rn::level_fwd_train_bf16c),
-                lds_attr(rn::level_fwd_bf16), lds_attr(rn::level_fwd_f16), lds_attr(rn::level_fwd_bf16_ring), lds_attr(rn::level_fwd_f16_ring));
+                lds_attr(rn::level_fwd_bf16), lds_attr(rn::level_fwd_f16), lds_attr(rn::level_fwd_bf16_ring), lds_attr(rn::level_fwd_f16_ring),
+                lds_attr(rn::level_fwd_f16x2), lds_attr(rn::level_fwd_f16x2_ring));
   rn::LevelArgs a;
   a.packed = d_packed;
   a.cfg = *cfg;
@@ -642,6 +707,9 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   a.g_means = nullptr; a.g_covs = nullptr; a.cov_full = 0;
   a.act = d_act; a.act_pitch = act_pitch;
   a.ring_off = (int)ring_off;
+#ifdef REFNERF_SPLIT_DUMP
+  a.dbg = g_split_dump;
+#endif
   if (rt().prof) {
     int prc = prof_buffer(&a.prof);
     if (prc) return prc;
@@ -653,7 +721,9 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
     int trc = timer_begin(st, &tslot);
     if (trc) return trc;
   }
-  if (bf && ps_ring && cfg->precision == REFNERF_PREC_F16) hipLaunchKernelGGL(rn::level_fwd_f16_ring, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  if (split && ps_ring) hipLaunchKernelGGL(rn::level_fwd_f16x2_ring, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  else if (split) hipLaunchKernelGGL(rn::level_fwd_f16x2, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  else if (bf && ps_ring && cfg->precision == REFNERF_PREC_F16) hipLaunchKernelGGL(rn::level_fwd_f16_ring, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else if (bf && ps_ring) hipLaunchKernelGGL(rn::level_fwd_bf16_ring, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else if (bf && cfg->precision == REFNERF_PREC_F16) hipLaunchKernelGGL(rn::level_fwd_f16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);

@@ -257,6 +257,45 @@ constexpr BfPacked make_bf_packed() {
 }
 constexpr BfPacked BFPACKED = make_bf_packed();
 
+/* ---------------- split-f16 operand image (REFNERF_PREC_F16X2) ----------------
+ * The parity-grade 16-bit mode: the spatial trunk and the scalar head block (density) take BOTH operands as
+ * hi + lo pairs of IEEE halves (x = hi + lo exactly to 22 bits), the directional trunk stays plain f16 (measured on the
+ * trained-like weights, scripts/exp_split_precision.py: only the density path needs more than 11 bits).
+ * Activations are N-PACKED: a wave owns 16 samples per spatial run and the 32 B columns of an MFMA are
+ * [hi of samples 0..15 | lo of samples 0..15]; MFMA(W_hi, B) + MFMA(W_lo, B) into ONE accumulator then hold the four
+ * products hi*hi + lo*hi (columns 0..15) and hi*lo + lo*lo (columns 16..31), summed across the lane halves in the
+ * epilogue.  Chunk kinds on top of the plain ones (same 17 KB chunks, same k maps as the plain image):
+ *   SREG0 / SREG1 : register k-steps 0..7 / 8..15, pieces [hi(k) lo(k)] x 8 = 16 MFMAs
+ *   SLDS          : the 6 real LDS k-steps of the IPE features, pieces [hi lo] x 6 = 12 MFMAs (4 pieces unused)
+ * sp0: [SLDS]; sp1-4, 6, 7: [SREG0][SREG1]; sp5: [SREG0][SREG1][SLDS]; heads: bottleneck blocks [REG] (hi weights
+ * only, over the N-packed input: w_hi (x_hi + x_lo)), scalar block [SREG0][SREG1]; directional ops as in the plain image.
+ * A pass = the spatial section TWICE (two runs of 16 samples per wave), then the directional section once over all 32. */
+enum { BF_SREG0 = 3, BF_SREG1 = 4, BF_SLDS = 5 };
+constexpr int BF_SLDS_KS = 2 * BF_IPE_REAL_KS;   /* MFMAs of an SLDS chunk */
+struct SpPacked { int chunk0[NUM_OPS]; int sp_chunks; int total_chunks; int chunks_per_pass; };
+constexpr int sp_slice_chunks(int op, int ob) {
+  if (op == 0) return 1;
+  if (op == 5) return 3;
+  if (op < OP_HEADS) return 2;
+  if (op == OP_HEADS) return ob < 4 ? 1 : 2;
+  return (op == 14) ? 2 : 1;
+}
+constexpr SpPacked make_sp_packed() {
+  SpPacked P{};
+  int c = 0;
+  for (int i = 0; i < NUM_OPS; ++i) {
+    P.chunk0[i] = c;
+    const int nob = (i == OP_HEADS) ? 5 : (i == OP_RGB ? 1 : 8);
+    for (int ob = 0; ob < nob; ++ob) c += sp_slice_chunks(i, ob);
+    if (i == OP_HEADS) P.sp_chunks = c;
+  }
+  P.total_chunks = c;
+  P.chunks_per_pass = c + P.sp_chunks;
+  return P;
+}
+constexpr SpPacked SPPACKED = make_sp_packed();
+static_assert(SPPACKED.sp_chunks == 134 && SPPACKED.total_chunks == 207, "split image layout");
+
 /* head rows inside op 8 (5 blocks of 32): 0..127 bottleneck, then */
 constexpr int HROW_DENSITY = 128, HROW_GRAD = 129, HROW_ROUGH = 132, HROW_DIFFUSE = 133, HROW_TINT = 136, HROWS = 139;
 

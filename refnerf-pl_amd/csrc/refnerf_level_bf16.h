@@ -87,6 +87,8 @@ struct Pipe {
   const char *src_end;   /* end of one pass worth of chunks (wrap point) for this lane */
   char *wbuf;        /* LDS ring base (3 slots) */
   const char *xp;    /* LDS encodings, pre-offset to this lane's B fragment (sample n, half h) */
+  const char *xps;   /* split mode: the same for the N-packed IPE planes (lanes 0-15 hi, 16-31 lo of sample n & 15) */
+  int seq;           /* split mode: chunks issued so far in this pass (the spatial section is streamed twice) */
   int cur_off, nxt_off, fil_off;   /* ring slots: being consumed / landed next / free */
   int dma_left;      /* chunks still to be DMA'd by this workgroup */
   int lane, wave, h;
@@ -98,6 +100,7 @@ struct Pipe {
  * instruction's immediate offset cover both the global and the LDS side.
  * (Measured alternatives: all pieces issued by the prioritised waves 4-7, or
  * 2 pieces per wave with 16 KB chunks -- both slower in the full kernel.) */
+template <bool SPLIT = false>
 __device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off) {
   if (p.dma_left > 0) {
     if (p.wave < 6) {
@@ -107,7 +110,14 @@ __device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off) {
       if (p.wave < 5) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 2048, 0);
     }
     p.src += BF_CHUNK_BYTES;
-    if (p.src == p.src_end) p.src -= (size_t)BFPACKED.chunks_per_pass * BF_CHUNK_BYTES;
+    if constexpr (SPLIT) {
+      /* a pass streams [spatial section][spatial section][directional section] */
+      p.seq += 1;
+      if (p.seq == SPPACKED.sp_chunks) p.src -= (size_t)SPPACKED.sp_chunks * BF_CHUNK_BYTES;
+      else if (p.seq == SPPACKED.chunks_per_pass) { p.src -= (size_t)SPPACKED.total_chunks * BF_CHUNK_BYTES; p.seq = 0; }
+    } else {
+      if (p.src == p.src_end) p.src -= (size_t)BFPACKED.chunks_per_pass * BF_CHUNK_BYTES;
+    }
     p.dma_left -= 1;
   }
 }
@@ -152,33 +162,45 @@ __device__ __forceinline__ typename MM::v8 lds_b(const Pipe &p, int kl) {
 }
 
 /* One chunk.  KIND: BF_REG (16 steps over `in`), BF_LDS8 (8 steps over LDS,
- * REAL_L real), BF_BNLDS (8 over `bn` + 8 over LDS, REAL_L real).
- * FIRST: the chunk opens a slice (accumulator starts from the bias piece).
+ * REAL_L real), BF_BNLDS (8 over `bn` + 8 over LDS, REAL_L real); split mode (refnerf_layout.h): BF_SREG0 / BF_SREG1
+ * (k-steps 0..7 / 8..15 of `in`, each with the hi and the lo weight fragment), BF_SLDS (the 6 real IPE steps from the
+ * N-packed LDS planes, hi and lo fragments).
+ * FIRST: the chunk opens a slice (accumulator starts from the bias piece; NPK: N-packed columns -- the lo columns,
+ * lanes 16-31 of each half, start from the zeros behind the bias).
  * `a` is the A-fragment ring; on entry it holds fragments 0..AF-1 of this chunk,
  * on exit those of the next one. */
-template <typename MM, int KIND, int REAL_L, bool FIRST>
+template <typename MM, int KIND, int REAL_L, bool FIRST, bool SPLIT = false, bool NPK = false>
 __device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
   typedef typename MM::v8 v8mm;
-  constexpr int KS = (KIND == BF_LDS8) ? 8 : 16;
+  constexpr bool SK = (KIND == BF_SREG0 || KIND == BF_SREG1 || KIND == BF_SLDS);
+  constexpr int KS = (KIND == BF_LDS8) ? 8 : (KIND == BF_SLDS ? BF_SLDS_KS : 16);
   constexpr int L0 = (KIND == BF_BNLDS) ? 8 : 0;      /* first LDS step (for the LDS kinds) */
+  static_assert(KS % AF == 0, "ring phase");
   const char *w = p.wbuf + p.cur_off;
   const char *cur = w + 1024 + p.lane * 16;
   const char *nxt = p.wbuf + p.nxt_off + 1024 + p.lane * 16;
   v8mm xr[2];
   if (KIND == BF_LDS8) { xr[0] = lds_b<MM, REAL_L>(p, 0); xr[1] = lds_b<MM, REAL_L>(p, 1); }
-  if (FIRST) acc = bias16(w, p.h);
+  if (KIND == BF_SLDS) { xr[0] = lds_frag<MM>(p.xps); xr[1] = lds_frag<MM>(p.xps + 2 * BT * 16); }
+  if (FIRST) acc = bias16(w + ((SK || NPK) ? ((p.lane & 16) << 3) : 0), p.h);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
     v8mm b;
     const bool lds_step = (KIND == BF_LDS8) || (KIND == BF_BNLDS && k >= 8);
-    if (lds_step) b = xr[(k - L0) & 1];
+    if (KIND == BF_SLDS) b = xr[(k >> 1) & 1];
+    else if (KIND == BF_SREG0) b = __builtin_bit_cast(v8mm, in[k >> 1]);
+    else if (KIND == BF_SREG1) b = __builtin_bit_cast(v8mm, in[8 + (k >> 1)]);
+    else if (lds_step) b = xr[(k - L0) & 1];
     else if (KIND == BF_REG) b = __builtin_bit_cast(v8mm, in[k]);
     else b = __builtin_bit_cast(v8mm, bn[k & 7]);
     acc = MM::mfma(a[k % AF], b, acc);
     /* A ring: fragment k+AF of this chunk, or the head of the next chunk (landed: k >= KS/2) */
     a[k % AF] = (k + AF < KS) ? lds_frag<MM>(cur + (k + AF) * 1024) : lds_frag<MM>(nxt + (k + AF - KS) * 1024);
-    if (KIND != BF_REG) {
+    if (KIND == BF_SLDS) {
+      const int s2 = (k >> 1) + 2;                      /* after the lo MFMA of step s: fetch step s + 2 into its slot */
+      if ((k & 1) && s2 < BF_IPE_REAL_KS) xr[s2 & 1] = lds_frag<MM>(p.xps + (2 * s2) * BT * 16);
+    } else if (KIND == BF_LDS8 || KIND == BF_BNLDS) {
       const int kl2 = k + 2 - L0;                       /* LDS step to fetch now */
       if (kl2 >= 0 && kl2 < 8 && !(KIND == BF_LDS8 && kl2 < 2)) xr[kl2 & 1] = lds_b<MM, REAL_L>(p, kl2);
     }
@@ -199,7 +221,7 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], cons
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
 #endif
-      issue_chunk(p, p.fil_off);
+      issue_chunk<SPLIT>(p, p.fil_off);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -213,12 +235,13 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], cons
  * samples into 2 x 256) takes no part in the MLP, but keeps the weight stream going: it joins every rendezvous of the pass
  * and issues its DMA pieces.  The matrix pipe of its SIMD then belongs to the one active wave -- a half-filled pass costs
  * about two thirds of a full one instead of all of it. */
+template <bool SPLIT = false>
 __device__ __forceinline__ void idle_pass(Pipe &p) {
 #pragma unroll 1
-  for (int c = 0; c < BFPACKED.chunks_per_pass; ++c) {
+  for (int c = 0; c < (SPLIT ? SPPACKED.chunks_per_pass : BFPACKED.chunks_per_pass); ++c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    issue_chunk(p, p.fil_off);
+    issue_chunk<SPLIT>(p, p.fil_off);
     const int t = p.cur_off;
     p.cur_off = p.nxt_off;
     p.nxt_off = p.fil_off;
@@ -486,6 +509,383 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16(const LevelArgs A) 
 /* the same with the per-sample records in a ring (rays_per_wg * N > 640) */
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16_ring(const LevelArgs A) { level_fwd_mm<MmBf16, true>(A); }
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16_ring(const LevelArgs A) { level_fwd_mm<MmF16, true>(A); }
+
+/* =====================================================================================================================
+ * REFNERF_PREC_F16X2 -- the parity-grade 16-bit mode (split operands, refnerf_layout.h "split-f16 operand image").
+ *
+ * Same skeleton as level_fwd_mm (8 waves, LDS-DMA chunk ring, one rendezvous per chunk, activations in registers), but
+ *   * the spatial trunk runs TWICE per pass on 16 samples per wave with N-packed B operands [hi x16 | lo x16]: two MFMAs
+ *     (W_hi, W_lo fragments) per k-step into one accumulator = all four partial products, fp32 accumulate; the epilogue
+ *     adds the two column halves (v_permlane16_swap), applies ReLU in fp32, splits the result into hi + lo halves again
+ *     and swaps them back into the N-packed layout -- 22 significand bits end to end;
+ *   * the scalar head block (density, grad_pred, roughness, diffuse, tint) likewise; the bottleneck takes W_hi only;
+ *   * the directional trunk is the plain f16 trunk over all 32 samples (the two runs' bottlenecks are merged with one
+ *     more v_permlane16_swap per dword);
+ *   * everything outside the contractions is the fp32 parity code: bit-exact resampler (sequential CDF), libm-accurate
+ *     encodings / activations / compositing.
+ * MFMA count per 32 samples: 2 x 2080 + 1168 = 5328 against 2272 of the plain kernel (2.35x).
+ * ===================================================================================================================== */
+typedef unsigned v2uu __attribute__((ext_vector_type(2)));
+
+/* N-packed accumulator tile (columns 0-15: products with x_hi, 16-31: with x_lo) -> 8 fp32 totals: lanes 0-15 of each half
+ * hold accumulator rows j, lanes 16-31 rows j + 8 (j = 0..7) of sample (lane & 15) */
+/* (by-value helpers: clang's __builtin_bit_cast applied directly to an ext-vector ELEMENT expression reads element 0) */
+__device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ void npk_totals(const v16f &a, float (&s)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float lo = a[j], hi = a[j + 8];
+    const v2uu r = __builtin_amdgcn_permlane16_swap(f2u(lo), f2u(hi), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    s[j] = u2f(r0) + u2f(r1);
+  }
+}
+__device__ __forceinline__ unsigned pk_f16(float lo, float hi) { return cvt_pk_mm<MmF16>(lo, hi); }
+/* (x0, x1) -> packed hi halves + packed lo halves, x = hi + lo.  The residual is formed from the BITS that get stored:
+ * hipcc otherwise converts the same value twice with different instructions -- v_cvt_pk_f16_f32 of the fp32 product for the
+ * stored half, v_fma_mixlo_f16 (the product rounded ONCE, to f16) for the copy the residual is taken from -- and the two
+ * disagree by an ulp of the hi half for one value in ~10^5 (double rounding): 0.3 % of the samples then carried one IPE
+ * feature that was off by 2^-11 (found with scripts/dbg_split_dump.py). */
+__device__ __forceinline__ void split_pair_f16(float x0, float x1, unsigned &hi, unsigned &lo) {
+  hi = pk_f16(x0, x1);
+  asm("" : "+v"(hi));
+  const MmF16::v2 hv = __builtin_bit_cast(MmF16::v2, hi);
+  const _Float16 h0 = hv[0], h1 = hv[1];
+  lo = pk_f16(x0 - (float)h0, x1 - (float)h1);
+}
+/* totals -> the next layer's two N-packed B fragments (hi + lo halves of ReLU(total)); same k order as pack_acc */
+__device__ __forceinline__ void pack_acc_split(const v16f &a, v4uu &f0, v4uu &f1, float *dbg = nullptr, int lane = 0) {
+  float s[8];
+  npk_totals(a, s);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x0 = fmaxf(s[2 * e], 0.0f), x1 = fmaxf(s[2 * e + 1], 0.0f);
+#ifdef REFNERF_SPLIT_DUMP
+    if (dbg) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int jj = 2 * e + u + ((lane & 16) ? 8 : 0);
+        dbg[(jj & 3) + 8 * (jj >> 2) + 4 * (lane >> 5)] = u ? x1 : x0;
+      }
+    }
+#endif
+    unsigned hi, lo;
+    split_pair_f16(x0, x1, hi, lo);
+    const v2uu r = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);
+    f0[e] = r[0];
+    f1[e] = r[1];
+  }
+}
+
+/* spatial slice: [SREG0][SREG1] (+ [SLDS] for the skip layer) */
+template <typename MM>
+__device__ __forceinline__ void sp_slice(Pipe &p, typename MM::v8 (&a)[AF], bool skip, const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
+  bf_chunk<MM, BF_SREG0, 0, true, true>(p, a, in, bn, acc);
+  bf_chunk<MM, BF_SREG1, 0, false, true>(p, a, in, bn, acc);
+  if (skip) bf_chunk<MM, BF_SLDS, 0, false, true>(p, a, in, bn, acc);
+}
+template <typename MM, bool LAYER0>
+__device__ __forceinline__ void sp_layer(Pipe &p, typename MM::v8 (&a)[AF], bool skip, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16], float *dbg = nullptr) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+    v16f acc;
+    if constexpr (LAYER0) bf_chunk<MM, BF_SLDS, 0, true, true>(p, a, in, bn, acc);
+    else sp_slice<MM>(p, a, skip, in, bn, acc);
+    pack_acc_split(acc, out[2 * ob], out[2 * ob + 1], dbg ? dbg + 32 * ob : nullptr, p.lane);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+/* directional layer of the split kernel: the plain layer on the split kernel's DMA schedule */
+template <typename MM, int KIND0, int REAL0>
+__device__ __forceinline__ void dir_layer(Pipe &p, typename MM::v8 (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16]) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+    v16f acc;
+    bf_chunk<MM, KIND0, REAL0, true, true>(p, a, in, bn, acc);
+    if constexpr (KIND0 == BF_REG) {
+      if (second == 2) bf_chunk<MM, BF_BNLDS, BF_DIR_REAL_KS, false, true>(p, a, in, bn, acc);
+    }
+    pack_acc<MM, true>(acc, out[2 * ob], out[2 * ob + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <bool RINGPS = false>
+__device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
+  typedef MmF16 MM;
+  constexpr int PSM = RINGPS ? BF_PS_RING - 1 : 0;
+  typedef typename MM::v8 v8mm;
+  typedef typename MM::t mm_t;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const refnerf_level_cfg &cfg = A.cfg;
+  const int N = cfg.n_samples;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rpw = A.rpw;
+  const int ray0 = blockIdx.x * rpw;
+  const int n_tot = rpw * N;
+  const int n_pass = (n_tot + BT - 1) / BT;
+
+  char *WB = reinterpret_cast<char *>(smem);                 /* 3 x 17 KB chunk ring     */
+  char *Xb = WB + BF_RING_BYTES;                             /* BF_X_BYTES: encodings    */
+  float *HD = reinterpret_cast<float *>(Xb + BF_X_BYTES);    /* [HD_ROWS][BT]            */
+  float *TD = HD + HD_ROWS * BT;                             /* [rpw][N+1]               */
+  float *XP = TD + rpw * (N + 1);                            /* [rpw][N+1]               */
+  float *PS = XP + rpw * (N + 1);                            /* [n_tot][NPS_EVAL] (RINGPS: [BF_PS_RING][NPS_EVAL]) */
+  float *PX = PS + (RINGPS ? BF_PS_RING : n_tot) * NPS_EVAL; /* [BT][3] grad_pred of the pass */
+  float *NRM = PX + 3 * BT;                                  /* [8] |direction| per ray  */
+  const float *RY = NRM + 8;                                 /* [rpw][12] o, d, viewdir, radius per ray */
+
+  const int h = lane >> 5, n = lane & 31;
+  const int col = wave * 32 + n;                             /* this lane's sample column (directional phase) */
+
+  Pipe p;
+  p.src = reinterpret_cast<const char *>(A.packed) + wave * 3072 + lane * 16;
+  p.src_end = nullptr;
+  p.wbuf = WB;
+  p.xp = Xb + (h * BT + col) * 16;
+  /* N-packed IPE planes: [k-group][plane (hi | lo)][128 columns = wave * 16 + sample][16 B] */
+  p.xps = Xb + (h * BT + (n >> 4) * (BT / 2) + wave * 16 + (n & 15)) * 16;
+  p.seq = 0;
+  p.cur_off = 0; p.nxt_off = BF_CHUNK_BYTES; p.fil_off = 2 * BF_CHUNK_BYTES;
+  p.dma_left = n_pass * SPPACKED.chunks_per_pass;
+  p.lane = lane; p.wave = wave; p.h = h;
+  p.t_vm = 0; p.t_bar = 0;
+  RN_STAMP(A, 0);
+  issue_chunk<true>(p, p.cur_off);                           /* overlaps with the resampler */
+  issue_chunk<true>(p, p.nxt_off);
+
+  resample_phase<BF_NW, true>(A, reinterpret_cast<float *>(Xb), TD, NRM, ray0, wave, lane);   /* P0: bit-exact CDF */
+  /* (the EXACT resampler leaves the ray geometry to its caller: park it here as the plain kernel's does) */
+#pragma clang loop unroll(disable)
+  for (int rl = wave; rl < rpw; rl += BF_NW) {
+    const int ray = ray0 + rl;
+    if (ray >= A.R) break;
+    float *RYw = NRM + 8 + rl * 12;
+    if (lane < 10) {
+      const float val = lane < 3 ? A.rays.d_origins[(size_t)ray * 3 + lane]
+                      : lane < 6 ? A.rays.d_directions[(size_t)ray * 3 + lane - 3]
+                      : lane < 9 ? A.rays.d_viewdirs[(size_t)ray * 3 + lane - 6] : A.rays.d_radii[ray];
+      RYw[lane] = val;
+      const float dx = __shfl(val, 3, 64), dy = __shfl(val, 4, 64), dz = __shfl(val, 5, 64);
+      if (lane == 0) NRM[rl] = sqrtf((dx * dx + dy * dy) + dz * dz);
+    }
+  }
+  RN_STAMP(A, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                           /* chunks 0 and 1 have landed */
+  RN_STAMP(A, 2);
+
+#ifndef REFNERF_BF_NOPRIO
+  if (wave >= BF_NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+  v4uu R0[16], R1[16], bn[8];
+  v8mm ar[AF];
+#pragma unroll
+  for (int d = 0; d < AF; ++d) ar[d] = lds_frag<MM>(WB + 1024 + lane * 16 + d * 1024);
+
+  for (int pass0 = 0; pass0 < n_tot; pass0 += BT) {
+    int lane_v = lane, col_v = col;
+    asm volatile("" : "+v"(lane_v), "+v"(col_v));
+    const int g = pass0 + col_v;
+    const int rl = g / N, si = g - rl * N;
+    const int ray = ray0 + rl;
+    const bool valid = (g < n_tot) && (ray < A.R);
+    auto pass_epilogue = [&]() {
+      if constexpr (RINGPS) {
+        __syncthreads();
+        const int end = (pass0 + BT < n_tot) ? pass0 + BT : n_tot;
+        composite_phase<BF_NW, false, NPS_EVAL, PSM>(A, TD, XP, PS, n_tot, ray0, wave, lane, nullptr, NRM, pass0 / N, end / N);
+      }
+    };
+    {
+      const int g0 = pass0 + wave * 32;
+      if (g0 >= n_tot || ray0 + g0 / N >= A.R) { idle_pass<true>(p); pass_epilogue(); continue; }
+    }
+    auto load_heads = [&](SampleHeads &sh) {
+      float v[3], gp[3], raw_dif[3], raw_tint[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        v[i] = RY[(valid ? rl : 0) * 12 + 6 + i];
+        gp[i] = HD[(1 + i) * BT + col];
+        raw_dif[i] = HD[(5 + i) * BT + col];
+        raw_tint[i] = HD[(8 + i) * BT + col];
+      }
+      sample_heads<false>(cfg, HD[0 * BT + col], gp, HD[4 * BT + col], raw_dif, raw_tint, v, sh);
+    };
+
+#pragma unroll 1
+    for (int phase = 0; phase < 3; ++phase) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { R0[e] = (v4uu){0, 0, 0, 0}; R1[e] = (v4uu){0, 0, 0, 0}; }
+      if (phase == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bn[e] = (v4uu){0, 0, 0, 0};
+      }
+      if (phase < 2) {
+        /* P1 of run `phase`: the wave's samples 16 * phase + (lane & 15); four lanes per sample, each 24 of the 96 IPE
+         * features: block hb = sin / "cos", degrees 8 qq .. 8 qq + 7 -- k-groups 6 hb + 3 qq + q, q = 0..2 */
+        const int i16 = lane_v & 15, part = lane_v >> 4;
+        const int hb = part >> 1, qq = part & 1;
+        const int cs = wave * 32 + 16 * phase + i16;          /* pass column of this lane's sample */
+        const int gs = pass0 + cs;
+        const int rls = gs / N, sis = gs - rls * N;
+        const bool vs = (gs < n_tot) && (ray0 + rls < A.R);
+        float o[3], d[3];
+        const float *ry = RY + (vs ? rls : 0) * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { o[i] = ry[i]; d[i] = ry[3 + i]; }
+        const float radius = ry[9];
+        const float *td = TD + (vs ? rls : 0) * (N + 1);
+        const float t0 = td[vs ? sis : 0], t1 = td[vs ? sis + 1 : 1];
+        float lm[3], lv[3];
+        cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
+        if (cfg.disable_integration) { lv[0] = 0.0f; lv[1] = 0.0f; lv[2] = 0.0f; }        /* models.py:228-231 */
+        char *xw = Xb + (wave * 16 + i16) * 16;
+        RN_STAMP(A, 17);
+        /* two features per trip (one dword of the hi plane, one of the lo plane): the libm sine is long, keep ONE copy pair */
+#pragma clang loop unroll(disable)
+        for (int t = 0; t < 12; ++t) {
+          unsigned whi, wlo;
+          {
+            float f[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int kk = 2 * t + u;                  /* 3 * (j - 8 qq) + b */
+              const int jj = kk / 3, b3 = kk - 3 * jj;
+              const float m = b3 == 0 ? lm[0] : (b3 == 1 ? lm[1] : lm[2]);
+              const float v = b3 == 0 ? lv[0] : (b3 == 1 ? lv[1] : lv[2]);
+              f[u] = ipe_feature<false>(m, v, 8 * qq + jj, hb);
+            }
+            split_pair_f16(f[0], f[1], whi, wlo);
+          }
+          char *dst = xw + (6 * hb + 3 * qq + (t >> 2)) * BT * 16 + (t & 3) * 4;
+          *reinterpret_cast<unsigned *>(dst) = whi;
+          *reinterpret_cast<unsigned *>(dst + (BT / 2) * 16) = wlo;
+#ifdef REFNERF_SPLIT_DUMP
+          if (A.dbg && vs) {
+            const MM::v2 vh = __builtin_bit_cast(MM::v2, whi), vl = __builtin_bit_cast(MM::v2, wlo);
+            float *dd = A.dbg + ((size_t)(ray0 + rls) * N + sis) * SPLIT_DUMP_STRIDE + 48 * hb + 24 * qq + 2 * t;
+            const mm_t a0 = vh[0], a1 = vh[1], b0 = vl[0], b1 = vl[1];
+            dd[0] = (float)a0 + (float)b0;
+            dd[1] = (float)a1 + (float)b1;
+          }
+#endif
+        }
+#ifdef REFNERF_SPLIT_DUMP
+        float *dbgs = (A.dbg && vs) ? A.dbg + ((size_t)(ray0 + rls) * N + sis) * SPLIT_DUMP_STRIDE + 96 : nullptr;
+#else
+        float *dbgs = nullptr;
+#endif
+        RN_STAMP(A, 18);
+        wave_sync();
+        RN_STAMP(A, 3 + phase * 8);
+        /* spatial trunk on the N-packed operands */
+        sp_layer<MM, true>(p, ar, false, R0, bn, R0, dbgs);
+        RN_STAMP(A, 4 + phase * 8);
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+          sp_layer<MM, false>(p, ar, it == 2, R0, bn, R1, dbgs ? dbgs + 256 * (2 * it + 1) : nullptr);
+          if (it < 3) sp_layer<MM, false>(p, ar, false, R1, bn, R0, dbgs ? dbgs + 256 * (2 * it + 2) : nullptr);
+        }
+        RN_STAMP(A, 5 + phase * 8);
+        /* P3: heads.  Bottleneck blocks: hi weights over the N-packed input; kept as packed f16 (run 0), merged with
+         * run 1's into the plain 32-sample B fragments of the directional trunk.  Scalar block: split, to LDS HD. */
+#pragma unroll
+        for (int ob = 0; ob < 5; ++ob) {
+          v16f acc;
+          float s[8];
+          if (ob < 4) {
+            bf_chunk<MM, BF_REG, 0, true, true, true>(p, ar, R1, bn, acc);
+            npk_totals(acc, s);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned pk = pk_f16(s[2 * e], s[2 * e + 1]);
+              if (phase == 0) bn[2 * ob][e] = pk;
+              else {
+                const v2uu r = __builtin_amdgcn_permlane16_swap(bn[2 * ob][e], pk, false, false);
+                bn[2 * ob][e] = r[0];
+                bn[2 * ob + 1][e] = r[1];
+              }
+            }
+          } else {
+            sp_slice<MM>(p, ar, false, R1, bn, acc);
+            npk_totals(acc, s);
+            if ((lane_v & 16) == 0) {
+#pragma unroll
+              for (int rr = 0; rr < 8; ++rr) {
+                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * h;
+                if (row < HD_ROWS) HD[row * BT + cs] = s[rr];
+#ifdef REFNERF_SPLIT_DUMP
+                if (row < HD_ROWS && dbgs) dbgs[8 * 256 + row] = s[rr];
+#endif
+              }
+            }
+          }
+        }
+        wave_sync();
+        RN_STAMP(A, 6 + phase * 8);
+      } else {
+        /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
+        char *xs = Xb + col * 16;
+        {
+          SampleHeads sh;
+          load_heads(sh);
+          float ide[40];
+#pragma unroll
+          for (int q = 36; q < 40; ++q) ide[q] = 0.0f;
+          if (cfg.dir_enc == REFNERF_DIRENC_POSENC) posenc_eval<false>(sh.refd[0], sh.refd[1], sh.refd[2], h, [&](int q, float val) { ide[q] = val; });
+          else ide_eval<false>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { ide[q] = val; });
+          if (h == 0) ide[36] = sh.dot;
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            v8mm pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk[e] = (mm_t)ide[q * 8 + e];
+            *reinterpret_cast<v8mm *>(xs + (5 * h + q) * BT * 16) = pk;
+          }
+        }
+        wave_sync();
+        RN_STAMP(A, 19);
+        dir_layer<MM, BF_BNLDS, BF_DIR_REAL_KS>(p, ar, 0, R0, bn, R0);
+        RN_STAMP(A, 20);
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+          dir_layer<MM, BF_REG, 0>(p, ar, (it == 2) ? 2 : 0, R0, bn, R1);
+          if (it < 3) dir_layer<MM, BF_REG, 0>(p, ar, 0, R1, bn, R0);
+        }
+        RN_STAMP(A, 21);
+        /* rgb: one slice */
+        v16f acc;
+        bf_chunk<MM, BF_REG, 0, true, true>(p, ar, R1, bn, acc);
+        float raw_rgb[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n, 64);
+        int lane_w = lane, g_w = g, pass_w = pass0;
+        asm volatile("" : "+v"(lane_w), "+v"(g_w), "+s"(pass_w));
+        if (valid && h == 0) {                                                            /* P6 */
+          SampleHeads sh;
+          load_heads(sh);
+          colour_store<false, NPS_EVAL, PSM>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
+        }
+        wave_sync();
+        history_flush<NPS_EVAL, PSM>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);
+        RN_STAMP(A, 14);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    pass_epilogue();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  RN_STAMP(A, 15);
+  if constexpr (!RINGPS) composite_phase<BF_NW, false, NPS_EVAL>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB), NRM);   /* P7 */
+  RN_STAMP(A, 16);
+}
+
+__global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16x2(const LevelArgs A) { level_fwd_split<false>(A); }
+__global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16x2_ring(const LevelArgs A) { level_fwd_split<true>(A); }
 
 /* ---------------- bf16 weight image ---------------- */
 __device__ __forceinline__ int ipe_col_of_kprime(int kp) { return kp; }   /* LDS order = canonical IPE order */

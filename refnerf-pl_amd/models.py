@@ -468,7 +468,8 @@ class PropMLP(MLP):
     pass
 
 
-_PREC = {"f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16, "f16": _hip.PREC_F16}
+_PREC = {"f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16, "f16": _hip.PREC_F16, "f16x2": _hip.PREC_F16X2}
+_TRAIN_PREC = ("f32", "bf16")     # arithmetic modes of the training forward / the backward chains
 
 
 class _Lean(threading.local):
@@ -567,6 +568,11 @@ class Model(nn.Module):
         if mode not in _hip.SRGB_MODES:
             raise ValueError('Mapping types are none, linear, norm_linear, srgb, norm_srgb')  # render.py:218
         prec = getattr(cfg, "hip_precision", "f32")
+        if prec not in _PREC:
+            raise ValueError("Config.hip_precision must be one of 'f32', 'f16x2', 'f16', 'bf16'")
+        train_prec = getattr(cfg, "hip_train_precision", "f32")
+        if train_prec not in _TRAIN_PREC:          # 'f16' / 'f16x2' are inference modes of the level kernel
+            raise ValueError("Config.hip_train_precision must be 'f32' or 'bf16'")
         wgrad = {"f32": _hip.WGRAD_F32, "bf16x3": _hip.WGRAD_BF16X3}.get(getattr(cfg, "hip_wgrad_mode", "bf16x3"))
         if wgrad is None:
             raise ValueError("Config.hip_wgrad_mode must be 'bf16x3' or 'f32'")
@@ -575,7 +581,7 @@ class Model(nn.Module):
             compute_extras=int(bool(compute_extras)), srgb_mapping=int(mlp.srgb_mapping),
             srgb_mapping_normalization=int(mlp.srgb_mapping_normalization), render_srgb_mode=mode,
             opaque_background=int(self.opaque_background), ray_shape=0 if self.ray_shape == 'cone' else 1,
-            precision=_PREC[getattr(cfg, "hip_train_precision", "f32")] if self.training else _PREC[prec], wgrad_mode=wgrad, anneal=float(anneal), resample_padding=float(self.resample_padding),
+            precision=_PREC[train_prec] if self.training else _PREC[prec], wgrad_mode=wgrad, anneal=float(anneal), resample_padding=float(self.resample_padding),
             s_near=float(self.init_s_near), s_far=float(self.init_s_far), density_bias=float(mlp.density_bias),
             dir_enc=mlp.kernel_dir_enc, raydist=self._raydist_enum(self.raydist_fn), disable_integration=int(bool(self.disable_integration)),
             roughness_bias=mlp.kernel_roughness_bias, rgb_premultiplier=float(mlp.rgb_premultiplier),
@@ -628,7 +634,7 @@ class Model(nn.Module):
                 # one autograd node per level; sdist / resampling inputs are detached (models.py:205-216)
                 mlp.flat_params()
                 bwd_prec = getattr(self.config, "hip_bwd_precision", "f32")
-                if bwd_prec not in _PREC:
+                if bwd_prec not in _TRAIN_PREC:
                     raise ValueError("Config.hip_bwd_precision must be 'f32' or 'bf16'")
                 flat_mode = bool(getattr(self.config, "hip_flat_grads", False))
                 holder = {"bwd_precision": _PREC[bwd_prec], "flat_mode": flat_mode}
