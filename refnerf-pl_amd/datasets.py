@@ -61,9 +61,10 @@ class TrainRayBatcher:
                 cam = torch.randint(0, self.n_examples, (num_patches, 1, 1), generator=self.gen, device=dev)
             else:
                 cam = torch.randint(0, self.n_examples, (1,), generator=self.gen, device=dev).reshape(1, 1, 1)
-        d = torch.arange(self.patch_size, device=dev)
-        px = px + d.reshape(1, 1, -1)                      # patch offsets (camera_utils.pixel_coordinates)
-        py = py + d.reshape(1, -1, 1)
+        if not self.debug_mode:                            # the reference adds the patch offsets in the random branch only (datasets.py:459-476)
+            d = torch.arange(self.patch_size, device=dev)
+            px = px + d.reshape(1, 1, -1)                  # patch offsets (camera_utils.pixel_coordinates)
+            py = py + d.reshape(1, -1, 1)
         px, py, cam = torch.broadcast_tensors(px, py, cam)
         shape = tuple(px.shape)
 

@@ -56,16 +56,25 @@ def _host_staged(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) != "nccl"
 
 
-def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = True) -> None:
-    """Sum (or average) the .grad of every parameter over the group with one
-    all-reduce of the flattened blob.  Parameters without a gradient contribute zeros."""
+def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = True, flat: bool = None) -> None:
+    """Sum (or average) the gradients over the group with one all-reduce per blob.
+    `flat` (default: `module.config.hip_flat_grads` when the module is a Model, else False) selects WHERE the gradients
+    live: True = one tensor per MLP (MLP.flat_parameter().grad, reduced in place), False = the nn.Parameters' .grad
+    (flattened, reduced, scattered back).  The choice comes from the configuration, never from leftover tensor state, and
+    in either mode every rank issues the same collectives: a missing gradient contributes zeros."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    # Config.hip_flat_grads: the gradient already is one tensor per MLP (MLP.flat_parameter().grad): reduce it in place
-    flat_done = False
-    for m in module.modules():
-        blob = getattr(m, "_flat", None)
-        if blob is not None and blob.requires_grad and blob.grad is not None:
+    if flat is None:
+        flat = bool(getattr(getattr(module, "config", None), "hip_flat_grads", False))
+    if flat:
+        seen = set()
+        for m in module.modules():
+            if not hasattr(m, "flat_parameter") or id(m) in seen:
+                continue
+            seen.add(id(m))
+            blob = m.flat_parameter()
+            if blob.grad is None:
+                blob.grad = torch.zeros_like(blob)
             g = blob.grad
             if _host_staged(g, group):
                 host = g.cpu()
@@ -75,25 +84,23 @@ def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = Tru
                 dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
             if average:
                 g /= dist.get_world_size(group)
-            flat_done = True
-    if flat_done:
         return
     params = [p for p in module.parameters() if p.requires_grad]
     if not params:
         return
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    if _host_staged(flat, group):
-        host = flat.cpu()
+    cat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    if _host_staged(cat, group):
+        host = cat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-        flat.copy_(host)
+        cat.copy_(host)
     else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(cat, op=dist.ReduceOp.SUM, group=group)
     if average:
-        flat /= dist.get_world_size(group)
+        cat /= dist.get_world_size(group)
     off = 0
     for p in params:
         n = p.numel()
-        g = flat[off:off + n].view_as(p)
+        g = cat[off:off + n].view_as(p)
         if p.grad is None:
             p.grad = g.clone()
         else:

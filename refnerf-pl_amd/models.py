@@ -182,6 +182,12 @@ class MLP(nn.Module):
                     ok = False
                     break
         if not ok:
+            if self._flat is not None and (self._flat.requires_grad or self._flat.grad is not None):
+                raise RuntimeError(
+                    "MLP.flat_params(): the parameters no longer alias the flat blob that Config.hip_flat_grads made a leaf "
+                    "(model.to() / a dtype cast / re-pointed .data after flat_parameter()).  An optimiser built on the old "
+                    "blob would silently stop training: call MLP.release_flat_parameter(), move the model, then rebuild "
+                    "the optimiser on flat_parameter().")
             flat = torch.empty(self.num_params, dtype=torch.float32, device=first.device)
             with torch.no_grad():
                 for spec, lin in self._named_linears():
@@ -203,6 +209,14 @@ class MLP(nn.Module):
         if not flat.requires_grad:
             flat.requires_grad_(True)
         return flat
+
+    def release_flat_parameter(self) -> None:
+        """Leave the flat-gradient mode: the blob stops being an autograd leaf and its gradient is dropped, so that a later
+        per-parameter training step (or allreduce_gradients) cannot pick up a stale flat gradient."""
+        if self._flat is not None:
+            self._flat.grad = None
+            if self._flat.requires_grad:
+                self._flat.requires_grad_(False)
 
     def load_flat_params(self, blob):
         """Copy a flat blob (numpy / tensor) into the parameters: this module's own blob (`num_params` elements,
@@ -254,24 +268,35 @@ class MLP(nn.Module):
     def _param_version(self):
         return tuple(p._version for p in self.parameters())
 
+    def mark_updated(self) -> None:
+        """Tell the weight-image cache that an optimiser step has been applied (call it after `optimizer.step()` when the
+        optimiser is fused, i.e. does not bump the tensors' version counters): the next inference call re-packs once and
+        later ones reuse that image.  Without it every inference call after a training forward re-packs (correct, 16 us)."""
+        self._step_pending = False
+        if self._packed:
+            self._packed = {k: (buf, None) for k, (buf, _) in self._packed.items()}
+
     def packed_weights(self, precision: int, force: bool = False) -> torch.Tensor:
         """MFMA operand image of the current parameters for a precision mode (one cached buffer per mode, re-packed in
         place when the parameters changed).  Change detection = the tensors' version counters, plus: `force` (a training
-        forward: an optimiser step follows it, and fused optimisers do not bump version counters), after which the
-        first inference use of EVERY mode re-packs as well."""
+        forward: an optimiser step follows it, and fused optimisers do not bump version counters) -- see mark_updated()."""
         flat = self.flat_params()
         key = (precision, flat.data_ptr(), self._param_version(), flat._version)
         if self._packed is None:
             self._packed = {}
         if force:
-            self._train_gen = getattr(self, "_train_gen", 0) + 1
-        gen = getattr(self, "_train_gen", 0)
-        buf, have, have_gen = self._packed.get(precision, (None, None, -1))
-        if force or have != key or have_gen != gen or self._packed_key is None:
+            # a training forward: an optimiser step follows at an unknown moment, and a fused optimiser leaves no trace in
+            # the version counters.  Until the version counters move or mark_updated() says the step is done, every
+            # image is packed "stale": inference calls in between (validation hooks, the noisy-ray pass) re-pack each
+            # time (16 us) instead of trusting an image that may predate the step.
+            self._step_pending = True
+        elif getattr(self, "_step_pending", False) and self._packed_key is not None and key[2:] != self._packed_key[2:]:
+            self._step_pending = False                      # the parameters' version counters moved: ordinary change detection works again
+        pending = getattr(self, "_step_pending", False)
+        buf, have = self._packed.get(precision, (None, None))
+        if force or pending or have != key:
             buf = _hip.pack_weights(self.canonical_blob(), buf, precision)
-            # an image packed by a training forward is stale after the optimiser step: gen - 1 makes the next
-            # inference call of this mode re-pack once more
-            self._packed[precision] = (buf, key, gen - 1 if force else gen)
+            self._packed[precision] = (buf, None if (force or pending) else key)
         self._packed_key = key
         return buf
 
@@ -608,6 +633,9 @@ class Model(nn.Module):
                            torch.full((R, 1), float(self.init_s_far), device=dev)], dim=-1)
         weights = torch.ones((R, 1), device=dev)
         renderings, ray_history = [], []
+        # diagnostic (not part of the reference's return value): the CDF bin index of every sample, per level --
+        # north_star's "sample indices"; bench.py and the parity tests compare them between arithmetic modes
+        self.last_bin_idx = []
         prod_num_samples = 1
         for i_level in range(self.num_levels):
             is_prop = i_level < (self.num_levels - 1)
@@ -637,6 +665,8 @@ class Model(nn.Module):
                 if bwd_prec not in _TRAIN_PREC:
                     raise ValueError("Config.hip_bwd_precision must be 'f32' or 'bf16'")
                 flat_mode = bool(getattr(self.config, "hip_flat_grads", False))
+                if not flat_mode and mlp._flat is not None and (mlp._flat.requires_grad or mlp._flat.grad is not None):
+                    mlp.release_flat_parameter()            # flat mode was switched off: no stale .grad on the blob
                 holder = {"bwd_precision": _PREC[bwd_prec], "flat_mode": flat_mode}
                 diff_inputs = (mlp.flat_parameter(),) if flat_mode else tuple(mlp.ordered_parameters())
                 outs = _LevelFunction.apply(mlp, cfg, r, holder, sdist.detach(), weights.detach(), *diff_inputs)
@@ -646,6 +676,7 @@ class Model(nn.Module):
                 res = _hip.level_forward(mlp.packed_weights(_hip.PREC_F32 if cfg.training else cfg.precision), cfg, r, sdist, weights,
                                          history=(("rgb",) if compute_extras else ()) if lean else True)
             sdist, weights = res["sdist"], res["weights"]
+            self.last_bin_idx.append(res.get("bin_idx"))
 
             def rs(x, *tail):
                 return x.reshape(batch_shape + tuple(tail))

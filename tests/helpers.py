@@ -14,7 +14,7 @@ def load_golden(name):
 
 
 def trained_blob():
-    """The "trained-like" weights: the blob the REFERENCE reached after 300 of its own Adam steps on an analytic
+    """The "trained-like" weights: the blob the REFERENCE reached after 400 of its own Adam steps on an analytic
     shiny sphere (tests/golden/make_golden.py::golden_trained), stored as float16; the float16 -> float32 upcast is
     the fixture's weight set (the reference outputs were computed from exactly these values)."""
     return np.load(os.path.join(GOLDEN, "trained_blob.npz"))["blob_f16"].astype(np.float32)

@@ -53,6 +53,21 @@ def _worker(rank, world, port, tmp):
     for i, p in enumerate(model.parameters()):
         want = (1.5 if i != 5 else 0.0) * (1 + i % 3)
         assert torch.allclose(p.grad, torch.full_like(p, want)), i
+    # flat-gradient mode (Config.hip_flat_grads): ONE blob per MLP, chosen from the configuration -- not from leftover
+    # tensor state -- and a rank without a gradient contributes zeros instead of skipping its collective
+    cfg.hip_flat_grads = True
+    blob = model.nerf_mlp.flat_parameter()
+    blob.grad = None if rank == 1 else torch.full_like(blob, 4.0)
+    distributed.allreduce_gradients(model, average=True)
+    assert torch.allclose(model.nerf_mlp.flat_parameter().grad, torch.full_like(blob, 2.0))
+    # ... and back: a stale flat gradient must not shadow the per-parameter gradients
+    cfg.hip_flat_grads = False
+    for i, p in enumerate(model.parameters()):
+        p.grad = torch.full_like(p, float(rank + 1))
+    distributed.allreduce_gradients(model, average=True)
+    assert all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in model.parameters())
+    model.nerf_mlp.release_flat_parameter()
+    assert not model.nerf_mlp.flat_params().requires_grad and model.nerf_mlp.flat_params().grad is None
     # ray sharding covers every ray exactly once, in order
     rd = synthetic.blender_rays(37, seed=3)
     rays = utils.rays_from_dict(rd)
