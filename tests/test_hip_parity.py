@@ -779,7 +779,7 @@ def test_record_ring_kernel(hip, n_rays, n_samples):
     rd = synthetic.blender_rays(n_rays, seed=21, center_frac=0.5)
     sub = {k: v[:600] for k, v in rd.items()}
     out = {}
-    for prec in ("f32", "bf16", "f16"):
+    for prec in ("f32", "bf16", "f16", "f16x2"):
         configs.clear_config()
         configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
                                                 [f"Model.num_prop_samples = {n_samples}", f"Model.num_nerf_samples = {n_samples}",
@@ -791,7 +791,7 @@ def test_record_ring_kernel(hip, n_rays, n_samples):
             if prec != "f32":
                 out[prec + "_sub"] = model(utils.rays_from_dict(sub, DEV), 1.0, True)
     ref_r, _ = out["f32"]
-    for prec in ("bf16", "f16"):
+    for prec in ("bf16", "f16", "f16x2"):
         (rend, hist), (rend_s, hist_s) = out[prec], out[prec + "_sub"]
         for L in range(2):
             for k in ("rgb", "diffuse", "specular", "acc", "distance", "normals_pred", "tint", "roughness", "distance_mean"):
@@ -809,7 +809,7 @@ def test_record_ring_kernel(hip, n_rays, n_samples):
 
 
 @pytest.mark.parametrize("name", ["model_variant_eval", "model_posenc_eval"])
-@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("prec", ["bf16", "f16", "f16x2"])
 def test_nerfmlp_variants_16bit_modes(hip, name, prec):
     """The 16-bit inference kernels take the same embedded image and the same cfg.dir_enc: rendered RGB against the
     reference's vectors (random-init-like weights: the 1e-4 bar holds)."""
@@ -827,7 +827,32 @@ def test_nerfmlp_variants_16bit_modes(hip, name, prec):
         renderings, _ = model(utils.rays_from_dict(rays_from_golden(g), DEV), 1.0, False)
     for L in range(2):
         err = np.abs(renderings[L]["rgb"].cpu().numpy() - g[f"L{L}_r_rgb"]).max()
+        assert err <= (1e-5 if prec == "f16x2" else 1e-4), (L, err)
+    configs.clear_config()
+
+
+@pytest.mark.parametrize("name", ["model_raydist_reciprocal_eval", "model_raydist_log_eval", "model_raydist_piecewise_eval",
+                                  "model_nointegration_eval"])
+def test_raydist_and_disable_integration_f16x2(hip, name):
+    """the same reference fixtures in the parity-grade 16-bit mode (Config.hip_precision = 'f16x2'): rendered RGB within
+    north_star's 1e-4 of the reference (measured ~1e-6; un-integrated encoding: sin(2^15 x) unattenuated)"""
+    import os
+    from refnerf_pl_amd import configs, models, utils
+    g = load_golden(name)
+    fn = {"": None, "piecewise": "piecewise", "reciprocal": torch.reciprocal, "log": "@torch.log"}[str(g["raydist_fn"])]
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                            [str(b) for b in g["bindings"] if str(b)] + ["Config.hip_precision = 'f16x2'"])
+    model = models.construct_model(utils.dummy_rays(), configs.Config()).to(DEV).eval()
+    model.raydist_fn, model.disable_integration = fn, bool(int(g["disable_integration"]))
+    model.nerf_mlp.load_flat_params(params_from_golden(g))
+    with torch.no_grad():
+        renderings, history = model(utils.rays_from_dict(rays_from_golden(g), DEV), 1.0, True)
+    for L in range(2):
+        err = np.abs(renderings[L]["rgb"].cpu().numpy() - g[f"L{L}_r_rgb"]).max()
+        print(name, "f16x2 L%d RGB L-inf vs reference %.2e" % (L, err))
         assert err <= 1e-4, (L, err)
+    assert np.array_equal(history[0]["sdist"].cpu().numpy(), g["L0_h_sdist"].reshape(history[0]["sdist"].shape))
     configs.clear_config()
 
 
