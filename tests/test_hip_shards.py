@@ -1,0 +1,185 @@
+"""GPU: what the ray-tile data-parallel layout promises (the reference's DDP semantics,
+train.py:84-88): the mean of the per-shard gradients IS the gradient of the unsharded batch, and the per-GPU shard
+shapes of the BASELINE configurations (C4: 512 LLFF rays per GPU, C5: 2048 rays x 256 samples per GPU with the
+nine-term geometry loss) behave like the full-size batches.  One GPU suffices: the shards run one after the other;
+the two-rank launcher test starts real rank processes (sharing the device)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from test_hip_parity import DEV, O, hip  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(gin, bindings):
+    from refnerf_pl_amd import configs, models, synthetic, utils
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", gin)], bindings)
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV)
+    model.nerf_mlp.load_flat_params(synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0))
+    return model, cfg
+
+
+def _slice_rays(rd, b, e):
+    from refnerf_pl_amd import utils
+    return utils.rays_from_dict({k: v[b:e] for k, v in rd.items()}, DEV)
+
+
+def _grad_of(model, loss_fn):
+    for p in model.parameters():
+        p.grad = None
+    model.train()
+    total, terms = loss_fn()
+    total.backward()
+    g = torch.cat([p.grad.flatten() for p in model.nerf_mlp.ordered_parameters()]).double().cpu().numpy()
+    return float(total.detach()), {k: float(torch.as_tensor(v).detach()) for k, v in terms.items()}, g
+
+
+def _check_invariance(whole, halves, tol=1e-5):
+    (l_w, t_w, g_w), parts = whole, halves
+    l_h = float(np.mean([p[0] for p in parts]))
+    g_h = np.mean([p[2] for p in parts], axis=0)
+    rel = float(np.linalg.norm(g_h - g_w) / np.linalg.norm(g_w))
+    print(f"loss whole {l_w:.9g} mean of shards {l_h:.9g}; gradient rel-L2 {rel:.2e} (|g| = {np.linalg.norm(g_w):.4g})")
+    assert l_h == pytest.approx(l_w, rel=2e-6)
+    for k in t_w:
+        # the consistency terms square 1e-3-sized differences of fp32 renderings (1e-7 -> 1e-4..1e-3 relative, as in
+        # tests/test_geometry_losses.py); their share of the total is 1e-4
+        rel_k = 2e-3 if "consistency" in k else 2e-5
+        assert float(np.mean([p[1][k] for p in parts])) == pytest.approx(t_w[k], rel=rel_k, abs=1e-9), k
+    assert np.isfinite(g_w).all() and np.linalg.norm(g_w) > 0
+    assert rel <= tol, rel
+
+
+def test_shard_invariance_three_losses(hip):
+    """blender_refnerf.gin (data + orientation + predicted-normal terms, f32 chains): a 256-ray batch against its two
+    128-ray halves -- equal shards, every term a plain mean over rays, so mean-of-shards == whole batch."""
+    from refnerf_pl_amd import synthetic, train_utils, utils
+    model, cfg = _model("refnerf_blender.gin", ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 96"])
+    rd = synthetic.blender_rays(256, seed=5, center_frac=0.6)
+    gt = synthetic.target_rgb(256, seed=9)
+
+    def run(b, e):
+        rays = _slice_rays(rd, b, e)
+        batch = utils.Batch(rays=rays, rgb=gt[b:e])
+
+        def loss():
+            renderings, history = model(rays, 1.0, False)
+            total, terms, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+            return total, terms
+        return _grad_of(model, loss)
+    _check_invariance(run(0, 256), [run(0, 128), run(128, 256)])
+
+
+def _geometry_run(model, cfg, rd, gt, b, e, rot, monkeypatch):
+    """one step of the nine-term geometry loss on rays [b, e): the noisy pass perturbs ALL rays of the shard with the
+    fixed rotations `rot`, and the acc thresholds are below zero, so every masked mean is a plain mean over the rays"""
+    from refnerf_pl_amd import sample_utils, train_utils, utils
+    rays = _slice_rays(rd, b, e)
+    batch = utils.Batch(rays=rays, rgb=gt[b:e])
+    cfg.sample_noise_size = e - b
+    orig = sample_utils.sample_noisy_rays
+    monkeypatch.setattr(sample_utils, "sample_noisy_rays", lambda *a, **k: orig(*a, **dict(k, rotations=rot)))
+
+    def loss():
+        total, terms, _, _ = train_utils.training_losses(model, batch, rays, cfg, global_step=200000)
+        return total, terms
+    out = _grad_of(model, loss)
+    monkeypatch.setattr(sample_utils, "sample_noisy_rays", orig)
+    return out
+
+
+GEOMETRY_BINDINGS = ["Config.acc_threshold_for_weights_entropy_loss = -1.0", "Config.acc_threshold_for_consistency_loss = -1.0"]
+
+
+def _rotations():
+    from refnerf_pl_amd import sample_utils
+    ang = torch.tensor([[0.02, 0.05, 0.01], [0.06, 0.01, 0.03], [0.03, 0.03, 0.07], [0.05, 0.02, 0.02]])
+    return sample_utils.euler_angles_to_matrix(ang)
+
+
+def test_shard_invariance_geometry_losses(hip, monkeypatch):
+    """llff_refnerf_geometry_losses.gin (nine terms, clean + noisy pass, norm_linear render-time map): 256 LLFF rays
+    against two 128-ray shards.  With all-pass masks and the noisy rays drawn from every ray of the shard the terms are
+    per-ray means, so the DDP average of the shard gradients must equal the unsharded gradient."""
+    from refnerf_pl_amd import synthetic
+    model, cfg = _model("refnerf_llff_geometry_losses.gin", ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 64"] + GEOMETRY_BINDINGS)
+    rd = synthetic.llff_rays(256, seed=4)
+    gt = synthetic.target_rgb(256, seed=8)
+    rot = _rotations()
+    whole = _geometry_run(model, cfg, rd, gt, 0, 256, rot, monkeypatch)
+    assert len(whole[1]) == 9, sorted(whole[1])
+    halves = [_geometry_run(model, cfg, rd, gt, 0, 128, rot, monkeypatch), _geometry_run(model, cfg, rd, gt, 128, 256, rot, monkeypatch)]
+    _check_invariance(whole, halves, tol=2e-5)
+
+
+def test_c5_shard_shape_training_step(hip, monkeypatch):
+    """The per-GPU shard of BASELINE config 5 at FULL size (2048 LLFF rays x 256 samples x 2 levels, nine-term loss, f32
+    chains): finite, bit-reproducible (fixed split-K order, no atomics), and itself shard-invariant (2 x 1024 rays)."""
+    from refnerf_pl_amd import synthetic
+    model, cfg = _model("refnerf_llff_geometry_losses.gin", ["Model.num_prop_samples = 256", "Model.num_nerf_samples = 256"] + GEOMETRY_BINDINGS)
+    rd = synthetic.llff_rays(2048, seed=6)
+    gt = synthetic.target_rgb(2048, seed=7)
+    rot = _rotations()
+    whole = _geometry_run(model, cfg, rd, gt, 0, 2048, rot, monkeypatch)
+    again = _geometry_run(model, cfg, rd, gt, 0, 2048, rot, monkeypatch)
+    assert whole[0] == again[0] and np.array_equal(whole[2], again[2]), "training step is not bit-reproducible"
+    halves = [_geometry_run(model, cfg, rd, gt, 0, 1024, rot, monkeypatch), _geometry_run(model, cfg, rd, gt, 1024, 2048, rot, monkeypatch)]
+    _check_invariance(whole, halves, tol=2e-5)
+
+
+def test_c4_shard_shape_eval_graph_replay(hip, O):
+    """The per-GPU shard of BASELINE config 4 (512 LLFF rays x 128 samples x 2 levels): the HIP-graph replay of the level
+    loop equals the eager call bit for bit in every arithmetic mode, on new rays too; the parity-grade modes match the
+    CPU oracle on a 64-ray prefix; size-independent properties hold."""
+    from refnerf_pl_amd import graphs, synthetic, utils
+    model, cfg = _model("refnerf_llff.gin", [])
+    model.eval()
+    rd_a, rd_b = synthetic.llff_rays(512, seed=1), synthetic.llff_rays(512, seed=2)
+    blob = model.nerf_mlp.flat_params().detach().cpu().numpy()
+    ref = O.model_forward(blob, {k: v[:64] for k, v in rd_b.items()}, srgb_mapping=int(model.nerf_mlp.srgb_mapping))
+    for prec in ("f32", "f16x2", "bf16"):
+        cfg.hip_precision = prec
+        ra, rb = utils.rays_from_dict(rd_a, DEV), utils.rays_from_dict(rd_b, DEV)
+        with torch.no_grad():
+            g = graphs.GraphedForward(model, ra, 1.0, True)
+            rend_g, hist_g = g(rb)                       # replay on NEW rays
+            rend_g = [{k: v.clone() for k, v in r.items()} for r in rend_g]
+            hist_g = [{k: (v.clone() if v is not None else None) for k, v in h.items()} for h in hist_g]
+            rend_e, hist_e = model(rb, 1.0, True)
+        for L in range(2):
+            for k in rend_e[L]:
+                assert torch.equal(rend_g[L][k], rend_e[L][k]), (prec, L, k)
+            for k in ("weights", "sdist", "rgb", "density"):
+                assert torch.equal(hist_g[L][k], hist_e[L][k]), (prec, L, k)
+            w, sd = hist_e[L]["weights"], hist_e[L]["sdist"]
+            assert float(w.min()) >= 0 and bool((w.sum(-1) <= 1 + 1e-5).all())
+            assert bool((sd[:, 1:] >= sd[:, :-1]).all()) and float(sd.min()) >= 0 and float(sd.max()) <= 1
+            err = float(np.abs(rend_e[L]["rgb"][:64].cpu().numpy() - ref[L]["r_rgb"]).max())
+            print(f"C4 shard {prec} L{L}: RGB L-inf vs oracle {err:.2e}")
+            assert err <= (1e-5 if prec in ("f32", "f16x2") else 1e-4), (prec, L, err)
+
+
+@pytest.mark.parametrize("config,extra", [("C4", []), ("C5", ["--rays", "1024", "--no-train"])])
+def test_two_rank_launcher_on_one_gpu(hip, config, extra):
+    """`bench.py --gpus 2` starts two fresh rank processes before anything touches the GPU (no exec of a process that has
+    initialised it); here they share device 0 and use gloo for the barrier / gradient all-reduce.  Rank 0's JSON line
+    must report both ranks and a finite value."""
+    env = dict(os.environ, REFNERF_BENCH_BACKEND="gloo", REFNERF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-image"] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["n_ranks_seen"] == 2
+    assert np.isfinite(line["value"]) and line["value"] > 0
+    assert line["config"]["rays_per_gpu"] * 2 == line["config"]["total_rays"]
