@@ -117,6 +117,43 @@ __device__ __forceinline__ float safe_arg(float x) {
   return m;
 }
 
+/* sin(a) for |a| < 1000 (safe_arg's range is |a| < 100 pi): quadrant reduction in float64 (two instructions, error 1e-13),
+ * 4-term minimax kernels in fp32; <= 9.2e-8 absolute (1.5 ulp) over |a| < 315 (checked against float64 on 2e8 arguments).
+ * The library's sinf carries its large-argument (Payne-Hanek) path through every call: ~150 instructions against ~25. */
+__device__ __forceinline__ float sin_reduced(float a) {
+  const double k = __builtin_rint((double)a * 0.63661977236758134308);
+  const float r = (float)__builtin_fma(-k, 1.57079632679489661923, (double)a);
+  const int q = (int)k;
+  const float r2 = r * r;
+  const float s = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f) * r2, r, r);
+  const float c = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f) * r2, r2, fmaf(-0.5f, r2, 1.0f));
+  const float v = (q & 1) ? c : s;
+  return (q & 2) ? -v : v;
+}
+/* safe_arg without branches or the library's fmodf loop (which hipcc inlines as a divergent 12-bits-per-trip reduction):
+ * x - trunc(x / T) T is exact in float64 for these 24-bit operands, x / T is never closer than 1e-7 to an integer without
+ * being one (both are multiples of 2^-15 below 2^18), so one correction step settles the truncation; the remainder is
+ * representable in fp32, and the floored form adds T in fp32 exactly as torch's `%` does.  Valid for |x| < 2^24. */
+__device__ __forceinline__ float safe_arg_f64(float x) {
+  const double T = (double)T100PI, xd = (double)x;
+  const double n = __builtin_trunc(xd * (1.0 / T));
+  double r = __builtin_fma(-n, T, xd);
+  const double up = r + T, dn = r - T;
+  r = (xd > 0.0) ? (r < 0.0 ? up : (r >= T ? dn : r)) : (r > 0.0 ? dn : (r <= -T ? up : r));
+  float m = (float)r;
+  m = (m < 0.0f) ? m + T100PI : m;
+  return (fabsf(x) < T100PI) ? x : m;
+}
+/* IPE feature of the split-f16 kernel: the reference's argument (fp32 product, fp32 + pi/2, the fp32 `mod 100 pi`), then
+ * sin_reduced and the hardware exp2 -- absolute error < 2e-7, below the 2^-22 of the hi + lo split it feeds */
+__device__ __forceinline__ float ipe_feature_split(float lm, float lv, int j, int cos_block) {
+  const float sc = __builtin_ldexpf(1.0f, j), sc2 = __builtin_ldexpf(1.0f, 2 * j);
+  float x = lm * sc;
+  if (cos_block) x = x + HALF_PI_F;
+  const float e = __builtin_amdgcn_exp2f((-0.5f * LOG2E_F) * (lv * sc2));
+  return e * sin_reduced(safe_arg_f64(x));
+}
+
 /* One IPE feature (coord.py:119-126): block 0 = sin, block 1 = "cos" =
  * sin(fl(x + pi/2)). */
 template <bool FAST = false>

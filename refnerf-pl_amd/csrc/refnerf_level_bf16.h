@@ -169,8 +169,11 @@ __device__ __forceinline__ typename MM::v8 lds_b(const Pipe &p, int kl) {
  * lanes 16-31 of each half, start from the zeros behind the bias).
  * `a` is the A-fragment ring; on entry it holds fragments 0..AF-1 of this chunk,
  * on exit those of the next one. */
-template <typename MM, int KIND, int REAL_L, bool FIRST, bool SPLIT = false, bool NPK = false>
-__device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+/* `hook(k)`: VALU work of the caller placed behind the MFMA of step k (the split kernel runs the epilogue of the previous
+ * slice there, in the issue gaps of this slice's matrix instructions) */
+template <typename MM, int KIND, int REAL_L, bool FIRST, bool SPLIT = false, bool NPK = false, typename Hook = NoHook>
+__device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc, Hook &&hook = Hook()) {
   typedef typename MM::v8 v8mm;
   constexpr bool SK = (KIND == BF_SREG0 || KIND == BF_SREG1 || KIND == BF_SLDS);
   constexpr int KS = (KIND == BF_LDS8) ? 8 : (KIND == BF_SLDS ? BF_SLDS_KS : 16);
@@ -197,6 +200,7 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], cons
     acc = MM::mfma(a[k % AF], b, acc);
     /* A ring: fragment k+AF of this chunk, or the head of the next chunk (landed: k >= KS/2) */
     a[k % AF] = (k + AF < KS) ? lds_frag<MM>(cur + (k + AF) * 1024) : lds_frag<MM>(nxt + (k + AF - KS) * 1024);
+    hook(k);
     if (KIND == BF_SLDS) {
       const int s2 = (k >> 1) + 2;                      /* after the lo MFMA of step s: fetch step s + 2 into its slot */
       if ((k & 1) && s2 < BF_IPE_REAL_KS) xr[s2 & 1] = lds_frag<MM>(p.xps + (2 * s2) * BT * 16);
@@ -554,39 +558,76 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, unsigned &hi,
   const _Float16 h0 = hv[0], h1 = hv[1];
   lo = pk_f16(x0 - (float)h0, x1 - (float)h1);
 }
-/* totals -> the next layer's two N-packed B fragments (hi + lo halves of ReLU(total)); same k order as pack_acc */
+/* one accumulator pair of an N-packed tile -> its fp32 total (see npk_totals) */
+__device__ __forceinline__ float npk_total1(const v16f &a, int j) {
+  const float lo = a[j], hi = a[j + 8];
+  const v2uu r = __builtin_amdgcn_permlane16_swap(f2u(lo), f2u(hi), false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return u2f(r0) + u2f(r1);
+}
+/* totals 2e, 2e+1 (after ReLU) -> dword e of the next layer's two N-packed B fragments (hi + lo halves); same k order
+ * as pack_acc */
+__device__ __forceinline__ void split_piece(const float (&s)[8], int e, v4uu &f0, v4uu &f1, float *dbg = nullptr, int lane = 0) {
+  const float x0 = fmaxf(s[2 * e], 0.0f), x1 = fmaxf(s[2 * e + 1], 0.0f);
+#ifdef REFNERF_SPLIT_DUMP
+  if (dbg) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int jj = 2 * e + u + ((lane & 16) ? 8 : 0);
+      dbg[(jj & 3) + 8 * (jj >> 2) + 4 * (lane >> 5)] = u ? x1 : x0;
+    }
+  }
+#endif
+  unsigned hi, lo;
+  split_pair_f16(x0, x1, hi, lo);
+  const v2uu r = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);
+  f0[e] = r[0];
+  f1[e] = r[1];
+}
 __device__ __forceinline__ void pack_acc_split(const v16f &a, v4uu &f0, v4uu &f1, float *dbg = nullptr, int lane = 0) {
   float s[8];
   npk_totals(a, s);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x0 = fmaxf(s[2 * e], 0.0f), x1 = fmaxf(s[2 * e + 1], 0.0f);
-#ifdef REFNERF_SPLIT_DUMP
-    if (dbg) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int jj = 2 * e + u + ((lane & 16) ? 8 : 0);
-        dbg[(jj & 3) + 8 * (jj >> 2) + 4 * (lane >> 5)] = u ? x1 : x0;
-      }
-    }
-#endif
-    unsigned hi, lo;
-    split_pair_f16(x0, x1, hi, lo);
-    const v2uu r = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);
-    f0[e] = r[0];
-    f1[e] = r[1];
-  }
+  for (int e = 0; e < 4; ++e) split_piece(s, e, f0, f1, dbg, lane);
 }
 
 /* spatial slice: [SREG0][SREG1] (+ [SLDS] for the skip layer) */
-template <typename MM>
-__device__ __forceinline__ void sp_slice(Pipe &p, typename MM::v8 (&a)[AF], bool skip, const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc) {
-  bf_chunk<MM, BF_SREG0, 0, true, true>(p, a, in, bn, acc);
+template <typename MM, typename Hook = NoHook>
+__device__ __forceinline__ void sp_slice(Pipe &p, typename MM::v8 (&a)[AF], bool skip, const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc, Hook &&hook = Hook()) {
+  bf_chunk<MM, BF_SREG0, 0, true, true>(p, a, in, bn, acc, hook);
   bf_chunk<MM, BF_SREG1, 0, false, true>(p, a, in, bn, acc);
   if (skip) bf_chunk<MM, BF_SLDS, 0, false, true>(p, a, in, bn, acc);
 }
+/* One spatial layer.  The epilogue of slice ob - 1 (column sums, ReLU, hi / lo split, swaps: ~60 VALU instructions) is
+ * SOFTWARE-PIPELINED into the first chunk of slice ob: one piece behind each of its first 12 MFMAs, on the other
+ * accumulator tile -- all eight waves run the chunks in lockstep, so an epilogue between two slices would idle the matrix
+ * pipe of every SIMD. */
+#ifndef REFNERF_SPLIT_PIPE
+#define REFNERF_SPLIT_PIPE 1
+#endif
 template <typename MM, bool LAYER0>
 __device__ __forceinline__ void sp_layer(Pipe &p, typename MM::v8 (&a)[AF], bool skip, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16], float *dbg = nullptr) {
+#if REFNERF_SPLIT_PIPE
+  v16f accs[2];
+  float s[8];
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+    v16f &acc = accs[ob & 1];
+    const v16f &prev = accs[(ob & 1) ^ 1];
+    auto hook = [&](int k) {
+      /* 12 pieces behind MFMAs 0..11: (total 2e, total 2e+1, split e) for e = 0..3 -- two totals live at a time, and the
+       * accumulator registers of the previous tile die pair by pair */
+      if (ob == 0 || k >= 12) return;
+      const int e = k / 3, r = k - 3 * e;
+      if (r < 2) s[2 * e + r] = npk_total1(prev, 2 * e + r);
+      else split_piece(s, e, out[2 * ob - 2], out[2 * ob - 1], dbg ? dbg + 32 * (ob - 1) : nullptr, p.lane);
+    };
+    if constexpr (LAYER0) bf_chunk<MM, BF_SLDS, 0, true, true>(p, a, in, bn, acc, hook);
+    else sp_slice<MM>(p, a, skip, in, bn, acc, hook);
+  }
+  pack_acc_split(accs[1], out[14], out[15], dbg ? dbg + 32 * 7 : nullptr, p.lane);
+  __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) {
     v16f acc;
@@ -595,10 +636,12 @@ __device__ __forceinline__ void sp_layer(Pipe &p, typename MM::v8 (&a)[AF], bool
     pack_acc_split(acc, out[2 * ob], out[2 * ob + 1], dbg ? dbg + 32 * ob : nullptr, p.lane);
     __builtin_amdgcn_sched_barrier(0);
   }
+#endif
 }
 /* directional layer of the split kernel: the plain layer on the split kernel's DMA schedule */
 template <typename MM, int KIND0, int REAL0>
 __device__ __forceinline__ void dir_layer(Pipe &p, typename MM::v8 (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16]) {
+  /* (pipelining this plain epilogue into the next slice as in sp_layer measured no gain: 105.6 k -> 104.6 k cycles) */
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) {
     v16f acc;
@@ -756,7 +799,7 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
               const int jj = kk / 3, b3 = kk - 3 * jj;
               const float m = b3 == 0 ? lm[0] : (b3 == 1 ? lm[1] : lm[2]);
               const float v = b3 == 0 ? lv[0] : (b3 == 1 ? lv[1] : lv[2]);
-              f[u] = ipe_feature<false>(m, v, 8 * qq + jj, hb);
+              f[u] = ipe_feature_split(m, v, 8 * qq + jj, hb);
             }
             split_pair_f16(f[0], f[1], whi, wlo);
           }
@@ -780,16 +823,16 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
 #endif
         RN_STAMP(A, 18);
         wave_sync();
-        RN_STAMP(A, 3 + phase * 8);
+        RN_STAMP(A, 3 + phase * 4);
         /* spatial trunk on the N-packed operands */
         sp_layer<MM, true>(p, ar, false, R0, bn, R0, dbgs);
-        RN_STAMP(A, 4 + phase * 8);
+        RN_STAMP(A, 4 + phase * 4);
 #pragma unroll 1
         for (int it = 0; it < 4; ++it) {
           sp_layer<MM, false>(p, ar, it == 2, R0, bn, R1, dbgs ? dbgs + 256 * (2 * it + 1) : nullptr);
           if (it < 3) sp_layer<MM, false>(p, ar, false, R1, bn, R0, dbgs ? dbgs + 256 * (2 * it + 2) : nullptr);
         }
-        RN_STAMP(A, 5 + phase * 8);
+        RN_STAMP(A, 5 + phase * 4);
         /* P3: heads.  Bottleneck blocks: hi weights over the N-packed input; kept as packed f16 (run 0), merged with
          * run 1's into the plain 32-sample B fragments of the directional trunk.  Scalar block: split, to LDS HD. */
 #pragma unroll
@@ -825,7 +868,7 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
           }
         }
         wave_sync();
-        RN_STAMP(A, 6 + phase * 8);
+        RN_STAMP(A, 6 + phase * 4);
       } else {
         /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
         char *xs = Xb + col * 16;
@@ -847,15 +890,15 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
           }
         }
         wave_sync();
-        RN_STAMP(A, 19);
+        RN_STAMP(A, 11);
         dir_layer<MM, BF_BNLDS, BF_DIR_REAL_KS>(p, ar, 0, R0, bn, R0);
-        RN_STAMP(A, 20);
+        RN_STAMP(A, 12);
 #pragma unroll 1
         for (int it = 0; it < 4; ++it) {
           dir_layer<MM, BF_REG, 0>(p, ar, (it == 2) ? 2 : 0, R0, bn, R1);
           if (it < 3) dir_layer<MM, BF_REG, 0>(p, ar, 0, R1, bn, R0);
         }
-        RN_STAMP(A, 21);
+        RN_STAMP(A, 13);
         /* rgb: one slice */
         v16f acc;
         bf_chunk<MM, BF_REG, 0, true, true>(p, ar, R1, bn, acc);

@@ -119,6 +119,11 @@ __device__ __forceinline__ void wave_sum_many(float (&v)[K], float *scr, int lan
   __builtin_amdgcn_wave_barrier();
 }
 
+/* value of lane `l` (compile-time) as a wave-uniform scalar: v_readlane_b32 */
+__device__ __forceinline__ float lane_value(float x, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+
 /* inclusive scan of doubles across the wave */
 __device__ __forceinline__ double wave_scan_incl(double v, int lane) {
 #pragma unroll
@@ -148,11 +153,15 @@ __device__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, f
   __builtin_amdgcn_wave_barrier();
   float sum = 0.0f;
   if (EXACT) {
-    if (lane == 0) {
-      #pragma clang loop unroll(disable)
-      for (int i = 0; i < M; ++i) sum += lg[i];
+    /* the sequential fp32 sum e_0 + e_1 + ... (torch's order), evaluated by EVERY lane on wave-uniform values: 64
+     * elements per trip travel lane -> SGPR (v_readlane) instead of through 64 dependent LDS round trips on lane 0
+     * (13 k -> 1.5 k cycles at M = 128; elements past M are +0.0, which leaves an fp32 sum unchanged) */
+    #pragma clang loop unroll(disable)
+    for (int i0 = 0; i0 < M; i0 += 64) {
+      const float x = (i0 + lane < M) ? lg[i0 + lane] : 0.0f;
+#pragma unroll
+      for (int l = 0; l < 64; ++l) sum += lane_value(x, l);
     }
-    sum = __shfl(sum, 0, 64);
   } else {
     #pragma clang loop unroll(disable)
     for (int i = lane; i < M; i += 64) sum += lg[i];
@@ -163,13 +172,21 @@ __device__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, f
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (EXACT) {
-    if (lane == 0) {
-      cw[0] = 0.0f;
-      double acc = 0.0;
-      #pragma clang loop unroll(disable)
-      for (int i = 0; i < M - 1; ++i) { acc += (double)lg[i]; cw[i + 1] = fminf(1.0f, (float)acc); }
-      cw[M] = 1.0f;
+    /* float64 running sum of p_0 .. p_{M-2} in index order (torch.cumsum on the reference's float64 promotion), again as a
+     * wave-uniform chain over v_readlane values; lane l keeps the partial sum that ends at its own element */
+    double acc = 0.0;
+    #pragma clang loop unroll(disable)
+    for (int i0 = 0; i0 < M; i0 += 64) {
+      const float x = (i0 + lane < M) ? lg[i0 + lane] : 0.0f;
+      float mine = 0.0f;
+#pragma unroll
+      for (int l = 0; l < 64; ++l) {
+        acc += (double)lane_value(x, l);
+        mine = (lane == l) ? (float)acc : mine;
+      }
+      if (i0 + lane < M - 1) cw[i0 + lane + 1] = fminf(1.0f, mine);
     }
+    if (lane == 0) { cw[0] = 0.0f; cw[M] = 1.0f; }
   } else {
     /* wave-parallel prefix sum (float64 partials, chunk per lane): same CDF up to
      * the summation order, not bit-identical to the sequential one */

@@ -25,7 +25,8 @@ KERNELS = {"level_fwd_bf16": "rn::level_fwd_bf16", "level_fwd_f32": "rn::level_f
            "wgrad_kernel": "rn::wgrad_kernel", "wgrad_bf16x3_kernel": "rn::wgrad_bf16x3_kernel", "level_bwd_bf16c": "rn::level_bwd_bf16c",
            "level_fwd_train_bf16c": "rn::level_fwd_train_bf16c", "level_fwd_f16": "rn::level_fwd_f16",
            "bwd_seed_kernel": "rn::bwd_seed_kernel", "wgrad_reduce": "rn::wgrad_reduce",
-           "level_fwd_bf16_ring": "rn::level_fwd_bf16_ring", "level_fwd_f16_ring": "rn::level_fwd_f16_ring"}
+           "level_fwd_bf16_ring": "rn::level_fwd_bf16_ring", "level_fwd_f16_ring": "rn::level_fwd_f16_ring",
+           "level_fwd_f16x2": "rn::level_fwd_f16x2", "level_fwd_f16x2_ring": "rn::level_fwd_f16x2_ring"}
 
 rows = list(csv.reader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
 with open(os.path.join(dst, f"kernel_stats{sfx}.csv"), "w", newline="") as f:
