@@ -238,7 +238,7 @@ __device__ __forceinline__ void ide_eval(float x, float y, float z, float kappa_
 /* coord.pos_enc(d, 0, 5, append_identity = True) (coord.py:136-147; MLP.use_directional_enc = False, models.py:487-492) with
  * the calling convention of ide_eval: part 0 emits slots 0..35 = [x y z | sin(2^j d_i), j-major (15) | 0 x18], part 1 slots
  * 0..35 of the second half = [sin(2^j d_i + pi/2) (15) | 0 x21] (as the reference: a sine of the shifted argument). */
-template <bool FAST = false, typename Emit>
+template <bool FAST = false, bool REDUCED = false, typename Emit>
 __device__ __forceinline__ void posenc_eval(float x, float y, float z, int part, Emit emit) {
   const float d[3] = {x, y, z};
   const float half_pi = (float)(0.5 * 3.14159265358979323846);
@@ -249,7 +249,8 @@ __device__ __forceinline__ void posenc_eval(float x, float y, float z, int part,
     const int k = part ? q : q - 3;                        /* 3 j + i inside the sin / shifted-sin block */
     if (k >= 0 && k < 15) {
       const float sx = d[k % 3] * (float)(1 << (k / 3)) + (part ? half_pi : 0.0f);
-      v = FAST ? __builtin_amdgcn_sinf(sx * (float)(0.5 / 3.14159265358979323846)) : sinf(sx);
+      /* REDUCED (split-f16 kernel): |sx| < 34, sin_reduced is 1.5 ulp there at a sixth of the library routine's code */
+      v = FAST ? __builtin_amdgcn_sinf(sx * (float)(0.5 / 3.14159265358979323846)) : (REDUCED ? sin_reduced(sx) : sinf(sx));
     }
     emit(q, v);
   }

@@ -514,6 +514,10 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16(const LevelArgs A) 
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16_ring(const LevelArgs A) { level_fwd_mm<MmBf16, true>(A); }
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16_ring(const LevelArgs A) { level_fwd_mm<MmF16, true>(A); }
 
+/* cycle stamp from the wave index / lane the kernel already holds (RN_STAMP re-derives both from threadIdx: two more live
+ * registers, which the split kernel spills) */
+#define RN_STAMPW(A, slot) do { asm volatile("; RNMARK " #slot); if ((A).prof && blockIdx.x == (gridDim.x >> 1) && lane == 0) (A).prof[wave * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+
 /* =====================================================================================================================
  * REFNERF_PREC_F16X2 -- the parity-grade 16-bit mode (split operands, refnerf_layout.h "split-f16 operand image").
  *
@@ -695,7 +699,7 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
   p.dma_left = n_pass * SPPACKED.chunks_per_pass;
   p.lane = lane; p.wave = wave; p.h = h;
   p.t_vm = 0; p.t_bar = 0;
-  RN_STAMP(A, 0);
+  RN_STAMPW(A, 0);
   issue_chunk<true>(p, p.cur_off);                           /* overlaps with the resampler */
   issue_chunk<true>(p, p.nxt_off);
 
@@ -715,10 +719,10 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
       if (lane == 0) NRM[rl] = sqrtf((dx * dx + dy * dy) + dz * dz);
     }
   }
-  RN_STAMP(A, 1);
+  RN_STAMPW(A, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                           /* chunks 0 and 1 have landed */
-  RN_STAMP(A, 2);
+  RN_STAMPW(A, 2);
 
 #ifndef REFNERF_BF_NOPRIO
   if (wave >= BF_NW / 2) __builtin_amdgcn_s_setprio(1);
@@ -729,12 +733,17 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
   for (int d = 0; d < AF; ++d) ar[d] = lds_frag<MM>(WB + 1024 + lane * 16 + d * 1024);
 
   for (int pass0 = 0; pass0 < n_tot; pass0 += BT) {
-    int lane_v = lane, col_v = col;
-    asm volatile("" : "+v"(lane_v), "+v"(col_v));
-    const int g = pass0 + col_v;
-    const int rl = g / N, si = g - rl * N;
-    const int ray = ray0 + rl;
-    const bool valid = (g < n_tot) && (ray < A.R);
+    int lane_v = lane;
+    asm volatile("" : "+v"(lane_v));
+    /* which (ray, sample) this lane's column is: recomputed where it is needed (P4, P6) from laundered inputs instead of
+     * being carried -- spilled -- across the two spatial runs */
+    auto locate = [&](int &g, int &rl, bool &valid) {
+      int col_l = col, pass_l = pass0;
+      asm volatile("" : "+v"(col_l), "+s"(pass_l));
+      g = pass_l + col_l;
+      rl = g / N;
+      valid = (g < n_tot) && (ray0 + rl < A.R);
+    };
     auto pass_epilogue = [&]() {
       if constexpr (RINGPS) {
         __syncthreads();
@@ -747,15 +756,21 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
       if (g0 >= n_tot || ray0 + g0 / N >= A.R) { idle_pass<true>(p); pass_epilogue(); continue; }
     }
     auto load_heads = [&](SampleHeads &sh) {
+      /* ONE address register for the twelve rows (HD sits past the 64 KB immediate range of the ds instructions: left to
+       * itself hipcc keeps a base per row, hoists them out of the pass loop and spills them) */
+      int g, rl; bool valid;
+      locate(g, rl, valid);
+      int ci = col, ro = (valid ? rl : 0) * 12;
+      asm volatile("" : "+v"(ci), "+v"(ro));
       float v[3], gp[3], raw_dif[3], raw_tint[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        v[i] = RY[(valid ? rl : 0) * 12 + 6 + i];
-        gp[i] = HD[(1 + i) * BT + col];
-        raw_dif[i] = HD[(5 + i) * BT + col];
-        raw_tint[i] = HD[(8 + i) * BT + col];
+        v[i] = RY[ro + 6 + i];
+        gp[i] = HD[(1 + i) * BT + ci];
+        raw_dif[i] = HD[(5 + i) * BT + ci];
+        raw_tint[i] = HD[(8 + i) * BT + ci];
       }
-      sample_heads<false>(cfg, HD[0 * BT + col], gp, HD[4 * BT + col], raw_dif, raw_tint, v, sh);
+      sample_heads<false>(cfg, HD[0 * BT + ci], gp, HD[4 * BT + ci], raw_dif, raw_tint, v, sh);
     };
 
 #pragma unroll 1
@@ -786,7 +801,7 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
         cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
         if (cfg.disable_integration) { lv[0] = 0.0f; lv[1] = 0.0f; lv[2] = 0.0f; }        /* models.py:228-231 */
         char *xw = Xb + (wave * 16 + i16) * 16;
-        RN_STAMP(A, 17);
+        RN_STAMPW(A, 17);
         /* two features per trip (one dword of the hi plane, one of the lo plane): the libm sine is long, keep ONE copy pair */
 #pragma clang loop unroll(disable)
         for (int t = 0; t < 12; ++t) {
@@ -821,18 +836,18 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
 #else
         float *dbgs = nullptr;
 #endif
-        RN_STAMP(A, 18);
+        RN_STAMPW(A, 18);
         wave_sync();
-        RN_STAMP(A, 3 + phase * 4);
+        RN_STAMPW(A, 3 + phase * 4);
         /* spatial trunk on the N-packed operands */
         sp_layer<MM, true>(p, ar, false, R0, bn, R0, dbgs);
-        RN_STAMP(A, 4 + phase * 4);
+        RN_STAMPW(A, 4 + phase * 4);
 #pragma unroll 1
         for (int it = 0; it < 4; ++it) {
           sp_layer<MM, false>(p, ar, it == 2, R0, bn, R1, dbgs ? dbgs + 256 * (2 * it + 1) : nullptr);
           if (it < 3) sp_layer<MM, false>(p, ar, false, R1, bn, R0, dbgs ? dbgs + 256 * (2 * it + 2) : nullptr);
         }
-        RN_STAMP(A, 5 + phase * 4);
+        RN_STAMPW(A, 5 + phase * 4);
         /* P3: heads.  Bottleneck blocks: hi weights over the N-packed input; kept as packed f16 (run 0), merged with
          * run 1's into the plain 32-sample B fragments of the directional trunk.  Scalar block: split, to LDS HD. */
 #pragma unroll
@@ -856,10 +871,12 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
             sp_slice<MM>(p, ar, false, R1, bn, acc);
             npk_totals(acc, s);
             if ((lane_v & 16) == 0) {
+              int csl = cs + 4 * h * BT;                 /* one laundered base: rows are immediate offsets from it */
+              asm volatile("" : "+v"(csl));
 #pragma unroll
               for (int rr = 0; rr < 8; ++rr) {
                 const int row = (rr & 3) + 8 * (rr >> 2) + 4 * h;
-                if (row < HD_ROWS) HD[row * BT + cs] = s[rr];
+                if (row < HD_ROWS) HD[((rr & 3) + 8 * (rr >> 2)) * BT + csl] = s[rr];
 #ifdef REFNERF_SPLIT_DUMP
                 if (row < HD_ROWS && dbgs) dbgs[8 * 256 + row] = s[rr];
 #endif
@@ -868,7 +885,7 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
           }
         }
         wave_sync();
-        RN_STAMP(A, 6 + phase * 4);
+        RN_STAMPW(A, 6 + phase * 4);
       } else {
         /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
         char *xs = Xb + col * 16;
@@ -878,7 +895,7 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
           float ide[40];
 #pragma unroll
           for (int q = 36; q < 40; ++q) ide[q] = 0.0f;
-          if (cfg.dir_enc == REFNERF_DIRENC_POSENC) posenc_eval<false>(sh.refd[0], sh.refd[1], sh.refd[2], h, [&](int q, float val) { ide[q] = val; });
+          if (cfg.dir_enc == REFNERF_DIRENC_POSENC) posenc_eval<false, true>(sh.refd[0], sh.refd[1], sh.refd[2], h, [&](int q, float val) { ide[q] = val; });
           else ide_eval<false>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { ide[q] = val; });
           if (h == 0) ide[36] = sh.dot;
 #pragma unroll
@@ -890,23 +907,25 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
           }
         }
         wave_sync();
-        RN_STAMP(A, 11);
+        RN_STAMPW(A, 11);
         dir_layer<MM, BF_BNLDS, BF_DIR_REAL_KS>(p, ar, 0, R0, bn, R0);
-        RN_STAMP(A, 12);
+        RN_STAMPW(A, 12);
 #pragma unroll 1
         for (int it = 0; it < 4; ++it) {
           dir_layer<MM, BF_REG, 0>(p, ar, (it == 2) ? 2 : 0, R0, bn, R1);
           if (it < 3) dir_layer<MM, BF_REG, 0>(p, ar, 0, R1, bn, R0);
         }
-        RN_STAMP(A, 13);
+        RN_STAMPW(A, 13);
         /* rgb: one slice */
         v16f acc;
         bf_chunk<MM, BF_REG, 0, true, true>(p, ar, R1, bn, acc);
         float raw_rgb[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n, 64);
-        int lane_w = lane, g_w = g, pass_w = pass0;
-        asm volatile("" : "+v"(lane_w), "+v"(g_w), "+s"(pass_w));
+        int g_w, rl_w; bool valid;
+        locate(g_w, rl_w, valid);
+        int lane_w = lane, pass_w = pass0;
+        asm volatile("" : "+v"(lane_w), "+s"(pass_w));
         if (valid && h == 0) {                                                            /* P6 */
           SampleHeads sh;
           load_heads(sh);
@@ -914,7 +933,7 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
         }
         wave_sync();
         history_flush<NPS_EVAL, PSM>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);
-        RN_STAMP(A, 14);
+        RN_STAMPW(A, 14);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -922,9 +941,9 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  RN_STAMP(A, 15);
+  RN_STAMPW(A, 15);
   if constexpr (!RINGPS) composite_phase<BF_NW, false, NPS_EVAL>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB), NRM);   /* P7 */
-  RN_STAMP(A, 16);
+  RN_STAMPW(A, 16);
 }
 
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16x2(const LevelArgs A) { level_fwd_split<false>(A); }

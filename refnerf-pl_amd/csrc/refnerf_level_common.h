@@ -140,7 +140,7 @@ __device__ __forceinline__ double wave_scan_incl(double v, int lane) {
  * The softmax sum and the float64 cumsum run sequentially on lane 0 so that the
  * CDF is bit-identical to the oracle / torch's accumulation order. */
 template <bool EXACT = true>
-__device__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, float *c, int M, int N,
+__device__ __forceinline__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, float *c, int M, int N,
                                       float smin, float smax, float *sd, int32_t *bin_idx_g, int lane) {
   /* softmax: max is order-independent */
   float mx = -INFINITY;
