@@ -284,6 +284,10 @@ __device__ __forceinline__ void bf_layer(Pipe &p, typename MM::v8 (&a)[AF], int 
   }
 }
 
+/* cycle stamp from the wave index / lane the kernel already holds (RN_STAMP re-derives both from threadIdx: two more live
+ * registers, which the split kernel spills) */
+#define RN_STAMPW(A, slot) do { asm volatile("; RNMARK " #slot); if ((A).prof && blockIdx.x == (gridDim.x >> 1) && lane == 0) (A).prof[wave * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+
 /* RINGPS: the workgroup owns more samples than per-sample records fit the LDS (rays_per_wg * N > 640: e.g. 4 rays x 192 =
  * three FULL passes instead of 2 rays = one and a half): the records live in a ring of BF_PS_RING rows and every ray is
  * composited right behind the pass that brings its last sample (N <= 256: a ray and the pass in flight fit the ring). */
@@ -325,15 +329,15 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
   p.dma_left = n_pass * BFPACKED.chunks_per_pass;
   p.lane = lane; p.wave = wave; p.h = h;
   p.t_vm = 0; p.t_bar = 0;
-  RN_STAMP(A, 0);
+  RN_STAMPW(A, 0);
   issue_chunk(p, p.cur_off);                                 /* overlaps with the resampler */
   issue_chunk(p, p.nxt_off);
 
   resample_phase<BF_NW, false>(A, reinterpret_cast<float *>(Xb), TD, NRM, ray0, wave, lane);   /* P0 */
-  RN_STAMP(A, 1);
+  RN_STAMPW(A, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                           /* chunks 0 and 1 have landed */
-  RN_STAMP(A, 2);
+  RN_STAMPW(A, 2);
 
   /* static priority for the younger wave of each SIMD (waves 4-7): age-based
    * arbitration otherwise lets waves 0-3 run ahead and idle at every rendezvous */
@@ -350,11 +354,16 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
      * arithmetic out of the pass loop (it then spills them to scratch) */
     int lane_v = lane, col_v = col;
     asm volatile("" : "+v"(lane_v), "+v"(col_v));
-    const int g = pass0 + col_v;
-    const int rl = g / N, si = g - rl * N;
-    const int ray = ray0 + rl;
-    const bool valid = (g < n_tot) && (ray < A.R);
-    const int rayc = valid ? ray : (A.R - 1);
+    /* which (ray, sample) this lane's column is: recomputed at every use (P1, P4, P6) from laundered inputs instead of being
+     * carried -- spilled -- across the MLP phases */
+    auto locate = [&](int &g, int &rl, int &si, bool &valid) {
+      int col_l = col, pass_l = pass0;
+      asm volatile("" : "+v"(col_l), "+s"(pass_l));
+      g = pass_l + col_l;
+      rl = g / N;
+      si = g - rl * N;
+      valid = (g < n_tot) && (ray0 + rl < A.R);
+    };
     /* RINGPS: the rays whose last sample this pass brings are composited behind it (every wave meets the barrier) */
     auto pass_epilogue = [&]() {
       if constexpr (RINGPS) {
@@ -371,15 +380,20 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
     /* head scalars of this sample live in LDS (HD); P4 and P6 both rebuild the
      * activations from them instead of keeping ~20 VGPRs alive across the dir MLP */
     auto load_heads = [&](SampleHeads &sh) {
+      /* ONE address register for the twelve HD rows and one for the ray record (see level_fwd_split) */
+      int g, rl, si; bool valid;
+      locate(g, rl, si, valid);
+      int ci = col, ro = (valid ? rl : 0) * 12;
+      asm volatile("" : "+v"(ci), "+v"(ro));
       float v[3], gp[3], raw_dif[3], raw_tint[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        v[i] = RY[(valid ? rl : 0) * 12 + 6 + i];
-        gp[i] = HD[(1 + i) * BT + col];
-        raw_dif[i] = HD[(5 + i) * BT + col];
-        raw_tint[i] = HD[(8 + i) * BT + col];
+        v[i] = RY[ro + 6 + i];
+        gp[i] = HD[(1 + i) * BT + ci];
+        raw_dif[i] = HD[(5 + i) * BT + ci];
+        raw_tint[i] = HD[(8 + i) * BT + ci];
       }
-      sample_heads<ENC_FAST>(cfg, HD[0 * BT + col], gp, HD[4 * BT + col], raw_dif, raw_tint, v, sh);
+      sample_heads<ENC_FAST>(cfg, HD[0 * BT + ci], gp, HD[4 * BT + ci], raw_dif, raw_tint, v, sh);
     };
 
 #pragma unroll 1
@@ -395,6 +409,8 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
       char *xs = Xb + col * 16;
       if (phase == 0) {
         /* P1: conical frustum -> lifted Gaussian -> IPE (half h computes block h: sin / cos) */
+        int g, rl, si; bool valid;
+        locate(g, rl, si, valid);
         float o[3], d[3];
         const float *ry = RY + (valid ? rl : 0) * 12;
 #pragma unroll
@@ -407,7 +423,7 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
         if (cfg.disable_integration) { lv[0] = 0.0f; lv[1] = 0.0f; lv[2] = 0.0f; }        /* models.py:228-231 */
         /* k' = canonical IPE index: half h owns block h (sin / cos) = k' 48h .. 48h+47 = 6 k-groups;
          * rolled over two halves of 24 features (8 degrees x 3 axes): the (axis, degree) pattern repeats */
-        RN_STAMP(A, 17);
+        RN_STAMPW(A, 17);
 #pragma unroll 1
         for (int qq = 0; qq < 2; ++qq) {
 #pragma unroll
@@ -421,7 +437,7 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
             *reinterpret_cast<v8mm *>(xs + (6 * h + 3 * qq + q) * BT * 16) = pk;
           }
         }
-        RN_STAMP(A, 18);
+        RN_STAMPW(A, 18);
       } else {
         /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
         SampleHeads sh;
@@ -442,12 +458,12 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
         }
       }
       wave_sync();
-      RN_STAMP(A, 3 + phase * 8);
+      RN_STAMPW(A, 3 + phase * 8);
 
       /* layer 0 of the trunk: inputs from LDS (+ bottleneck registers for the dir MLP) -> R0 */
       if (phase == 0) bf_layer<MM, BF_LDS8, BF_IPE_REAL_KS>(p, ar, 0, R0, bn, R0);
       else bf_layer<MM, BF_BNLDS, BF_DIR_REAL_KS>(p, ar, 0, R0, bn, R0);
-      RN_STAMP(A, 4 + phase * 8);
+      RN_STAMPW(A, 4 + phase * 8);
       /* layers 1..7: A (R0->R1), B (R1->R0); the third A carries the skip input */
 #pragma unroll 1
       for (int it = 0; it < 4; ++it) {
@@ -455,7 +471,7 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
         bf_layer<MM, BF_REG, 0>(p, ar, second, R0, bn, R1);
         if (it < 3) bf_layer<MM, BF_REG, 0>(p, ar, 0, R1, bn, R0);
       }
-      RN_STAMP(A, 5 + phase * 8);
+      RN_STAMPW(A, 5 + phase * 8);
       if (phase == 0) {
         /* P3: heads: 4 bottleneck blocks stay in registers, the scalar block goes to LDS HD */
 #pragma unroll
@@ -464,15 +480,17 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
           bf_slice<MM, BF_REG, 0>(p, ar, 0, R1, bn, acc);
           if (ob < 4) pack_acc<MM, false>(acc, bn[2 * ob], bn[2 * ob + 1]);
           else {
+            int cb = col + 4 * h * BT;                   /* one laundered base: rows are immediate offsets from it */
+            asm volatile("" : "+v"(cb));
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
               int row = (rr & 3) + 8 * (rr >> 2) + 4 * h;
-              if (row < HD_ROWS) HD[row * BT + col] = acc[rr];
+              if (row < HD_ROWS) HD[((rr & 3) + 8 * (rr >> 2)) * BT + cb] = acc[rr];
             }
           }
         }
         wave_sync();
-        RN_STAMP(A, 6);
+        RN_STAMPW(A, 6);
       } else {
         /* rgb: one slice */
         v16f acc;
@@ -482,8 +500,10 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
         for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n, 64);
         /* opaque copies taken HERE: the per-lane output addresses of P6 must not be computed at
          * the top of the pass and carried (spilled) across both MLP phases */
-        int lane_w = lane, g_w = g, pass_w = pass0;
-        asm volatile("" : "+v"(lane_w), "+v"(g_w), "+s"(pass_w));
+        int g_w, rl_w, si_w; bool valid;
+        locate(g_w, rl_w, si_w, valid);
+        int lane_w = lane, pass_w = pass0;
+        asm volatile("" : "+v"(lane_w), "+s"(pass_w));
         if (valid && h == 0) {                                                            /* P6 */
           SampleHeads sh;
           load_heads(sh);
@@ -491,7 +511,7 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
         }
         wave_sync();
         history_flush<NPS_EVAL, PSM>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);
-        RN_STAMP(A, 14);
+        RN_STAMPW(A, 14);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -499,13 +519,13 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  RN_STAMP(A, 15);
+  RN_STAMPW(A, 15);
 #ifdef REFNERF_PROF_WAITS
   if (A.prof && blockIdx.x == 0 && lane == 0) { A.prof[wave * 32 + 20] = p.t_vm; A.prof[wave * 32 + 21] = p.t_bar; }
 #endif
 
   if constexpr (!RINGPS) composite_phase<BF_NW, true, NPS_EVAL>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB), NRM);   /* P7 */
-  RN_STAMP(A, 16);
+  RN_STAMPW(A, 16);
 }
 
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A) { level_fwd_mm<MmBf16>(A); }
@@ -513,10 +533,6 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16(const LevelArgs A) 
 /* the same with the per-sample records in a ring (rays_per_wg * N > 640) */
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16_ring(const LevelArgs A) { level_fwd_mm<MmBf16, true>(A); }
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16_ring(const LevelArgs A) { level_fwd_mm<MmF16, true>(A); }
-
-/* cycle stamp from the wave index / lane the kernel already holds (RN_STAMP re-derives both from threadIdx: two more live
- * registers, which the split kernel spills) */
-#define RN_STAMPW(A, slot) do { asm volatile("; RNMARK " #slot); if ((A).prof && blockIdx.x == (gridDim.x >> 1) && lane == 0) (A).prof[wave * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 /* =====================================================================================================================
  * REFNERF_PREC_F16X2 -- the parity-grade 16-bit mode (split operands, refnerf_layout.h "split-f16 operand image").
