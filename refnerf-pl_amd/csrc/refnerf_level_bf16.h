@@ -945,7 +945,7 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
         if (valid && h == 0) {                                                            /* P6 */
           SampleHeads sh;
           load_heads(sh);
-          colour_store<false, NPS_EVAL, PSM>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
+          colour_store<false, NPS_EVAL, PSM, true>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
         }
         wave_sync();
         history_flush<NPS_EVAL, PSM>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);

@@ -323,7 +323,9 @@ __device__ __forceinline__ void sample_heads(const refnerf_level_cfg &cfg, float
 template <int PSM>
 __device__ __forceinline__ int ps_row(int g) { return PSM ? (g & PSM) : g; }
 
-template <bool FAST = false, int NP = NPS_TRAIN, int PSM = 0>
+/* FAST_SRGB: the 5/12 power of the sRGB curve through v_log_f32 / v_exp_f32 (2-3 ulp) instead of the library powf (nine
+ * calls of ~100 instructions per sample); set by the split-f16 kernel, whose other transcendentals stay libm-accurate */
+template <bool FAST = false, int NP = NPS_TRAIN, int PSM = 0, bool FAST_SRGB = FAST>
 __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHeads &s, const float raw_rgb[3],
                                              float *PS, float *PX, int n_tot, int g_sample, int gcol) {
   const int g = ps_row<PSM>(g_sample);
@@ -344,9 +346,9 @@ __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHea
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      rgb[i] = clip01(linear_to_srgb<FAST>(rgb[i]));
-      dif[i] = clip01(linear_to_srgb<FAST>(dif_lin[i]));
-      spc[i] = clip01(linear_to_srgb<FAST>(spec_lin[i]));
+      rgb[i] = clip01(linear_to_srgb<FAST_SRGB>(rgb[i]));
+      dif[i] = clip01(linear_to_srgb<FAST_SRGB>(dif_lin[i]));
+      spc[i] = clip01(linear_to_srgb<FAST_SRGB>(spec_lin[i]));
     }
   } else {
 #pragma unroll
