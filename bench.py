@@ -80,8 +80,9 @@ def parse():
     ap.add_argument("--precision", default="f16x2", choices=list(EVAL_MODES),
                     help="arithmetic of the MLP contractions for the headline value (eval configurations); the other modes are "
                          "reported alongside.  Default: the parity-grade 16-bit mode")
-    ap.add_argument("--train-precision", default="f32", choices=["f32", "bf16"],
-                    help="MLP chains of the training step that carries the C5 headline (f32 = the parity mode)")
+    ap.add_argument("--train-precision", default="f32", choices=["f32", "f16x2", "bf16"],
+                    help="MLP chains of the training step that carries the C5 headline (f32 = exact; f16x2 = split-f16 forward + f32 "
+                         "backward, parity-grade; bf16 = throughput mode)")
     ap.add_argument("--no-other-configs", action="store_true", help="C2 only: skip the short C3 / C4-shard / C5-shard legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-image", action="store_true")
@@ -502,6 +503,7 @@ def main():
             del img, rendering
         if not args.no_train and args.config == "C2":
             line["train_step"] = train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync, max_over_ranks, "f32")
+            line["train_step_f16x2"] = train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync, max_over_ranks, "f16x2")
             line["train_step_bf16"] = train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync, max_over_ranks, "bf16")
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(blob, spec, rays_np, hip_outputs)
@@ -541,7 +543,9 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     import torch
     from refnerf_pl_amd import _hip, distributed, synthetic, train_utils, utils
     model.train()
-    cfg.hip_train_precision = cfg.hip_bwd_precision = chains
+    fwd_chains = chains                                   # 'f32' | 'f16x2' (split f16 forward, f32 backward: parity-grade) | 'bf16'
+    bwd_chains = "f32" if chains == "f16x2" else chains
+    cfg.hip_train_precision, cfg.hip_bwd_precision = fwd_chains, bwd_chains
     cfg.hip_fused_losses = True          # data + orientation + predicted-normal terms through the fused loss kernels
     cfg.hip_flat_grads = True            # gradient, all-reduce and Adam on ONE flat tensor per MLP
     R = rays.origins.shape[0]
@@ -590,8 +594,9 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     passes = 2 if geometry else 1           # clean + noisy pass: two launches of each family per level and step
     samples_per_launch = (R + extra_rays) * N / passes
     kernels = {}
-    names = {"fwd": "rn::level_fwd_train_" + ("bf16c" if chains == "bf16" else "f32"),
-             "bwd": "rn::level_bwd_" + ("bf16c" if chains == "bf16" else "f32"), "wgrad": "rn::wgrad_bf16x3_kernel"}
+    names = {"fwd": "rn::level_fwd_train_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[fwd_chains],
+             "bwd": "rn::level_bwd_" + ("bf16c" if bwd_chains == "bf16" else "f32"), "wgrad": "rn::wgrad_bf16x3_kernel"}
+    peak_of = {"fwd": PEAK_TFLOPS[fwd_chains], "bwd": PEAK_TFLOPS[bwd_chains]}
     for k, (ms, cnt) in fam.items():
         if not cnt:
             continue
@@ -608,8 +613,8 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
             # the MLP's contractions -- the other half of the backward FLOPs, dW, is the wgrad GEMM's)
             flop = samples_per_launch * ((FLOP_PER_SAMPLE + NORMALS_VJP_FLOP) if k == "fwd" else FLOP_PER_SAMPLE)
             ach = flop / (avg * 1e-3) / 1e12
-            kernels[k] = {"kernel": names[k], "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[chains], "unit": "TFLOP/s",
-                          "frac": ach / PEAK_TFLOPS[chains], "avg_launch_ms": avg, "launches": cnt, "flop_per_launch": flop}
+            kernels[k] = {"kernel": names[k], "bound": "mfma", "achieved": ach, "peak": peak_of[k], "unit": "TFLOP/s",
+                          "frac": ach / peak_of[k], "avg_launch_ms": avg, "launches": cnt, "flop_per_launch": flop}
     out = {"value": rate, "unit": "ray-samples/s (fwd+bwd+Adam)", "ms_per_step": 1e3 * el / n, "steps": n,
            "dtype": chains, "wgrad": getattr(cfg, "hip_wgrad_mode", "bf16x3"), "losses": "fused kernels (Config.hip_fused_losses)", "gradients": "one flat tensor per MLP (Config.hip_flat_grads)",
            "loss": float(loss.detach()),
@@ -617,6 +622,9 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
            "kernels_ms_per_step": sum(ms for ms, _ in fam.values()) / n,
            "mode": ("parity mode: f32 MLP chains (gradient rel-L2 <= 2e-4 vs the reference's autograd, 1e-3 on trained-like weights)"
                     if chains == "f32" else
+                    "parity-grade fast mode: training forward on split-f16 chains (22-bit products, fp32 ACT rows), fp32 backward chains; "
+                    "gradient rel-L2 5e-5 vs the reference's autograd also on trained-like weights"
+                    if chains == "f16x2" else
                     "throughput mode: bf16 MLP chains; gradient 1e-2 (random-init) / 1e-1 (trained-like weights) relative L2 from the "
                     "reference -- for from-scratch training, not a parity mode"),
            "note": "`kernels` holds one roofline per kernel family from HIP event pairs (chains against the MFMA peak of their "

@@ -223,7 +223,8 @@ def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, histo
         check(lib().refnerf_level_forward_train(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out),
                                                 ptr(act), act.numel(), stream_ptr()))
         res["activations"] = act
-        res["activations_format"] = int(cfg.precision)                   # REFNERF_ACT_F32 / REFNERF_ACT_BF16
+        # REFNERF_ACT_F32 / REFNERF_ACT_BF16: only the bf16-chain forward writes bf16 rows (the split-f16 chains write fp32 rows)
+        res["activations_format"] = 1 if int(cfg.precision) == PREC_BF16 else 0
     else:
         check(lib().refnerf_level_forward(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out), stream_ptr()))
     return res

@@ -176,6 +176,58 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
       }
       dst[idx] = (__bf16)v;
     }
+  } else if (op < 2 * NUM_OPS + 3 * NUM_TOPS) {
+    /* split-f16 transposed ops (refnerf_layout.h: ht_off): the bt_off values as hi + lo halves, [k-step][hi | lo][ob][lane][8] */
+    const int t = op - 2 * NUM_OPS - 2 * NUM_TOPS;
+    const Op o = PACKED.top[t];
+    const TopSrc src = PACKED.top_src[t];
+    const int steps = (t == TOP_HEADS) ? BT_HEADS_STEPS : BT_CHAIN_STEPS;
+    _Float16 *dst = reinterpret_cast<_Float16 *>(out + PACKED.ht_off[t]);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < steps * 64 * 8 * 8; idx += gridDim.x * blockDim.x) {
+      const int e = idx & 7, lane = (idx >> 3) & 63, ob = (idx >> 9) & 7, st = idx >> 12;
+      const int h = lane >> 5, in_row = ob * 32 + (lane & 31);
+      float v = 0.0f;
+      if (ob < o.nob) {
+        if (t == TOP_HEADS) {
+          const int hr = 16 * st + 8 * h + e;
+          v = (hr < HROWS) ? canon_w(P, OP_HEADS, hr, in_row) : 0.0f;
+        } else {
+          const int r = 8 * (st & 1) + e;
+          const int oo = 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int n_rows = (o.nob == 8) ? WIDTH : (o.nob == 3 ? IPE_DIM : DIR_IN);
+          v = (in_row < n_rows) ? canon_w(P, src.fwd_op, oo, src.col0 + in_row) : 0.0f;
+        }
+      }
+      const _Float16 hi = (_Float16)v;
+      const size_t base = (size_t)st * (2 * 64 * 8 * 8) + (idx & 4095);
+      dst[base] = hi;
+      dst[base + 4096] = (_Float16)(v - (float)hi);
+    }
+  } else if (op < 3 * NUM_OPS + 3 * NUM_TOPS) {
+    /* split-f16 forward ops (refnerf_layout.h: hf_off) */
+    const int fo = op - 2 * NUM_OPS - 3 * NUM_TOPS;
+    const Op o = PACKED.op[fo];
+    const int rst = bf_reg_steps(fo), steps = rst + bf_lds_steps(fo);
+    const int valid_k = (fo == 0 || fo == 5) ? IPE_DIM : DIR_IN;
+    _Float16 *dst = reinterpret_cast<_Float16 *>(out + PACKED.hf_off[fo]);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < steps * 64 * 8 * 8; idx += gridDim.x * blockDim.x) {
+      const int e = idx & 7, lane = (idx >> 3) & 63, ob = (idx >> 9) & 7, st = idx >> 12;
+      const int h = lane >> 5, row = ob * 32 + (lane & 31);
+      float v = 0.0f;
+      if (ob < o.nob) {
+        if (st < rst) {
+          const int r = 8 * (st & 1) + e;
+          v = canon_w(P, fo, row, 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h);
+        } else {
+          const int kl = 16 * (st - rst) + 8 * h + e;
+          v = (kl < valid_k) ? canon_w(P, fo, row, (rst ? WIDTH : 0) + kl) : 0.0f;
+        }
+      }
+      const _Float16 hi = (_Float16)v;
+      const size_t base = (size_t)st * (2 * 64 * 8 * 8) + (idx & 4095);
+      dst[base] = hi;
+      dst[base + 4096] = (_Float16)(v - (float)hi);
+    }
   } else {
     /* WD / WRGB: raw_density.weight and rgb_layer.weight rows in accumulator layout [ob][h][16] */
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < 4 * 8 * 32; b += gridDim.x * blockDim.x) {
@@ -571,7 +623,7 @@ size_t refnerf_packed_weights_bytes(int precision) {
 int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, void *stream) {
   if (!d_params || !d_packed) return fail(REFNERF_EINVAL, "refnerf_pack_weights: null pointer%s");
   if (precision == REFNERF_PREC_F32) {
-    dim3 grid(64, 2 * rn::NUM_OPS + 2 * rn::NUM_TOPS + 1);
+    dim3 grid(64, 3 * rn::NUM_OPS + 3 * rn::NUM_TOPS + 1);
     hipLaunchKernelGGL(rn::pack_weights_f32, grid, dim3(256), 0, (hipStream_t)stream, d_params, (float *)d_packed);
   } else if (precision == REFNERF_PREC_BF16) {
     dim3 grid(8, rn::NUM_OPS);
@@ -641,15 +693,17 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
     return fail(REFNERF_EINVAL, "unknown raydist (REFNERF_RAYDIST_*)%s");
   if (cfg->dir_enc != REFNERF_DIRENC_IDE && cfg->dir_enc != REFNERF_DIRENC_POSENC)
     return fail(REFNERF_EINVAL, "unknown dir_enc (REFNERF_DIRENC_IDE / REFNERF_DIRENC_POSENC)%s");
-  if (cfg->training && (cfg->precision == REFNERF_PREC_F16 || cfg->precision == REFNERF_PREC_F16X2))
-    return fail(REFNERF_EUNSUPPORTED, "REFNERF_PREC_F16 / REFNERF_PREC_F16X2 are inference modes (training levels: REFNERF_PREC_F32 or REFNERF_PREC_BF16)%s");
+  if (cfg->training && cfg->precision == REFNERF_PREC_F16)
+    return fail(REFNERF_EUNSUPPORTED, "REFNERF_PREC_F16 is an inference mode (training levels: REFNERF_PREC_F32, REFNERF_PREC_F16X2 or REFNERF_PREC_BF16)%s");
   /* training + BF16: the fp32-structure kernel with its MLP chains on bf16 MFMA (level_fwd_train_bf16c); d_packed is
    * the REFNERF_PREC_F32 image in that case (it carries the bf16 copies of the ops) */
   const bool train_bf = cfg->training && cfg->precision == REFNERF_PREC_BF16;
   if (!rays->d_origins || !rays->d_directions || !rays->d_viewdirs || !rays->d_radii || !rays->d_near || !rays->d_far)
     return fail(REFNERF_EINVAL, "refnerf_level_forward: null ray field%s");
   const int N = cfg->n_samples;
-  const bool split = cfg->precision == REFNERF_PREC_F16X2;
+  /* training + F16X2: the same kernel with its chains on split-f16 operands (level_fwd_train_f16x2c), fp32 ACT rows */
+  const bool train_split = cfg->training && cfg->precision == REFNERF_PREC_F16X2;
+  const bool split = cfg->precision == REFNERF_PREC_F16X2 && !train_split;
   const bool bf = (cfg->precision == REFNERF_PREC_BF16 && !train_bf) || cfg->precision == REFNERF_PREC_F16 || split;     /* the LDS-ring 16-bit eval kernels */
   int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
   /* 16-bit inference, rays that do not tile the 256-sample pass within 640 samples (N = 192: 2 rays = one and a half
@@ -691,7 +745,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   if (train_bf) lds = ring_off + rn::RING_BYTES;
   lds += (size_t)rt().lds_pad;   /* debug (REFNERF_LDS_PAD): force 1 workgroup/CU */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget of this precision mode%s");
-  LDS_ATTR_ONCE(lds_attr(rn::level_fwd_f32), lds_attr(rn::level_fwd_train_f32), lds_attr(rn::level_fwd_train_bf16c),
+  LDS_ATTR_ONCE(lds_attr(rn::level_fwd_f32), lds_attr(rn::level_fwd_train_f32), lds_attr(rn::level_fwd_train_bf16c), lds_attr(rn::level_fwd_train_f16x2c),
                 lds_attr(rn::level_fwd_bf16), lds_attr(rn::level_fwd_f16), lds_attr(rn::level_fwd_bf16_ring), lds_attr(rn::level_fwd_f16_ring),
                 lds_attr(rn::level_fwd_f16x2), lds_attr(rn::level_fwd_f16x2_ring));
   rn::LevelArgs a;
@@ -728,6 +782,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   else if (bf && cfg->precision == REFNERF_PREC_F16) hipLaunchKernelGGL(rn::level_fwd_f16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else if (train_bf) hipLaunchKernelGGL(rn::level_fwd_train_bf16c, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
+  else if (train_split) hipLaunchKernelGGL(rn::level_fwd_train_f16x2c, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (cfg->training) hipLaunchKernelGGL(rn::level_fwd_train_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else hipLaunchKernelGGL(rn::level_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());

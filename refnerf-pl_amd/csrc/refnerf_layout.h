@@ -102,8 +102,11 @@ constexpr int BT_CHAIN_STEPS = 16, BT_HEADS_STEPS = 9, BT_STEP_FLOATS = 64 * 8 *
  * the two layers fed from LDS only), then the LDS-fed inputs in plain order k' = 16 s + 8 h + e over the fp32 LDS tile:
  * BF_IPE_STEPS = 6 (96 IPE features) / BF_DIN_STEPS = 13 (the 204-row dir input, rows >= 201 zero). */
 constexpr int BF_IPE_STEPS = 6, BF_DIN_STEPS = 13;
+/* ... and split-f16 copies of both sets for the split-chain training forward (cfg.training with REFNERF_PREC_F16X2): per
+ * k-step TWO fragment blocks, [k-step][hi | lo][ob][lane][8 halves], w = hi + lo (hf_off: forward ops, ht_off: transposed
+ * ops; same step counts and k order as bf_off / bt_off) */
 struct Packed { Op op[NUM_OPS]; Op top[NUM_TOPS]; TopSrc top_src[NUM_TOPS]; int wd_off; int wrgb_off; int bt_off[NUM_TOPS];
-                int bf_off[NUM_OPS]; int total; };
+                int bf_off[NUM_OPS]; int ht_off[NUM_TOPS]; int hf_off[NUM_OPS]; int total; };
 constexpr int bf_lds_steps(int op) { return (op == 0 || op == 5) ? BF_IPE_STEPS : ((op == 9 || op == 14) ? BF_DIN_STEPS : 0); }
 constexpr int bf_reg_steps(int op) { return (op == 0 || op == 9) ? 0 : BT_CHAIN_STEPS; }
 
@@ -154,7 +157,16 @@ constexpr Packed make_packed() {
     P.bf_off[i] = p;
     p += (bf_reg_steps(i) + bf_lds_steps(i)) * BT_STEP_FLOATS;
   }
-  P.total = p + 4 * BT_STEP_FLOATS;   /* tail pad: the bf16 A prefetch runs up to 4 steps past an op */
+  p += 4 * BT_STEP_FLOATS;            /* tail pad: the bf16 A prefetch runs up to 4 steps past an op */
+  for (int i = 0; i < NUM_TOPS; ++i) {
+    P.ht_off[i] = p;
+    p += ((i == TOP_HEADS) ? BT_HEADS_STEPS : BT_CHAIN_STEPS) * 2 * BT_STEP_FLOATS;
+  }
+  for (int i = 0; i < NUM_OPS; ++i) {
+    P.hf_off[i] = p;
+    p += (bf_reg_steps(i) + bf_lds_steps(i)) * 2 * BT_STEP_FLOATS;
+  }
+  P.total = p + 4 * 2 * BT_STEP_FLOATS;   /* tail pad: the split A prefetch runs up to 2 steps past an op */
   return P;
 }
 constexpr Packed PACKED = make_packed();

@@ -287,6 +287,108 @@ __device__ __forceinline__ void gemm_op_bf16(__amdgpu_buffer_rsrc_t rs, int a_of
   }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * split-f16 chains (training forward with cfg.precision = REFNERF_PREC_F16X2): the same GEMMs with BOTH operands as hi + lo
+ * pairs of IEEE halves, x = hi + lo (22 significand bits), products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with
+ * fp32 accumulation -- the arithmetic of the parity-grade inference mode (refnerf_level_bf16.h) in the 4-wave training
+ * skeleton: 32 samples per wave, the two halves of a layer input in 2 x 64 registers (one wave per SIMD: 512 registers),
+ * three MFMAs per weight-fragment pair.  Every wave streams its own fragments ([k-step][hi | lo][ob][lane][8 halves], 16 KB
+ * per k-step) through a register ring; the saved layer inputs leave as FP32 rows (hi + lo is exact in fp32), so the fp32
+ * backward and the weight-gradient GEMM take them unchanged (REFNERF_ACT_F32).
+ * ------------------------------------------------------------------------------------------------ */
+typedef _Float16 v8hf __attribute__((ext_vector_type(8)));
+typedef _Float16 v2hf __attribute__((ext_vector_type(2)));
+/* (x0, x1) -> packed hi halves, packed lo halves; the residual is taken from the bits that are stored (hipcc otherwise
+ * converts the same value twice with different roundings: see split_pair_f16 in refnerf_level_bf16.h) */
+__device__ __forceinline__ void split_pair_h(float x0, float x1, unsigned &hi, unsigned &lo) {
+  v2hf hv = __builtin_convertvector((v2f){x0, x1}, v2hf);
+  hi = __builtin_bit_cast(unsigned, hv);
+  asm("" : "+v"(hi));
+  hv = __builtin_bit_cast(v2hf, hi);
+  const _Float16 h0 = hv[0], h1 = hv[1];
+  const v2hf lv = __builtin_convertvector((v2f){x0 - (float)h0, x1 - (float)h1}, v2hf);
+  lo = __builtin_bit_cast(unsigned, lv);
+}
+/* element e (0..7) of a packed hi / lo fragment pair back as fp32 (exact) */
+__device__ __forceinline__ float split_elem(const v4uu &ph, const v4uu &pl, int e) {
+  const unsigned wh = ph[e >> 1], wl = pl[e >> 1];
+  const v2hf a = __builtin_bit_cast(v2hf, wh), b = __builtin_bit_cast(v2hf, wl);
+  const _Float16 ah = (e & 1) ? a[1] : a[0], bl = (e & 1) ? b[1] : b[0];
+  return (float)ah + (float)bl;
+}
+/* as gemm_op_bf16, on the split operands: `ih` / `il` = the packed hi / lo halves of the register k-steps; LDS k-steps are
+ * split on the fly from the fp32 tile.  hook(step) once per register k-step.
+ * ONE set of fragment registers (2 x NOB x 4): a block's hi / lo fragments of the next k-step are requested right behind
+ * its three MFMAs of this one (24 MFMAs = 768 cycles per k-step cover the L2 round trip), the blocks go in pairs so that
+ * no MFMA waits for the accumulator of its predecessor. */
+template <int NOB, int REG_STEPS16, int LDS_STEPS, bool BIAS, typename Hook = NoStepHook, int LDS_MAXROW = (1 << 30)>
+__device__ __forceinline__ void gemm_op_split(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
+                                              const v4uu (&ih)[16], const v4uu (&il)[16], v16f (&out)[NOB], const float *xc, Hook hook = Hook()) {
+  constexpr int STEPS = REG_STEPS16 + LDS_STEPS;
+  constexpr int STEP_BYTES = 2 * BT_STEP_FLOATS * 4;
+  const int voff = lane * 16;
+  const int soff = a_off * 4;
+  int hi = 128 * T_TILE;                         /* LDS rows >= 128: one laundered base (see tile_hi) */
+  if constexpr (LDS_STEPS * 16 > 128) asm volatile("" : "+v"(hi));
+  v8hf ah[NOB], al[NOB];
+  auto fetch = [&](int ob, int step) {
+    ah[ob] = __builtin_bit_cast(v8hf, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + step * STEP_BYTES + ob * 1024, 0));
+    al[ob] = __builtin_bit_cast(v8hf, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + step * STEP_BYTES + BT_STEP_FLOATS * 4 + ob * 1024, 0));
+  };
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) fetch(ob, 0);
+  if constexpr (BIAS) load_acc<NOB>(rs, b_off, h, out);
+  else {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[ob][r] = 0.0f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int step = 0; step < STEPS; ++step) {
+    v8hf bh, bl;
+    if (step >= REG_STEPS16) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int row = 16 * (step - REG_STEPS16) + 8 * h + e;
+        if (row > LDS_MAXROW) row = LDS_MAXROW;          /* pad rows (zero weights) must still read finite values */
+        x[e] = (16 * (step - REG_STEPS16) + 15 < 128) ? xc[row * T_TILE] : xc[(row - 128) * T_TILE + hi];
+      }
+      v4uu ph, pl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned hh, ll;
+        split_pair_h(x[2 * e], x[2 * e + 1], hh, ll);
+        ph[e] = hh; pl[e] = ll;
+      }
+      bh = __builtin_bit_cast(v8hf, ph);
+      bl = __builtin_bit_cast(v8hf, pl);
+    } else {
+      bh = __builtin_bit_cast(v8hf, ih[step < 16 ? step : 0]);
+      bl = __builtin_bit_cast(v8hf, il[step < 16 ? step : 0]);
+    }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ob += 2) {
+      constexpr int dummy = 0; (void)dummy;
+      const bool two = ob + 1 < NOB;
+      out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ob], bh, out[ob], 0, 0, 0);
+      if (two) out[ob + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ob + 1], bh, out[ob + 1], 0, 0, 0);
+      out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ob], bh, out[ob], 0, 0, 0);
+      if (two) out[ob + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ob + 1], bh, out[ob + 1], 0, 0, 0);
+      out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ob], bl, out[ob], 0, 0, 0);
+      if (two) out[ob + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ob + 1], bl, out[ob + 1], 0, 0, 0);
+      /* (reads one step past the op at the end: the next op's data or the image's tail pad) */
+      fetch(ob, step + 1);
+      if (two) fetch(ob + 1, step + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (step < REG_STEPS16) hook(step);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 /* sample-major block of the bf16 ACT format (refnerf_layout.h SMB_*): slot `slot` of lane (gs, h) */
 __device__ __forceinline__ v4u *smb_slot(const float *act, long long pitch, size_t gs, int h, int slot) {
   char *base = reinterpret_cast<char *>(const_cast<float *>(act)) + (size_t)SMB_ROW0 * (size_t)pitch * 4;
@@ -469,6 +571,44 @@ __device__ __forceinline__ void relu_into(const v16f (&out)[8], v16f (&in)[8]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) in[ob][r] = fmaxf(out[ob][r], 0.0f);
 }
+
+/* forward: ReLU, its sign pattern and the packed hi / lo input of the next layer */
+__device__ __forceinline__ void relu_mask_split(const v16f (&out)[8], unsigned (&mk)[4], v4uu (&ph)[16], v4uu (&pl)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) mk[q] = 0u;
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = relu_bit(out[ob][r], mk[ob >> 1], 16 * (ob & 1) + r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned h0, l0, h1, l1;
+      split_pair_h(v[2 * e], v[2 * e + 1], h0, l0);
+      split_pair_h(v[8 + 2 * e], v[8 + 2 * e + 1], h1, l1);
+      ph[2 * ob][e] = h0; pl[2 * ob][e] = l0;
+      ph[2 * ob + 1][e] = h1; pl[2 * ob + 1][e] = l1;
+    }
+  }
+}
+/* delta through a recorded ReLU mask into the next transposed GEMM's packed hi / lo fragments */
+__device__ __forceinline__ void mask_split(const v16f (&out)[8], const unsigned (&mk)[4], v4uu (&ph)[16], v4uu (&pl)[16]) {
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = keep_if_bit(out[ob][r], mk[ob >> 1], 16 * (ob & 1) + r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned h0, l0, h1, l1;
+      split_pair_h(v[2 * e], v[2 * e + 1], h0, l0);
+      split_pair_h(v[8 + 2 * e], v[8 + 2 * e + 1], h1, l1);
+      ph[2 * ob][e] = h0; pl[2 * ob][e] = l0;
+      ph[2 * ob + 1][e] = h1; pl[2 * ob + 1][e] = l1;
+    }
+  }
+}
+
 
 /* rows [row0 + 32*blk + row(r,h)] of a [rows][pitch] matrix, column gs: 128 B
  * contiguous per (row, half-wave).  Uniform 64-bit row base + 32-bit lane offset. */
@@ -673,13 +813,47 @@ __device__ __forceinline__ void density_normals_bf16(__amdgpu_buffer_rsrc_t rs, 
   for (int b = 0; b < 3; ++b) nrm_out[b] = -(gx[b] / ng);
 }
 
+/* density_normals on the split-f16 chains: the same VJP with 22-bit deltas; d feature / d mean recomputed exactly as in
+ * the fp32 kernel (ipe_vjp_accum) */
+__device__ __forceinline__ void density_normals_split(__amdgpu_buffer_rsrc_t rs, int lane, int h, v16f (&out)[8], v4uu (&ph)[16], v4uu (&pl)[16],
+                                                      unsigned (&M)[8][4], const float lm[3], const float lv[3], float nrm_out[3]) {
+  load_acc<8>(rs, PACKED.wd_off, h, out);
+  mask_split(out, M[7], ph, pl);
+  float gl[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+  for (int i = 7; i >= 0; --i) {
+    if (i == 5 || i == 0) {
+      v16f gi[3];
+      gemm_op_split<3, 16, 0, false>(rs, PACKED.ht_off[i == 5 ? TOP_SP5_IPE : TOP_SP0], 0, lane, h, ph, pl, gi, nullptr);
+      ipe_vjp_accum(gi, lm, lv, h, gl);
+    }
+    if (i > 0) {
+      gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[i - 1], 0, lane, h, ph, pl, out, nullptr);
+#pragma unroll
+      for (int l = 7; l > 0; --l)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[l][q] = M[l - 1][q];
+      mask_split(out, M[7], ph, pl);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 3; ++b) gl[b] += __shfl_xor(gl[b], 32, 64);
+  const float gx[3] = {-gl[2], -gl[1], -gl[0]};
+  const float ng = sqrtf(fmaxf((gx[0] * gx[0] + gx[1] * gx[1]) + gx[2] * gx[2], EPS32));
+#pragma unroll
+  for (int b = 0; b < 3; ++b) nrm_out[b] = -(gx[b] / ng);
+}
+
 /* STAGE: MLP.__call__ on caller-supplied Gaussians (no resampling, no compositing): the per-sample
  * outputs of models.py:533-750 for means / covariances given per sample. */
 /* BFC (training forward only): the MLP chains on v_mfma_f32_32x32x16_bf16 (cfg.precision = BF16 with cfg.training):
  * activations rounded to bf16 once per layer (what ACT then holds), everything per sample fp32. */
-template <bool TRAIN, bool STAGE = false, bool BFC = false>
+/* SPC (training forward only): the MLP chains on split-f16 operands (cfg.precision = F16X2 with cfg.training): 22-bit
+ * products, fp32 everything else, ACT in the fp32 format -- the parity-grade fast training forward. */
+template <bool TRAIN, bool STAGE = false, bool BFC = false, bool SPC = false>
 __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   static_assert(!BFC || (TRAIN && !STAGE), "bf16 chains: training forward only");
+  static_assert(!SPC || (TRAIN && !STAGE && !BFC), "split-f16 chains: training forward only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   RN_STAMP(A, 0);
   const refnerf_level_cfg &cfg = A.cfg;
@@ -707,7 +881,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   const int col = wave * 32 + sl;                /* this lane's column in X / HD */
   const float *xl = X + h * T_TILE + col;
   v16f in[8], out[8];
-  v4uu pk[16];                                   /* packed bf16 layer input (bf16 chains only; dead otherwise) */
+  v4uu pk[16];                                   /* packed bf16 layer input (bf16 chains) / hi halves (split chains); dead otherwise */
+  v4uu pl[16];                                   /* lo halves (split chains only) */
   const float *xc = X + col;
 
   RN_STAMP(A, 1);
@@ -781,7 +956,16 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         for (int e = 0; e < 4; ++e) hk(4 * t + e, pk[t][e]);       /* the k-step's B fragment as it is */
       };
     };
-    if constexpr (BFC) {
+    auto row_hook = [&](int row0) {              /* split chains: the layer input leaves as fp32 rows, 8 per k-step */
+      return [&, hk = RowStoreHook(A.act, rpitch, row0, rcol, h, save)](int t) mutable {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hk(8 * t + e, split_elem(pk[t], pl[t], e));
+      };
+    };
+    if constexpr (SPC) {
+      gemm_op_split<8, 0, BF_IPE_STEPS, true>(rs, PACKED.hf_off[0], PACKED.op[0].b_off, lane, h, pk, pl, out, xc);
+      relu_mask_split(out, M[7], pk, pl);
+    } else if constexpr (BFC) {
       gemm_op_bf16<8, 0, BF_IPE_STEPS, true>(rs, PACKED.bf_off[0], PACKED.op[0].b_off, lane, h, pk, out, xc);
       relu_mask_pack(out, M[7], pk);
     } else {
@@ -800,7 +984,12 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 #pragma unroll 1
     for (int op = 1; op < 8; ++op) {
       /* training: the layer input leaves for the ACT matrix through the store hook (one row per k-step) */
-      if constexpr (BFC) {
+      if constexpr (SPC) {
+        if (op == 5) gemm_op_split<8, 16, BF_IPE_STEPS, true>(rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, pk, pl, out, xc,
+                                                             row_hook(ACT_SP + (op - 1) * WIDTH));
+        else gemm_op_split<8, 16, 0, true>(rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, pk, pl, out, xc,
+                                           row_hook(ACT_SP + (op - 1) * WIDTH));
+      } else if constexpr (BFC) {
         if (op == 5) gemm_op_bf16<8, 16, BF_IPE_STEPS, true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, pk, out, xc,
                                                             act_hook(ACT_SP + (op - 1) * WIDTH));
         else gemm_chain_bf16_shared<true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, wave, pk, out,
@@ -815,7 +1004,9 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         for (int l = 0; l < 7; ++l)
 #pragma unroll
           for (int q = 0; q < 4; ++q) M[l][q] = M[l + 1][q];
-        if constexpr (BFC) relu_mask_pack(out, M[7], pk); else relu_mask_into(out, in, M[7]);
+        if constexpr (SPC) relu_mask_split(out, M[7], pk, pl);
+        else if constexpr (BFC) relu_mask_pack(out, M[7], pk);
+        else relu_mask_into(out, in, M[7]);
         if constexpr (!STAGE) { if (A.act) save_mask(op, M[7]); }
       } else relu_into(out, in);
     }
@@ -824,7 +1015,10 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     {
       v16f hd[5];
       if constexpr (BFC) { if (save) smb_store_pk(A.act, act_pitch, gsx, h, SMB_X7, pk); }
-      if constexpr (BFC)
+      if constexpr (SPC)
+        gemm_op_split<5, 16, 0, true>(rs, PACKED.hf_off[OP_HEADS], PACKED.op[OP_HEADS].b_off, lane, h, pk, pl, hd, xc,
+                                      row_hook(ACT_SP + 7 * WIDTH));
+      else if constexpr (BFC)
         gemm_op_bf16<5, 16, 0, true>(rs, PACKED.bf_off[OP_HEADS], PACKED.op[OP_HEADS].b_off, lane, h, pk, hd, xc,
                                      act_hook(ACT_SP + 7 * WIDTH));
       else if constexpr (TRAIN && !STAGE)
@@ -848,7 +1042,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 
     SampleHeads sh;
     RN_STAMP(A, 5);
-    if constexpr (BFC) density_normals_bf16(rs, lane, h, wave, reinterpret_cast<char *>(smem) + A.ring_off, out, pk, M, X, col, sh.normals);
+    if constexpr (SPC) density_normals_split(rs, lane, h, out, pk, pl, M, lm, lv, sh.normals);
+    else if constexpr (BFC) density_normals_bf16(rs, lane, h, wave, reinterpret_cast<char *>(smem) + A.ring_off, out, pk, M, X, col, sh.normals);
     else if constexpr (TRAIN) density_normals(rs, lane, h, in, out, M, lm, lv, xl, sh.normals);
 
     RN_STAMP(A, 6);
@@ -882,7 +1077,12 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 
     RN_STAMP(A, 7);
     /* P5: directional MLP (models.py:690-694) + rgb (699-700) */
-    if constexpr (BFC) {
+    if constexpr (SPC) {
+      unsigned mk[4];
+      gemm_op_split<8, 0, BF_DIN_STEPS, true, NoStepHook, DIR_PAD - 1>(rs, PACKED.hf_off[9], PACKED.op[9].b_off, lane, h, pk, pl, out, xc);
+      relu_mask_split(out, mk, pk, pl);
+      if (A.act) save_mask(8, mk);
+    } else if constexpr (BFC) {
       unsigned mk[4];
       gemm_op_bf16<8, 0, BF_DIN_STEPS, true, NoStepHook, DIR_PAD - 1>(rs, PACKED.bf_off[9], PACKED.op[9].b_off, lane, h, pk, out, xc);
       relu_mask_pack(out, mk, pk);
@@ -897,7 +1097,12 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     }
 #pragma unroll 1
     for (int op = 10; op < 17; ++op) {
-      if constexpr (BFC) {
+      if constexpr (SPC) {
+        if (op == 14) gemm_op_split<8, 16, BF_DIN_STEPS, true, decltype(row_hook(0)), DIR_PAD - 1>(
+            rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, pk, pl, out, xc, row_hook(ACT_VD + (op - 10) * WIDTH));
+        else gemm_op_split<8, 16, 0, true>(rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, pk, pl, out, xc,
+                                           row_hook(ACT_VD + (op - 10) * WIDTH));
+      } else if constexpr (BFC) {
         if (op == 14) gemm_op_bf16<8, 16, BF_DIN_STEPS, true, decltype(act_hook(0)), DIR_PAD - 1>(
             rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, pk, out, xc, act_hook(ACT_VD + (op - 10) * WIDTH));
         else gemm_chain_bf16_shared<true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, wave, pk, out,
@@ -909,14 +1114,18 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
       if constexpr (TRAIN && !STAGE) {
         unsigned mk[4];
-        if constexpr (BFC) relu_mask_pack(out, mk, pk); else relu_mask_into(out, in, mk);
+        if constexpr (SPC) relu_mask_split(out, mk, pk, pl);
+        else if constexpr (BFC) relu_mask_pack(out, mk, pk);
+        else relu_mask_into(out, in, mk);
         if (A.act) save_mask(op - 1, mk);
       } else relu_into(out, in);
     }
     RN_STAMP(A, 8);
     v16f rgbv[1];
     if constexpr (BFC) { if (save) smb_store_pk(A.act, act_pitch, gsx, h, SMB_V7, pk); }
-    if constexpr (BFC)
+    if constexpr (SPC)
+      gemm_op_split<1, 16, 0, true>(rs, PACKED.hf_off[OP_RGB], PACKED.op[OP_RGB].b_off, lane, h, pk, pl, rgbv, xc, row_hook(ACT_VD + 7 * WIDTH));
+    else if constexpr (BFC)
       gemm_op_bf16<1, 16, 0, true>(rs, PACKED.bf_off[OP_RGB], PACKED.op[OP_RGB].b_off, lane, h, pk, rgbv, xc, act_hook(ACT_VD + 7 * WIDTH));
     else if constexpr (TRAIN && !STAGE)
       gemm_op<1, 1, true>(rs, PACKED.op[OP_RGB].a_off, PACKED.op[OP_RGB].b_off, lane, h, in, rgbv, xl, 0,
@@ -946,6 +1155,8 @@ __global__ __launch_bounds__(NTHREADS) void level_fwd_f32(const LevelArgs A) { l
 __global__ __launch_bounds__(NTHREADS) void level_fwd_train_f32(const LevelArgs A) { level_fwd_f32_body<true>(A); }
 /* training forward with the MLP chains on bf16 MFMA (cfg.training && cfg.precision = REFNERF_PREC_BF16) */
 __global__ __launch_bounds__(NTHREADS) void level_fwd_train_bf16c(const LevelArgs A) { level_fwd_f32_body<true, false, true>(A); }
+/* training forward with the MLP chains on split-f16 operands (cfg.training && cfg.precision = REFNERF_PREC_F16X2) */
+__global__ __launch_bounds__(NTHREADS) void level_fwd_train_f16x2c(const LevelArgs A) { level_fwd_f32_body<true, false, false, true>(A); }
 /* MLP.__call__ stage entry (eval / training) */
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false, true>(A); }
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_train_f32(const LevelArgs A) { level_fwd_f32_body<true, true>(A); }

@@ -494,7 +494,8 @@ class PropMLP(MLP):
 
 
 _PREC = {"f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16, "f16": _hip.PREC_F16, "f16x2": _hip.PREC_F16X2}
-_TRAIN_PREC = ("f32", "bf16")     # arithmetic modes of the training forward / the backward chains
+_TRAIN_FWD_PREC = ("f32", "f16x2", "bf16")   # MLP chains of the training forward: exact fp32 | split f16 (parity-grade, fp32 ACT rows) | bf16
+_TRAIN_PREC = ("f32", "bf16")                # transposed chains of the backward
 
 
 class _Lean(threading.local):
@@ -596,8 +597,8 @@ class Model(nn.Module):
         if prec not in _PREC:
             raise ValueError("Config.hip_precision must be one of 'f32', 'f16x2', 'f16', 'bf16'")
         train_prec = getattr(cfg, "hip_train_precision", "f32")
-        if train_prec not in _TRAIN_PREC:          # 'f16' / 'f16x2' are inference modes of the level kernel
-            raise ValueError("Config.hip_train_precision must be 'f32' or 'bf16'")
+        if train_prec not in _TRAIN_FWD_PREC:      # 'f16' is an inference mode of the level kernel
+            raise ValueError("Config.hip_train_precision must be 'f32', 'f16x2' or 'bf16'")
         wgrad = {"f32": _hip.WGRAD_F32, "bf16x3": _hip.WGRAD_BF16X3}.get(getattr(cfg, "hip_wgrad_mode", "bf16x3"))
         if wgrad is None:
             raise ValueError("Config.hip_wgrad_mode must be 'bf16x3' or 'f32'")
