@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--precision", default="f16x2", choices=list(EVAL_MODES),
                     help="arithmetic of the MLP contractions for the headline value (eval configurations); the other modes are "
                          "reported alongside.  Default: the parity-grade 16-bit mode")
-    ap.add_argument("--train-precision", default="f32", choices=["f32", "f16x2", "bf16"],
+    ap.add_argument("--train-precision", default="f16x2", choices=["f32", "f16x2", "bf16"],
                     help="MLP chains of the training step that carries the C5 headline (f32 = exact; f16x2 = split-f16 forward + f32 "
                          "backward, parity-grade; bf16 = throughput mode)")
     ap.add_argument("--no-other-configs", action="store_true", help="C2 only: skip the short C3 / C4-shard / C5-shard legs")
@@ -299,7 +299,7 @@ def other_configs(args, dev, sync, max_over_ranks):
     """Short legs of the other BASELINE configurations inside the default (C2) run, so that the driver's line carries
     them: C3 (8192 x 192, shiny network: the ring-of-records kernel variant) in the headline mode and in bf16, the
     per-GPU shard of C4 (512 LLFF rays, HIP-graph replay) and the per-GPU shard of C5 (2048 rays x 256 samples,
-    nine-term geometry loss, training step in the parity mode).  A few steps each."""
+    nine-term geometry loss, training step in the parity-grade split-f16 chain mode, the exact-fp32 chains beside it).  A few steps each."""
     import argparse as _ap
     import torch
     from refnerf_pl_amd import _hip, graphs, utils
@@ -337,9 +337,11 @@ def other_configs(args, dev, sync, max_over_ranks):
         spec = dict(CONFIGS["C5"], rays=2048)
         model, cfg, _ = build_model(a, spec, dev)
         rays = utils.rays_from_dict(make_rays(spec, spec["rays"], seed=1), dev)
-        res = train_step_bench(a, spec, model, cfg, rays, 0, 1, dev, None, sync, max_over_ranks, "f32", n_steps=3, n_warm=1, geometry=True)
+        res = train_step_bench(a, spec, model, cfg, rays, 0, 1, dev, None, sync, max_over_ranks, args.train_precision, n_steps=3, n_warm=1, geometry=True)
         res["workload"] = spec["workload"] + " [2048 rays on this GPU: the per-GPU shard at 8 ranks]"
         out["C5_shard"] = res
+        if args.train_precision != "f32":
+            out["C5_shard_f32_chains"] = train_step_bench(a, spec, model, cfg, rays, 0, 1, dev, None, sync, max_over_ranks, "f32", n_steps=2, n_warm=1, geometry=True)
         del model, rays
         torch.cuda.empty_cache()
     return out
@@ -516,10 +518,12 @@ def main():
         res = train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync, max_over_ranks,
                                args.train_precision, n_steps=args.steps, n_warm=args.warmup, geometry=True)
         line["dtype"] = args.train_precision
-        if args.train_precision == "f32" and not args.no_train:
-            # the throughput mode beside the parity step (its gradient is 1e-1 relative L2 from the reference on trained-like weights)
-            line["train_step_bf16"] = train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync, max_over_ranks,
-                                                       "bf16", n_steps=max(2, args.steps // 2), n_warm=1, geometry=True)
+        if not args.no_train:
+            # the other chain modes beside the headline step: exact fp32 chains (strict parity) and the bf16 throughput mode
+            # (its gradient is 1e-1 relative L2 from the reference on trained-like weights)
+            for other in [m for m in ("f32", "f16x2", "bf16") if m != args.train_precision]:
+                line["train_step_" + other] = train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync, max_over_ranks,
+                                                               other, n_steps=max(2, args.steps // 4), n_warm=1, geometry=True)
         line["metric"] = (f"ray-samples/s ({spec['rays']} rays x {N} samples x 2 levels, Ref-NeRF LLFF geometry losses, "
                           "training step fwd+bwd+all-reduce+Adam)")
         line["value"] = res["value"]
@@ -543,8 +547,9 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     import torch
     from refnerf_pl_amd import _hip, distributed, synthetic, train_utils, utils
     model.train()
-    fwd_chains = chains                                   # 'f32' | 'f16x2' (split f16 forward, f32 backward: parity-grade) | 'bf16'
-    bwd_chains = "f32" if chains == "f16x2" else chains
+    fwd_chains = bwd_chains = chains                      # 'f32' | 'f16x2' (split-f16 chains both ways: parity-grade) | 'bf16'
+    if os.environ.get("REFNERF_BENCH_BWD"):               # A/B: e.g. f16x2 forward with the f32 backward
+        bwd_chains = os.environ["REFNERF_BENCH_BWD"]
     cfg.hip_train_precision, cfg.hip_bwd_precision = fwd_chains, bwd_chains
     cfg.hip_fused_losses = True          # data + orientation + predicted-normal terms through the fused loss kernels
     cfg.hip_flat_grads = True            # gradient, all-reduce and Adam on ONE flat tensor per MLP
@@ -595,7 +600,7 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     samples_per_launch = (R + extra_rays) * N / passes
     kernels = {}
     names = {"fwd": "rn::level_fwd_train_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[fwd_chains],
-             "bwd": "rn::level_bwd_" + ("bf16c" if bwd_chains == "bf16" else "f32"), "wgrad": "rn::wgrad_bf16x3_kernel"}
+             "bwd": "rn::level_bwd_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[bwd_chains], "wgrad": "rn::wgrad_bf16x3_kernel"}
     peak_of = {"fwd": PEAK_TFLOPS[fwd_chains], "bwd": PEAK_TFLOPS[bwd_chains]}
     for k, (ms, cnt) in fam.items():
         if not cnt:
@@ -622,7 +627,7 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
            "kernels_ms_per_step": sum(ms for ms, _ in fam.values()) / n,
            "mode": ("parity mode: f32 MLP chains (gradient rel-L2 <= 2e-4 vs the reference's autograd, 1e-3 on trained-like weights)"
                     if chains == "f32" else
-                    "parity-grade fast mode: training forward on split-f16 chains (22-bit products, fp32 ACT rows), fp32 backward chains; "
+                    "parity-grade fast mode: forward and backward chains on split-f16 operands (22-bit products, fp32 ACT / DELTA rows); "
                     "gradient rel-L2 5e-5 vs the reference's autograd also on trained-like weights"
                     if chains == "f16x2" else
                     "throughput mode: bf16 MLP chains; gradient 1e-2 (random-init) / 1e-1 (trained-like weights) relative L2 from the "

@@ -220,7 +220,7 @@ class Config:
     # 'f32' (exact fp32 MFMA, the parity mode) or 'bf16'.
     hip_precision: str = 'f32'
     hip_train_precision: str = 'f32'  # MLP chains of the training forward: 'f32' (exact) | 'f16x2' (split f16: 22-bit products, parity-grade, ~3x faster) | 'bf16' (throughput mode)
-    hip_bwd_precision: str = 'f32'  # transposed GEMM chains of the backward: 'f32' (parity) | 'bf16' (bf16 MFMA, gradients at bf16 accuracy)
+    hip_bwd_precision: str = 'f32'  # transposed GEMM chains of the backward: 'f32' (exact) | 'f16x2' (split f16, parity-grade) | 'bf16' (throughput mode)
     hip_fused_losses: bool = False  # data (mse) + orientation + predicted-normal losses of a level as ONE fused kernel each way (train_utils.fused_refnerf_losses)
     hip_flat_grads: bool = False  # route the backward's gradient to MLP.flat_parameter().grad (one tensor) instead of the 46 nn.Parameters
     hip_wgrad_mode: str = 'bf16x3'  # weight-gradient GEMM of the backward: 'bf16x3' (split-bf16 MFMA, fp32-level accuracy) | 'f32'

@@ -893,8 +893,10 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   if (R <= 0) return fail(REFNERF_EINVAL, "refnerf_level_backward: R must be positive%s");
   if (cfg->n_samples <= 1) return fail(REFNERF_EINVAL, "num_samples must be > 1%s");
   if (cfg->ray_shape != 0 && cfg->ray_shape != 1) return fail(REFNERF_EINVAL, "ray_shape must be 'cone' or 'cylinder'%s");
-  if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16)
-    return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown precision mode%s");
+  if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16 && cfg->precision != REFNERF_PREC_F16X2)
+    return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown precision mode (REFNERF_PREC_F32, REFNERF_PREC_F16X2 or REFNERF_PREC_BF16)%s");
+  if (cfg->precision == REFNERF_PREC_F16X2 && saved->activations_format != REFNERF_ACT_F32)
+    return fail(REFNERF_EUNSUPPORTED, "the split-f16 backward chains read fp32 activation rows (forward with REFNERF_PREC_F32 or REFNERF_PREC_F16X2)%s");
   if (cfg->wgrad_mode != REFNERF_WGRAD_F32 && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown wgrad_mode%s");
   if (!saved->d_sdist || !saved->d_density || !saved->d_rgb || !saved->d_weights || !grads->d_g_r_rgb)
@@ -911,7 +913,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   const size_t ring_off = (lds + 15) / 16 * 16;
   if (cfg->precision == REFNERF_PREC_BF16) lds = ring_off + rn::RING_BYTES;       /* the chains' shared weight-stream ring */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget%s");
-  LDS_ATTR_ONCE(lds_attr(rn::level_bwd_f32), lds_attr(rn::level_bwd_bf16c),
+  LDS_ATTR_ONCE(lds_attr(rn::level_bwd_f32), lds_attr(rn::level_bwd_bf16c), lds_attr(rn::level_bwd_f16x2c),
                 lds_attr(rn::wgrad_kernel, (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4),
                 lds_attr(rn::wgrad_bf16x3_kernel<false, false>, rn::wb_lds(false, false)),
                 lds_attr(rn::wgrad_bf16x3_kernel<false, true>, rn::wb_lds(false, true)),
@@ -954,6 +956,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   { int trc = timer_begin(st, &tslot, REFNERF_TIMER_BACKWARD); if (trc) return trc; }
   if (cfg->precision == REFNERF_PREC_BF16)
     hipLaunchKernelGGL(rn::level_bwd_bf16c, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
+  else if (cfg->precision == REFNERF_PREC_F16X2)
+    hipLaunchKernelGGL(rn::level_bwd_f16x2c, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
   else
     hipLaunchKernelGGL(rn::level_bwd_f32, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());

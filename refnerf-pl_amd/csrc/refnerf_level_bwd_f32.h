@@ -208,8 +208,11 @@ __device__ __forceinline__ void shift_masks(unsigned (&M)[8][4]) {
     for (int q = 0; q < 4; ++q) M[l][q] = M[l - 1][q];
 }
 
-template <bool BF>
+/* BF: transposed chains on bf16 MFMA; SP: on split-f16 operands (22-bit deltas and weights, hi*hi + lo*hi + hi*lo on
+ * v_mfma_f32_32x32x16_f16: the parity-grade fast chains, see refnerf_level_f32.h), fp32 ACT / DELTA rows */
+template <bool BF, bool SP = false>
 __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
+  static_assert(!(BF && SP), "one chain arithmetic");
   constexpr bool D16 = BF && (REFNERF_DELTA16 != 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const refnerf_level_cfg &cfg = A.cfg;
@@ -388,13 +391,18 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
       for (int r = 0; r < 16; ++r) out[ob][r] = (w0[r] * g_raw_rgb[0] + w1[r] * g_raw_rgb[1]) + w2[r] * g_raw_rgb[2];
     }
     RN_STAMP(A, 4);
-    v4uu pk[BF ? 16 : 1];                          /* packed delta (bf16 chains) */
-    if constexpr (BF) mask_pack(out, M[7], pk); else masked_into(out, in, M[7]);
+    v4uu pk[(BF || SP) ? 16 : 1];                  /* packed delta (bf16 chains) / its hi halves (split chains) */
+    v4uu pl[SP ? 16 : 1];                          /* lo halves (split chains) */
+    float cs = 1.0f;                               /* split chains: this sample's power-of-two factor on the packed delta (mask_split) */
+    if constexpr (SP) mask_split(out, M[7], pk, pl, cs);
+    else if constexpr (BF) mask_pack(out, M[7], pk);
+    else masked_into(out, in, M[7]);
     /* ---- directional MLP, layers 7..0 ---- */
     v16f(&gd)[DIN_BLOCKS] = reinterpret_cast<v16f(&)[DIN_BLOCKS]>(out);   /* gradient w.r.t. the 201 dir inputs */
     const int din_hi = tile_hi(col);
     auto park_din = [&](int i) {
       /* layer 5 (skip connection) parks its share in LDS; layer 0 adds it back */
+      const float unscale = SP ? 1.0f / cs : 1.0f;     /* split chains: the GEMM result carries the delta's factor */
 #pragma unroll
       for (int blk = 0; blk < DIN_BLOCKS; ++blk)
 #pragma unroll
@@ -402,6 +410,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
           const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (blk < 6 || row < DIR_PAD) {
             float *px = X + (blk < 4 ? row * T_TILE + col : (row - 128) * T_TILE + din_hi);
+            if constexpr (SP) gd[blk][r] *= unscale;
             if (i == 0) gd[blk][r] += *px;
             *px = gd[blk][r];
           }
@@ -430,6 +439,20 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
           shift_masks(M);
           mask_pack(out, M[7], pk);
           if (i == 7) RN_STAMP(A, 10);
+        }
+      } else if constexpr (SP) {
+        RowStoreHook sh_(A.delta, rpitch, DEL_VD + i * WIDTH, dcol, h, valid);
+        const float inv = 1.0f / cs;
+        auto hook = [&](int t) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sh_(8 * t + e, split_elem(pk[t], pl[t], e) * inv);
+        };
+        if (i == 5) { gemm_op_split<DIN_BLOCKS, 16, 0, false>(rs, PACKED.ht_off[TOP_VD5_DIN], 0, lane, h, pk, pl, gd, nullptr); park_din(5); }
+        if (i == 0) { gemm_op_split<DIN_BLOCKS, 16, 0, false>(rs, PACKED.ht_off[TOP_VD0], 0, lane, h, pk, pl, gd, nullptr, hook); park_din(0); }
+        if (i > 0) {
+          gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[TOP_VD1 + i - 1], 0, lane, h, pk, pl, out, nullptr, hook);
+          shift_masks(M);
+          mask_split(out, M[7], pk, pl, cs);
         }
       } else {
         if (i == 5 || i == 0) {
@@ -525,6 +548,38 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
           store_rows<8, D16>(A.delta, rpitch, DEL_SP, dcol, h, valid, in);
         }
       }
+    } else if constexpr (SP) {
+      /* the 139 head-row gradients of this sample sit in the fp32 tile: their factor first (9 k-steps x 8 rows per lane) */
+      {
+        float m = 0.0f;
+        const int hi2 = tile_hi(col);
+#pragma unroll
+        for (int t = 0; t < BT_HEADS_STEPS; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const int row = 16 * t + 8 * h + e; m = fmaxf(m, fabsf(X[tile_idx(row, col, hi2)])); }
+        cs = pow2_scale_for(m);
+      }
+      gemm_op_split<8, 0, BT_HEADS_STEPS, false>(rs, PACKED.ht_off[TOP_HEADS], 0, lane, h, pk, pl, out, X + col, NoStepHook(), cs);
+      mask_split(out, M[7], pk, pl, cs);
+#pragma unroll 1
+      for (int i = 7; i >= 0; --i) {
+        if (i > 0) {
+          RowStoreHook sh_(A.delta, rpitch, DEL_SP + i * WIDTH, dcol, h, valid);
+          const float inv = 1.0f / cs;
+          gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[i - 1], 0, lane, h, pk, pl, out, nullptr, [&](int t) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sh_(8 * t + e, split_elem(pk[t], pl[t], e) * inv);
+          });
+          shift_masks(M);
+          mask_split(out, M[7], pk, pl, cs);
+        } else {                                                             /* no GEMM consumes delta_0 */
+#pragma unroll
+          for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) in[blk][r] = split_elem(pk[2 * blk + (r >> 3)], pl[2 * blk + (r >> 3)], r & 7) * (1.0f / cs);
+          store_rows<8, false>(A.delta, rpitch, DEL_SP, dcol, h, valid, in);
+        }
+      }
     } else {
       gemm_op<8, 8, false, false>(rs, PACKED.top[TOP_HEADS].a_off, 0, lane, h, in, out, xl, HEADS_T_STEPS);
       masked_into(out, in, M[7]);
@@ -554,5 +609,7 @@ __global__ __launch_bounds__(NTHREADS) void bwd_seed_kernel(const BwdArgs A) {
 __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) { level_bwd_body<false>(A); }
 /* bf16 chains (cfg.precision = REFNERF_PREC_BF16): gradients at bf16 accuracy */
 __global__ __launch_bounds__(NTHREADS) void level_bwd_bf16c(const BwdArgs A) { level_bwd_body<true>(A); }
+/* transposed chains on split-f16 operands (cfg.precision = REFNERF_PREC_F16X2 in refnerf_level_backward) */
+__global__ __launch_bounds__(NTHREADS) void level_bwd_f16x2c(const BwdArgs A) { level_bwd_body<false, true>(A); }
 
 }  // namespace rn

@@ -495,7 +495,7 @@ class PropMLP(MLP):
 
 _PREC = {"f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16, "f16": _hip.PREC_F16, "f16x2": _hip.PREC_F16X2}
 _TRAIN_FWD_PREC = ("f32", "f16x2", "bf16")   # MLP chains of the training forward: exact fp32 | split f16 (parity-grade, fp32 ACT rows) | bf16
-_TRAIN_PREC = ("f32", "bf16")                # transposed chains of the backward
+_TRAIN_PREC = ("f32", "bf16")                # (kept for callers: the modes both directions share with the bf16-row format)
 
 
 class _Lean(threading.local):
@@ -663,8 +663,10 @@ class Model(nn.Module):
                 # one autograd node per level; sdist / resampling inputs are detached (models.py:205-216)
                 mlp.flat_params()
                 bwd_prec = getattr(self.config, "hip_bwd_precision", "f32")
-                if bwd_prec not in _TRAIN_PREC:
-                    raise ValueError("Config.hip_bwd_precision must be 'f32' or 'bf16'")
+                if bwd_prec not in _TRAIN_FWD_PREC:
+                    raise ValueError("Config.hip_bwd_precision must be 'f32', 'f16x2' or 'bf16'")
+                if bwd_prec == "f16x2" and getattr(self.config, "hip_train_precision", "f32") == "bf16":
+                    raise ValueError("Config.hip_bwd_precision = 'f16x2' reads fp32 activation rows: use hip_train_precision 'f32' or 'f16x2'")
                 flat_mode = bool(getattr(self.config, "hip_flat_grads", False))
                 if not flat_mode and mlp._flat is not None and (mlp._flat.requires_grad or mlp._flat.grad is not None):
                     mlp.release_flat_parameter()            # flat mode was switched off: no stale .grad on the blob

@@ -164,7 +164,7 @@ def test_f16x2_through_the_model_api(hip):
 
 
 # ---------------------------------------------------------------- split-f16 chains in the training forward
-@pytest.mark.parametrize("bwd", ["f32"])
+@pytest.mark.parametrize("bwd", ["f32", "f16x2"])
 @pytest.mark.parametrize("name", ["model_blender_sharp_train", "model_llff_linear_train", "model_shiny_train", "model_trained_train"])
 def test_f16x2_chain_training_step_vs_reference(hip, name, bwd):
     """Config.hip_train_precision = 'f16x2': the training forward with its MLP chains on split-f16 operands (22-bit products,
