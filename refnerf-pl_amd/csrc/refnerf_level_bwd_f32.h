@@ -443,9 +443,10 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
       } else if constexpr (SP) {
         RowStoreHook sh_(A.delta, rpitch, DEL_VD + i * WIDTH, dcol, h, valid);
         const float inv = 1.0f / cs;
-        auto hook = [&](int t) {
+        auto hook = [&](int t, int quarter = -1) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) sh_(8 * t + e, split_elem(pk[t], pl[t], e) * inv);
+          for (int e = 0; e < 8; ++e)
+            if (quarter < 0 || (e >> 1) == quarter) sh_(8 * t + e, split_elem(pk[t], pl[t], e) * inv);
         };
         if (i == 5) { gemm_op_split<DIN_BLOCKS, 16, 0, false>(rs, PACKED.ht_off[TOP_VD5_DIN], 0, lane, h, pk, pl, gd, nullptr); park_din(5); }
         if (i == 0) { gemm_op_split<DIN_BLOCKS, 16, 0, false>(rs, PACKED.ht_off[TOP_VD0], 0, lane, h, pk, pl, gd, nullptr, hook); park_din(0); }
@@ -566,9 +567,10 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
         if (i > 0) {
           RowStoreHook sh_(A.delta, rpitch, DEL_SP + i * WIDTH, dcol, h, valid);
           const float inv = 1.0f / cs;
-          gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[i - 1], 0, lane, h, pk, pl, out, nullptr, [&](int t) {
+          gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[i - 1], 0, lane, h, pk, pl, out, nullptr, [&](int t, int quarter = -1) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sh_(8 * t + e, split_elem(pk[t], pl[t], e) * inv);
+            for (int e = 0; e < 8; ++e)
+              if (quarter < 0 || (e >> 1) == quarter) sh_(8 * t + e, split_elem(pk[t], pl[t], e) * inv);
           });
           shift_masks(M);
           mask_split(out, M[7], pk, pl, cs);

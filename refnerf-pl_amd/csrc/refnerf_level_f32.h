@@ -78,6 +78,7 @@ constexpr int PF = REFNERF_PF;
 struct NoStepHook {
   __device__ __forceinline__ void operator()(int, float) {}
   __device__ __forceinline__ void operator()(int) {}
+  __device__ __forceinline__ void operator()(int, int) {}
 };
 
 /* Hook of gemm_op that streams the op's B operand (the 256 register values of this lane, i.e. a
@@ -383,9 +384,12 @@ __device__ __forceinline__ void gemm_op_split(__amdgpu_buffer_rsrc_t rs, int a_o
       /* (reads one step past the op at the end: the next op's data or the image's tail pad) */
       fetch(ob, step + 1);
       if (two) fetch(ob + 1, step + 1);
+      /* the hook's work (8 row stores + their hi + lo sums per k-step) in quarters behind the block pairs: at the end of the
+       * step it ran after the last MFMA had issued, i.e. unhidden (one wave per SIMD) */
+      if constexpr (NOB == 8) { if (step < REG_STEPS16) hook(step, ob >> 1); }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (step < REG_STEPS16) hook(step);
+    if constexpr (NOB != 8) { if (step < REG_STEPS16) hook(step); }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -982,9 +986,10 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       };
     };
     auto row_hook = [&](int row0) {              /* split chains: the layer input leaves as fp32 rows, 8 per k-step */
-      return [&, hk = RowStoreHook(A.act, rpitch, row0, rcol, h, save)](int t) mutable {
+      return [&, hk = RowStoreHook(A.act, rpitch, row0, rcol, h, save)](int t, int quarter = -1) mutable {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) hk(8 * t + e, split_elem(pk[t], pl[t], e));
+        for (int e = 0; e < 8; ++e)
+          if (quarter < 0 || (e >> 1) == quarter) hk(8 * t + e, split_elem(pk[t], pl[t], e));
       };
     };
     if constexpr (SPC) {
