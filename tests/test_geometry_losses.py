@@ -251,14 +251,17 @@ def test_oracle_separate_propmlp_and_interlevel_loss():
 
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
+@pytest.mark.parametrize("chains", ["f32", "f16x2"])
 @pytest.mark.parametrize("name", CASES)
-def test_hip_full_loss_set_vs_reference_and_oracle(name):
+def test_hip_full_loss_set_vs_reference_and_oracle(name, chains):
     """Model.__call__ (clean + noisy pass) + training_losses + backward on the HIP path: the nine
-    loss terms and the parameter gradient match the reference's autograd and the oracle."""
+    loss terms and the parameter gradient match the reference's autograd and the oracle -- with the exact fp32 chains and
+    with the split-f16 chains (Config.hip_train_precision = hip_bwd_precision = 'f16x2'), same tolerances."""
     from refnerf_pl_amd import _hip, layout, models, train_utils, utils
     _hip.require_device()
     g = load_golden(name)
     cfg = _config(g)
+    cfg.hip_train_precision = cfg.hip_bwd_precision = chains
     model = models.construct_model(utils.dummy_rays(), cfg).to("cuda:0").train()
     model.nerf_mlp.load_flat_params(params_from_golden(g))
     rays, noisy, batch = _inputs(g, "cuda:0")
