@@ -356,13 +356,15 @@ def test_hip_backward_output_by_output_vs_reference(name):
 
 
 @pytest.mark.gpu
-def test_hip_separate_propmlp_and_interlevel_loss():
+@pytest.mark.parametrize("chains", ["f32", "f16x2"])
+def test_hip_separate_propmlp_and_interlevel_loss(chains):
     """The same on the HIP path: Model(single_mlp=False) keeps two parameter sets / packed images and the
-    interlevel loss reaches the proposal network through the `weights` seed of its level."""
+    interlevel loss reaches the proposal network through the `weights` seed of its level (f32 and split-f16 chains)."""
     from refnerf_pl_amd import _hip, layout, models, train_utils, utils
     _hip.require_device()
     g = load_golden("propmlp_interlevel")
     cfg, prop = _propmlp_setup(g)
+    cfg.hip_train_precision = cfg.hip_bwd_precision = chains
     model = models.construct_model(utils.dummy_rays(), cfg).to("cuda:0").train()
     assert model.prop_mlp is not model.nerf_mlp and model.prop_mlp.density_bias == -3.0
     model.nerf_mlp.load_flat_params(params_from_golden(g))

@@ -633,8 +633,8 @@ def test_model_training_step_autograd(hip):
 
 @pytest.mark.parametrize("name", ["model_variant_eval", "model_variant_train", "model_variant_nonormals_train",
                                   "model_posenc_eval", "model_posenc_train"])
-@pytest.mark.parametrize("flat", [False, True])
-def test_nerfmlp_variants_vs_reference(hip, name, flat):
+@pytest.mark.parametrize("flat,chains", [(False, "f32"), (True, "f32"), (False, "f16x2")])
+def test_nerfmlp_variants_vs_reference(hip, name, flat, chains):
     """the NerfMLP variants the reference runs and this build serves by embedding (net_width_viewdirs = 128,
     no n.v input, no tint head, no roughness head; disable_density_normals) -- Model.__call__ with the reference's gin
     bindings against the reference's own outputs, dict keys, losses and autograd gradients (tests/golden/model_variant_*)."""
@@ -643,8 +643,8 @@ def test_nerfmlp_variants_vs_reference(hip, name, flat):
     from refnerf_pl_amd import configs, layout, models, train_utils, utils
     g = load_golden(name)
     train = name.endswith("train")
-    if flat and not train:
-        pytest.skip("flat gradients: training only")
+    if (flat or chains != "f32") and not train:
+        pytest.skip("flat gradients / chain modes: training only")
     posenc = "posenc" in name      # `use_directional_enc = False` (coord.pos_enc of the reflected direction), all heads present
     _, true_blob, idx = posenc_params(g) if posenc else variant_params(g)
     hist_keys, rend_keys = (HIST_KEYS, REND_KEYS) if posenc else (VARIANT_HIST_KEYS, VARIANT_REND_KEYS)
@@ -654,6 +654,7 @@ def test_nerfmlp_variants_vs_reference(hip, name, flat):
         bindings += ["Config.predicted_normal_loss_mult = 0.", "Config.predicted_normal_coarse_loss_mult = 0."]
     if flat:
         bindings += ["Config.hip_flat_grads = True"]
+    bindings += [f"Config.hip_train_precision = '{chains}'", f"Config.hip_bwd_precision = '{chains}'"]   # f16x2: split-f16 chains, same bars
     configs.clear_config()
     configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")], bindings)
     cfg = configs.Config()
@@ -715,7 +716,8 @@ def test_nerfmlp_variants_vs_reference(hip, name, flat):
 
 @pytest.mark.parametrize("name", ["model_raydist_reciprocal_eval", "model_raydist_log_eval", "model_raydist_piecewise_eval",
                                   "model_nointegration_eval", "model_raydist_nointegration_train"])
-def test_raydist_and_disable_integration_vs_reference(hip, name):
+@pytest.mark.parametrize("chains", ["f32", "f16x2"])
+def test_raydist_and_disable_integration_vs_reference(hip, name, chains):
     """Model.raydist_fn (coord.construct_ray_warps: reciprocal / log / 'piecewise') and Model.disable_integration through
     cfg.raydist / cfg.disable_integration: Model.__call__ against the reference's outputs, and for the training fixture its
     losses and autograd gradients.  Tolerances of the un-integrated encoding as in the oracle test (level-1 positions differ by
@@ -724,11 +726,14 @@ def test_raydist_and_disable_integration_vs_reference(hip, name):
     from refnerf_pl_amd import configs, layout, models, train_utils, utils
     g = load_golden(name)
     train = name.endswith("train")
+    if chains != "f32" and not train:
+        pytest.skip("chain modes: training only")
     noint = bool(int(g["disable_integration"]))
     fn = {"": None, "piecewise": "piecewise", "reciprocal": torch.reciprocal, "log": "@torch.log"}[str(g["raydist_fn"])]
     configs.clear_config()
     configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
-                                            [str(b) for b in g["bindings"] if str(b)])
+                                            [str(b) for b in g["bindings"] if str(b)]
+                                            + [f"Config.hip_train_precision = '{chains}'", f"Config.hip_bwd_precision = '{chains}'"])
     cfg = configs.Config()
     model = models.construct_model(utils.dummy_rays(), cfg).to(DEV)
     model.raydist_fn, model.disable_integration = fn, noint          # read at call time, as in the reference
