@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 7   /* v7: REFNERF_PREC_F16X2 (split-operand f16: the parity-grade 16-bit inference mode); v6: cfg.dir_enc (REFNERF_DIRENC_*), cfg.raydist (REFNERF_RAYDIST_*), cfg.disable_integration; v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
+#define REFNERF_ABI_VERSION 8   /* v8: cfg.ipe_groups, refnerf_pack_weights_basis (general IPE bases: icosahedron); v7: REFNERF_PREC_F16X2 (split-operand f16: the parity-grade 16-bit inference mode); v6: cfg.dir_enc (REFNERF_DIRENC_*), cfg.raydist (REFNERF_RAYDIST_*), cfg.disable_integration; v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {
@@ -108,6 +108,8 @@ typedef struct refnerf_level_cfg {
   int32_t dir_enc;            /* REFNERF_DIRENC_*: MLP.use_directional_enc (:484-492)      */
   int32_t raydist;            /* REFNERF_RAYDIST_*: Model.raydist_fn (:147, coord.py:63-99) */
   int32_t disable_integration;/* Model.disable_integration (:228-231): zero covariances -> plain positional encoding */
+  int32_t ipe_groups;         /* MLP.basis_shape / basis_subdivisions (:384-385, 482-484): 0 or 1 = the octahedron/1 basis the kernels are
+                                 built around; G = 2..7: 3 G basis directions, d_packed from refnerf_pack_weights_basis */
   float anneal;               /* models.py:190-195                                         */
   float resample_padding;     /* Model.resample_padding (:202)                             */
   float s_near, s_far;        /* Model.init_s_near / init_s_far (:213)                     */
@@ -168,6 +170,18 @@ size_t refnerf_packed_weights_bytes(int precision);
  * reference (its weights are consumed in place by nn.Linear, models.py:576-
  * 700); must be re-run after every optimiser step. */
 int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, void *stream);
+
+/* The same for an MLP whose integrated positional encoding projects onto a general basis (geopoly.generate_basis,
+ * internal/geopoly.py:78-123; coord.lift_and_diagonalize, internal/coord.py:129-133; NerfMLP's constructor default is
+ * the 21 directions of 'icosahedron' / 2): d_basis [3 * ipe_groups][3] = the basis rows in the reference's order and
+ * component order, ipe_groups <= 7.  d_params is then REFNERF_NUM_PARAMS_EXT floats: the canonical blob, whose IPE
+ * columns of spatial_net.0 / .5 belong to directions 0..2, followed by W_ext[layer: 0, 5][g = 1..6][256][96] = the
+ * columns of direction group g (directions 3 g .. 3 g + 2; column 48 c + 3 j + b = (sin | cos block c, degree j,
+ * direction 3 g + b); unused groups zero).  REFNERF_PREC_F32 only; the image is
+ * refnerf_packed_weights_bytes_basis(precision, ipe_groups) bytes and levels run with cfg.ipe_groups = ipe_groups. */
+#define REFNERF_NUM_PARAMS_EXT (REFNERF_NUM_PARAMS + 2 * 6 * 256 * 96)
+size_t refnerf_packed_weights_bytes_basis(int precision, int ipe_groups);
+int refnerf_pack_weights_basis(const float *d_params, const float *d_basis, int ipe_groups, void *d_packed, int precision, void *stream);
 
 /* One fused launch = one iteration of the level loop of Model.__call__
  * (models.py:162-306): resample (stepfun.py:209-258) -> s_to_t (coord.py:96-98)

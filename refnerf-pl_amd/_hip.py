@@ -15,7 +15,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
 
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X2 = 0, 1, 2, 3
-ABI_VERSION = 7   # REFNERF_ABI_VERSION
+ABI_VERSION = 8   # REFNERF_ABI_VERSION
 WGRAD_F32, WGRAD_BF16X3 = 0, 1
 DIRENC_IDE, DIRENC_POSENC = 0, 1   # REFNERF_DIRENC_*
 RAYDIST = {None: 0, "piecewise": 1, "reciprocal": 2, "log": 3, "exp": 4, "sqrt": 5, "square": 6}   # REFNERF_RAYDIST_*
@@ -23,13 +23,15 @@ SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 
 
 _FP = C.c_void_p
 NUM_PARAMS = 1110158   # REFNERF_NUM_PARAMS
+NUM_PARAMS_EXT = NUM_PARAMS + 2 * 6 * 256 * 96   # REFNERF_NUM_PARAMS_EXT (general IPE basis: canonical blob + group tail)
+IPE_MAX_GROUPS = 7
 
 
 class LevelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_samples", "n_in", "training", "compute_extras", "srgb_mapping",
         "srgb_mapping_normalization", "render_srgb_mode", "opaque_background",
-        "ray_shape", "precision", "wgrad_mode", "dir_enc", "raydist", "disable_integration")] + [(n, C.c_float) for n in (
+        "ray_shape", "precision", "wgrad_mode", "dir_enc", "raydist", "disable_integration", "ipe_groups")] + [(n, C.c_float) for n in (
             "anneal", "resample_padding", "s_near", "s_far", "density_bias",
             "roughness_bias", "rgb_premultiplier", "rgb_bias", "rgb_padding", "bg_rgb")]
 
@@ -86,6 +88,9 @@ def lib():
         L.refnerf_packed_weights_bytes.restype = C.c_size_t
         L.refnerf_packed_weights_bytes.argtypes = [C.c_int]
         L.refnerf_pack_weights.argtypes = [_FP, _FP, C.c_int, _FP]
+        L.refnerf_packed_weights_bytes_basis.restype = C.c_size_t
+        L.refnerf_packed_weights_bytes_basis.argtypes = [C.c_int, C.c_int]
+        L.refnerf_pack_weights_basis.argtypes = [_FP, _FP, C.c_int, _FP, C.c_int, _FP]
         L.refnerf_level_forward.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
                                             _FP, _FP, C.POINTER(LevelOut), _FP]
         L.refnerf_activation_workspace_bytes.restype = C.c_size_t
@@ -158,16 +163,25 @@ def packed_weights_bytes(precision=PREC_F32) -> int:
     return int(lib().refnerf_packed_weights_bytes(precision))
 
 
-def pack_weights(params: torch.Tensor, packed: torch.Tensor = None, precision=PREC_F32) -> torch.Tensor:
-    """canonical fp32 blob (device) -> MFMA operand image (device)."""
+def pack_weights(params: torch.Tensor, packed: torch.Tensor = None, precision=PREC_F32, basis: torch.Tensor = None) -> torch.Tensor:
+    """canonical fp32 blob (device) -> MFMA operand image (device).  `basis` ([3 G, 3] fp32 device tensor, G = 2..7: a general
+    IPE basis, refnerf_pack_weights_basis): `params` is then the extended blob (NUM_PARAMS_EXT)."""
     require_device()
-    assert params.dtype == torch.float32 and params.numel() == 1110158
-    nbytes = packed_weights_bytes(precision)
+    groups = 0 if basis is None else basis.shape[0] // 3
+    assert params.dtype == torch.float32 and params.numel() == (NUM_PARAMS_EXT if groups > 1 else NUM_PARAMS)
+    nbytes = int(lib().refnerf_packed_weights_bytes_basis(precision, groups))
     if nbytes == 0:
+        if groups > 1:
+            raise ValueError("a general IPE basis (NerfMLP.basis_shape / basis_subdivisions other than 'octahedron' / 1) runs in the "
+                             "f32 precision mode only (Config.hip_precision = 'f32'), with at most 21 directions")
         raise HipLibraryError("precision mode not built")
     if packed is None or packed.numel() * packed.element_size() != nbytes or packed.device != params.device:
         packed = torch.empty(nbytes // 4, dtype=torch.float32, device=params.device)
-    check(lib().refnerf_pack_weights(ptr(params), ptr(packed), precision, stream_ptr()))
+    if groups > 1:
+        assert basis.dtype == torch.float32 and basis.is_contiguous() and basis.device == params.device and basis.shape == (3 * groups, 3)
+        check(lib().refnerf_pack_weights_basis(ptr(params), ptr(basis), groups, ptr(packed), precision, stream_ptr()))
+    else:
+        check(lib().refnerf_pack_weights(ptr(params), ptr(packed), precision, stream_ptr()))
     return packed
 
 

@@ -74,11 +74,8 @@ __device__ __forceinline__ float linspace_u(int k, int n) {
   return (k < n / 2) ? fmaf(step, (float)k, start) : fmaf(-step, (float)(n - 1 - k), end);
 }
 
-/* render.py:46-80 / 83-102 + 22-43 + coord.py:129-133 (octahedron/1 basis):
- * lifted mean (-z,-y,-x) and lifted variance (C_zz,C_yy,C_xx). */
-__device__ __forceinline__ void cast_sample(const float o[3], const float d[3], float radius, float t0,
-                                            float t1, int ray_shape, float lmean[3], float lvar[3]) {
-  float t_mean, t_var, r_var;
+/* render.py:46-80 (conical frustum) / 83-102 (cylinder): moments of the interval [t0, t1] along the ray */
+__device__ __forceinline__ void frustum_moments(float radius, float t0, float t1, int ray_shape, float &t_mean, float &t_var, float &r_var) {
   if (ray_shape == 0) {
     float mu = (t0 + t1) / 2.0f;
     float hw = (t1 - t0) / 2.0f;
@@ -96,6 +93,14 @@ __device__ __forceinline__ void cast_sample(const float o[3], const float d[3], 
     float dt = t1 - t0;
     t_var = (dt * dt) / 12.0f;
   }
+}
+
+/* render.py:46-80 / 83-102 + 22-43 + coord.py:129-133 (octahedron/1 basis):
+ * lifted mean (-z,-y,-x) and lifted variance (C_zz,C_yy,C_xx). */
+__device__ __forceinline__ void cast_sample(const float o[3], const float d[3], float radius, float t0,
+                                            float t1, int ray_shape, float lmean[3], float lvar[3]) {
+  float t_mean, t_var, r_var;
+  frustum_moments(radius, t0, t1, ray_shape, t_mean, t_var, r_var);
   float dms = fmaxf(1e-10f, (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
   float mean[3], cd[3];
 #pragma unroll
@@ -107,6 +112,38 @@ __device__ __forceinline__ void cast_sample(const float o[3], const float d[3], 
   }
   lmean[0] = -mean[2]; lmean[1] = -mean[1]; lmean[2] = -mean[0];
   lvar[0] = cd[2]; lvar[1] = cd[1]; lvar[2] = cd[0];
+}
+
+/* The same for a general basis (NerfMLP.basis_shape / basis_subdivisions, geopoly.generate_basis): the Gaussian with its
+ * FULL covariance (render.py:22-43 with diag = False, as models.py:214-227 calls it), then coord.lift_and_diagonalize
+ * (coord.py:129-133) onto three directions b[0..2] (rows of the basis; the image keeps them in the reference's component
+ * order): lifted mean = mean . b (fma chain over x, y, z: the order of ATen's [.., 3] x [3, n] product at batch sizes
+ * that matter), lifted variance = sum_i b_i (sum_k C_ik b_k). */
+__device__ __forceinline__ void cast_sample_full(const float o[3], const float d[3], float radius, float t0, float t1, int ray_shape,
+                                                 float mean[3], float cov[9]) {
+  float t_mean, t_var, r_var;
+  frustum_moments(radius, t0, t1, ray_shape, t_mean, t_var, r_var);
+  const float dms = fmaxf(1e-10f, (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    mean[i] = d[i] * t_mean + o[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float d_outer = d[i] * d[k];
+      const float null_outer = (i == k ? 1.0f : 0.0f) - d[i] * (d[k] / dms);
+      cov[3 * i + k] = t_var * d_outer + r_var * null_outer;
+    }
+  }
+}
+__device__ __forceinline__ void lift_onto(const float mean[3], const float cov[9], const float b[3], float &lm, float &lv) {
+  lm = fmaf(mean[2], b[2], fmaf(mean[1], b[1], mean[0] * b[0]));
+  float acc = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float cb = fmaf(cov[3 * i + 2], b[2], fmaf(cov[3 * i + 1], b[1], cov[3 * i] * b[0]));
+    acc = (i == 0) ? b[0] * cb : acc + b[i] * cb;
+  }
+  lv = acc;
 }
 
 /* math.py:22-34: where(|x| < 100pi, x, x % 100pi), floored remainder */

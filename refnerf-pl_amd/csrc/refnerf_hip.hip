@@ -239,6 +239,37 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
   }
 }
 
+/* Tail of the fp32 image for a general IPE basis (refnerf_layout.h): the basis directions, the forward group ops
+ * (op 0's LDS-step format: A[step][q][lane][4] = W[32 ob + lane % 32][k = 2 step + h]) and their transposes (TOP_SP0's
+ * format: A[step][lane][4] = W[o(step, h)][in_row = 32 ob + lane % 32], ob < 3) of the tail weights. */
+__global__ void pack_weights_ext(const float *__restrict__ P, const float *__restrict__ basis, int groups, float *__restrict__ out) {
+  const int e0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  const int which = blockIdx.y;              /* 0: basis, 1..12 forward, 13..24 transposed */
+  if (which == 0) {
+    for (int e = e0; e < 64; e += stride) out[PEXT_BASIS + e] = (e < 9 * groups) ? basis[e] : 0.0f;
+    return;
+  }
+  const int idx = (which - 1) % (2 * EXT_GROUPS), L = idx / EXT_GROUPS, g = idx % EXT_GROUPS + 1;
+  const float *W = P + ext_w_off(L, g);      /* [256][96] */
+  const bool live = g < groups;
+  if (which <= 2 * EXT_GROUPS) {
+    float *dst = out + pext_fwd_off(L, g);
+    for (int e = e0; e < PEXT_FWD_FLOATS; e += stride) {
+      const int step = e >> 9, rem = e & 511, ob = (rem >> 8) * 4 + (rem & 3), lane = (rem & 255) >> 2;
+      const int h = lane >> 5, row = ob * 32 + (lane & 31), k = 2 * step + h;
+      dst[e] = live ? W[row * IPE_DIM + k] : 0.0f;
+    }
+  } else {
+    float *dst = out + pext_t_off(L, g);
+    for (int e = e0; e < PEXT_T_FLOATS; e += stride) {
+      const int ob = e & 3, lane = (e >> 2) & 63, step = e >> 8;
+      const int h = lane >> 5, in_row = ob * 32 + (lane & 31), kb = step >> 4, r = step & 15;
+      const int oo = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+      dst[e] = (live && ob < 3) ? W[oo * IPE_DIM + in_row] : 0.0f;
+    }
+  }
+}
+
 /* One plain 17 KB chunk of the 16-bit images (refnerf_layout.h): bias piece + 16 fragment pieces. */
 template <typename E>
 __device__ void fill_chunk_plain(const float *__restrict__ P, char *__restrict__ chunk, int op, int ob, int kind, bool first, int base) {
@@ -596,7 +627,7 @@ void refnerf_level_cfg_default(refnerf_level_cfg *c) {
   memset(c, 0, sizeof(*c));
   c->n_samples = 128; c->n_in = 1; c->training = 0; c->compute_extras = 1;
   c->srgb_mapping = 1; c->srgb_mapping_normalization = 1; c->render_srgb_mode = REFNERF_SRGB_NONE;
-  c->opaque_background = 0; c->ray_shape = 0; c->precision = REFNERF_PREC_F32; c->wgrad_mode = REFNERF_WGRAD_BF16X3; c->dir_enc = REFNERF_DIRENC_IDE; c->raydist = REFNERF_RAYDIST_NONE; c->disable_integration = 0;
+  c->opaque_background = 0; c->ray_shape = 0; c->precision = REFNERF_PREC_F32; c->wgrad_mode = REFNERF_WGRAD_BF16X3; c->dir_enc = REFNERF_DIRENC_IDE; c->raydist = REFNERF_RAYDIST_NONE; c->disable_integration = 0; c->ipe_groups = 0;
   c->anneal = 1.0f; c->resample_padding = 0.01f; c->s_near = 0.0f; c->s_far = 1.0f;
   c->density_bias = 0.5f; c->roughness_bias = -1.0f;
   c->rgb_premultiplier = 1.0f; c->rgb_bias = 0.0f; c->rgb_padding = 0.001f; c->bg_rgb = 1.0f;
@@ -637,6 +668,25 @@ int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, v
   } else {
     return fail(REFNERF_EINVAL, "refnerf_pack_weights: unknown precision%s");
   }
+  HIP_TRY(hipGetLastError());
+  return REFNERF_OK;
+}
+
+size_t refnerf_packed_weights_bytes_basis(int precision, int ipe_groups) {
+  if (ipe_groups <= 1) return refnerf_packed_weights_bytes(precision);
+  if (precision != REFNERF_PREC_F32 || ipe_groups > rn::IPE_MAX_GROUPS) return 0;
+  return (size_t)rn::PACKED_EXT_TOTAL * sizeof(float);
+}
+
+int refnerf_pack_weights_basis(const float *d_params, const float *d_basis, int ipe_groups, void *d_packed, int precision, void *stream) {
+  if (ipe_groups <= 1) return refnerf_pack_weights(d_params, d_packed, precision, stream);
+  if (!d_basis) return fail(REFNERF_EINVAL, "refnerf_pack_weights_basis: null basis%s");
+  if (ipe_groups > rn::IPE_MAX_GROUPS) return fail(REFNERF_EUNSUPPORTED, "refnerf_pack_weights_basis: at most 7 groups of three directions (21: icosahedron / 2)%s");
+  if (precision != REFNERF_PREC_F32)
+    return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1) runs in the REFNERF_PREC_F32 kernels only%s");
+  const int rc = refnerf_pack_weights(d_params, d_packed, precision, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rn::pack_weights_ext, dim3(32, 1 + 4 * rn::EXT_GROUPS), dim3(256), 0, (hipStream_t)stream, d_params, d_basis, ipe_groups, (float *)d_packed);
   HIP_TRY(hipGetLastError());
   return REFNERF_OK;
 }
@@ -695,6 +745,12 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
     return fail(REFNERF_EINVAL, "unknown dir_enc (REFNERF_DIRENC_IDE / REFNERF_DIRENC_POSENC)%s");
   if (cfg->training && cfg->precision == REFNERF_PREC_F16)
     return fail(REFNERF_EUNSUPPORTED, "REFNERF_PREC_F16 is an inference mode (training levels: REFNERF_PREC_F32, REFNERF_PREC_F16X2 or REFNERF_PREC_BF16)%s");
+  const bool gbasis = cfg->ipe_groups > 1;
+  if (cfg->ipe_groups < 0 || cfg->ipe_groups > rn::IPE_MAX_GROUPS) return fail(REFNERF_EINVAL, "ipe_groups must be in [0,7]%s");
+  if (gbasis && cfg->precision != REFNERF_PREC_F32)
+    return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1) runs in the REFNERF_PREC_F32 kernels only%s");
+  if (gbasis && cfg->training)
+    return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1): inference only in this build%s");
   /* training + BF16: the fp32-structure kernel with its MLP chains on bf16 MFMA (level_fwd_train_bf16c); d_packed is
    * the REFNERF_PREC_F32 image in that case (it carries the bf16 copies of the ops) */
   const bool train_bf = cfg->training && cfg->precision == REFNERF_PREC_BF16;
@@ -747,7 +803,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget of this precision mode%s");
   LDS_ATTR_ONCE(lds_attr(rn::level_fwd_f32), lds_attr(rn::level_fwd_train_f32), lds_attr(rn::level_fwd_train_bf16c), lds_attr(rn::level_fwd_train_f16x2c),
                 lds_attr(rn::level_fwd_bf16), lds_attr(rn::level_fwd_f16), lds_attr(rn::level_fwd_bf16_ring), lds_attr(rn::level_fwd_f16_ring),
-                lds_attr(rn::level_fwd_f16x2), lds_attr(rn::level_fwd_f16x2_ring));
+                lds_attr(rn::level_fwd_f16x2), lds_attr(rn::level_fwd_f16x2_ring), lds_attr(rn::level_fwd_f32_gb));
   rn::LevelArgs a;
   a.packed = d_packed;
   a.cfg = *cfg;
@@ -784,6 +840,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   else if (train_bf) hipLaunchKernelGGL(rn::level_fwd_train_bf16c, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (train_split) hipLaunchKernelGGL(rn::level_fwd_train_f16x2c, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (cfg->training) hipLaunchKernelGGL(rn::level_fwd_train_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
+  else if (gbasis) hipLaunchKernelGGL(rn::level_fwd_f32_gb, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else hipLaunchKernelGGL(rn::level_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());
   {

@@ -171,6 +171,29 @@ constexpr Packed make_packed() {
 }
 constexpr Packed PACKED = make_packed();
 
+/* ---------------- general IPE bases (NerfMLP.basis_shape / basis_subdivisions; internal/models.py:384-385,482-484) --------
+ * The fused kernels are built around the 3 directions of the octahedron/1 basis (96 IPE features).  A basis of 3 G
+ * directions (G <= 7: icosahedron/2 = the reference's constructor default has 21) is served as G GROUPS of three
+ * directions: group 0 takes the places of the built-in basis (the canonical blob's IPE columns, ops 0 / 5, the X tile),
+ * groups 1..G-1 are run through the same 96-row X tile one after the other, each with its own [256][96] weight block of
+ * layers 0 and 5 accumulating into the layer's output.  Feature k of a group = 48 (cos block) + 3 (degree) + direction in
+ * group, i.e. the canonical order with the group's directions.
+ *   parameters: the canonical blob + a tail  W_ext[layer L = 0 (layer 0), 1 (layer 5)][g - 1][256][96]   (NUM_PARAMS_EXT)
+ *   fp32 image:  PACKED.total floats + [basis 64][12 forward group ops, [48 steps][2][64][4]][12 transposed, [128][64][4]] */
+constexpr int IPE_MAX_GROUPS = 7;
+constexpr int EXT_GROUPS = IPE_MAX_GROUPS - 1;
+constexpr int EXT_W = WIDTH * IPE_DIM;
+constexpr int NUM_PARAMS_EXT = NUM_PARAMS + 2 * EXT_GROUPS * EXT_W;
+constexpr int ext_w_off(int L, int g) { return NUM_PARAMS + (L * EXT_GROUPS + (g - 1)) * EXT_W; }
+constexpr int PEXT_BASIS = PACKED.total;
+constexpr int PEXT_FWD = PEXT_BASIS + 64;
+constexpr int PEXT_FWD_FLOATS = (IPE_DIM / 2) * 64 * 8;
+constexpr int PEXT_T = PEXT_FWD + 2 * EXT_GROUPS * PEXT_FWD_FLOATS;
+constexpr int PEXT_T_FLOATS = REG_STEPS * 64 * 4;
+constexpr int PACKED_EXT_TOTAL = PEXT_T + 2 * EXT_GROUPS * PEXT_T_FLOATS + 8 * 64 * 8;
+constexpr int pext_fwd_off(int L, int g) { return PEXT_FWD + (L * EXT_GROUPS + (g - 1)) * PEXT_FWD_FLOATS; }
+constexpr int pext_t_off(int L, int g) { return PEXT_T + (L * EXT_GROUPS + (g - 1)) * PEXT_T_FLOATS; }
+
 /* ---------------- backward workspace (weight-gradient operands) ----------------
  * The backward kernel writes, for every sample s, the input of every linear
  * layer (ACT) and the gradient w.r.t. its pre-activation output (DELTA) as

@@ -160,7 +160,7 @@ struct PairStoreHook {
   }
 };
 
-template <int NOB, int STRIDE, bool HAS_REG, bool BIAS = true, typename Hook = NoStepHook, int PF = rn::PF>
+template <int NOB, int STRIDE, bool HAS_REG, bool BIAS = true, typename Hook = NoStepHook, int PF = rn::PF, bool ACC = false>
 __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
                                         const v16f (&in)[8], v16f (&out)[NOB], const float *xl,
                                         int lds_steps, Hook hook = Hook()) {
@@ -171,7 +171,8 @@ __device__ __forceinline__ void gemm_op(__amdgpu_buffer_rsrc_t rs, int a_off, in
 #pragma unroll
   for (int d = 0; d < PF; ++d) load_a<NOB, STRIDE>(rs, voff, soff + d * STEP_BYTES, a[d]);
   soff += PF * STEP_BYTES;
-  if constexpr (BIAS) load_acc<NOB>(rs, b_off, h, out);
+  if constexpr (ACC) { /* `out` carries on (a further input group of the same layer) */ }
+  else if constexpr (BIAS) load_acc<NOB>(rs, b_off, h, out);
   else {
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
@@ -879,10 +880,14 @@ __device__ __forceinline__ void density_normals_split(__amdgpu_buffer_rsrc_t rs,
  * activations rounded to bf16 once per layer (what ACT then holds), everything per sample fp32. */
 /* SPC (training forward only): the MLP chains on split-f16 operands (cfg.precision = F16X2 with cfg.training): 22-bit
  * products, fp32 everything else, ACT in the fp32 format -- the parity-grade fast training forward. */
-template <bool TRAIN, bool STAGE = false, bool BFC = false, bool SPC = false>
+/* GB: general IPE basis (cfg.ipe_groups = G > 1 groups of three directions, refnerf_layout.h): the groups pass through
+ * the X tile one after the other in layers 0 and 5, each recomputed from the ray where it is consumed (nothing of it
+ * stays live across the trunk) */
+template <bool TRAIN, bool STAGE = false, bool BFC = false, bool SPC = false, bool GB = false>
 __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   static_assert(!BFC || (TRAIN && !STAGE), "bf16 chains: training forward only");
   static_assert(!SPC || (TRAIN && !STAGE && !BFC), "split-f16 chains: training forward only");
+  static_assert(!GB || (!STAGE && !BFC && !SPC), "general IPE basis: fp32 level kernels only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   RN_STAMP(A, 0);
   const refnerf_level_cfg &cfg = A.cfg;
@@ -926,7 +931,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     constexpr long long rpitch = RB;               /* unit pitch of the blocked ACT / DELTA rows (refnerf_layout.h) */
     int hdb = DIR_PAD * T_TILE + col;                /* the HD tile (beyond the 64 KB immediate range) through one laundered base */
     asm volatile("" : "+v"(hdb));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)packed_l, 0, PACKED.total * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)packed_l, 0, (GB ? PACKED_EXT_TOTAL : PACKED.total) * 4, 0x00020000);
     const int g = pass0 + col;                   /* sample index inside the workgroup */
     const int rl = g / N, si = g - rl * N;
     const int ray = ray0 + rl;
@@ -946,7 +951,33 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     }
     /* P1: conical frustum -> lifted Gaussian -> IPE (half 0: sin, half 1: cos) */
     float lm[3], lv[3];
-    {
+    /* general basis: the IPE features of direction group gq into the X tile (and, training, into their ACT rows) */
+    auto ipe_group = [&](int gq) {
+      float og[3], dg[3], mean[3], cov[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        og[i] = A.rays.d_origins[(size_t)rayc * 3 + i];
+        dg[i] = A.rays.d_directions[(size_t)rayc * 3 + i];
+      }
+      const float *td = TD + (valid ? rl : 0) * (N + 1);
+      cast_sample_full(og, dg, A.rays.d_radii[rayc], td[valid ? si : 0], td[valid ? si + 1 : 1], cfg.ray_shape, mean, cov);
+      const float *bs = reinterpret_cast<const float *>(A.packed) + PEXT_BASIS + 9 * gq;
+      float gm[3], gv[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const float bb[3] = {bs[3 * b], bs[3 * b + 1], bs[3 * b + 2]};
+        lift_onto(mean, cov, bb, gm[b], gv[b]);
+        if (cfg.disable_integration) gv[b] = 0.0f;
+      }
+#pragma unroll 1
+      for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) X[(48 * h + j * 3 + b) * T_TILE + col] = ipe_feature(gm[b], gv[b], j, h);
+    };
+    if constexpr (GB) {
+      lm[0] = lm[1] = lm[2] = 0.0f; lv[0] = lv[1] = lv[2] = 0.0f;
+      ipe_group(0);
+    } else {
       if constexpr (STAGE) {
         /* coord.lift_and_diagonalize (coord.py:129-133) with the octahedron/1 basis:
          * lifted mean = (-z,-y,-x), lifted var = (C_zz, C_yy, C_xx) */
@@ -992,6 +1023,16 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
           if (quarter < 0 || (e >> 1) == quarter) hk(8 * t + e, split_elem(pk[t], pl[t], e));
       };
     };
+    /* general basis: groups 1..G-1 of layer L (0: layer 0, 1: layer 5) accumulate into `out` through the same X rows */
+    auto more_groups = [&](int L) {
+#pragma unroll 1
+      for (int gq = 1; gq < cfg.ipe_groups; ++gq) {
+        wave_sync();                               /* the previous group's X reads are done */
+        ipe_group(gq);
+        wave_sync();
+        gemm_op<8, 8, false, false, NoStepHook, rn::PF, true>(rs, pext_fwd_off(L, gq), 0, lane, h, in, out, xl, IPE_DIM / 2);
+      }
+    };
     if constexpr (SPC) {
       gemm_op_split<8, 0, BF_IPE_STEPS, true>(rs, PACKED.hf_off[0], PACKED.op[0].b_off, lane, h, pk, pl, out, xc);
       relu_mask_split(out, M[7], pk, pl);
@@ -1000,6 +1041,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       relu_mask_pack(out, M[7], pk);
     } else {
       gemm_op<8, 8, false>(rs, PACKED.op[0].a_off, PACKED.op[0].b_off, lane, h, in, out, xl, PACKED.op[0].lds_steps);
+      if constexpr (GB) more_groups(0);
       if constexpr (TRAIN) relu_mask_into(out, in, M[7]); else relu_into(out, in);
     }
     auto save_mask = [&](int layer, const unsigned (&mk)[4]) {
@@ -1027,8 +1069,11 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       } else if constexpr (TRAIN && !STAGE)
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
                             RowStoreHook(A.act, rpitch, ACT_SP + (op - 1) * WIDTH, rcol, h, save));
-      else
+      else {
+        if constexpr (GB) { if (op == 5) { wave_sync(); ipe_group(0); wave_sync(); } }     /* X holds the last group of layer 0 */
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
+        if constexpr (GB) { if (op == 5) more_groups(1); }
+      }
       if constexpr (TRAIN) {
 #pragma unroll
         for (int l = 0; l < 7; ++l)
@@ -1187,6 +1232,8 @@ __global__ __launch_bounds__(NTHREADS) void level_fwd_train_f32(const LevelArgs 
 __global__ __launch_bounds__(NTHREADS) void level_fwd_train_bf16c(const LevelArgs A) { level_fwd_f32_body<true, false, true>(A); }
 /* training forward with the MLP chains on split-f16 operands (cfg.training && cfg.precision = REFNERF_PREC_F16X2) */
 __global__ __launch_bounds__(NTHREADS) void level_fwd_train_f16x2c(const LevelArgs A) { level_fwd_f32_body<true, false, false, true>(A); }
+/* eval forward with a general IPE basis (cfg.ipe_groups > 1: icosahedron / tesselated bases) */
+__global__ __launch_bounds__(NTHREADS) void level_fwd_f32_gb(const LevelArgs A) { level_fwd_f32_body<false, false, false, false, true>(A); }
 /* MLP.__call__ stage entry (eval / training) */
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false, true>(A); }
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_train_f32(const LevelArgs A) { level_fwd_f32_body<true, true>(A); }

@@ -84,8 +84,31 @@ def posenc_slots(deg_view):
     return list(range(3)) + [3 + k for k in range(n)] + [IDE_DIM // 2 + k for k in range(n)]
 
 
+# A general IPE basis (NerfMLP.basis_shape / basis_subdivisions: n_basis = 3 G directions, G <= 7) widens spatial_net.0 / .5
+# to 32 n_basis IPE columns.  The kernels take them as G groups of three directions (csrc/refnerf_layout.h): group 0 in the
+# canonical blob's 96 IPE columns, groups 1.. in a TAIL behind the canonical blob, W_ext[layer 0 | 5][g - 1][256][96]; column
+# 16 n c + n j + d of the true weight (cos block c, degree j, direction d; coord.py:102-126) = column 48 c + 3 j + d % 3 of
+# group d // 3.
+IPE_MAX_GROUPS = 7
+EXT_GROUPS = IPE_MAX_GROUPS - 1
+NUM_PARAMS_EXT = NUM_PARAMS + 2 * EXT_GROUPS * WIDTH * IPE_DIM
+
+
+def ipe_column_positions(spec, layer_slot, col0, n_basis):
+    """canonical / tail positions of the 32 n_basis IPE columns of every row of spatial_net.0 (layer_slot 0, col0 0) or
+    spatial_net.5 (layer_slot 1, col0 256): int64 [256, 32 n_basis]"""
+    import numpy as np
+    deg = IPE_DIM // 6
+    c, j, d = np.meshgrid(np.arange(2), np.arange(deg), np.arange(n_basis), indexing="ij")
+    g, k = d // 3, (IPE_DIM // 2) * c + 3 * j + d % 3
+    rows = np.arange(WIDTH, dtype=np.int64)[:, None]
+    in_canon = spec.w_off + rows * spec.in_dim + (col0 + k.reshape(-1))[None, :]
+    in_tail = NUM_PARAMS + ((layer_slot * EXT_GROUPS + (g.reshape(-1) - 1))[None, :] * WIDTH + rows) * IPE_DIM + k.reshape(-1)[None, :]
+    return np.where(g.reshape(-1)[None, :] == 0, in_canon, in_tail)
+
+
 def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint=True, enable_pred_roughness=True,
-                   use_directional_enc=True, deg_view=5):
+                   use_directional_enc=True, deg_view=5, n_basis=3):
     """-> (specs, index): `specs` = ParamSpec list of the variant (true shapes, offsets into ITS flat blob, state_dict
     order), `index` = int64 numpy array, index[i] = canonical-blob position of element i of the variant's flat blob; or
     (PARAM_SPECS, None) for the Ref-NeRF network itself."""
@@ -93,7 +116,10 @@ def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint
     wv = int(net_width_viewdirs)
     if not 1 <= wv <= WIDTH:
         raise ValueError(f"net_width_viewdirs must be in [1, {WIDTH}] for the fused kernels, got {wv}")
-    if wv == WIDTH and use_n_dot_v and use_specular_tint and enable_pred_roughness and use_directional_enc:
+    if n_basis % 3 or not 3 <= n_basis <= 3 * IPE_MAX_GROUPS:
+        raise ValueError(f"IPE basis of {n_basis} directions: the fused kernels take 3, 6, ... {3 * IPE_MAX_GROUPS} "
+                         "(octahedron / 1-2, icosahedron / 1-2)")
+    if wv == WIDTH and use_n_dot_v and use_specular_tint and enable_pred_roughness and use_directional_enc and n_basis == 3:
         return PARAM_SPECS, None
     enc_cols = list(range(IDE_DIM)) if use_directional_enc else posenc_slots(deg_view)
     din_cols = list(range(BNECK)) + [BNECK + k for k in enc_cols] + ([BNECK + IDE_DIM] if use_n_dot_v else [])
@@ -116,11 +142,16 @@ def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint
                 cols = list(range(wv))
         elif c.name == "rgb":
             cols = list(range(wv))
-        out_dim, in_dim = len(rows), len(cols)
-        specs.append(ParamSpec(c.name, out_dim, in_dim, p, p + out_dim * in_dim))
-        p += out_dim * in_dim + out_dim
         r = np.asarray(rows, np.int64)[:, None]
         k = np.asarray(cols, np.int64)[None, :]
-        idx.append((c.w_off + r * c.in_dim + k).reshape(-1))
+        pos = c.w_off + r * c.in_dim + k
+        if n_basis != 3 and c.name in ("spatial_net.0", f"spatial_net.{SKIP + 1}"):
+            first = c.name == "spatial_net.0"
+            ipe = ipe_column_positions(c, 0 if first else 1, 0 if first else WIDTH, n_basis)
+            pos = ipe if first else np.concatenate([pos[:, :WIDTH], ipe], axis=1)
+        out_dim, in_dim = pos.shape
+        specs.append(ParamSpec(c.name, out_dim, in_dim, p, p + out_dim * in_dim))
+        p += out_dim * in_dim + out_dim
+        idx.append(pos.reshape(-1))
         idx.append(c.b_off + np.asarray(rows, np.int64))
     return specs, np.concatenate(idx)

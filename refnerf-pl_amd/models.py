@@ -12,10 +12,11 @@ import math as python_math
 import threading
 from typing import Any, Callable, List, Mapping, MutableMapping, Optional, Text, Tuple
 
+import numpy as np
 import torch
 from torch import nn
 
-from . import _hip, configs, layout, utils
+from . import _hip, configs, geopoly, layout, utils
 
 
 def _reset_parameters(linear: nn.Linear):
@@ -92,9 +93,18 @@ class MLP(nn.Module):
             raise ValueError('Specular density is useless if not using diffuse color.')
         self._check_supported()
 
+        # the IPE basis (models.py:482-484): 'octahedron' / 1 = the three directions the kernels are built around; other
+        # tesselations (the constructor default 'icosahedron' / 2 has 21 directions) go through the kernels as groups of
+        # three (csrc/refnerf_layout.h), f32 mode
+        basis = geopoly.generate_basis(self.basis_shape, self.basis_subdivisions)
+        self.pos_basis_t = torch.tensor(basis).T                      # [3, n] as in the reference
+        self.ipe_basis_dirs = int(basis.shape[0])
+        self._basis_np = np.ascontiguousarray(basis, np.float32)
+        self._basis_dev = None
         # same module names / shapes as the reference after its lazy init (models.py:497-531)
         W = self.net_width
-        sp_in = [layout.IPE_DIM if i == 0 else (W + layout.IPE_DIM if i == self.skip_layer + 1 else W)
+        ipe_dim = 2 * (self.max_deg_point - self.min_deg_point) * self.ipe_basis_dirs
+        sp_in = [ipe_dim if i == 0 else (W + ipe_dim if i == self.skip_layer + 1 else W)
                  for i in range(self.net_depth)]
         self.spatial_net = nn.ModuleList([_linear(sp_in[i], W) for i in range(self.net_depth)])
         self.raw_density = _linear(W, 1)
@@ -102,7 +112,9 @@ class MLP(nn.Module):
         # the variants the reference runs and the fused kernels serve by embedding (layout.variant_layout): same module
         # names and TRUE shapes as the reference gives them (models.py:509-531)
         self.specs, idx = layout.variant_layout(self.net_width_viewdirs, self.use_n_dot_v, self.use_specular_tint,
-                                                self.enable_pred_roughness, self.use_directional_enc, self.deg_view)
+                                                self.enable_pred_roughness, self.use_directional_enc, self.deg_view,
+                                                n_basis=self.ipe_basis_dirs)
+        self.canon_size = layout.NUM_PARAMS_EXT if self.ipe_basis_dirs != 3 else layout.NUM_PARAMS
         self.num_params = self.specs[-1].b_off + self.specs[-1].out_dim
         self._embed_index_np = idx                 # None: the parameters ARE the canonical blob
         self._embed_index = None
@@ -144,7 +156,7 @@ class MLP(nn.Module):
                     min_deg_point=0, max_deg_point=16, skip_layer=4,
                     num_rgb_channels=3,
                     enable_pred_specular_density=False, bottleneck_noise=0.0,
-                    density_noise=0., disable_rgb=False, warp_fn=None, basis_shape='octahedron', basis_subdivisions=1)
+                    density_noise=0., disable_rgb=False, warp_fn=None)
         bad = {k: getattr(self, k) for k, v in want.items() if getattr(self, k) != v}
         if not 1 <= int(self.net_width_viewdirs) <= layout.WIDTH:
             bad["net_width_viewdirs"] = self.net_width_viewdirs
@@ -223,7 +235,7 @@ class MLP(nn.Module):
         state_dict order) or, for a variant, also a CANONICAL blob -- its embedded elements are taken, the rest ignored."""
         flat = self.flat_params()
         blob = torch.as_tensor(blob, dtype=torch.float32).to(flat.device).reshape(-1)
-        if blob.numel() == layout.NUM_PARAMS and self._embed_index_np is not None:
+        if blob.numel() == self.canon_size and self._embed_index_np is not None:
             blob = blob[self.embed_index()]
         with torch.no_grad():
             flat.copy_(blob)
@@ -243,10 +255,24 @@ class MLP(nn.Module):
         if self._embed_index_np is None:
             return flat
         if self._canon is None or self._canon.device != flat.device:
-            self._canon = torch.zeros(layout.NUM_PARAMS, dtype=torch.float32, device=flat.device)
+            self._canon = torch.zeros(self.canon_size, dtype=torch.float32, device=flat.device)
         with torch.no_grad():
             self._canon.index_copy_(0, self.embed_index(), flat.detach())
         return self._canon
+
+    @property
+    def ipe_groups(self) -> int:
+        """cfg.ipe_groups of the level kernels: 0 = the built-in octahedron / 1 basis, else groups of three directions"""
+        return 0 if self.ipe_basis_dirs == 3 else self.ipe_basis_dirs // 3
+
+    def kernel_basis(self):
+        """general basis only: the [3 G, 3] direction rows on the parameters' device (refnerf_pack_weights_basis)"""
+        if self.ipe_groups == 0:
+            return None
+        dev = self.spatial_net[0].weight.device
+        if self._basis_dev is None or self._basis_dev.device != dev:
+            self._basis_dev = torch.as_tensor(self._basis_np, device=dev).contiguous()
+        return self._basis_dev
 
     @property
     def kernel_dir_enc(self) -> int:
@@ -295,7 +321,7 @@ class MLP(nn.Module):
         pending = getattr(self, "_step_pending", False)
         buf, have = self._packed.get(precision, (None, None))
         if force or pending or have != key:
-            buf = _hip.pack_weights(self.canonical_blob(), buf, precision)
+            buf = _hip.pack_weights(self.canonical_blob(), buf, precision, basis=self.kernel_basis())
             self._packed[precision] = (buf, None if (force or pending) else key)
         self._packed_key = key
         return buf
@@ -311,6 +337,9 @@ class MLP(nn.Module):
         forward-only: gradients flow through Model.__call__ (refnerf_level_backward)."""
         del imageplane                                   # unused by the reference as well (models.py:536)
         _hip.require_device()
+        if self.ipe_groups:
+            raise ValueError("MLP.__call__ on caller-supplied Gaussians is built for the 'octahedron' / 1 basis; a general IPE basis "
+                             "runs through Model.__call__ (the fused level kernel)")
         means, covs = gaussians
         if viewdirs is None:
             raise ValueError("the fused Ref-NeRF MLP needs viewdirs (use_viewdirs / use_reflections)")
@@ -599,6 +628,10 @@ class Model(nn.Module):
         train_prec = getattr(cfg, "hip_train_precision", "f32")
         if train_prec not in _TRAIN_FWD_PREC:      # 'f16' is an inference mode of the level kernel
             raise ValueError("Config.hip_train_precision must be 'f32', 'f16x2' or 'bf16'")
+        if mlp.ipe_groups and (self.training or prec != "f32"):
+            raise ValueError(f"IPE basis '{mlp.basis_shape}' / {mlp.basis_subdivisions} ({mlp.ipe_basis_dirs} directions): the fused kernels run a "
+                             "general basis in the f32 inference mode only (Config.hip_precision = 'f32', model.eval()); training and "
+                             "the 16-bit modes are built for 'octahedron' / 1")
         wgrad = {"f32": _hip.WGRAD_F32, "bf16x3": _hip.WGRAD_BF16X3}.get(getattr(cfg, "hip_wgrad_mode", "bf16x3"))
         if wgrad is None:
             raise ValueError("Config.hip_wgrad_mode must be 'bf16x3' or 'f32'")
@@ -610,6 +643,7 @@ class Model(nn.Module):
             precision=_PREC[train_prec] if self.training else _PREC[prec], wgrad_mode=wgrad, anneal=float(anneal), resample_padding=float(self.resample_padding),
             s_near=float(self.init_s_near), s_far=float(self.init_s_far), density_bias=float(mlp.density_bias),
             dir_enc=mlp.kernel_dir_enc, raydist=self._raydist_enum(self.raydist_fn), disable_integration=int(bool(self.disable_integration)),
+            ipe_groups=mlp.ipe_groups,
             roughness_bias=mlp.kernel_roughness_bias, rgb_premultiplier=float(mlp.rgb_premultiplier),
             rgb_bias=float(mlp.rgb_bias), rgb_padding=float(mlp.rgb_padding), bg_rgb=float(bg))
 

@@ -59,6 +59,21 @@ def make_params(seed: int = 0, bias_scale: float = 0.0, sharpen: float = 1.0,
     return blob
 
 
+def make_basis_params(seed: int = 0, n_basis: int = 21, **kw) -> np.ndarray:
+    """Extended canonical blob (layout.NUM_PARAMS_EXT) for an MLP with a general IPE basis of `n_basis` directions:
+    make_params(seed, **kw) with the IPE columns of spatial_net.0 / .5 re-drawn for the wider fan-in, plus the tail
+    blocks of direction groups 1 .. n_basis / 3 - 1 (unused groups stay zero)."""
+    blob = np.zeros(layout.NUM_PARAMS_EXT, dtype=np.float32)
+    blob[:layout.NUM_PARAMS] = make_params(seed=seed, **kw)
+    specs, idx = layout.variant_layout(n_basis=n_basis)
+    for sid, name in ((91, "spatial_net.0"), (92, f"spatial_net.{layout.SKIP + 1}")):
+        sp = next(s for s in specs if s.name == name)
+        n = sp.out_dim * sp.in_dim
+        w = ((hash_uniform(seed, sid, n) * 2.0 - 1.0) / math.sqrt(sp.in_dim)).astype(np.float32)
+        blob[idx[sp.w_off:sp.w_off + n]] = w
+    return blob
+
+
 def _rot(seed: int) -> np.ndarray:
     """Seeded rotation matrix (float64)."""
     u = hash_uniform(seed, 101, 3)

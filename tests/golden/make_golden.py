@@ -788,6 +788,80 @@ def golden_variant_models():
         print(name, "history keys", list(res["history_keys"]), "rendering keys", list(res["rendering_keys"]))
 
 
+def golden_basis_models():
+    """NerfMLP.basis_shape / basis_subdivisions other than 'octahedron' / 1 (internal/models.py:384-385, 482-484;
+    geopoly.generate_basis): the reference's constructor default 'icosahedron' / 2 (21 directions, 672 IPE features) in eval
+    mode and for one training step, and 'icosahedron' / 1 (6 directions) in eval mode; otherwise blender_refnerf.gin.
+    Also tests/golden/geopoly.npz: the reference's basis matrices themselves.  Weights: synthetic.make_basis_params
+    (extended canonical blob), gradients in the module's own flat order."""
+    from internal import geopoly
+    save("geopoly", **{f"{shape}_{v}_{int(rs)}": geopoly.generate_basis(shape, v, rs)
+                       for shape in ("octahedron", "icosahedron") for v in (1, 2, 3) for rs in (True, False)})
+    pk = dict(seed=7, bias_scale=0.05, sharpen=20.0)
+    small = ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 96"]
+    ico2 = ["NerfMLP.basis_shape = 'icosahedron'", "NerfMLP.basis_subdivisions = 2"]
+    ico1 = ["NerfMLP.basis_shape = 'icosahedron'", "NerfMLP.basis_subdivisions = 1"]
+    cases = {"model_ico_eval": (ico2, 21, synthetic.blender_rays(16, seed=71, center_frac=0.4), False),
+             "model_ico_train": (ico2 + small, 21, synthetic.blender_rays(12, seed=72, center_frac=0.4), True),
+             "model_ico1_eval": (ico1, 6, synthetic.blender_rays(16, seed=73, center_frac=0.4), False)}
+    for name, (bindings, n_basis, rays, train) in cases.items():
+        specs, idx = layout.variant_layout(n_basis=n_basis)
+        canon = synthetic.make_basis_params(n_basis=n_basis, **pk)
+        gin.clear_config()
+        gin.parse_config_files_and_bindings([REF_CFG], list(bindings))
+        cfg = configs.Config()
+        model = models.construct_model(utils.dummy_rays(), cfg)
+        sd = model.nerf_mlp.state_dict()
+        assert len(sd) == 2 * len(specs), (len(sd), len(specs))
+        true = canon[idx]
+        for sp in specs:
+            w = true[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim].reshape(sp.out_dim, sp.in_dim)
+            assert tuple(sd[sp.name + ".weight"].shape) == w.shape, (sp, sd[sp.name + ".weight"].shape)
+            sd[sp.name + ".weight"].copy_(torch.tensor(w))
+            sd[sp.name + ".bias"].copy_(torch.tensor(true[sp.b_off:sp.b_off + sp.out_dim]))
+        r = to_rays(rays)
+        gt = synthetic.target_rgb(rays["origins"].shape[0], seed=2)
+        res = {}
+        if not train:
+            model.eval()
+            with torch.no_grad():
+                rend, hist = model(r, 1.0, True)
+        else:
+            model.train()
+            model.zero_grad()
+            rend, hist = model(r, 1.0, True)
+            batch = utils.Batch(rays=r, rgb=gt)
+            data_loss, _ = train_utils.compute_data_loss(batch, rend, r, cfg)
+            o_loss = train_utils.orientation_loss(r, model, hist, cfg)
+            n_loss = train_utils.predicted_normal_loss(model, hist, cfg)
+            loss = data_loss + o_loss + n_loss
+            res["loss_data"], res["loss_orientation"], res["loss_normal"] = data_loss.item(), o_loss.item(), n_loss.item()
+            loss.backward()
+            res["loss_total"] = loss.item()
+            named = dict(model.nerf_mlp.named_parameters())
+            g = np.zeros(len(idx), np.float32)
+            for sp in specs:
+                g[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim] = named[sp.name + ".weight"].grad.numpy().reshape(-1)
+                g[sp.b_off:sp.b_off + sp.out_dim] = named[sp.name + ".bias"].grad.numpy()
+            res["grads_sub"] = g[::61].copy()
+            res["grads_tensor_l2"] = np.array([[np.linalg.norm(g[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim]),
+                                                np.linalg.norm(g[sp.b_off:sp.b_off + sp.out_dim])] for sp in specs])
+        for lvl, (rd, hs) in enumerate(zip(rend, hist)):
+            for k, v in rd.items():
+                res[f"L{lvl}_r_{k}"] = v.detach().numpy()
+            for k, v in hs.items():
+                if v is not None:
+                    res[f"L{lvl}_h_{k}"] = v.detach().numpy()
+        res["bindings"] = np.array(bindings)
+        res["n_basis"] = n_basis
+        res["basis"] = model.nerf_mlp.pos_basis_t.numpy().T.copy()
+        res["param_kw"] = np.array([pk["seed"], pk["bias_scale"], pk["sharpen"], 0.0])
+        for k, v in rays.items():
+            res["rays_" + k] = v
+        res["gt_rgb"] = gt
+        save(name, **res)
+
+
 def golden_posenc_models():
     """`NerfMLP.use_directional_enc = False`: coord.pos_enc of the reflected direction instead of the IDE (models.py:487-492),
     otherwise the Ref-NeRF config -- eval and one training step, gradients in the variant's own flat order."""
@@ -931,6 +1005,6 @@ def golden_variants():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models", "posenc_models", "raydist_models"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models", "posenc_models", "raydist_models", "basis_models"]
     for w in which:
         globals()["golden_" + w]()

@@ -1,0 +1,117 @@
+"""General IPE bases (NerfMLP.basis_shape / basis_subdivisions; internal/models.py:384-385, 482-484,
+internal/geopoly.py:78-123, internal/coord.py:129-133): the basis directions bit for bit against the reference's own, the
+weight-column layout of the direction groups, and -- on the GPU -- Model.__call__ with the reference's constructor default
+('icosahedron' / 2: 21 directions, 672 IPE features) and with 'icosahedron' / 1 against the reference's outputs
+(tests/golden/model_ico*.npz, captured by tests/golden/make_golden.py::golden_basis_models)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import HIST_KEYS, REND_KEYS, load_golden, rays_from_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+
+def test_generate_basis_matches_reference_bit_for_bit():
+    from refnerf_pl_amd import geopoly
+    g = load_golden("geopoly")
+    for key in g.files:
+        shape, v, rs = key.rsplit("_", 2)
+        ours = geopoly.generate_basis(shape, int(v), bool(int(rs)))
+        assert ours.dtype == np.float32 and ours.shape == g[key].shape, key
+        assert np.array_equal(ours, g[key]), key
+    assert geopoly.generate_basis("icosahedron", 2).shape == (21, 3)
+    assert np.array_equal(geopoly.generate_basis("octahedron", 1), np.array([[0, 0, -1], [0, -1, 0], [-1, 0, 0]], np.float32))
+    with pytest.raises(ValueError):
+        geopoly.generate_basis("cube", 1)
+    with pytest.raises(ValueError):
+        geopoly.generate_basis("icosahedron", 0)
+
+
+def test_basis_layout_is_a_permutation_of_the_extended_blob():
+    """every element of the 672- / 928-column weights has its own place: group 0 in the canonical IPE columns, groups 1..6 in
+    the tail; column 336 c + 21 j + d of the true weight <-> column 48 c + 3 j + d % 3 of group d // 3"""
+    from refnerf_pl_amd import layout
+    specs, idx = layout.variant_layout(n_basis=21)
+    assert len(idx) == layout.NUM_PARAMS_EXT and len(np.unique(idx)) == len(idx) and idx.max() == layout.NUM_PARAMS_EXT - 1
+    s0, s5 = specs[0], specs[5]
+    assert (s0.out_dim, s0.in_dim, s5.out_dim, s5.in_dim) == (256, 672, 256, 928)
+    c0 = layout.SPEC_BY_NAME["spatial_net.0"]
+    row, c, j, d = 7, 1, 11, 13
+    pos = idx[s0.w_off + row * 672 + 336 * c + 21 * j + d]
+    g, k = d // 3, 48 * c + 3 * j + d % 3
+    assert pos == layout.NUM_PARAMS + ((g - 1) * 256 + row) * 96 + k
+    assert idx[s0.w_off + row * 672 + 336 * c + 21 * j + 2] == c0.w_off + row * 96 + 48 * c + 3 * j + 2
+    assert idx[s5.w_off + row * 928 + 100] == layout.SPEC_BY_NAME["spatial_net.5"].w_off + row * (256 + 96) + 100
+    pos5 = idx[s5.w_off + row * 928 + 256 + 336 * c + 21 * j + d]
+    assert pos5 == layout.NUM_PARAMS + ((6 + g - 1) * 256 + row) * 96 + k
+    specs6, idx6 = layout.variant_layout(n_basis=6)
+    assert specs6[0].in_dim == 192 and idx6.max() < layout.NUM_PARAMS + 256 * 96 or idx6.max() < layout.NUM_PARAMS_EXT
+    with pytest.raises(ValueError):
+        layout.variant_layout(n_basis=46)          # icosahedron / 3: beyond the seven groups
+
+
+def test_model_constructs_with_the_reference_default_basis():
+    """module names / true shapes as the reference gives them; the modes that are not built raise with the reason"""
+    from refnerf_pl_amd import configs, models, utils
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", "refnerf_blender.gin")],
+                                            ["NerfMLP.basis_shape = 'icosahedron'", "NerfMLP.basis_subdivisions = 2"])
+    model = models.construct_model(utils.dummy_rays(), configs.Config())
+    mlp = model.nerf_mlp
+    assert tuple(mlp.spatial_net[0].weight.shape) == (256, 672) and tuple(mlp.spatial_net[5].weight.shape) == (256, 928)
+    assert tuple(mlp.pos_basis_t.shape) == (3, 21) and mlp.ipe_groups == 7 and mlp.canon_size == mlp.num_params
+    assert len(mlp.state_dict()) == 46
+    configs.clear_config()
+
+
+def _basis_model(g, extra=()):
+    from refnerf_pl_amd import configs, models, synthetic, utils
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", "refnerf_blender.gin")], [str(b) for b in g["bindings"]] + list(extra))
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV)
+    pk = g["param_kw"]
+    blob = synthetic.make_basis_params(seed=int(pk[0]), n_basis=int(g["n_basis"]), bias_scale=float(pk[1]), sharpen=float(pk[2]))
+    model.nerf_mlp.load_flat_params(blob)              # the extended canonical blob -> the module's true shapes
+    return model, cfg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["model_ico_eval", "model_ico1_eval"])
+def test_general_basis_eval_vs_reference(name):
+    import torch
+    from refnerf_pl_amd import _hip, utils
+    _hip.require_device()
+    g = load_golden(name)
+    model, cfg = _basis_model(g)
+    assert np.array_equal(model.nerf_mlp.pos_basis_t.numpy().T, g["basis"])
+    rays = utils.rays_from_dict(rays_from_golden(g), DEV)
+    model.eval()
+    with torch.no_grad():
+        renderings, history = model(rays, 1.0, True)
+    worst = {}
+    for L in range(2):
+        for k in HIST_KEYS:
+            a = g[f"L{L}_h_{k}"]
+            x = history[L][k].cpu().numpy().reshape(a.shape)
+            tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 2e-6)
+            if L > 0 and k not in ("sdist", "weights"):
+                tol = max(tol, 5e-5)                   # level-1 sample positions differ by an ulp
+            worst[(L, k)] = float(np.abs(x - a).max())
+            np.testing.assert_allclose(x, a, rtol=0, atol=tol, err_msg=f"L{L} {k}")
+        for k in REND_KEYS:
+            a = g[f"L{L}_r_{k}"]
+            x = renderings[L][k].cpu().numpy().reshape(a.shape)
+            tol = 5e-6 + (1e-6 / np.maximum(g[f"L{L}_r_acc"], 1e-6) if k == "distance_mean" else 0.0)
+            assert np.all(np.abs(x - a) <= tol), (L, k, np.abs(x - a).max())
+        err = float(np.abs(renderings[L]["rgb"].cpu().numpy() - g[f"L{L}_r_rgb"]).max())
+        print(f"{name} L{L}: RGB L-inf vs reference {err:.2e}, density {worst[(L, 'density')]:.2e}, weights {worst[(L, 'weights')]:.2e}")
+        assert err <= 1e-5
+    # the modes a general basis is not built for say so
+    for prec in ("f16x2", "bf16"):
+        cfg.hip_precision = prec
+        with pytest.raises(ValueError, match="basis"):
+            model(rays, 1.0, True)

@@ -31,11 +31,11 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.lib()
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.refnerf_abi_version() == 7
+    assert lib.refnerf_abi_version() == 8
     assert _hip.packed_weights_bytes(_hip.PREC_F32) > 4 * layout.NUM_PARAMS
     c = _hip.default_cfg()
     assert (c.n_samples, c.resample_padding, c.density_bias) == (128, pytest.approx(0.01), pytest.approx(0.5))
-    assert C.sizeof(_hip.LevelCfg) == 96 and c.dir_enc == _hip.DIRENC_IDE and c.raydist == 0 and c.disable_integration == 0 and c.wgrad_mode == _hip.WGRAD_BF16X3 and C.sizeof(_hip.LevelOut) == 23 * 8
+    assert C.sizeof(_hip.LevelCfg) == 100 and c.ipe_groups == 0 and _hip.lib().refnerf_packed_weights_bytes_basis(_hip.PREC_F32, 7) > 4 * _hip.NUM_PARAMS_EXT and c.dir_enc == _hip.DIRENC_IDE and c.raydist == 0 and c.disable_integration == 0 and c.wgrad_mode == _hip.WGRAD_BF16X3 and C.sizeof(_hip.LevelOut) == 23 * 8
 
 
 def test_gin_loader_syntax(tmp_path):
@@ -103,13 +103,13 @@ def test_unsupported_configurations_raise(cfg):
 def test_variant_gate_matches_reference_status():
     """what the reference itself survives (tests/golden/variants_status.json, captured by
     make_golden.py `variants`) against this build's gate.  Both shipped mip-NeRF configs and the flag settings behind them
-    die inside the reference; of the single flags it does run, all but the icosahedron basis (192 IPE features) are served."""
+    die inside the reference; every single flag it does run is served (the icosahedron basis as direction groups: tests/test_basis.py)."""
     import json
     st = json.load(open(os.path.join(ROOT, "tests", "golden", "variants_status.json")))
     assert st["configs"]["blender_mipnerf.gin"].startswith("KeyError: 'diffuse'")
     assert st["configs"]["llff_mipnerf.gin"].startswith("KeyError: 'diffuse'")
     assert all(v == "ok" for k, v in st["configs"].items() if "mipnerf" not in k)
-    not_built = {"NerfMLP.basis_shape = 'icosahedron'"}            # 192 IPE features: a different layer-0 / skip width
+    not_built = set()
     ref_cfg = os.path.join(ROOT, "configs", "refnerf_blender.gin")
     for flag, status in st["refnerf_with_flag"].items():
         configs.clear_config()
@@ -123,7 +123,7 @@ def test_variant_gate_matches_reference_status():
         else:
             mlp = models.NerfMLP()
             name, val = flag.split(" = ")
-            assert str(getattr(mlp, name.split(".")[1])) == val
+            assert str(getattr(mlp, name.split(".")[1])) == val.strip("'")
     configs.clear_config()
 
 
