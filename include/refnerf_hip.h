@@ -175,9 +175,9 @@ int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, v
  * internal/geopoly.py:78-123; coord.lift_and_diagonalize, internal/coord.py:129-133; NerfMLP's constructor default is
  * the 21 directions of 'icosahedron' / 2): d_basis [3 * ipe_groups][3] = the basis rows in the reference's order and
  * component order, ipe_groups <= 7.  d_params is then REFNERF_NUM_PARAMS_EXT floats: the canonical blob, whose IPE
- * columns of spatial_net.0 / .5 belong to directions 0..2, followed by W_ext[layer: 0, 5][g = 1..6][256][96] = the
- * columns of direction group g (directions 3 g .. 3 g + 2; column 48 c + 3 j + b = (sin | cos block c, degree j,
- * direction 3 g + b); unused groups zero).  REFNERF_PREC_F32 only; the image is
+ * columns of spatial_net.0 / .5 belong to directions 0..2, followed by W_ext[layer: 0, 5][256 rows][576]: column
+ * 96 (g - 1) + 48 c + 3 j + b = (direction group g = 1..6, sin | cos block c, degree j, direction 3 g + b); unused
+ * groups zero.  REFNERF_PREC_F32 only; the image is
  * refnerf_packed_weights_bytes_basis(precision, ipe_groups) bytes and levels run with cfg.ipe_groups = ipe_groups. */
 #define REFNERF_NUM_PARAMS_EXT (REFNERF_NUM_PARAMS + 2 * 6 * 256 * 96)
 size_t refnerf_packed_weights_bytes_basis(int precision, int ipe_groups);
@@ -255,6 +255,11 @@ int refnerf_level_forward_train(const void *d_packed, const refnerf_level_cfg *c
  * bf16 MFMA with deltas rounded to bf16 once per layer, gradients within ~1e-3 relative L2 of the f32 mode),
  * cfg->wgrad_mode that of the weight-gradient GEMM. */
 size_t refnerf_backward_workspace_bytes(int32_t R, int32_t n_samples);
+/* ... and of both buffers for a level with a general IPE basis (cfg.ipe_groups > 1: the IPE features of the extra direction
+ * groups behind the activations, the tail's partial sums behind the workspace; d_param_grads is then
+ * REFNERF_NUM_PARAMS_EXT floats; f32 chains and the bf16x3 weight-gradient GEMM) */
+size_t refnerf_backward_workspace_bytes_basis(int32_t R, int32_t n_samples, int32_t ipe_groups);
+size_t refnerf_activation_workspace_bytes_basis(int32_t R, int32_t n_samples, int32_t ipe_groups);
 
 int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg,
                            const refnerf_rays *rays, int32_t R,

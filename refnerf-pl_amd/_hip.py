@@ -98,6 +98,10 @@ def lib():
         L.refnerf_level_forward_train.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
                                                   _FP, _FP, C.POINTER(LevelOut), _FP, C.c_size_t, _FP]
         L.refnerf_backward_workspace_bytes.restype = C.c_size_t
+        L.refnerf_backward_workspace_bytes_basis.restype = C.c_size_t
+        L.refnerf_backward_workspace_bytes_basis.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+        L.refnerf_activation_workspace_bytes_basis.restype = C.c_size_t
+        L.refnerf_activation_workspace_bytes_basis.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         L.refnerf_backward_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.refnerf_level_backward.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
                                              C.POINTER(LevelSaved), C.POINTER(LevelGrads), _FP, _FP, C.c_size_t, _FP]
@@ -233,7 +237,7 @@ def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, histo
     sd = sdist_in.to(torch.float32).contiguous()
     w = weights_in.to(torch.float32).contiguous()
     if save_activations:
-        act = torch.empty(lib().refnerf_activation_workspace_bytes(R, N), dtype=torch.uint8, device=dev)
+        act = torch.empty(lib().refnerf_activation_workspace_bytes_basis(R, N, cfg.ipe_groups), dtype=torch.uint8, device=dev)
         check(lib().refnerf_level_forward_train(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out),
                                                 ptr(act), act.numel(), stream_ptr()))
         res["activations"] = act
@@ -289,9 +293,9 @@ def mlp_forward(packed, cfg: LevelCfg, means, covs, viewdirs):
 _workspace = {}
 
 
-def backward_workspace(R: int, n_samples: int, device) -> torch.Tensor:
+def backward_workspace(R: int, n_samples: int, device, ipe_groups: int = 0) -> torch.Tensor:
     """Cached byte workspace for refnerf_level_backward (grown on demand, one per device)."""
-    need = lib().refnerf_backward_workspace_bytes(R, n_samples)
+    need = lib().refnerf_backward_workspace_bytes_basis(R, n_samples, ipe_groups)
     ws = _workspace.get(device)
     if ws is None or ws.numel() < need:
         _workspace[device] = None
@@ -333,8 +337,8 @@ def level_backward(packed, cfg: LevelCfg, rays: dict, saved: dict, g_r_rgb, g_we
             t = t.to(torch.float32).contiguous()
             keep.append(t)
             setattr(gr, name, t.data_ptr())
-    assert param_grads.dtype == torch.float32 and param_grads.is_contiguous() and param_grads.numel() == NUM_PARAMS
-    ws = backward_workspace(R, N, param_grads.device)
+    assert param_grads.dtype == torch.float32 and param_grads.is_contiguous() and param_grads.numel() == (NUM_PARAMS_EXT if cfg.ipe_groups > 1 else NUM_PARAMS)
+    ws = backward_workspace(R, N, param_grads.device, cfg.ipe_groups)
     check(lib().refnerf_level_backward(ptr(packed), C.byref(cfg), C.byref(rs), R, C.byref(sv), C.byref(gr),
                                        ptr(param_grads), ptr(ws), ws.numel(), stream_ptr()))
     return param_grads

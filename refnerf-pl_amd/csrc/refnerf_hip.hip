@@ -250,14 +250,14 @@ __global__ void pack_weights_ext(const float *__restrict__ P, const float *__res
     return;
   }
   const int idx = (which - 1) % (2 * EXT_GROUPS), L = idx / EXT_GROUPS, g = idx % EXT_GROUPS + 1;
-  const float *W = P + ext_w_off(L, g);      /* [256][96] */
+  const float *W = P + ext_w_off(L, g);      /* [256 rows, pitch EXT_K][96] */
   const bool live = g < groups;
   if (which <= 2 * EXT_GROUPS) {
     float *dst = out + pext_fwd_off(L, g);
     for (int e = e0; e < PEXT_FWD_FLOATS; e += stride) {
       const int step = e >> 9, rem = e & 511, ob = (rem >> 8) * 4 + (rem & 3), lane = (rem & 255) >> 2;
       const int h = lane >> 5, row = ob * 32 + (lane & 31), k = 2 * step + h;
-      dst[e] = live ? W[row * IPE_DIM + k] : 0.0f;
+      dst[e] = live ? W[row * EXT_K + k] : 0.0f;
     }
   } else {
     float *dst = out + pext_t_off(L, g);
@@ -265,7 +265,7 @@ __global__ void pack_weights_ext(const float *__restrict__ P, const float *__res
       const int ob = e & 3, lane = (e >> 2) & 63, step = e >> 8;
       const int h = lane >> 5, in_row = ob * 32 + (lane & 31), kb = step >> 4, r = step & 15;
       const int oo = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
-      dst[e] = (live && ob < 3) ? W[oo * IPE_DIM + in_row] : 0.0f;
+      dst[e] = (live && ob < 3) ? W[oo * EXT_K + in_row] : 0.0f;
     }
   }
 }
@@ -701,8 +701,9 @@ static int rays_per_wg(int N, int tile) {
 }
 
 namespace {
-struct BwdPlan { long long S, pitch; int slices, k_per_slice; size_t act_bytes, delta_off, part_off, seed_off, total; };
-BwdPlan bwd_plan(int R, int N) {
+struct BwdPlan { long long S, pitch; int slices, k_per_slice; size_t act_bytes, delta_off, part_off, seed_off, total, act_ext_off, part_ext_off; };
+/* groups > 1 (general IPE basis): the tail matrix of the groups' IPE features behind ACT, the tail's split-K partials behind the seeds */
+BwdPlan bwd_plan(int R, int N, int groups = 0) {
   BwdPlan p;
   p.S = (long long)R * N;
   p.pitch = (p.S + 127) / 128 * 128;
@@ -715,6 +716,12 @@ BwdPlan bwd_plan(int R, int N) {
   p.part_off = p.delta_off + sizeof(float) * (size_t)rn::DEL_ALLOC_ROWS * p.pitch;
   p.seed_off = p.part_off + sizeof(float) * (size_t)p.slices * rn::NUM_PARAMS;
   p.total = p.seed_off + sizeof(float) * (size_t)rn::NGS * p.pitch;
+  p.act_ext_off = p.act_bytes;
+  p.part_ext_off = p.total;
+  if (groups > 1) {
+    p.act_bytes += sizeof(float) * (size_t)rn::ACT_EXT_UNITS * p.pitch;
+    p.total += sizeof(float) * (size_t)p.slices * rn::EXT_PARAMS;
+  }
   return p;
 }
 }  // namespace
@@ -749,8 +756,6 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   if (cfg->ipe_groups < 0 || cfg->ipe_groups > rn::IPE_MAX_GROUPS) return fail(REFNERF_EINVAL, "ipe_groups must be in [0,7]%s");
   if (gbasis && cfg->precision != REFNERF_PREC_F32)
     return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1) runs in the REFNERF_PREC_F32 kernels only%s");
-  if (gbasis && cfg->training)
-    return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1): inference only in this build%s");
   /* training + BF16: the fp32-structure kernel with its MLP chains on bf16 MFMA (level_fwd_train_bf16c); d_packed is
    * the REFNERF_PREC_F32 image in that case (it carries the bf16 copies of the ops) */
   const bool train_bf = cfg->training && cfg->precision == REFNERF_PREC_BF16;
@@ -803,7 +808,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget of this precision mode%s");
   LDS_ATTR_ONCE(lds_attr(rn::level_fwd_f32), lds_attr(rn::level_fwd_train_f32), lds_attr(rn::level_fwd_train_bf16c), lds_attr(rn::level_fwd_train_f16x2c),
                 lds_attr(rn::level_fwd_bf16), lds_attr(rn::level_fwd_f16), lds_attr(rn::level_fwd_bf16_ring), lds_attr(rn::level_fwd_f16_ring),
-                lds_attr(rn::level_fwd_f16x2), lds_attr(rn::level_fwd_f16x2_ring), lds_attr(rn::level_fwd_f32_gb));
+                lds_attr(rn::level_fwd_f16x2), lds_attr(rn::level_fwd_f16x2_ring), lds_attr(rn::level_fwd_f32_gb), lds_attr(rn::level_fwd_train_f32_gb));
   rn::LevelArgs a;
   a.packed = d_packed;
   a.cfg = *cfg;
@@ -839,6 +844,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   else if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else if (train_bf) hipLaunchKernelGGL(rn::level_fwd_train_bf16c, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (train_split) hipLaunchKernelGGL(rn::level_fwd_train_f16x2c, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
+  else if (cfg->training && gbasis) hipLaunchKernelGGL(rn::level_fwd_train_f32_gb, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (cfg->training) hipLaunchKernelGGL(rn::level_fwd_train_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (gbasis) hipLaunchKernelGGL(rn::level_fwd_f32_gb, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else hipLaunchKernelGGL(rn::level_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
@@ -873,7 +879,7 @@ int refnerf_level_forward_train(const void *d_packed, const refnerf_level_cfg *c
   if (!cfg || !d_activations) return fail(REFNERF_EINVAL, "refnerf_level_forward_train: null pointer%s");
   if (!cfg->training) return fail(REFNERF_EINVAL, "refnerf_level_forward_train: cfg->training must be 1%s");
   if (R <= 0 || cfg->n_samples <= 1) return fail(REFNERF_EINVAL, "refnerf_level_forward_train: bad R / num_samples%s");
-  const BwdPlan plan = bwd_plan(R, cfg->n_samples);
+  const BwdPlan plan = bwd_plan(R, cfg->n_samples, cfg->ipe_groups);
   if (activations_bytes < plan.act_bytes)
     return fail(REFNERF_EINVAL, "refnerf_level_forward_train: activation buffer too small (see refnerf_activation_workspace_bytes)%s");
   return level_forward_impl(d_packed, cfg, rays, R, d_sdist_in, d_weights_in, out, (float *)d_activations, plan.pitch, stream);
@@ -942,6 +948,16 @@ size_t refnerf_activation_workspace_bytes(int32_t R, int32_t n_samples) {
   return bwd_plan(R, n_samples).act_bytes;
 }
 
+size_t refnerf_backward_workspace_bytes_basis(int32_t R, int32_t n_samples, int32_t ipe_groups) {
+  if (R <= 0 || n_samples <= 1 || ipe_groups < 0 || ipe_groups > rn::IPE_MAX_GROUPS) return 0;
+  return bwd_plan(R, n_samples, ipe_groups).total;
+}
+
+size_t refnerf_activation_workspace_bytes_basis(int32_t R, int32_t n_samples, int32_t ipe_groups) {
+  if (R <= 0 || n_samples <= 1 || ipe_groups < 0 || ipe_groups > rn::IPE_MAX_GROUPS) return 0;
+  return bwd_plan(R, n_samples, ipe_groups).act_bytes;
+}
+
 int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays, int32_t R,
                            const refnerf_level_saved *saved, const refnerf_level_grads *grads, float *d_param_grads,
                            void *d_workspace, size_t workspace_bytes, void *stream) {
@@ -963,7 +979,11 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   if (!rays->d_origins || !rays->d_directions || !rays->d_viewdirs || !rays->d_radii || !rays->d_near || !rays->d_far)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: null ray field%s");
   const int N = cfg->n_samples;
-  const BwdPlan plan = bwd_plan(R, N);
+  const bool gbasis = cfg->ipe_groups > 1;
+  if (cfg->ipe_groups < 0 || cfg->ipe_groups > rn::IPE_MAX_GROUPS) return fail(REFNERF_EINVAL, "ipe_groups must be in [0,7]%s");
+  if (gbasis && (cfg->precision != REFNERF_PREC_F32 || cfg->wgrad_mode != REFNERF_WGRAD_BF16X3 || saved->activations_format != REFNERF_ACT_F32))
+    return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1) trains with the f32 chains and the bf16x3 weight-gradient GEMM%s");
+  const BwdPlan plan = bwd_plan(R, N, cfg->ipe_groups);
   if (workspace_bytes < plan.total) return fail(REFNERF_EINVAL, "refnerf_level_backward: workspace too small (see refnerf_backward_workspace_bytes)%s");
   const int rpw = rays_per_wg(N, rn::T_TILE);
   size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + rpw * (N + 1) + 8);
@@ -975,7 +995,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
                 lds_attr(rn::wgrad_bf16x3_kernel<false, false>, rn::wb_lds(false, false)),
                 lds_attr(rn::wgrad_bf16x3_kernel<false, true>, rn::wb_lds(false, true)),
                 lds_attr(rn::wgrad_bf16x3_kernel<true, false>, rn::wb_lds(true, false)),
-                lds_attr(rn::wgrad_bf16x3_kernel<true, true>, rn::wb_lds(true, true)));
+                lds_attr(rn::wgrad_bf16x3_kernel<true, true>, rn::wb_lds(true, true)),
+                lds_attr(rn::wgrad_bf16x3_kernel<false, false, true>, rn::wb_lds(false, false)));
   char *ws = (char *)d_workspace;
   rn::BwdArgs a;
   a.packed = d_packed;
@@ -1049,7 +1070,19 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     hipLaunchKernelGGL(rn::wgrad_kernel, dim3(rn::WJOBS.tiles, slices), dim3(256), (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4, st, w);
   HIP_TRY(hipGetLastError());
   { int trc = timer_end(st, tslot); if (trc) return trc; }
-  hipLaunchKernelGGL(rn::wgrad_reduce, dim3(1024), dim3(256), 0, st, w.part, slices, d_param_grads);
+  hipLaunchKernelGGL(rn::wgrad_reduce, dim3(1024), dim3(256), 0, st, w.part, slices, d_param_grads, (int)rn::NUM_PARAMS);
+  if (gbasis) {
+    /* the tail of the parameter blob: dW_ext[L] = DELTA(layer 0 | 5) x (IPE features of groups 1..)^T, same kernel on the
+     * tail matrix behind ACT and its own job table, partials behind the seeds */
+    rn::WgradArgs we = w;
+    we.act = (const float *)((const char *)saved->d_activations + plan.act_ext_off);
+    we.a_units = rn::ACT_EXT_UNITS;
+    we.part = (float *)(ws + plan.part_ext_off);
+    if (plan.pitch > plan.S)
+      hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(we.act), rn::ACT_EXT_ROWS, rn::ACT_EXT_UNITS, plan.pitch, plan.S);
+    hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<false, false, true>), dim3(8 * ((slices + 7) / 8) * rn::WJOBS_EXT.tiles), dim3(256), rn::wb_lds(false, false), st, we, slices);
+    hipLaunchKernelGGL(rn::wgrad_reduce, dim3(256), dim3(256), 0, st, we.part, slices, d_param_grads + rn::NUM_PARAMS, (int)rn::EXT_PARAMS);
+  }
   HIP_TRY(hipGetLastError());
   return REFNERF_OK;
 }

@@ -178,13 +178,15 @@ constexpr Packed PACKED = make_packed();
  * groups 1..G-1 are run through the same 96-row X tile one after the other, each with its own [256][96] weight block of
  * layers 0 and 5 accumulating into the layer's output.  Feature k of a group = 48 (cos block) + 3 (degree) + direction in
  * group, i.e. the canonical order with the group's directions.
- *   parameters: the canonical blob + a tail  W_ext[layer L = 0 (layer 0), 1 (layer 5)][g - 1][256][96]   (NUM_PARAMS_EXT)
+ *   parameters: the canonical blob + a tail  W_ext[layer L = 0 (layer 0), 1 (layer 5)][256 rows][(g - 1) 96 + k]  (NUM_PARAMS_EXT;
+ *               row-major with 576 columns, so that the tail's weight gradient is one GEMM job per layer)
  *   fp32 image:  PACKED.total floats + [basis 64][12 forward group ops, [48 steps][2][64][4]][12 transposed, [128][64][4]] */
 constexpr int IPE_MAX_GROUPS = 7;
 constexpr int EXT_GROUPS = IPE_MAX_GROUPS - 1;
-constexpr int EXT_W = WIDTH * IPE_DIM;
-constexpr int NUM_PARAMS_EXT = NUM_PARAMS + 2 * EXT_GROUPS * EXT_W;
-constexpr int ext_w_off(int L, int g) { return NUM_PARAMS + (L * EXT_GROUPS + (g - 1)) * EXT_W; }
+constexpr int EXT_K = EXT_GROUPS * IPE_DIM;                  /* 576 tail columns per row */
+constexpr int EXT_PARAMS = 2 * WIDTH * EXT_K;
+constexpr int NUM_PARAMS_EXT = NUM_PARAMS + EXT_PARAMS;
+constexpr int ext_w_off(int L, int g) { return NUM_PARAMS + L * WIDTH * EXT_K + (g - 1) * IPE_DIM; }   /* + row * EXT_K + k */
 constexpr int PEXT_BASIS = PACKED.total;
 constexpr int PEXT_FWD = PEXT_BASIS + 64;
 constexpr int PEXT_FWD_FLOATS = (IPE_DIM / 2) * 64 * 8;
@@ -193,6 +195,9 @@ constexpr int PEXT_T_FLOATS = REG_STEPS * 64 * 4;
 constexpr int PACKED_EXT_TOTAL = PEXT_T + 2 * EXT_GROUPS * PEXT_T_FLOATS + 8 * 64 * 8;
 constexpr int pext_fwd_off(int L, int g) { return PEXT_FWD + (L * EXT_GROUPS + (g - 1)) * PEXT_FWD_FLOATS; }
 constexpr int pext_t_off(int L, int g) { return PEXT_T + (L * EXT_GROUPS + (g - 1)) * PEXT_T_FLOATS; }
+/* training: the IPE features of groups 1..G-1 (the weight-gradient operand of the tail) are a second blocked matrix
+ * behind ACT in the activations buffer: row (g - 1) 96 + k, ACT_EXT_UNITS units per 64-sample block (odd, as ACT's) */
+constexpr int ACT_EXT_ROWS = EXT_K, ACT_EXT_UNITS = EXT_K + 1;
 
 /* ---------------- backward workspace (weight-gradient operands) ----------------
  * The backward kernel writes, for every sample s, the input of every linear

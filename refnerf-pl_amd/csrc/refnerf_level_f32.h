@@ -807,6 +807,50 @@ __device__ __forceinline__ void density_normals(__amdgpu_buffer_rsrc_t rs, int l
 }
 
 
+/* The same for a general IPE basis (G groups of three directions): each group's 96 IPE-gradient rows come from its own
+ * transposed block (group 0: the canonical TOP ops, groups 1..: the image tail), go through the IPE with the group's lifted
+ * mean / variance (`lift(g, lm, lv)`), and the three per-direction derivatives are carried back to world space with the
+ * basis rows (the transpose of coord.py:131's `mean @ basis`). */
+template <typename Lift>
+__device__ __forceinline__ void density_normals_gb(__amdgpu_buffer_rsrc_t rs, int lane, int h, v16f (&in)[8], v16f (&out)[8],
+                                                   unsigned (&M)[8][4], const float *xl, int groups, const float *basis, Lift &&lift,
+                                                   float nrm_out[3]) {
+  load_acc<8>(rs, PACKED.wd_off, h, out);
+  masked_into(out, in, M[7]);
+  float gw[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+  for (int i = 7; i >= 0; --i) {
+    if (i == 5 || i == 0) {
+#pragma unroll 1
+      for (int gq = 0; gq < groups; ++gq) {
+        v16f gi[3];
+        const int a_off = gq == 0 ? PACKED.top[i == 5 ? TOP_SP5_IPE : TOP_SP0].a_off : pext_t_off(i == 5 ? 1 : 0, gq);
+        gemm_op<3, 4, true, false>(rs, a_off, 0, lane, h, in, gi, xl, 0);
+        float lm[3], lv[3], gl[3] = {0.0f, 0.0f, 0.0f};
+        lift(gq, lm, lv);
+        ipe_vjp_accum(gi, lm, lv, h, gl);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gw[c] += gl[b] * basis[9 * gq + 3 * b + c];
+      }
+    }
+    if (i > 0) {
+      gemm_op<8, 8, true, false>(rs, PACKED.top[i - 1].a_off, 0, lane, h, in, out, xl, 0);
+#pragma unroll
+      for (int l = 7; l > 0; --l)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[l][q] = M[l - 1][q];
+      masked_into(out, in, M[7]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) gw[c] += __shfl_xor(gw[c], 32, 64);
+  const float ng = sqrtf(fmaxf((gw[0] * gw[0] + gw[1] * gw[1]) + gw[2] * gw[2], EPS32));
+#pragma unroll
+  for (int c = 0; c < 3; ++c) nrm_out[c] = -(gw[c] / ng);
+}
+
 /* density_normals on the bf16 chains: same VJP, deltas rounded to bf16 once per layer */
 __device__ __forceinline__ void density_normals_bf16(__amdgpu_buffer_rsrc_t rs, int lane, int h, int wave, char *ring, v16f (&out)[8], v4uu (&pk)[16],
                                                      unsigned (&M)[8][4], const float *X, int col, float nrm_out[3]) {
@@ -951,8 +995,9 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     }
     /* P1: conical frustum -> lifted Gaussian -> IPE (half 0: sin, half 1: cos) */
     float lm[3], lv[3];
-    /* general basis: the IPE features of direction group gq into the X tile (and, training, into their ACT rows) */
-    auto ipe_group = [&](int gq) {
+    /* general basis: lifted mean / variance of this lane's sample on the three directions of group gq (recomputed from
+     * the ray where it is needed: nothing of it stays live across the trunk) */
+    auto lift_group = [&](int gq, float (&gm)[3], float (&gv)[3]) {
       float og[3], dg[3], mean[3], cov[9];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -962,21 +1007,37 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       const float *td = TD + (valid ? rl : 0) * (N + 1);
       cast_sample_full(og, dg, A.rays.d_radii[rayc], td[valid ? si : 0], td[valid ? si + 1 : 1], cfg.ray_shape, mean, cov);
       const float *bs = reinterpret_cast<const float *>(A.packed) + PEXT_BASIS + 9 * gq;
-      float gm[3], gv[3];
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         const float bb[3] = {bs[3 * b], bs[3 * b + 1], bs[3 * b + 2]};
         lift_onto(mean, cov, bb, gm[b], gv[b]);
         if (cfg.disable_integration) gv[b] = 0.0f;
       }
+    };
+    /* ... and its IPE features into the X tile; `keep` (training, first use): also into their rows of ACT (group 0) / of
+     * the tail matrix behind ACT (groups 1.., refnerf_layout.h: ACT_EXT_*) for the weight-gradient GEMM */
+    auto ipe_group = [&](int gq, bool keep) {
+      float gm[3], gv[3];
+      lift_group(gq, gm, gv);
+      float *act_ext = A.act + (size_t)ACT_ALLOC_ROWS * (size_t)act_pitch;
+      const size_t xcol = (size_t)rb_col((long long)gsx, ACT_EXT_UNITS);
 #pragma unroll 1
       for (int j = 0; j < 16; ++j)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) X[(48 * h + j * 3 + b) * T_TILE + col] = ipe_feature(gm[b], gv[b], j, h);
+        for (int b = 0; b < 3; ++b) {
+          const float fe = ipe_feature(gm[b], gv[b], j, h);
+          X[(48 * h + j * 3 + b) * T_TILE + col] = fe;
+          if constexpr (TRAIN) {
+            if (keep && save) {
+              if (gq == 0) store_row1(A.act, rpitch, ACT_IPE + 48 * h + j * 3 + b, rcol, fe);
+              else store_row1(act_ext, rpitch, (gq - 1) * IPE_DIM + 48 * h + j * 3 + b, xcol, fe);
+            }
+          }
+        }
     };
     if constexpr (GB) {
       lm[0] = lm[1] = lm[2] = 0.0f; lv[0] = lv[1] = lv[2] = 0.0f;
-      ipe_group(0);
+      ipe_group(0, true);
     } else {
       if constexpr (STAGE) {
         /* coord.lift_and_diagonalize (coord.py:129-133) with the octahedron/1 basis:
@@ -1028,7 +1089,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 #pragma unroll 1
       for (int gq = 1; gq < cfg.ipe_groups; ++gq) {
         wave_sync();                               /* the previous group's X reads are done */
-        ipe_group(gq);
+        ipe_group(gq, L == 0);
         wave_sync();
         gemm_op<8, 8, false, false, NoStepHook, rn::PF, true>(rs, pext_fwd_off(L, gq), 0, lane, h, in, out, xl, IPE_DIM / 2);
       }
@@ -1066,11 +1127,13 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
                                                             act_hook(ACT_SP + (op - 1) * WIDTH));
         else gemm_chain_bf16_shared<true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, wave, pk, out,
                                           reinterpret_cast<char *>(smem) + A.ring_off, act_hook(ACT_SP + (op - 1) * WIDTH));
-      } else if constexpr (TRAIN && !STAGE)
+      } else if constexpr (TRAIN && !STAGE) {
+        if constexpr (GB) { if (op == 5) { wave_sync(); ipe_group(0, false); wave_sync(); } }
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps,
                             RowStoreHook(A.act, rpitch, ACT_SP + (op - 1) * WIDTH, rcol, h, save));
-      else {
-        if constexpr (GB) { if (op == 5) { wave_sync(); ipe_group(0); wave_sync(); } }     /* X holds the last group of layer 0 */
+        if constexpr (GB) { if (op == 5) more_groups(1); }
+      } else {
+        if constexpr (GB) { if (op == 5) { wave_sync(); ipe_group(0, false); wave_sync(); } }     /* X holds the last group of layer 0 */
         gemm_op<8, 8, true>(rs, PACKED.op[op].a_off, PACKED.op[op].b_off, lane, h, in, out, xl, PACKED.op[op].lds_steps);
         if constexpr (GB) { if (op == 5) more_groups(1); }
       }
@@ -1119,6 +1182,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     RN_STAMP(A, 5);
     if constexpr (SPC) density_normals_split(rs, lane, h, out, pk, pl, M, lm, lv, sh.normals);
     else if constexpr (BFC) density_normals_bf16(rs, lane, h, wave, reinterpret_cast<char *>(smem) + A.ring_off, out, pk, M, X, col, sh.normals);
+    else if constexpr (TRAIN && GB) density_normals_gb(rs, lane, h, in, out, M, xl, cfg.ipe_groups, reinterpret_cast<const float *>(A.packed) + PEXT_BASIS, lift_group, sh.normals);
     else if constexpr (TRAIN) density_normals(rs, lane, h, in, out, M, lm, lv, xl, sh.normals);
 
     RN_STAMP(A, 6);
@@ -1234,6 +1298,7 @@ __global__ __launch_bounds__(NTHREADS) void level_fwd_train_bf16c(const LevelArg
 __global__ __launch_bounds__(NTHREADS) void level_fwd_train_f16x2c(const LevelArgs A) { level_fwd_f32_body<true, false, false, true>(A); }
 /* eval forward with a general IPE basis (cfg.ipe_groups > 1: icosahedron / tesselated bases) */
 __global__ __launch_bounds__(NTHREADS) void level_fwd_f32_gb(const LevelArgs A) { level_fwd_f32_body<false, false, false, false, true>(A); }
+__global__ __launch_bounds__(NTHREADS) void level_fwd_train_f32_gb(const LevelArgs A) { level_fwd_f32_body<true, false, false, false, true>(A); }
 /* MLP.__call__ stage entry (eval / training) */
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false, true>(A); }
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_train_f32(const LevelArgs A) { level_fwd_f32_body<true, true>(A); }

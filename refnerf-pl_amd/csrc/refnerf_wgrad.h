@@ -61,6 +61,23 @@ constexpr WJobs make_wjobs() {
   return J;
 }
 constexpr WJobs WJOBS = make_wjobs();
+/* general IPE basis: the tail W_ext[L][256][EXT_K] (refnerf_layout.h) = deltas of layer 0 / 5 x the tail matrix's 576 rows;
+ * offsets relative to the tail (its partials and its part of the gradient blob are addressed from NUM_PARAMS on) */
+constexpr WJobs make_wjobs_ext() {
+  WJobs J{};
+  int t = 0;
+  for (int L = 0; L < 2; ++L) {
+    WJob j{};
+    j.d_row = DEL_SP + (L ? 5 : 0) * WIDTH; j.n_out = WIDTH; j.a_row = 0; j.n_in = EXT_K; j.w_off = L * WIDTH * EXT_K; j.ld = EXT_K; j.b_off = -1;
+    j.tiles_n = (EXT_K + WG_TN - 1) / WG_TN;
+    j.tile0 = t;
+    t += ((WIDTH + WG_TM - 1) / WG_TM) * j.tiles_n;
+    J.job[L] = j;
+  }
+  J.n = 2; J.tiles = t;
+  return J;
+}
+constexpr WJobs WJOBS_EXT = make_wjobs_ext();
 
 struct HeadRows { int w[HROWS], b[HROWS]; };
 constexpr HeadRows make_head_rows() {
@@ -205,10 +222,10 @@ __global__ void wgrad_zero_tail(float *m, int rows, int units, long long pitch, 
 }
 
 /* grads[i] += sum over slices (fixed order) of PART[slice][i] */
-__global__ void wgrad_reduce(const float *__restrict__ part, int slices, float *__restrict__ grads) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NUM_PARAMS; i += gridDim.x * blockDim.x) {
+__global__ void wgrad_reduce(const float *__restrict__ part, int slices, float *__restrict__ grads, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float s = 0.0f;
-    for (int c = 0; c < slices; ++c) s += part[(size_t)c * NUM_PARAMS + i];
+    for (int c = 0; c < slices; ++c) s += part[(size_t)c * n + i];
     grads[i] += s;
   }
 }

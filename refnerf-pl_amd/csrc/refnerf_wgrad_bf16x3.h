@@ -40,8 +40,10 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, uns
 
 /* grid = 8 * ceil(slices / 8) * WJOBS.tiles workgroups of 256 threads (waves 2x2 over the 128x128 tile) */
 /* D16 / A16: that operand is a matrix of bf16 rows (written by the bf16-chain kernels): read as is, its low half is 0 */
-template <bool D16, bool A16>
+/* EXT: the tail job table of a general IPE basis (WJOBS_EXT; partials [slices][EXT_PARAMS]) */
+template <bool D16, bool A16, bool EXT = false>
 __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, int slices) {
+  constexpr const WJobs &JT = EXT ? WJOBS_EXT : WJOBS;
   extern __shared__ __attribute__((aligned(16))) char wbs[];
   char *Dh = wbs, *Dl = wbs + WB_TILE, *Ah = wbs + (D16 ? 1 : 2) * WB_TILE, *Al = Ah + WB_TILE;   /* Dl / Al: only for fp32 operands */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,12 +51,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
   const int wm = wave >> 1, wn = wave & 1;
   /* XCD-aware decode: id % 8 = XCD; that XCD walks the tiles of slices xcd, xcd + 8, ... one slice at a time */
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int tile = q % WJOBS.tiles, slice = (q / WJOBS.tiles) * 8 + xcd;
+  const int tile = q % JT.tiles, slice = (q / JT.tiles) * 8 + xcd;
   if (slice >= slices) return;
   int ji = 0;
 #pragma unroll 1
-  for (int j = 1; j < WJOBS.n; ++j) if (tile >= WJOBS.job[j].tile0) ji = j;
-  const WJob J = WJOBS.job[ji];
+  for (int j = 1; j < JT.n; ++j) if (tile >= JT.job[j].tile0) ji = j;
+  const WJob J = JT.job[ji];
   const int tl = tile - J.tile0;
   const int tm = tl / J.tiles_n, tn = tl - tm * J.tiles_n;
   const long long k_begin = (long long)slice * A.k_per_slice;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(const WgradArgs A, in
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  float *part = A.part + (size_t)slice * NUM_PARAMS;
+  float *part = A.part + (size_t)slice * (EXT ? EXT_PARAMS : NUM_PARAMS);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll

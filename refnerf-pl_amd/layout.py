@@ -86,7 +86,7 @@ def posenc_slots(deg_view):
 
 # A general IPE basis (NerfMLP.basis_shape / basis_subdivisions: n_basis = 3 G directions, G <= 7) widens spatial_net.0 / .5
 # to 32 n_basis IPE columns.  The kernels take them as G groups of three directions (csrc/refnerf_layout.h): group 0 in the
-# canonical blob's 96 IPE columns, groups 1.. in a TAIL behind the canonical blob, W_ext[layer 0 | 5][g - 1][256][96]; column
+# canonical blob's 96 IPE columns, groups 1.. in a TAIL behind the canonical blob, W_ext[layer 0 | 5][256][96 (g - 1) + k]; column
 # 16 n c + n j + d of the true weight (cos block c, degree j, direction d; coord.py:102-126) = column 48 c + 3 j + d % 3 of
 # group d // 3.
 IPE_MAX_GROUPS = 7
@@ -103,7 +103,7 @@ def ipe_column_positions(spec, layer_slot, col0, n_basis):
     g, k = d // 3, (IPE_DIM // 2) * c + 3 * j + d % 3
     rows = np.arange(WIDTH, dtype=np.int64)[:, None]
     in_canon = spec.w_off + rows * spec.in_dim + (col0 + k.reshape(-1))[None, :]
-    in_tail = NUM_PARAMS + ((layer_slot * EXT_GROUPS + (g.reshape(-1) - 1))[None, :] * WIDTH + rows) * IPE_DIM + k.reshape(-1)[None, :]
+    in_tail = NUM_PARAMS + (layer_slot * WIDTH + rows) * (EXT_GROUPS * IPE_DIM) + ((g.reshape(-1) - 1) * IPE_DIM + k.reshape(-1))[None, :]
     return np.where(g.reshape(-1)[None, :] == 0, in_canon, in_tail)
 
 

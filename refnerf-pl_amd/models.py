@@ -487,7 +487,7 @@ class _LevelFunction(torch.autograd.Function):
         if mlp._packed_key != ctx.packed_key:
             raise _hip.HipLibraryError("parameters changed between the training forward and backward of a level")
         g = {k: v for k, v in zip(ctx.diff_keys, gouts) if v is not None}
-        grads = torch.zeros(layout.NUM_PARAMS, dtype=torch.float32, device=ctx.saved["sdist"].device)
+        grads = torch.zeros(mlp.canon_size, dtype=torch.float32, device=ctx.saved["sdist"].device)
         g_rgb = g.get("r_rgb")
         if g_rgb is None:
             g_rgb = torch.zeros_like(ctx.saved["sdist"][:, :3])
@@ -628,9 +628,9 @@ class Model(nn.Module):
         train_prec = getattr(cfg, "hip_train_precision", "f32")
         if train_prec not in _TRAIN_FWD_PREC:      # 'f16' is an inference mode of the level kernel
             raise ValueError("Config.hip_train_precision must be 'f32', 'f16x2' or 'bf16'")
-        if mlp.ipe_groups and (self.training or prec != "f32"):
+        if mlp.ipe_groups and (train_prec if self.training else prec) != "f32":
             raise ValueError(f"IPE basis '{mlp.basis_shape}' / {mlp.basis_subdivisions} ({mlp.ipe_basis_dirs} directions): the fused kernels run a "
-                             "general basis in the f32 inference mode only (Config.hip_precision = 'f32', model.eval()); training and "
+                             "general basis in the f32 modes only (Config.hip_precision / hip_train_precision / hip_bwd_precision = 'f32'); "
                              "the 16-bit modes are built for 'octahedron' / 1")
         wgrad = {"f32": _hip.WGRAD_F32, "bf16x3": _hip.WGRAD_BF16X3}.get(getattr(cfg, "hip_wgrad_mode", "bf16x3"))
         if wgrad is None:
@@ -699,6 +699,8 @@ class Model(nn.Module):
                 bwd_prec = getattr(self.config, "hip_bwd_precision", "f32")
                 if bwd_prec not in _TRAIN_FWD_PREC:
                     raise ValueError("Config.hip_bwd_precision must be 'f32', 'f16x2' or 'bf16'")
+                if mlp.ipe_groups and (bwd_prec != "f32" or cfg.wgrad_mode != _hip.WGRAD_BF16X3):
+                    raise ValueError("a general IPE basis trains with Config.hip_bwd_precision = 'f32' and hip_wgrad_mode = 'bf16x3'")
                 if bwd_prec == "f16x2" and getattr(self.config, "hip_train_precision", "f32") == "bf16":
                     raise ValueError("Config.hip_bwd_precision = 'f16x2' reads fp32 activation rows: use hip_train_precision 'f32' or 'f16x2'")
                 flat_mode = bool(getattr(self.config, "hip_flat_grads", False))

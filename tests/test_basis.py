@@ -42,13 +42,13 @@ def test_basis_layout_is_a_permutation_of_the_extended_blob():
     row, c, j, d = 7, 1, 11, 13
     pos = idx[s0.w_off + row * 672 + 336 * c + 21 * j + d]
     g, k = d // 3, 48 * c + 3 * j + d % 3
-    assert pos == layout.NUM_PARAMS + ((g - 1) * 256 + row) * 96 + k
+    assert pos == layout.NUM_PARAMS + row * 576 + (g - 1) * 96 + k
     assert idx[s0.w_off + row * 672 + 336 * c + 21 * j + 2] == c0.w_off + row * 96 + 48 * c + 3 * j + 2
     assert idx[s5.w_off + row * 928 + 100] == layout.SPEC_BY_NAME["spatial_net.5"].w_off + row * (256 + 96) + 100
     pos5 = idx[s5.w_off + row * 928 + 256 + 336 * c + 21 * j + d]
-    assert pos5 == layout.NUM_PARAMS + ((6 + g - 1) * 256 + row) * 96 + k
+    assert pos5 == layout.NUM_PARAMS + (256 + row) * 576 + (g - 1) * 96 + k
     specs6, idx6 = layout.variant_layout(n_basis=6)
-    assert specs6[0].in_dim == 192 and idx6.max() < layout.NUM_PARAMS + 256 * 96 or idx6.max() < layout.NUM_PARAMS_EXT
+    assert specs6[0].in_dim == 192 and idx6.max() < layout.NUM_PARAMS_EXT
     with pytest.raises(ValueError):
         layout.variant_layout(n_basis=46)          # icosahedron / 3: beyond the seven groups
 
@@ -115,3 +115,61 @@ def test_general_basis_eval_vs_reference(name):
         cfg.hip_precision = prec
         with pytest.raises(ValueError, match="basis"):
             model(rays, 1.0, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flat", [False, True])
+def test_general_basis_training_step_vs_reference(flat):
+    """one training step with the 21-direction basis (f32 chains): the reference's losses and autograd gradients of all 46
+    tensors in their TRUE shapes (spatial_net.0 [256, 672], spatial_net.5 [256, 928]) -- the density-gradient normals go
+    through every direction group's transposed block, the tail's weight gradient through its own GEMM job table"""
+    import torch
+    from refnerf_pl_amd import _hip, train_utils, utils
+    _hip.require_device()
+    g = load_golden("model_ico_train")
+    model, cfg = _basis_model(g, ["Config.hip_flat_grads = True"] if flat else [])
+    mlp = model.nerf_mlp
+    rays = utils.rays_from_dict(rays_from_golden(g), DEV)
+    model.train()
+    renderings, history = model(rays, 1.0, True)
+    for L in range(2):
+        for k in HIST_KEYS:
+            a = g[f"L{L}_h_{k}"]
+            x = history[L][k].detach().cpu().numpy().reshape(a.shape)
+            tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 2e-6)
+            if L > 0 and k not in ("sdist", "weights"):
+                tol = max(tol, 5e-5)
+            np.testing.assert_allclose(x, a, rtol=0, atol=tol, err_msg=f"L{L} {k}")
+        # density-gradient normals: ill-conditioned where the gradient is tiny -- bulk tight, tail loose (the bars of
+        # tests/test_hip_parity.py::test_training_forward_density_normals against the reference)
+        nerr = np.abs(history[L]["normals"].detach().cpu().numpy() - g[f"L{L}_h_normals"]).max(-1)
+        print(f"L{L} density normals vs reference: median {np.median(nerr):.1e}, {100 * np.mean(nerr < 1e-3):.1f} % below 1e-3")
+        assert np.median(nerr) < 1e-4 and np.mean(nerr < 1e-3) > 0.97
+        assert np.abs(renderings[L]["rgb"].detach().cpu().numpy() - g[f"L{L}_r_rgb"]).max() <= 1e-5
+    batch = utils.Batch(rays=rays, rgb=np.asarray(g["gt_rgb"], np.float32))
+    total, terms, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
+    assert float(terms["data"].detach()) == pytest.approx(float(g["loss_data"]), rel=1e-5)
+    assert float(terms["orientation"].detach()) == pytest.approx(float(g["loss_orientation"]), rel=2e-4)
+    assert float(terms["predicted_normals"].detach()) == pytest.approx(float(g["loss_normal"]), rel=2e-4)
+    assert float(total.detach()) == pytest.approx(float(g["loss_total"]), rel=1e-5)
+    total.backward()
+    if flat:
+        grads = mlp.flat_parameter().grad.cpu().numpy()
+    else:
+        grads = np.zeros(mlp.num_params, np.float32)
+        for spec, lin in mlp._named_linears():
+            assert tuple(lin.weight.grad.shape) == (spec.out_dim, spec.in_dim), spec.name
+            grads[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = lin.weight.grad.reshape(-1).cpu().numpy()
+            grads[spec.b_off:spec.b_off + spec.out_dim] = lin.bias.grad.cpu().numpy()
+    ref = g["grads_sub"]
+    rel = float(np.linalg.norm(grads[::61] - ref) / np.linalg.norm(ref))
+    norms = g["grads_tensor_l2"]
+    worst = max(abs(np.linalg.norm(grads[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim]) / norms[i, 0] - 1.0) for i, sp in enumerate(mlp.specs))
+    print(f"model_ico_train: gradient rel-L2 vs reference {rel:.2e}, worst tensor-norm error {worst:.2e}")
+    # (2e-4 for the octahedron fixtures; here 2.0e-4: 0.8 % of this fixture's level-1 samples have an ill-conditioned density
+    # normal, see above, which enters the orientation / predicted-normal terms)
+    assert rel < 5e-4 and worst < 2e-3
+    # the chain modes a general basis is not built for say so
+    cfg.hip_train_precision = "f16x2"
+    with pytest.raises(ValueError, match="basis"):
+        model(rays, 1.0, True)
