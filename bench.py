@@ -333,6 +333,35 @@ def other_configs(args, dev, sync, max_over_ranks):
 
     eval_leg("C3", dict(CONFIGS["C3"]), (args.precision, "bf16") if args.precision != "bf16" else ("bf16", "f16x2"), 5, 2, False)
     eval_leg("C4_shard", dict(CONFIGS["C4"], rays=512), (args.precision,), 20, 5, not args.no_graph)
+    # the reference's constructor-default IPE basis ('icosahedron' / 2: 21 directions, 672 IPE features) at
+    # the C2 shape: the f32 kernel with seven direction groups through layers 0 and 5 (FLOPs counted accordingly)
+    try:
+        from refnerf_pl_amd import configs, models, synthetic
+        spec = dict(CONFIGS["C2"])
+        configs.clear_config()
+        configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", spec["gin"])], [
+            f"Model.num_prop_samples = {spec['samples']}", f"Model.num_nerf_samples = {spec['samples']}",
+            "Config.hip_precision = 'f32'", "NerfMLP.basis_shape = 'icosahedron'", "NerfMLP.basis_subdivisions = 2"])
+        model = models.construct_model(None, configs.Config()).to(dev).eval()
+        model.nerf_mlp.load_flat_params(synthetic.make_basis_params(n_basis=21, **spec["params"]))
+        R, N = spec["rays"], spec["samples"]
+        rays = utils.rays_from_dict(make_rays(spec, R, seed=1), dev)
+
+        def ico_step():
+            with torch.no_grad():
+                return model(rays, 1.0, True)
+        el, k, l, o = timed_steps(ico_step, 5, 2, True, sync, max_over_ranks)
+        assert torch.isfinite(o[0][-1]["rgb"]).all()
+        flop = R * N * (FLOP_PER_SAMPLE + 2 * 2 * 256 * 576)        # + the 6 extra direction groups of layers 0 and 5
+        out["C2_icosahedron_basis"] = {
+            "workload": spec["workload"] + " with NerfMLP.basis_shape = 'icosahedron', basis_subdivisions = 2 (the reference's constructor default)",
+            "rays": R, "samples_per_level": N,
+            "f32": {"value": R * N * 2 * 5 / el, "unit": "ray-samples/s", "ms_per_step": 1e3 * el / 5, "steps": 5, "dtype": "f32",
+                    "roofline": mfma_roofline("f32", "rn::level_fwd_f32_gb", k, l, flop, "C2", R, N)}}
+        del model, rays
+        torch.cuda.empty_cache()
+    except Exception as e:      # never lose the headline line over an extra leg
+        out["C2_icosahedron_basis"] = {"error": repr(e)}
     if not args.no_train:
         spec = dict(CONFIGS["C5"], rays=2048)
         model, cfg, _ = build_model(a, spec, dev)
