@@ -67,6 +67,28 @@ def test_model_constructs_with_the_reference_default_basis():
     configs.clear_config()
 
 
+@pytest.mark.parametrize("name", ["model_ico_eval", "model_ico1_eval"])
+def test_cpu_oracle_with_general_basis_vs_reference(name):
+    """the unfused ATen restatement of the level loop (oracle/torch_path.py, test infrastructure) with the icosahedron bases
+    against the REFERENCE's outputs: the CPU-side pin of the general-basis path (the C oracle has the octahedron only)"""
+    from oracle import torch_path as T
+    from refnerf_pl_amd import geopoly, layout, synthetic
+    g = load_golden(name)
+    n_basis = int(g["n_basis"])
+    pk = g["param_kw"]
+    specs, idx = layout.variant_layout(n_basis=n_basis)
+    true_blob = synthetic.make_basis_params(seed=int(pk[0]), n_basis=n_basis, bias_scale=float(pk[1]), sharpen=float(pk[2]))[idx]
+    basis = geopoly.generate_basis("icosahedron", 2 if n_basis == 21 else 1)
+    assert np.array_equal(basis, g["basis"])
+    out = T.model_forward(true_blob, rays_from_golden(g), num_prop_samples=128, num_nerf_samples=128, specs=specs, basis=basis)
+    for L in range(2):
+        same = np.abs(out[L]["sdist"] - g[f"L{L}_h_sdist"]).max(-1) < 2e-6          # level-1 positions may move by an ulp
+        assert same.mean() > 0.9
+        np.testing.assert_allclose(out[L]["r_rgb"][same], g[f"L{L}_r_rgb"][same], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(out[L]["weights"][same], g[f"L{L}_h_weights"][same], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(out[L]["r_acc"][same], g[f"L{L}_r_acc"][same], rtol=0, atol=5e-6)
+
+
 def _basis_model(g, extra=()):
     from refnerf_pl_amd import configs, models, synthetic, utils
     configs.clear_config()
