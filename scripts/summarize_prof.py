@@ -26,12 +26,13 @@ KERNELS = {"level_fwd_bf16": "rn::level_fwd_bf16", "level_fwd_f32": "rn::level_f
            "level_fwd_train_bf16c": "rn::level_fwd_train_bf16c", "level_fwd_f16": "rn::level_fwd_f16",
            "bwd_seed_kernel": "rn::bwd_seed_kernel", "wgrad_reduce": "rn::wgrad_reduce",
            "level_fwd_bf16_ring": "rn::level_fwd_bf16_ring", "level_fwd_f16_ring": "rn::level_fwd_f16_ring",
-           "level_fwd_f16x2": "rn::level_fwd_f16x2", "level_fwd_f16x2_ring": "rn::level_fwd_f16x2_ring"}
+           "level_fwd_f16x2": "rn::level_fwd_f16x2", "level_fwd_f16x2_ring": "rn::level_fwd_f16x2_ring",
+           "level_fwd_train_f16x2c": "rn::level_fwd_train_f16x2c", "level_bwd_f16x2c": "rn::level_bwd_f16x2c"}
 
 rows = list(csv.reader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
 with open(os.path.join(dst, f"kernel_stats{sfx}.csv"), "w", newline="") as f:
     w = csv.writer(f)
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-image{bench_args}\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-image --no-other-configs{bench_args}\n")
     w.writerow(rows[0])
     for r in rows[1:]:
         if r and (r[0].startswith("rn::") or r[0].startswith("void rn::")):
@@ -49,7 +50,7 @@ for path in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
 for short, counters in stats.items():
     with open(os.path.join(dst, f"pmc_{short}{sfx}.csv"), "w") as f:
         g = meta[short]
-        f.write(f"# rocprofv3 --pmc passes (separate runs) of: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-image{bench_args}\n")
+        f.write(f"# rocprofv3 --pmc passes (separate runs) of: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-image --no-other-configs{bench_args}\n")
         f.write(f"# kernel {KERNELS[short]}, grid {g[0]}, wg {g[1]}, VGPR {g[2]}, AGPR {g[3]}, SGPR {g[4]}, scratch {g[5]}\n")
         f.write("counter,dispatches,mean_per_dispatch,min,max\n")
         for c in sorted(counters):
