@@ -195,3 +195,53 @@ def test_general_basis_training_step_vs_reference(flat):
     cfg.hip_train_precision = "f16x2"
     with pytest.raises(ValueError, match="basis"):
         model(rays, 1.0, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,subdiv,n_rays,n_prop,n_nerf,gin", [("icosahedron", 1, 37, 96, 64, "refnerf_blender.gin"),
+                                                                  ("octahedron", 2, 29, 48, 200, "refnerf_llff.gin"),
+                                                                  ("icosahedron", 2, 130, 128, 256, "refnerf_blender.gin")])
+def test_general_basis_ragged_shapes_vs_cpu_oracle(shape, subdiv, n_rays, n_prop, n_nerf, gin):
+    """shapes and bases beyond the fixtures (ray counts that do not fill a workgroup, sample counts that do not tile the
+    128-sample pass, 6 / 9 / 21 directions, the LLFF render-time map) against the CPU oracle with the same basis (itself
+    pinned by the reference's icosahedron fixtures above); training-mode forward = the same values + density normals"""
+    import torch
+    from oracle import torch_path as T
+    from refnerf_pl_amd import _hip, configs, geopoly, layout, models, synthetic, utils
+    _hip.require_device()
+    basis = geopoly.generate_basis(shape, subdiv)
+    n_basis = basis.shape[0]
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", gin)], [
+        f"NerfMLP.basis_shape = '{shape}'", f"NerfMLP.basis_subdivisions = {subdiv}",
+        f"Model.num_prop_samples = {n_prop}", f"Model.num_nerf_samples = {n_nerf}"] + (
+            ["NerfMLP.srgb_mapping = False", "Config.srgb_mapping_when_rendering = True", "Config.srgb_mapping_type = 'norm_linear'"]
+            if "llff" in gin else []))                       # llff_refnerf_geometry_losses.gin's colour handling
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV)
+    blob = synthetic.make_basis_params(seed=11, n_basis=n_basis, bias_scale=0.05, sharpen=20.0)
+    model.nerf_mlp.load_flat_params(blob)
+    llff = "llff" in gin
+    rd = synthetic.llff_rays(n_rays, seed=3) if llff else synthetic.blender_rays(n_rays, seed=3, center_frac=0.5)
+    specs, idx = layout.variant_layout(n_basis=n_basis)
+    tkw = dict(srgb_mapping=False, render_srgb_mode="norm_linear") if llff else {}
+    ref = T.model_forward(blob[idx], rd, num_prop_samples=n_prop, num_nerf_samples=n_nerf, specs=specs, basis=basis, **tkw)
+    rays = utils.rays_from_dict(rd, DEV)
+    model.eval()
+    with torch.no_grad():
+        rend, hist = model(rays, 1.0, True)
+    for L in range(2):
+        sd = hist[L]["sdist"].cpu().numpy()
+        same = np.abs(sd - ref[L]["sdist"]).max(-1) < 2e-6
+        assert same.mean() > 0.9, (L, same.mean())
+        err = np.abs(rend[L]["rgb"].cpu().numpy() - ref[L]["r_rgb"])[same].max()
+        werr = np.abs(hist[L]["weights"].cpu().numpy() - ref[L]["weights"])[same].max()
+        print(f"{shape}/{subdiv} {n_rays} x {n_prop}/{n_nerf} L{L}: RGB L-inf vs oracle {err:.2e}, weights {werr:.2e}, same positions {100 * same.mean():.0f} %")
+        assert err <= 1e-5 and werr <= 5e-6
+    model.train()
+    rend_t, hist_t = model(rays, 1.0, True)
+    for L in range(2):
+        assert float((rend_t[L]["rgb"].detach() - rend[L]["rgb"]).abs().max()) <= 2e-6
+        nrm = hist_t[L]["normals"].detach()
+        assert bool(torch.isfinite(nrm).all()) and float(((nrm * nrm).sum(-1) - 1).abs().max()) < 1e-3
+    configs.clear_config()
