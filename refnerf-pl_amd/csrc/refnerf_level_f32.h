@@ -383,8 +383,10 @@ __device__ __forceinline__ void gemm_op_split(__amdgpu_buffer_rsrc_t rs, int a_o
       out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ob], bl, out[ob], 0, 0, 0);
       if (two) out[ob + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ob + 1], bl, out[ob + 1], 0, 0, 0);
       /* (reads one step past the op at the end: the next op's data or the image's tail pad) */
+#ifndef REFNERF_EXPERIMENT_NO_WSTREAM   /* timing experiment only: the operand stream stops after step 0 (wrong results) */
       fetch(ob, step + 1);
       if (two) fetch(ob + 1, step + 1);
+#endif
       /* the hook's work (8 row stores + their hi + lo sums per k-step) in quarters behind the block pairs: at the end of the
        * step it ran after the last MFMA had issued, i.e. unhidden (one wave per SIMD) */
       if constexpr (NOB == 8) { if (step < REG_STEPS16) hook(step, ob >> 1); }
