@@ -94,35 +94,46 @@ EXT_GROUPS = IPE_MAX_GROUPS - 1
 NUM_PARAMS_EXT = NUM_PARAMS + 2 * EXT_GROUPS * WIDTH * IPE_DIM
 
 
-def ipe_column_positions(spec, layer_slot, col0, n_basis):
-    """canonical / tail positions of the 32 n_basis IPE columns of every row of spatial_net.0 (layer_slot 0, col0 0) or
-    spatial_net.5 (layer_slot 1, col0 256): int64 [256, 32 n_basis]"""
+def ipe_column_positions(spec, layer_slot, col0, n_basis, rows=None, min_deg=0, max_deg=IPE_DIM // 6):
+    """canonical / tail positions of the 2 (max_deg - min_deg) n_basis IPE columns of the rows `rows` (default: all 256) of
+    spatial_net.0 (layer_slot 0, col0 0) or spatial_net.5 (layer_slot 1, col0 256): int64 [len(rows), columns].  The
+    kernels always evaluate degrees 0..15 (scale 2^j); the columns of absent degrees keep zero weights."""
     import numpy as np
-    deg = IPE_DIM // 6
-    c, j, d = np.meshgrid(np.arange(2), np.arange(deg), np.arange(n_basis), indexing="ij")
+    c, j, d = np.meshgrid(np.arange(2), np.arange(min_deg, max_deg), np.arange(n_basis), indexing="ij")
     g, k = d // 3, (IPE_DIM // 2) * c + 3 * j + d % 3
-    rows = np.arange(WIDTH, dtype=np.int64)[:, None]
+    rows = np.arange(WIDTH, dtype=np.int64)[:, None] if rows is None else np.asarray(rows, np.int64)[:, None]
     in_canon = spec.w_off + rows * spec.in_dim + (col0 + k.reshape(-1))[None, :]
     in_tail = NUM_PARAMS + (layer_slot * WIDTH + rows) * (EXT_GROUPS * IPE_DIM) + ((g.reshape(-1) - 1) * IPE_DIM + k.reshape(-1))[None, :]
     return np.where(g.reshape(-1)[None, :] == 0, in_canon, in_tail)
 
 
 def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint=True, enable_pred_roughness=True,
-                   use_directional_enc=True, deg_view=5, n_basis=3):
+                   use_directional_enc=True, deg_view=5, n_basis=3, net_width=WIDTH, bottleneck_width=BNECK,
+                   min_deg_point=0, max_deg_point=IPE_DIM // 6):
     """-> (specs, index): `specs` = ParamSpec list of the variant (true shapes, offsets into ITS flat blob, state_dict
     order), `index` = int64 numpy array, index[i] = canonical-blob position of element i of the variant's flat blob; or
-    (PARAM_SPECS, None) for the Ref-NeRF network itself."""
+    (PARAM_SPECS, None) for the Ref-NeRF network itself.
+    Narrower networks (net_width / net_width_viewdirs <= 256, bottleneck_width <= 128) are dead units of the canonical one
+    (zero rows and columns: exact), fewer IPE degrees (0 <= min_deg_point < max_deg_point <= 16) zero columns."""
     import numpy as np
-    wv = int(net_width_viewdirs)
+    wv, w, bw = int(net_width_viewdirs), int(net_width), int(bottleneck_width)
+    lo, hi = int(min_deg_point), int(max_deg_point)
     if not 1 <= wv <= WIDTH:
         raise ValueError(f"net_width_viewdirs must be in [1, {WIDTH}] for the fused kernels, got {wv}")
+    if not 1 <= w <= WIDTH:
+        raise ValueError(f"net_width must be in [1, {WIDTH}] for the fused kernels, got {w}")
+    if not 1 <= bw <= BNECK:
+        raise ValueError(f"bottleneck_width must be in [1, {BNECK}] for the fused kernels, got {bw}")
+    if not 0 <= lo < hi <= IPE_DIM // 6:
+        raise ValueError(f"min_deg_point / max_deg_point must satisfy 0 <= min < max <= {IPE_DIM // 6} for the fused kernels, got {lo}, {hi}")
     if n_basis % 3 or not 3 <= n_basis <= 3 * IPE_MAX_GROUPS:
         raise ValueError(f"IPE basis of {n_basis} directions: the fused kernels take 3, 6, ... {3 * IPE_MAX_GROUPS} "
                          "(octahedron / 1-2, icosahedron / 1-2)")
-    if wv == WIDTH and use_n_dot_v and use_specular_tint and enable_pred_roughness and use_directional_enc and n_basis == 3:
+    if (wv == WIDTH and w == WIDTH and bw == BNECK and (lo, hi) == (0, IPE_DIM // 6) and use_n_dot_v and use_specular_tint
+            and enable_pred_roughness and use_directional_enc and n_basis == 3):
         return PARAM_SPECS, None
     enc_cols = list(range(IDE_DIM)) if use_directional_enc else posenc_slots(deg_view)
-    din_cols = list(range(BNECK)) + [BNECK + k for k in enc_cols] + ([BNECK + IDE_DIM] if use_n_dot_v else [])
+    din_cols = list(range(bw)) + [BNECK + k for k in enc_cols] + ([BNECK + IDE_DIM] if use_n_dot_v else [])
     specs, idx, p = [], [], 0
     for c in PARAM_SPECS:
         if c.name == "raw_tint" and not use_specular_tint:
@@ -131,7 +142,14 @@ def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint
             continue
         rows = list(range(c.out_dim))
         cols = list(range(c.in_dim))
-        if c.name.startswith("viewdir_mlp."):
+        ipe = None                                   # (layer slot, first canonical IPE column) of the two layers that read the IPE
+        if c.name.startswith("spatial_net."):
+            i = int(c.name.split(".")[1])
+            rows = list(range(w))
+            cols = [] if i == 0 else list(range(w))
+            if i == 0 or i == SKIP + 1:
+                ipe = (0, 0) if i == 0 else (1, WIDTH)
+        elif c.name.startswith("viewdir_mlp."):
             i = int(c.name.split(".")[1])
             rows = list(range(wv))
             if i == 0:
@@ -142,13 +160,15 @@ def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint
                 cols = list(range(wv))
         elif c.name == "rgb":
             cols = list(range(wv))
+        else:                                        # heads on the spatial trunk's output
+            cols = list(range(w))
+            if c.name == "bottleneck":
+                rows = list(range(bw))
         r = np.asarray(rows, np.int64)[:, None]
         k = np.asarray(cols, np.int64)[None, :]
         pos = c.w_off + r * c.in_dim + k
-        if n_basis != 3 and c.name in ("spatial_net.0", f"spatial_net.{SKIP + 1}"):
-            first = c.name == "spatial_net.0"
-            ipe = ipe_column_positions(c, 0 if first else 1, 0 if first else WIDTH, n_basis)
-            pos = ipe if first else np.concatenate([pos[:, :WIDTH], ipe], axis=1)
+        if ipe is not None:
+            pos = np.concatenate([pos, ipe_column_positions(c, ipe[0], ipe[1], n_basis, rows, lo, hi)], axis=1)
         out_dim, in_dim = pos.shape
         specs.append(ParamSpec(c.name, out_dim, in_dim, p, p + out_dim * in_dim))
         p += out_dim * in_dim + out_dim

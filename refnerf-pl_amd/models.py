@@ -113,7 +113,9 @@ class MLP(nn.Module):
         # names and TRUE shapes as the reference gives them (models.py:509-531)
         self.specs, idx = layout.variant_layout(self.net_width_viewdirs, self.use_n_dot_v, self.use_specular_tint,
                                                 self.enable_pred_roughness, self.use_directional_enc, self.deg_view,
-                                                n_basis=self.ipe_basis_dirs)
+                                                n_basis=self.ipe_basis_dirs, net_width=self.net_width,
+                                                bottleneck_width=self.bottleneck_width, min_deg_point=self.min_deg_point,
+                                                max_deg_point=self.max_deg_point)
         self.canon_size = layout.NUM_PARAMS_EXT if self.ipe_basis_dirs != 3 else layout.NUM_PARAMS
         self.num_params = self.specs[-1].b_off + self.specs[-1].out_dim
         self._embed_index_np = idx                 # None: the parameters ARE the canonical blob
@@ -127,7 +129,7 @@ class MLP(nn.Module):
         self.bottleneck = _linear(W, self.bottleneck_width)
         Wv = self.net_width_viewdirs
         enc = layout.IDE_DIM if self.use_directional_enc else 3 + 6 * self.deg_view      # IDE / coord.pos_enc (models.py:484-492)
-        din = layout.BNECK + enc + (1 if self.use_n_dot_v else 0)
+        din = self.bottleneck_width + enc + (1 if self.use_n_dot_v else 0)
         vd_in = [din if i == 0 else (Wv + din if i == self.skip_layer + 1 else Wv)
                  for i in range(self.net_depth_viewdirs)]
         self.viewdir_mlp = nn.ModuleList([_linear(vd_in[i], Wv) for i in range(self.net_depth_viewdirs)])
@@ -152,21 +154,24 @@ class MLP(nn.Module):
             dead["enable_pred_normals"] = "False: TypeError in ref_utils.reflect at internal/ref_utils.py:37 in the reference"
         if dead:
             raise ValueError(f"MLP flags the reference itself cannot run (so there is nothing to match): {dead}")
-        want = dict(net_depth=8, net_width=256, bottleneck_width=128, net_depth_viewdirs=8,
-                    min_deg_point=0, max_deg_point=16, skip_layer=4,
+        want = dict(net_depth=8, net_depth_viewdirs=8, skip_layer=4,
                     num_rgb_channels=3,
                     enable_pred_specular_density=False, bottleneck_noise=0.0,
                     density_noise=0., disable_rgb=False, warp_fn=None)
         bad = {k: getattr(self, k) for k, v in want.items() if getattr(self, k) != v}
-        if not 1 <= int(self.net_width_viewdirs) <= layout.WIDTH:
-            bad["net_width_viewdirs"] = self.net_width_viewdirs
+        for k, top in (("net_width_viewdirs", layout.WIDTH), ("net_width", layout.WIDTH), ("bottleneck_width", layout.BNECK)):
+            if not 1 <= int(getattr(self, k)) <= top:
+                bad[k] = getattr(self, k)
+        if not 0 <= int(self.min_deg_point) < int(self.max_deg_point) <= layout.IPE_DIM // 6:
+            bad["min_deg_point / max_deg_point"] = (self.min_deg_point, self.max_deg_point)
         if (self.use_directional_enc and self.deg_view != 5) or not 1 <= int(self.deg_view) <= layout.POSENC_MAX_DEG:
             bad["deg_view"] = self.deg_view            # the IDE table is built for degree 5, pos_enc has slots for <= 5
         if bad:
             raise ValueError(
                 "MLP configuration outside the fused Ref-NeRF family (configs/*refnerf*.gin; served variants: "
-                "net_width_viewdirs <= 256, use_n_dot_v / use_specular_tint / enable_pred_roughness / "
-                f"use_directional_enc / disable_density_normals either way): {bad}; expected {({k: want.get(k, '<= 256') for k in bad})}")
+                "net_width / net_width_viewdirs <= 256, bottleneck_width <= 128, IPE degrees within [0, 16], bases of <= 21 directions, "
+                "use_n_dot_v / use_specular_tint / enable_pred_roughness / "
+                f"use_directional_enc / disable_density_normals either way): {bad}; expected {({k: want.get(k, 'see above') for k in bad})}")
         if self.net_activation is not torch.nn.functional.relu:
             raise ValueError("net_activation must be relu")
         if self.density_activation is not torch.nn.functional.softplus or \

@@ -7,6 +7,7 @@ reference's OUTPUTS only -- no reference source travels.  Weights are not
 stored: every fixture records the (seed, bias_scale, sharpen, roughness_bias)
 arguments of refnerf_pl_amd.synthetic.make_params that regenerate them.
 """
+import json
 import os
 import sys
 
@@ -801,12 +802,23 @@ def golden_basis_models():
     small = ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 96"]
     ico2 = ["NerfMLP.basis_shape = 'icosahedron'", "NerfMLP.basis_subdivisions = 2"]
     ico1 = ["NerfMLP.basis_shape = 'icosahedron'", "NerfMLP.basis_subdivisions = 1"]
-    cases = {"model_ico_eval": (ico2, 21, synthetic.blender_rays(16, seed=71, center_frac=0.4), False),
-             "model_ico_train": (ico2 + small, 21, synthetic.blender_rays(12, seed=72, center_frac=0.4), True),
-             "model_ico1_eval": (ico1, 6, synthetic.blender_rays(16, seed=73, center_frac=0.4), False)}
-    for name, (bindings, n_basis, rays, train) in cases.items():
-        specs, idx = layout.variant_layout(n_basis=n_basis)
-        canon = synthetic.make_basis_params(n_basis=n_basis, **pk)
+    # narrower networks / fewer IPE degrees (dead units and zero columns of the canonical network: layout.variant_layout)
+    narrow = ["NerfMLP.net_width = 128", "NerfMLP.bottleneck_width = 64", "NerfMLP.min_deg_point = 1", "NerfMLP.max_deg_point = 12",
+              "NerfMLP.net_width_viewdirs = 192"]
+    narrow_kw = dict(net_width=128, bottleneck_width=64, min_deg_point=1, max_deg_point=12, net_width_viewdirs=192)
+    cases = {"model_ico_eval": (ico2, dict(n_basis=21), synthetic.blender_rays(16, seed=71, center_frac=0.4), False),
+             "model_ico_train": (ico2 + small, dict(n_basis=21), synthetic.blender_rays(12, seed=72, center_frac=0.4), True),
+             "model_ico1_eval": (ico1, dict(n_basis=6), synthetic.blender_rays(16, seed=73, center_frac=0.4), False),
+             "model_narrow_eval": (narrow, narrow_kw, synthetic.blender_rays(16, seed=74, center_frac=0.4), False),
+             "model_narrow_train": (narrow + small, narrow_kw, synthetic.blender_rays(12, seed=75, center_frac=0.4), True),
+             "model_narrow_ico1_train": (narrow + ico1 + small, dict(narrow_kw, n_basis=6), synthetic.blender_rays(12, seed=76, center_frac=0.4), True)}
+    only = os.environ.get("GOLDEN_ONLY")
+    for name, (bindings, lkw, rays, train) in cases.items():
+        if only and only not in name:
+            continue
+        n_basis = lkw.get("n_basis", 3)
+        specs, idx = layout.variant_layout(**lkw)
+        canon = synthetic.make_basis_params(n_basis=n_basis, **pk) if n_basis != 3 else synthetic.make_params(**pk)
         gin.clear_config()
         gin.parse_config_files_and_bindings([REF_CFG], list(bindings))
         cfg = configs.Config()
@@ -854,6 +866,7 @@ def golden_basis_models():
                     res[f"L{lvl}_h_{k}"] = v.detach().numpy()
         res["bindings"] = np.array(bindings)
         res["n_basis"] = n_basis
+        res["layout_kw"] = np.array(json.dumps(lkw))
         res["basis"] = model.nerf_mlp.pos_basis_t.numpy().T.copy()
         res["param_kw"] = np.array([pk["seed"], pk["bias_scale"], pk["sharpen"], 0.0])
         for k, v in rays.items():

@@ -96,14 +96,17 @@ def _basis_model(g, extra=()):
     cfg = configs.Config()
     model = models.construct_model(utils.dummy_rays(), cfg).to(DEV)
     pk = g["param_kw"]
-    blob = synthetic.make_basis_params(seed=int(pk[0]), n_basis=int(g["n_basis"]), bias_scale=float(pk[1]), sharpen=float(pk[2]))
-    model.nerf_mlp.load_flat_params(blob)              # the extended canonical blob -> the module's true shapes
+    kw = dict(seed=int(pk[0]), bias_scale=float(pk[1]), sharpen=float(pk[2]))
+    blob = synthetic.make_basis_params(n_basis=int(g["n_basis"]), **kw) if int(g["n_basis"]) != 3 else synthetic.make_params(**kw)
+    model.nerf_mlp.load_flat_params(blob)              # the (extended) canonical blob -> the module's true shapes
     return model, cfg
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["model_ico_eval", "model_ico1_eval"])
+@pytest.mark.parametrize("name", ["model_ico_eval", "model_ico1_eval", "model_narrow_eval"])
 def test_general_basis_eval_vs_reference(name):
+    """(model_narrow_eval: net_width 128, bottleneck_width 64, net_width_viewdirs 192, IPE degrees 1..11 -- dead units and
+    zero columns of the canonical network, every arithmetic mode)"""
     import torch
     from refnerf_pl_amd import _hip, utils
     _hip.require_device()
@@ -132,23 +135,30 @@ def test_general_basis_eval_vs_reference(name):
         err = float(np.abs(renderings[L]["rgb"].cpu().numpy() - g[f"L{L}_r_rgb"]).max())
         print(f"{name} L{L}: RGB L-inf vs reference {err:.2e}, density {worst[(L, 'density')]:.2e}, weights {worst[(L, 'weights')]:.2e}")
         assert err <= 1e-5
-    # the modes a general basis is not built for say so
     for prec in ("f16x2", "bf16"):
         cfg.hip_precision = prec
-        with pytest.raises(ValueError, match="basis"):
-            model(rays, 1.0, True)
+        if model.nerf_mlp.ipe_groups:               # the modes a general basis is not built for say so
+            with pytest.raises(ValueError, match="basis"):
+                model(rays, 1.0, True)
+        else:
+            with torch.no_grad():
+                r16, _ = model(rays, 1.0, True)
+            err = max(float(np.abs(r16[L]["rgb"].cpu().numpy() - g[f"L{L}_r_rgb"]).max()) for L in range(2))
+            print(f"{name} [{prec}]: RGB L-inf vs reference {err:.2e}")
+            assert err <= (1e-5 if prec == "f16x2" else 1e-4)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flat", [False, True])
-def test_general_basis_training_step_vs_reference(flat):
+@pytest.mark.parametrize("name,flat", [("model_ico_train", False), ("model_ico_train", True), ("model_narrow_train", False),
+                                       ("model_narrow_ico1_train", False)])
+def test_general_basis_training_step_vs_reference(name, flat):
     """one training step with the 21-direction basis (f32 chains): the reference's losses and autograd gradients of all 46
     tensors in their TRUE shapes (spatial_net.0 [256, 672], spatial_net.5 [256, 928]) -- the density-gradient normals go
     through every direction group's transposed block, the tail's weight gradient through its own GEMM job table"""
     import torch
     from refnerf_pl_amd import _hip, train_utils, utils
     _hip.require_device()
-    g = load_golden("model_ico_train")
+    g = load_golden(name)
     model, cfg = _basis_model(g, ["Config.hip_flat_grads = True"] if flat else [])
     mlp = model.nerf_mlp
     rays = utils.rays_from_dict(rays_from_golden(g), DEV)
@@ -172,7 +182,8 @@ def test_general_basis_training_step_vs_reference(flat):
     total, terms, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
     assert float(terms["data"].detach()) == pytest.approx(float(g["loss_data"]), rel=1e-5)
     assert float(terms["orientation"].detach()) == pytest.approx(float(g["loss_orientation"]), rel=2e-4)
-    assert float(terms["predicted_normals"].detach()) == pytest.approx(float(g["loss_normal"]), rel=2e-4)
+    # (this term averages |n - n_pred|^2 over the density normals, a few of which are ill-conditioned: see above)
+    assert float(terms["predicted_normals"].detach()) == pytest.approx(float(g["loss_normal"]), rel=1e-3)
     assert float(total.detach()) == pytest.approx(float(g["loss_total"]), rel=1e-5)
     total.backward()
     if flat:
@@ -187,14 +198,27 @@ def test_general_basis_training_step_vs_reference(flat):
     rel = float(np.linalg.norm(grads[::61] - ref) / np.linalg.norm(ref))
     norms = g["grads_tensor_l2"]
     worst = max(abs(np.linalg.norm(grads[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim]) / norms[i, 0] - 1.0) for i, sp in enumerate(mlp.specs))
-    print(f"model_ico_train: gradient rel-L2 vs reference {rel:.2e}, worst tensor-norm error {worst:.2e}")
+    print(f"{name}: gradient rel-L2 vs reference {rel:.2e}, worst tensor-norm error {worst:.2e}")
     # (2e-4 for the octahedron fixtures; here 2.0e-4: 0.8 % of this fixture's level-1 samples have an ill-conditioned density
     # normal, see above, which enters the orientation / predicted-normal terms)
     assert rel < 5e-4 and worst < 2e-3
-    # the chain modes a general basis is not built for say so
-    cfg.hip_train_precision = "f16x2"
-    with pytest.raises(ValueError, match="basis"):
-        model(rays, 1.0, True)
+    cfg.hip_train_precision = cfg.hip_bwd_precision = "f16x2"
+    if mlp.ipe_groups:                               # the chain modes a general basis is not built for say so
+        with pytest.raises(ValueError, match="basis"):
+            model(rays, 1.0, True)
+    else:                                            # narrower network: the split-f16 chains as well
+        for prm in model.parameters():
+            prm.grad = None
+        rend2, hist2 = model(rays, 1.0, True)
+        total2, _, _ = train_utils.compute_losses(model, batch, rays, rend2, hist2, cfg)
+        total2.backward()
+        g2 = np.zeros(mlp.num_params, np.float32)
+        for spec, lin in mlp._named_linears():
+            g2[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = lin.weight.grad.reshape(-1).cpu().numpy()
+            g2[spec.b_off:spec.b_off + spec.out_dim] = lin.bias.grad.cpu().numpy()
+        rel2 = float(np.linalg.norm(g2[::61] - ref) / np.linalg.norm(ref))
+        print(f"{name} [f16x2 chains]: gradient rel-L2 vs reference {rel2:.2e}")
+        assert rel2 < 5e-4 and float(total2.detach()) == pytest.approx(float(g["loss_total"]), rel=1e-5)
 
 
 @pytest.mark.gpu
