@@ -7,7 +7,7 @@ checkpoint only loads into the right columns when the directions come out in the
 fixed by three conventions, kept here: the seed polyhedron's vertex / face enumeration, barycentric subdivision points
 enumerated (i, j) -> weights (i, j, v - i - j) / v over the faces in order with first occurrences kept, and antipodes
 dropped by keeping the vertex that appears first.  tests/golden/geopoly.npz holds the reference's own output for
-('octahedron', 1..2) and ('icosahedron', 1..3); tests/test_host_cpu.py compares bit for bit.
+('octahedron', 1..2) and ('icosahedron', 1..3); tests/test_basis.py compares bit for bit.
 """
 import numpy as np
 
