@@ -53,6 +53,36 @@ def test_basis_layout_is_a_permutation_of_the_extended_blob():
         layout.variant_layout(n_basis=46)          # icosahedron / 3: beyond the seven groups
 
 
+def test_variant_layouts_are_injective_and_shape_consistent():
+    """every combination of the embedded variants (widths, bottleneck, degree range, heads, view encoding, basis size) maps
+    its elements one-to-one into the (extended) canonical blob, offsets contiguous in state_dict order"""
+    import itertools
+    from refnerf_pl_amd import layout
+    combos = itertools.product((256, 96), (256, 128), (128, 32), ((0, 16), (2, 9)), (True, False), (True, False), (3, 9, 21))
+    for wv, w, bw, (lo, hi), tint, ide, nb in combos:
+        specs, idx = layout.variant_layout(wv, use_n_dot_v=tint, use_specular_tint=tint, enable_pred_roughness=ide, use_directional_enc=ide,
+                                           n_basis=nb, net_width=w, bottleneck_width=bw, min_deg_point=lo, max_deg_point=hi)
+        if idx is None:
+            assert specs is layout.PARAM_SPECS
+            continue
+        n = specs[-1].b_off + specs[-1].out_dim
+        assert len(idx) == n and len(np.unique(idx)) == n and idx.min() >= 0
+        assert idx.max() < (layout.NUM_PARAMS_EXT if nb != 3 else layout.NUM_PARAMS)
+        p = 0
+        for sp in specs:
+            assert sp.w_off == p and sp.b_off == p + sp.out_dim * sp.in_dim
+            p = sp.b_off + sp.out_dim
+        by = {sp.name: sp for sp in specs}
+        ipe = 2 * (hi - lo) * nb
+        assert (by["spatial_net.0"].out_dim, by["spatial_net.0"].in_dim) == (w, ipe)
+        assert (by["spatial_net.5"].out_dim, by["spatial_net.5"].in_dim) == (w, w + ipe)
+        assert (by["bottleneck"].out_dim, by["bottleneck"].in_dim) == (bw, w)
+        din = bw + (72 if ide else 3 + 6 * 5) + (1 if tint else 0)
+        assert (by["viewdir_mlp.0"].out_dim, by["viewdir_mlp.0"].in_dim) == (wv, din)
+        assert (by["viewdir_mlp.5"].out_dim, by["viewdir_mlp.5"].in_dim) == (wv, wv + din)
+        assert ("raw_tint" in by) == tint and ("raw_roughness" in by) == ide
+
+
 def test_model_constructs_with_the_reference_default_basis():
     """module names / true shapes as the reference gives them; the modes that are not built raise with the reason"""
     from refnerf_pl_amd import configs, models, utils
