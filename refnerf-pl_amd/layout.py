@@ -107,14 +107,38 @@ def ipe_column_positions(spec, layer_slot, col0, n_basis, rows=None, min_deg=0, 
     return np.where(g.reshape(-1)[None, :] == 0, in_canon, in_tail)
 
 
+def _check_depth(name, d):
+    d = int(d)
+    if not 1 <= d <= DEPTH or d == SKIP + 1:
+        raise ValueError(f"{name} must be in [1, {DEPTH}] and not {SKIP + 1} for the fused kernels (with {SKIP + 1} layers the reference "
+                         f"feeds the skip concatenation straight into the heads), got {d}")
+    return d
+
+
+def identity_fill(net_depth=DEPTH, net_depth_viewdirs=DEPTH, net_width=WIDTH, net_width_viewdirs=WIDTH):
+    """Shallower trunks (net_depth / net_depth_viewdirs < 8) run as the canonical 8 layers with IDENTITY layers behind the
+    real ones: the activations are post-ReLU (>= 0), so relu(1 x + 0) = x exactly, in every arithmetic mode, and the backward
+    passes the deltas through unchanged.  -> int64 positions of the canonical blob that hold 1.0 (not parameters)."""
+    import numpy as np
+    out = []
+    for pre, d, w in (("spatial_net.", _check_depth("net_depth", net_depth), int(net_width)),
+                      ("viewdir_mlp.", _check_depth("net_depth_viewdirs", net_depth_viewdirs), int(net_width_viewdirs))):
+        for i in range(d, DEPTH):
+            c = SPEC_BY_NAME[pre + str(i)]
+            u = np.arange(w, dtype=np.int64)
+            out.append(c.w_off + u * c.in_dim + u)
+    return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+
 def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint=True, enable_pred_roughness=True,
                    use_directional_enc=True, deg_view=5, n_basis=3, net_width=WIDTH, bottleneck_width=BNECK,
-                   min_deg_point=0, max_deg_point=IPE_DIM // 6):
+                   min_deg_point=0, max_deg_point=IPE_DIM // 6, net_depth=DEPTH, net_depth_viewdirs=DEPTH):
     """-> (specs, index): `specs` = ParamSpec list of the variant (true shapes, offsets into ITS flat blob, state_dict
     order), `index` = int64 numpy array, index[i] = canonical-blob position of element i of the variant's flat blob; or
     (PARAM_SPECS, None) for the Ref-NeRF network itself.
     Narrower networks (net_width / net_width_viewdirs <= 256, bottleneck_width <= 128) are dead units of the canonical one
-    (zero rows and columns: exact), fewer IPE degrees (0 <= min_deg_point < max_deg_point <= 16) zero columns."""
+    (zero rows and columns: exact), fewer IPE degrees (0 <= min_deg_point < max_deg_point <= 16) zero columns, shallower
+    trunks (net_depth / net_depth_viewdirs < 8) leave out the layers that identity_fill() turns into identities."""
     import numpy as np
     wv, w, bw = int(net_width_viewdirs), int(net_width), int(bottleneck_width)
     lo, hi = int(min_deg_point), int(max_deg_point)
@@ -129,8 +153,9 @@ def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint
     if n_basis % 3 or not 3 <= n_basis <= 3 * IPE_MAX_GROUPS:
         raise ValueError(f"IPE basis of {n_basis} directions: the fused kernels take 3, 6, ... {3 * IPE_MAX_GROUPS} "
                          "(octahedron / 1-2, icosahedron / 1-2)")
+    ds, dv = _check_depth("net_depth", net_depth), _check_depth("net_depth_viewdirs", net_depth_viewdirs)
     if (wv == WIDTH and w == WIDTH and bw == BNECK and (lo, hi) == (0, IPE_DIM // 6) and use_n_dot_v and use_specular_tint
-            and enable_pred_roughness and use_directional_enc and n_basis == 3):
+            and enable_pred_roughness and use_directional_enc and n_basis == 3 and ds == DEPTH and dv == DEPTH):
         return PARAM_SPECS, None
     enc_cols = list(range(IDE_DIM)) if use_directional_enc else posenc_slots(deg_view)
     din_cols = list(range(bw)) + [BNECK + k for k in enc_cols] + ([BNECK + IDE_DIM] if use_n_dot_v else [])
@@ -145,12 +170,16 @@ def variant_layout(net_width_viewdirs=WIDTH, use_n_dot_v=True, use_specular_tint
         ipe = None                                   # (layer slot, first canonical IPE column) of the two layers that read the IPE
         if c.name.startswith("spatial_net."):
             i = int(c.name.split(".")[1])
+            if i >= ds:
+                continue                             # an identity layer of the canonical network (identity_fill)
             rows = list(range(w))
             cols = [] if i == 0 else list(range(w))
             if i == 0 or i == SKIP + 1:
                 ipe = (0, 0) if i == 0 else (1, WIDTH)
         elif c.name.startswith("viewdir_mlp."):
             i = int(c.name.split(".")[1])
+            if i >= dv:
+                continue
             rows = list(range(wv))
             if i == 0:
                 cols = din_cols

@@ -115,7 +115,9 @@ class MLP(nn.Module):
                                                 self.enable_pred_roughness, self.use_directional_enc, self.deg_view,
                                                 n_basis=self.ipe_basis_dirs, net_width=self.net_width,
                                                 bottleneck_width=self.bottleneck_width, min_deg_point=self.min_deg_point,
-                                                max_deg_point=self.max_deg_point)
+                                                max_deg_point=self.max_deg_point, net_depth=self.net_depth,
+                                                net_depth_viewdirs=self.net_depth_viewdirs)
+        self._identity_fill_np = layout.identity_fill(self.net_depth, self.net_depth_viewdirs, self.net_width, self.net_width_viewdirs)
         self.canon_size = layout.NUM_PARAMS_EXT if self.ipe_basis_dirs != 3 else layout.NUM_PARAMS
         self.num_params = self.specs[-1].b_off + self.specs[-1].out_dim
         self._embed_index_np = idx                 # None: the parameters ARE the canonical blob
@@ -154,13 +156,15 @@ class MLP(nn.Module):
             dead["enable_pred_normals"] = "False: TypeError in ref_utils.reflect at internal/ref_utils.py:37 in the reference"
         if dead:
             raise ValueError(f"MLP flags the reference itself cannot run (so there is nothing to match): {dead}")
-        want = dict(net_depth=8, net_depth_viewdirs=8, skip_layer=4,
-                    num_rgb_channels=3,
+        want = dict(skip_layer=4, num_rgb_channels=3,
                     enable_pred_specular_density=False, bottleneck_noise=0.0,
                     density_noise=0., disable_rgb=False, warp_fn=None)
         bad = {k: getattr(self, k) for k, v in want.items() if getattr(self, k) != v}
         for k, top in (("net_width_viewdirs", layout.WIDTH), ("net_width", layout.WIDTH), ("bottleneck_width", layout.BNECK)):
             if not 1 <= int(getattr(self, k)) <= top:
+                bad[k] = getattr(self, k)
+        for k in ("net_depth", "net_depth_viewdirs"):
+            if not 1 <= int(getattr(self, k)) <= layout.DEPTH or int(getattr(self, k)) == layout.SKIP + 1:
                 bad[k] = getattr(self, k)
         if not 0 <= int(self.min_deg_point) < int(self.max_deg_point) <= layout.IPE_DIM // 6:
             bad["min_deg_point / max_deg_point"] = (self.min_deg_point, self.max_deg_point)
@@ -169,7 +173,7 @@ class MLP(nn.Module):
         if bad:
             raise ValueError(
                 "MLP configuration outside the fused Ref-NeRF family (configs/*refnerf*.gin; served variants: "
-                "net_width / net_width_viewdirs <= 256, bottleneck_width <= 128, IPE degrees within [0, 16], bases of <= 21 directions, "
+                "net_width / net_width_viewdirs <= 256, bottleneck_width <= 128, net_depth / net_depth_viewdirs in 1..8 except 5, IPE degrees within [0, 16], bases of <= 21 directions, "
                 "use_n_dot_v / use_specular_tint / enable_pred_roughness / "
                 f"use_directional_enc / disable_density_normals either way): {bad}; expected {({k: want.get(k, 'see above') for k in bad})}")
         if self.net_activation is not torch.nn.functional.relu:
@@ -261,6 +265,8 @@ class MLP(nn.Module):
             return flat
         if self._canon is None or self._canon.device != flat.device:
             self._canon = torch.zeros(self.canon_size, dtype=torch.float32, device=flat.device)
+            if len(self._identity_fill_np):          # shallower trunks: identity layers behind the real ones (layout.identity_fill)
+                self._canon[torch.as_tensor(self._identity_fill_np, device=flat.device)] = 1.0
         with torch.no_grad():
             self._canon.index_copy_(0, self.embed_index(), flat.detach())
         return self._canon

@@ -811,7 +811,12 @@ def golden_basis_models():
              "model_ico1_eval": (ico1, dict(n_basis=6), synthetic.blender_rays(16, seed=73, center_frac=0.4), False),
              "model_narrow_eval": (narrow, narrow_kw, synthetic.blender_rays(16, seed=74, center_frac=0.4), False),
              "model_narrow_train": (narrow + small, narrow_kw, synthetic.blender_rays(12, seed=75, center_frac=0.4), True),
-             "model_narrow_ico1_train": (narrow + ico1 + small, dict(narrow_kw, n_basis=6), synthetic.blender_rays(12, seed=76, center_frac=0.4), True)}
+             "model_narrow_ico1_train": (narrow + ico1 + small, dict(narrow_kw, n_basis=6), synthetic.blender_rays(12, seed=76, center_frac=0.4), True),
+             # shallower trunks: identity layers of the canonical network (layout.identity_fill)
+             "model_shallow_eval": (["NerfMLP.net_depth = 3", "NerfMLP.net_depth_viewdirs = 7"], dict(net_depth=3, net_depth_viewdirs=7),
+                                    synthetic.blender_rays(16, seed=77, center_frac=0.4), False),
+             "model_shallow_train": (["NerfMLP.net_depth = 6", "NerfMLP.net_depth_viewdirs = 2", "NerfMLP.net_width = 192"] + small,
+                                     dict(net_depth=6, net_depth_viewdirs=2, net_width=192), synthetic.blender_rays(12, seed=78, center_frac=0.4), True)}
     only = os.environ.get("GOLDEN_ONLY")
     for name, (bindings, lkw, rays, train) in cases.items():
         if only and only not in name:

@@ -58,10 +58,13 @@ def test_variant_layouts_are_injective_and_shape_consistent():
     its elements one-to-one into the (extended) canonical blob, offsets contiguous in state_dict order"""
     import itertools
     from refnerf_pl_amd import layout
-    combos = itertools.product((256, 96), (256, 128), (128, 32), ((0, 16), (2, 9)), (True, False), (True, False), (3, 9, 21))
-    for wv, w, bw, (lo, hi), tint, ide, nb in combos:
+    combos = itertools.product((256, 96), (256, 128), (128, 32), ((0, 16), (2, 9)), (True, False), (True, False), (3, 9, 21), ((8, 8), (6, 3)))
+    for wv, w, bw, (lo, hi), tint, ide, nb, (ds, dv) in combos:
         specs, idx = layout.variant_layout(wv, use_n_dot_v=tint, use_specular_tint=tint, enable_pred_roughness=ide, use_directional_enc=ide,
-                                           n_basis=nb, net_width=w, bottleneck_width=bw, min_deg_point=lo, max_deg_point=hi)
+                                           n_basis=nb, net_width=w, bottleneck_width=bw, min_deg_point=lo, max_deg_point=hi,
+                                           net_depth=ds, net_depth_viewdirs=dv)
+        ones = layout.identity_fill(ds, dv, w, wv)
+        assert len(ones) == (8 - ds) * w + (8 - dv) * wv and (idx is None or not np.intersect1d(ones, idx).size)
         if idx is None:
             assert specs is layout.PARAM_SPECS
             continue
@@ -79,7 +82,9 @@ def test_variant_layouts_are_injective_and_shape_consistent():
         assert (by["bottleneck"].out_dim, by["bottleneck"].in_dim) == (bw, w)
         din = bw + (72 if ide else 3 + 6 * 5) + (1 if tint else 0)
         assert (by["viewdir_mlp.0"].out_dim, by["viewdir_mlp.0"].in_dim) == (wv, din)
-        assert (by["viewdir_mlp.5"].out_dim, by["viewdir_mlp.5"].in_dim) == (wv, wv + din)
+        if dv > 5:
+            assert (by["viewdir_mlp.5"].out_dim, by["viewdir_mlp.5"].in_dim) == (wv, wv + din)
+        assert ("viewdir_mlp.7" in by) == (dv == 8) and ("spatial_net.6" in by) == (ds == 8)
         assert ("raw_tint" in by) == tint and ("raw_roughness" in by) == ide
 
 
@@ -133,10 +138,11 @@ def _basis_model(g, extra=()):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["model_ico_eval", "model_ico1_eval", "model_narrow_eval"])
+@pytest.mark.parametrize("name", ["model_ico_eval", "model_ico1_eval", "model_narrow_eval", "model_shallow_eval"])
 def test_general_basis_eval_vs_reference(name):
     """(model_narrow_eval: net_width 128, bottleneck_width 64, net_width_viewdirs 192, IPE degrees 1..11 -- dead units and
-    zero columns of the canonical network, every arithmetic mode)"""
+    zero columns of the canonical network, every arithmetic mode; model_shallow_eval: net_depth 3, net_depth_viewdirs 7 --
+    identity layers behind the real ones)"""
     import torch
     from refnerf_pl_amd import _hip, utils
     _hip.require_device()
@@ -180,7 +186,7 @@ def test_general_basis_eval_vs_reference(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,flat", [("model_ico_train", False), ("model_ico_train", True), ("model_narrow_train", False),
-                                       ("model_narrow_ico1_train", False)])
+                                       ("model_narrow_ico1_train", False), ("model_shallow_train", False)])
 def test_general_basis_training_step_vs_reference(name, flat):
     """one training step with the 21-direction basis (f32 chains): the reference's losses and autograd gradients of all 46
     tensors in their TRUE shapes (spatial_net.0 [256, 672], spatial_net.5 [256, 928]) -- the density-gradient normals go
