@@ -1,10 +1,12 @@
-"""Kernel list of ONE training step from a rocprofv3 --kernel-trace CSV: python scripts/trace_step.py <trace_kernel_trace.csv> [kernel marker]
-Prints span / busy / gaps of the last complete step (two launches of the marker kernel per step) and its kernels by name."""
+"""Kernel list of ONE training step from a rocprofv3 --kernel-trace CSV: python scripts/trace_step.py <trace_kernel_trace.csv> [kernel marker] [marker launches per step]
+Prints span / busy / gaps of the last complete step (default: two launches of the marker kernel per step; the nine-term
+geometry step has four: clean + noisy pass) and its kernels by name."""
 import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 marker = sys.argv[2] if len(sys.argv) > 2 else "level_fwd_train_bf16c"
+per = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
-i0, i1 = idx[-4], idx[-2]
+i0, i1 = idx[-2 * per], idx[-per]
 seg = rows[i0:i1]
 t0 = int(seg[0]["Start_Timestamp"])
 busy = gaps = 0
