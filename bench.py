@@ -350,14 +350,16 @@ def other_configs(args, dev, sync, max_over_ranks):
         def ico_step():
             with torch.no_grad():
                 return model(rays, 1.0, True)
-        el, k, l, o = timed_steps(ico_step, 5, 2, True, sync, max_over_ranks)
-        assert torch.isfinite(o[0][-1]["rgb"]).all()
         flop = R * N * (FLOP_PER_SAMPLE + 2 * 2 * 256 * 576)        # + the 6 extra direction groups of layers 0 and 5
-        out["C2_icosahedron_basis"] = {
-            "workload": spec["workload"] + " with NerfMLP.basis_shape = 'icosahedron', basis_subdivisions = 2 (the reference's constructor default)",
-            "rays": R, "samples_per_level": N,
-            "f32": {"value": R * N * 2 * 5 / el, "unit": "ray-samples/s", "ms_per_step": 1e3 * el / 5, "steps": 5, "dtype": "f32",
-                    "roofline": mfma_roofline("f32", "rn::level_fwd_f32_gb", k, l, flop, "C2", R, N)}}
+        leg = {"workload": spec["workload"] + " with NerfMLP.basis_shape = 'icosahedron', basis_subdivisions = 2 (the reference's constructor default)",
+               "rays": R, "samples_per_level": N}
+        for prec, kern in (("f16x2", "rn::level_fwd_f16x2c_gb"), ("f32", "rn::level_fwd_f32_gb")):
+            model.config.hip_precision = prec
+            el, k, l, o = timed_steps(ico_step, 5, 2, True, sync, max_over_ranks)
+            assert torch.isfinite(o[0][-1]["rgb"]).all()
+            leg[prec] = {"value": R * N * 2 * 5 / el, "unit": "ray-samples/s", "ms_per_step": 1e3 * el / 5, "steps": 5, "dtype": prec,
+                         "roofline": mfma_roofline(prec, kern, k, l, flop, "C2", R, N)}
+        out["C2_icosahedron_basis"] = leg
         del model, rays
         torch.cuda.empty_cache()
     except Exception as e:      # never lose the headline line over an extra leg

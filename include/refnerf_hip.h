@@ -177,7 +177,8 @@ int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, v
  * component order, ipe_groups <= 7.  d_params is then REFNERF_NUM_PARAMS_EXT floats: the canonical blob, whose IPE
  * columns of spatial_net.0 / .5 belong to directions 0..2, followed by W_ext[layer: 0, 5][256 rows][576]: column
  * 96 (g - 1) + 48 c + 3 j + b = (direction group g = 1..6, sin | cos block c, degree j, direction 3 g + b); unused
- * groups zero.  REFNERF_PREC_F32 only; the image is
+ * groups zero.  The image is built for REFNERF_PREC_F32 only (levels then run with cfg.precision REFNERF_PREC_F32 or
+ * REFNERF_PREC_F16X2 on it: it carries the split-f16 copies); it is
  * refnerf_packed_weights_bytes_basis(precision, ipe_groups) bytes and levels run with cfg.ipe_groups = ipe_groups. */
 #define REFNERF_NUM_PARAMS_EXT (REFNERF_NUM_PARAMS + 2 * 6 * 256 * 96)
 size_t refnerf_packed_weights_bytes_basis(int precision, int ipe_groups);

@@ -244,7 +244,7 @@ __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict_
  * format: A[step][lane][4] = W[o(step, h)][in_row = 32 ob + lane % 32], ob < 3) of the tail weights. */
 __global__ void pack_weights_ext(const float *__restrict__ P, const float *__restrict__ basis, int groups, float *__restrict__ out) {
   const int e0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-  const int which = blockIdx.y;              /* 0: basis, 1..12 forward, 13..24 transposed */
+  const int which = blockIdx.y;              /* 0: basis, then 12 blocks each: fp32 forward, fp32 transposed, split forward, split transposed */
   if (which == 0) {
     for (int e = e0; e < 64; e += stride) out[PEXT_BASIS + e] = (e < 9 * groups) ? basis[e] : 0.0f;
     return;
@@ -252,20 +252,45 @@ __global__ void pack_weights_ext(const float *__restrict__ P, const float *__res
   const int idx = (which - 1) % (2 * EXT_GROUPS), L = idx / EXT_GROUPS, g = idx % EXT_GROUPS + 1;
   const float *W = P + ext_w_off(L, g);      /* [256 rows, pitch EXT_K][96] */
   const bool live = g < groups;
-  if (which <= 2 * EXT_GROUPS) {
+  const int kind = (which - 1) / (2 * EXT_GROUPS);   /* 0: fp32 forward, 1: fp32 transposed, 2: split forward, 3: split transposed */
+  if (kind == 0) {
     float *dst = out + pext_fwd_off(L, g);
     for (int e = e0; e < PEXT_FWD_FLOATS; e += stride) {
       const int step = e >> 9, rem = e & 511, ob = (rem >> 8) * 4 + (rem & 3), lane = (rem & 255) >> 2;
       const int h = lane >> 5, row = ob * 32 + (lane & 31), k = 2 * step + h;
       dst[e] = live ? W[row * EXT_K + k] : 0.0f;
     }
-  } else {
+  } else if (kind == 1) {
     float *dst = out + pext_t_off(L, g);
     for (int e = e0; e < PEXT_T_FLOATS; e += stride) {
       const int ob = e & 3, lane = (e >> 2) & 63, step = e >> 8;
       const int h = lane >> 5, in_row = ob * 32 + (lane & 31), kb = step >> 4, r = step & 15;
       const int oo = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
       dst[e] = (live && ob < 3) ? W[oo * EXT_K + in_row] : 0.0f;
+    }
+  } else {
+    /* split copies: element idx = [step][ob][lane][e] of a 4096-half plane pair (hi plane, lo plane 4096 halves behind) */
+    const bool fwd = kind == 2;
+    const int steps = fwd ? BF_IPE_STEPS : BT_CHAIN_STEPS;
+    _Float16 *dst = reinterpret_cast<_Float16 *>(out + (fwd ? pext_hf_off(L, g) : pext_ht_off(L, g)));
+    for (int i = e0; i < steps * 4096; i += stride) {
+      const int e = i & 7, lane = (i >> 3) & 63, ob = (i >> 9) & 7, st = i >> 12;
+      const int h = lane >> 5, r32 = ob * 32 + (lane & 31);
+      float v = 0.0f;
+      if (live) {
+        if (fwd) {
+          const int kl = 16 * st + 8 * h + e;                     /* plain order over the fp32 X tile (bf_off's LDS steps) */
+          v = W[r32 * EXT_K + kl];
+        } else if (ob < 3) {
+          const int r = 8 * (st & 1) + e;
+          const int oo = 32 * (st >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+          v = W[oo * EXT_K + r32];
+        }
+      }
+      const _Float16 hi = (_Float16)v;
+      const size_t base = (size_t)st * (2 * 4096) + (i & 4095);
+      dst[base] = hi;
+      dst[base + 4096] = (_Float16)(v - (float)hi);
     }
   }
 }
@@ -686,7 +711,7 @@ int refnerf_pack_weights_basis(const float *d_params, const float *d_basis, int 
     return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1) runs in the REFNERF_PREC_F32 kernels only%s");
   const int rc = refnerf_pack_weights(d_params, d_packed, precision, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(rn::pack_weights_ext, dim3(32, 1 + 4 * rn::EXT_GROUPS), dim3(256), 0, (hipStream_t)stream, d_params, d_basis, ipe_groups, (float *)d_packed);
+  hipLaunchKernelGGL(rn::pack_weights_ext, dim3(32, 1 + 8 * rn::EXT_GROUPS), dim3(256), 0, (hipStream_t)stream, d_params, d_basis, ipe_groups, (float *)d_packed);
   HIP_TRY(hipGetLastError());
   return REFNERF_OK;
 }
@@ -754,8 +779,8 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
     return fail(REFNERF_EUNSUPPORTED, "REFNERF_PREC_F16 is an inference mode (training levels: REFNERF_PREC_F32, REFNERF_PREC_F16X2 or REFNERF_PREC_BF16)%s");
   const bool gbasis = cfg->ipe_groups > 1;
   if (cfg->ipe_groups < 0 || cfg->ipe_groups > rn::IPE_MAX_GROUPS) return fail(REFNERF_EINVAL, "ipe_groups must be in [0,7]%s");
-  if (gbasis && cfg->precision != REFNERF_PREC_F32)
-    return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1) runs in the REFNERF_PREC_F32 kernels only%s");
+  if (gbasis && cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_F16X2)
+    return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1) runs with REFNERF_PREC_F32 or REFNERF_PREC_F16X2 (d_packed: the REFNERF_PREC_F32 image of refnerf_pack_weights_basis in both)%s");
   /* training + BF16: the fp32-structure kernel with its MLP chains on bf16 MFMA (level_fwd_train_bf16c); d_packed is
    * the REFNERF_PREC_F32 image in that case (it carries the bf16 copies of the ops) */
   const bool train_bf = cfg->training && cfg->precision == REFNERF_PREC_BF16;
@@ -763,7 +788,9 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
     return fail(REFNERF_EINVAL, "refnerf_level_forward: null ray field%s");
   const int N = cfg->n_samples;
   /* training + F16X2: the same kernel with its chains on split-f16 operands (level_fwd_train_f16x2c), fp32 ACT rows */
-  const bool train_split = cfg->training && cfg->precision == REFNERF_PREC_F16X2;
+  /* (a general basis in F16X2 takes that kernel in inference as well: level_fwd_f16x2c_gb) */
+  const bool gb_split = gbasis && cfg->precision == REFNERF_PREC_F16X2;
+  const bool train_split = (cfg->training && cfg->precision == REFNERF_PREC_F16X2) || gb_split;
   const bool split = cfg->precision == REFNERF_PREC_F16X2 && !train_split;
   const bool bf = (cfg->precision == REFNERF_PREC_BF16 && !train_bf) || cfg->precision == REFNERF_PREC_F16 || split;     /* the LDS-ring 16-bit eval kernels */
   int rpw = rays_per_wg(N, bf ? rn::BT : rn::T_TILE);
@@ -808,7 +835,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget of this precision mode%s");
   LDS_ATTR_ONCE(lds_attr(rn::level_fwd_f32), lds_attr(rn::level_fwd_train_f32), lds_attr(rn::level_fwd_train_bf16c), lds_attr(rn::level_fwd_train_f16x2c),
                 lds_attr(rn::level_fwd_bf16), lds_attr(rn::level_fwd_f16), lds_attr(rn::level_fwd_bf16_ring), lds_attr(rn::level_fwd_f16_ring),
-                lds_attr(rn::level_fwd_f16x2), lds_attr(rn::level_fwd_f16x2_ring), lds_attr(rn::level_fwd_f32_gb), lds_attr(rn::level_fwd_train_f32_gb));
+                lds_attr(rn::level_fwd_f16x2), lds_attr(rn::level_fwd_f16x2_ring), lds_attr(rn::level_fwd_f32_gb), lds_attr(rn::level_fwd_train_f32_gb), lds_attr(rn::level_fwd_f16x2c_gb));
   rn::LevelArgs a;
   a.packed = d_packed;
   a.cfg = *cfg;
@@ -843,6 +870,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   else if (bf && cfg->precision == REFNERF_PREC_F16) hipLaunchKernelGGL(rn::level_fwd_f16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else if (bf) hipLaunchKernelGGL(rn::level_fwd_bf16, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   else if (train_bf) hipLaunchKernelGGL(rn::level_fwd_train_bf16c, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
+  else if (gb_split) hipLaunchKernelGGL(rn::level_fwd_f16x2c_gb, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (train_split) hipLaunchKernelGGL(rn::level_fwd_train_f16x2c, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (cfg->training && gbasis) hipLaunchKernelGGL(rn::level_fwd_train_f32_gb, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
   else if (cfg->training) hipLaunchKernelGGL(rn::level_fwd_train_f32, dim3(grid), dim3(rn::NTHREADS), lds, st, a);
@@ -981,8 +1009,9 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   const int N = cfg->n_samples;
   const bool gbasis = cfg->ipe_groups > 1;
   if (cfg->ipe_groups < 0 || cfg->ipe_groups > rn::IPE_MAX_GROUPS) return fail(REFNERF_EINVAL, "ipe_groups must be in [0,7]%s");
-  if (gbasis && (cfg->precision != REFNERF_PREC_F32 || cfg->wgrad_mode != REFNERF_WGRAD_BF16X3 || saved->activations_format != REFNERF_ACT_F32))
-    return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1) trains with the f32 chains and the bf16x3 weight-gradient GEMM%s");
+  if (gbasis && ((cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_F16X2) || cfg->wgrad_mode != REFNERF_WGRAD_BF16X3 ||
+                 saved->activations_format != REFNERF_ACT_F32))
+    return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1) trains with the f32 or split-f16 chains and the bf16x3 weight-gradient GEMM%s");
   const BwdPlan plan = bwd_plan(R, N, cfg->ipe_groups);
   if (workspace_bytes < plan.total) return fail(REFNERF_EINVAL, "refnerf_level_backward: workspace too small (see refnerf_backward_workspace_bytes)%s");
   const int rpw = rays_per_wg(N, rn::T_TILE);

@@ -180,7 +180,8 @@ constexpr Packed PACKED = make_packed();
  * group, i.e. the canonical order with the group's directions.
  *   parameters: the canonical blob + a tail  W_ext[layer L = 0 (layer 0), 1 (layer 5)][256 rows][(g - 1) 96 + k]  (NUM_PARAMS_EXT;
  *               row-major with 576 columns, so that the tail's weight gradient is one GEMM job per layer)
- *   fp32 image:  PACKED.total floats + [basis 64][12 forward group ops, [48 steps][2][64][4]][12 transposed, [128][64][4]] */
+ *   fp32 image:  PACKED.total floats + [basis 64][12 forward group ops, [48 steps][2][64][4]][12 transposed, [128][64][4]]
+ *                + the split-f16 copies of both sets (6 MB in all) */
 constexpr int IPE_MAX_GROUPS = 7;
 constexpr int EXT_GROUPS = IPE_MAX_GROUPS - 1;
 constexpr int EXT_K = EXT_GROUPS * IPE_DIM;                  /* 576 tail columns per row */
@@ -192,9 +193,17 @@ constexpr int PEXT_FWD = PEXT_BASIS + 64;
 constexpr int PEXT_FWD_FLOATS = (IPE_DIM / 2) * 64 * 8;
 constexpr int PEXT_T = PEXT_FWD + 2 * EXT_GROUPS * PEXT_FWD_FLOATS;
 constexpr int PEXT_T_FLOATS = REG_STEPS * 64 * 4;
-constexpr int PACKED_EXT_TOTAL = PEXT_T + 2 * EXT_GROUPS * PEXT_T_FLOATS + 8 * 64 * 8;
+/* ... and their split-f16 copies for the split chains (formats of hf_off / ht_off: [k-step][hi | lo][ob (8)][lane][8 halves];
+ * forward: the 6 LDS k-steps of op 0, transposed: 16 k-steps with 3 live blocks) */
+constexpr int PEXT_HF = PEXT_T + 2 * EXT_GROUPS * PEXT_T_FLOATS + 8 * 64 * 8;       /* (behind the fp32 prefetch pad) */
+constexpr int PEXT_HF_FLOATS = BF_IPE_STEPS * 2 * BT_STEP_FLOATS;
+constexpr int PEXT_HT = PEXT_HF + 2 * EXT_GROUPS * PEXT_HF_FLOATS;
+constexpr int PEXT_HT_FLOATS = BT_CHAIN_STEPS * 2 * BT_STEP_FLOATS;
+constexpr int PACKED_EXT_TOTAL = PEXT_HT + 2 * EXT_GROUPS * PEXT_HT_FLOATS + 4 * 2 * BT_STEP_FLOATS;
 constexpr int pext_fwd_off(int L, int g) { return PEXT_FWD + (L * EXT_GROUPS + (g - 1)) * PEXT_FWD_FLOATS; }
 constexpr int pext_t_off(int L, int g) { return PEXT_T + (L * EXT_GROUPS + (g - 1)) * PEXT_T_FLOATS; }
+constexpr int pext_hf_off(int L, int g) { return PEXT_HF + (L * EXT_GROUPS + (g - 1)) * PEXT_HF_FLOATS; }
+constexpr int pext_ht_off(int L, int g) { return PEXT_HT + (L * EXT_GROUPS + (g - 1)) * PEXT_HT_FLOATS; }
 /* training: the IPE features of groups 1..G-1 (the weight-gradient operand of the tail) are a second blocked matrix
  * behind ACT in the activations buffer: row (g - 1) 96 + k, ACT_EXT_UNITS units per 64-sample block (odd, as ACT's) */
 constexpr int ACT_EXT_ROWS = EXT_K, ACT_EXT_UNITS = EXT_K + 1;

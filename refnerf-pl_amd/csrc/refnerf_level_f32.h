@@ -323,7 +323,7 @@ __device__ __forceinline__ float split_elem(const v4uu &ph, const v4uu &pl, int 
  * ONE set of fragment registers (2 x NOB x 4): a block's hi / lo fragments of the next k-step are requested right behind
  * its three MFMAs of this one (24 MFMAs = 768 cycles per k-step cover the L2 round trip), the blocks go in pairs so that
  * no MFMA waits for the accumulator of its predecessor. */
-template <int NOB, int REG_STEPS16, int LDS_STEPS, bool BIAS, typename Hook = NoStepHook, int LDS_MAXROW = (1 << 30)>
+template <int NOB, int REG_STEPS16, int LDS_STEPS, bool BIAS, typename Hook = NoStepHook, int LDS_MAXROW = (1 << 30), bool ACC = false>
 __device__ __forceinline__ void gemm_op_split(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h,
                                               const v4uu (&ih)[16], const v4uu (&il)[16], v16f (&out)[NOB], const float *xc, Hook hook = Hook(),
                                               float lds_scale = 1.0f) {
@@ -340,7 +340,8 @@ __device__ __forceinline__ void gemm_op_split(__amdgpu_buffer_rsrc_t rs, int a_o
   };
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob) fetch(ob, 0);
-  if constexpr (BIAS) load_acc<NOB>(rs, b_off, h, out);
+  if constexpr (ACC) { /* `out` carries on (a further input group of the same layer) */ }
+  else if constexpr (BIAS) load_acc<NOB>(rs, b_off, h, out);
   else {
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
@@ -920,6 +921,52 @@ __device__ __forceinline__ void density_normals_split(__amdgpu_buffer_rsrc_t rs,
   for (int b = 0; b < 3; ++b) nrm_out[b] = -(gx[b] / ng);
 }
 
+/* ... and for a general IPE basis (see density_normals_gb) */
+template <typename Lift>
+__device__ __forceinline__ void density_normals_split_gb(__amdgpu_buffer_rsrc_t rs, int lane, int h, v16f (&out)[8], v4uu (&ph)[16], v4uu (&pl)[16],
+                                                         unsigned (&M)[8][4], int groups, const float *basis, Lift &&lift, float nrm_out[3]) {
+  load_acc<8>(rs, PACKED.wd_off, h, out);
+  float c = 1.0f;
+  mask_split(out, M[7], ph, pl, c);
+  float gw[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+  for (int i = 7; i >= 0; --i) {
+    if (i == 5 || i == 0) {
+      const float inv = 1.0f / c;
+#pragma unroll 1
+      for (int gq = 0; gq < groups; ++gq) {
+        v16f gi[3];
+        const int a_off = gq == 0 ? PACKED.ht_off[i == 5 ? TOP_SP5_IPE : TOP_SP0] : pext_ht_off(i == 5 ? 1 : 0, gq);
+        gemm_op_split<3, 16, 0, false>(rs, a_off, 0, lane, h, ph, pl, gi, nullptr);
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gi[blk][r] *= inv;
+        float lm[3], lv[3], gl[3] = {0.0f, 0.0f, 0.0f};
+        lift(gq, lm, lv);
+        ipe_vjp_accum(gi, lm, lv, h, gl);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) gw[cc] += gl[b] * basis[9 * gq + 3 * b + cc];
+      }
+    }
+    if (i > 0) {
+      gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[i - 1], 0, lane, h, ph, pl, out, nullptr);
+#pragma unroll
+      for (int l = 7; l > 0; --l)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) M[l][q] = M[l - 1][q];
+      mask_split(out, M[7], ph, pl, c);
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc) gw[cc] += __shfl_xor(gw[cc], 32, 64);
+  const float ng = sqrtf(fmaxf((gw[0] * gw[0] + gw[1] * gw[1]) + gw[2] * gw[2], EPS32));
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc) nrm_out[cc] = -(gw[cc] / ng);
+}
+
 /* STAGE: MLP.__call__ on caller-supplied Gaussians (no resampling, no compositing): the per-sample
  * outputs of models.py:533-750 for means / covariances given per sample. */
 /* BFC (training forward only): the MLP chains on v_mfma_f32_32x32x16_bf16 (cfg.precision = BF16 with cfg.training):
@@ -933,7 +980,7 @@ template <bool TRAIN, bool STAGE = false, bool BFC = false, bool SPC = false, bo
 __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   static_assert(!BFC || (TRAIN && !STAGE), "bf16 chains: training forward only");
   static_assert(!SPC || (TRAIN && !STAGE && !BFC), "split-f16 chains: training forward only");
-  static_assert(!GB || (!STAGE && !BFC && !SPC), "general IPE basis: fp32 level kernels only");
+  static_assert(!GB || (!STAGE && !BFC), "general IPE basis: the fp32 skeleton with fp32 or split-f16 chains");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   RN_STAMP(A, 0);
   const refnerf_level_cfg &cfg = A.cfg;
@@ -1093,11 +1140,13 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         wave_sync();                               /* the previous group's X reads are done */
         ipe_group(gq, L == 0);
         wave_sync();
-        gemm_op<8, 8, false, false, NoStepHook, rn::PF, true>(rs, pext_fwd_off(L, gq), 0, lane, h, in, out, xl, IPE_DIM / 2);
+        if constexpr (SPC) gemm_op_split<8, 0, BF_IPE_STEPS, false, NoStepHook, (1 << 30), true>(rs, pext_hf_off(L, gq), 0, lane, h, pk, pl, out, xc);
+        else gemm_op<8, 8, false, false, NoStepHook, rn::PF, true>(rs, pext_fwd_off(L, gq), 0, lane, h, in, out, xl, IPE_DIM / 2);
       }
     };
     if constexpr (SPC) {
       gemm_op_split<8, 0, BF_IPE_STEPS, true>(rs, PACKED.hf_off[0], PACKED.op[0].b_off, lane, h, pk, pl, out, xc);
+      if constexpr (GB) more_groups(0);
       relu_mask_split(out, M[7], pk, pl);
     } else if constexpr (BFC) {
       gemm_op_bf16<8, 0, BF_IPE_STEPS, true>(rs, PACKED.bf_off[0], PACKED.op[0].b_off, lane, h, pk, out, xc);
@@ -1120,10 +1169,12 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     for (int op = 1; op < 8; ++op) {
       /* training: the layer input leaves for the ACT matrix through the store hook (one row per k-step) */
       if constexpr (SPC) {
+        if constexpr (GB) { if (op == 5) { wave_sync(); ipe_group(0, false); wave_sync(); } }     /* X holds the last group of layer 0 */
         if (op == 5) gemm_op_split<8, 16, BF_IPE_STEPS, true>(rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, pk, pl, out, xc,
                                                              row_hook(ACT_SP + (op - 1) * WIDTH));
         else gemm_op_split<8, 16, 0, true>(rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, pk, pl, out, xc,
                                            row_hook(ACT_SP + (op - 1) * WIDTH));
+        if constexpr (GB) { if (op == 5) more_groups(1); }
       } else if constexpr (BFC) {
         if (op == 5) gemm_op_bf16<8, 16, BF_IPE_STEPS, true>(rs, PACKED.bf_off[op], PACKED.op[op].b_off, lane, h, pk, out, xc,
                                                             act_hook(ACT_SP + (op - 1) * WIDTH));
@@ -1182,7 +1233,11 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
 
     SampleHeads sh;
     RN_STAMP(A, 5);
-    if constexpr (SPC) density_normals_split(rs, lane, h, out, pk, pl, M, lm, lv, sh.normals);
+    if constexpr (SPC && GB) {
+      /* (this kernel also serves cfg.precision = F16X2 in inference for a general basis: no normals then) */
+      if (cfg.training) density_normals_split_gb(rs, lane, h, out, pk, pl, M, cfg.ipe_groups, reinterpret_cast<const float *>(A.packed) + PEXT_BASIS, lift_group, sh.normals);
+      else { sh.normals[0] = 0.0f; sh.normals[1] = 0.0f; sh.normals[2] = 0.0f; }
+    } else if constexpr (SPC) density_normals_split(rs, lane, h, out, pk, pl, M, lm, lv, sh.normals);
     else if constexpr (BFC) density_normals_bf16(rs, lane, h, wave, reinterpret_cast<char *>(smem) + A.ring_off, out, pk, M, X, col, sh.normals);
     else if constexpr (TRAIN && GB) density_normals_gb(rs, lane, h, in, out, M, xl, cfg.ipe_groups, reinterpret_cast<const float *>(A.packed) + PEXT_BASIS, lift_group, sh.normals);
     else if constexpr (TRAIN) density_normals(rs, lane, h, in, out, M, lm, lv, xl, sh.normals);
@@ -1301,6 +1356,9 @@ __global__ __launch_bounds__(NTHREADS) void level_fwd_train_f16x2c(const LevelAr
 /* eval forward with a general IPE basis (cfg.ipe_groups > 1: icosahedron / tesselated bases) */
 __global__ __launch_bounds__(NTHREADS) void level_fwd_f32_gb(const LevelArgs A) { level_fwd_f32_body<false, false, false, false, true>(A); }
 __global__ __launch_bounds__(NTHREADS) void level_fwd_train_f32_gb(const LevelArgs A) { level_fwd_f32_body<true, false, false, false, true>(A); }
+/* ... with the chains on split-f16 operands: the training forward (cfg.training) and, with cfg.training = 0 and no
+ * activation buffer, the parity-grade 16-bit inference mode of a general basis */
+__global__ __launch_bounds__(NTHREADS) void level_fwd_f16x2c_gb(const LevelArgs A) { level_fwd_f32_body<true, false, false, true, true>(A); }
 /* MLP.__call__ stage entry (eval / training) */
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false, true>(A); }
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_train_f32(const LevelArgs A) { level_fwd_f32_body<true, true>(A); }

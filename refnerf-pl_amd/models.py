@@ -639,10 +639,10 @@ class Model(nn.Module):
         train_prec = getattr(cfg, "hip_train_precision", "f32")
         if train_prec not in _TRAIN_FWD_PREC:      # 'f16' is an inference mode of the level kernel
             raise ValueError("Config.hip_train_precision must be 'f32', 'f16x2' or 'bf16'")
-        if mlp.ipe_groups and (train_prec if self.training else prec) != "f32":
+        if mlp.ipe_groups and (train_prec if self.training else prec) not in ("f32", "f16x2"):
             raise ValueError(f"IPE basis '{mlp.basis_shape}' / {mlp.basis_subdivisions} ({mlp.ipe_basis_dirs} directions): the fused kernels run a "
-                             "general basis in the f32 modes only (Config.hip_precision / hip_train_precision / hip_bwd_precision = 'f32'); "
-                             "the 16-bit modes are built for 'octahedron' / 1")
+                             "general basis in the parity-grade modes (Config.hip_precision / hip_train_precision / hip_bwd_precision = 'f32' or "
+                             "'f16x2'); the plain bf16 / f16 throughput modes are built for 'octahedron' / 1")
         wgrad = {"f32": _hip.WGRAD_F32, "bf16x3": _hip.WGRAD_BF16X3}.get(getattr(cfg, "hip_wgrad_mode", "bf16x3"))
         if wgrad is None:
             raise ValueError("Config.hip_wgrad_mode must be 'bf16x3' or 'f32'")
@@ -710,8 +710,8 @@ class Model(nn.Module):
                 bwd_prec = getattr(self.config, "hip_bwd_precision", "f32")
                 if bwd_prec not in _TRAIN_FWD_PREC:
                     raise ValueError("Config.hip_bwd_precision must be 'f32', 'f16x2' or 'bf16'")
-                if mlp.ipe_groups and (bwd_prec != "f32" or cfg.wgrad_mode != _hip.WGRAD_BF16X3):
-                    raise ValueError("a general IPE basis trains with Config.hip_bwd_precision = 'f32' and hip_wgrad_mode = 'bf16x3'")
+                if mlp.ipe_groups and (bwd_prec not in ("f32", "f16x2") or cfg.wgrad_mode != _hip.WGRAD_BF16X3):
+                    raise ValueError("a general IPE basis trains with Config.hip_bwd_precision = 'f32' or 'f16x2' and hip_wgrad_mode = 'bf16x3'")
                 if bwd_prec == "f16x2" and getattr(self.config, "hip_train_precision", "f32") == "bf16":
                     raise ValueError("Config.hip_bwd_precision = 'f16x2' reads fp32 activation rows: use hip_train_precision 'f32' or 'f16x2'")
                 flat_mode = bool(getattr(self.config, "hip_flat_grads", False))
@@ -723,7 +723,7 @@ class Model(nn.Module):
                 res = dict(zip(holder["keys"], outs))
             else:
                 lean = _LEAN.depth > 0 and not self.training
-                res = _hip.level_forward(mlp.packed_weights(_hip.PREC_F32 if cfg.training else cfg.precision), cfg, r, sdist, weights,
+                res = _hip.level_forward(mlp.packed_weights(_hip.PREC_F32 if (cfg.training or mlp.ipe_groups) else cfg.precision), cfg, r, sdist, weights,
                                          history=(("rgb",) if compute_extras else ()) if lean else True)
             sdist, weights = res["sdist"], res["weights"]
             self.last_bin_idx.append(res.get("bin_idx"))

@@ -173,7 +173,7 @@ def test_general_basis_eval_vs_reference(name):
         assert err <= 1e-5
     for prec in ("f16x2", "bf16"):
         cfg.hip_precision = prec
-        if model.nerf_mlp.ipe_groups:               # the modes a general basis is not built for say so
+        if model.nerf_mlp.ipe_groups and prec == "bf16":   # the throughput modes are not built for a general basis, and say so
             with pytest.raises(ValueError, match="basis"):
                 model(rays, 1.0, True)
         else:
@@ -238,11 +238,12 @@ def test_general_basis_training_step_vs_reference(name, flat):
     # (2e-4 for the octahedron fixtures; here 2.0e-4: 0.8 % of this fixture's level-1 samples have an ill-conditioned density
     # normal, see above, which enters the orientation / predicted-normal terms)
     assert rel < 5e-4 and worst < 2e-3
-    cfg.hip_train_precision = cfg.hip_bwd_precision = "f16x2"
-    if mlp.ipe_groups:                               # the chain modes a general basis is not built for say so
+    cfg.hip_train_precision = cfg.hip_bwd_precision = "bf16"
+    if mlp.ipe_groups:                               # the chain mode a general basis is not built for says so
         with pytest.raises(ValueError, match="basis"):
             model(rays, 1.0, True)
-    else:                                            # narrower network: the split-f16 chains as well
+    cfg.hip_train_precision = cfg.hip_bwd_precision = "f16x2"
+    if not flat:                                     # the split-f16 chains as well (general basis: level_fwd_f16x2c_gb)
         for prm in model.parameters():
             prm.grad = None
         rend2, hist2 = model(rays, 1.0, True)
@@ -298,6 +299,15 @@ def test_general_basis_ragged_shapes_vs_cpu_oracle(shape, subdiv, n_rays, n_prop
         werr = np.abs(hist[L]["weights"].cpu().numpy() - ref[L]["weights"])[same].max()
         print(f"{shape}/{subdiv} {n_rays} x {n_prop}/{n_nerf} L{L}: RGB L-inf vs oracle {err:.2e}, weights {werr:.2e}, same positions {100 * same.mean():.0f} %")
         assert err <= 1e-5 and werr <= 5e-6
+    cfg.hip_precision = "f16x2"                         # the parity-grade 16-bit mode of a general basis (split-f16 chains)
+    with torch.no_grad():
+        rend16, _ = model(rays, 1.0, True)
+    cfg.hip_precision = "f32"
+    for L in range(2):
+        same = np.abs(hist[L]["sdist"].cpu().numpy() - ref[L]["sdist"]).max(-1) < 2e-6
+        err16 = np.abs(rend16[L]["rgb"].cpu().numpy() - ref[L]["r_rgb"])[same].max()
+        print(f"   [f16x2] L{L}: RGB L-inf vs oracle {err16:.2e}")
+        assert err16 <= 1e-5
     model.train()
     rend_t, hist_t = model(rays, 1.0, True)
     for L in range(2):
