@@ -176,8 +176,9 @@ def pack_weights(params: torch.Tensor, packed: torch.Tensor = None, precision=PR
     nbytes = int(lib().refnerf_packed_weights_bytes_basis(precision, groups))
     if nbytes == 0:
         if groups > 1:
-            raise ValueError("a general IPE basis (NerfMLP.basis_shape / basis_subdivisions other than 'octahedron' / 1) runs in the "
-                             "f32 precision mode only (Config.hip_precision = 'f32'), with at most 21 directions")
+            raise ValueError("a general IPE basis (NerfMLP.basis_shape / basis_subdivisions other than 'octahedron' / 1) has at most 21 "
+                             "directions and runs on the f32 operand image ('f32' and 'f16x2' modes); the plain bf16 / f16 images have "
+                             "no direction groups")
         raise HipLibraryError("precision mode not built")
     if packed is None or packed.numel() * packed.element_size() != nbytes or packed.device != params.device:
         packed = torch.empty(nbytes // 4, dtype=torch.float32, device=params.device)

@@ -708,7 +708,7 @@ int refnerf_pack_weights_basis(const float *d_params, const float *d_basis, int 
   if (!d_basis) return fail(REFNERF_EINVAL, "refnerf_pack_weights_basis: null basis%s");
   if (ipe_groups > rn::IPE_MAX_GROUPS) return fail(REFNERF_EUNSUPPORTED, "refnerf_pack_weights_basis: at most 7 groups of three directions (21: icosahedron / 2)%s");
   if (precision != REFNERF_PREC_F32)
-    return fail(REFNERF_EUNSUPPORTED, "a general IPE basis (ipe_groups > 1) runs in the REFNERF_PREC_F32 kernels only%s");
+    return fail(REFNERF_EUNSUPPORTED, "refnerf_pack_weights_basis builds the REFNERF_PREC_F32 image (levels with REFNERF_PREC_F32 or REFNERF_PREC_F16X2 run on it); the plain bf16 / f16 images have no direction groups%s");
   const int rc = refnerf_pack_weights(d_params, d_packed, precision, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(rn::pack_weights_ext, dim3(32, 1 + 8 * rn::EXT_GROUPS), dim3(256), 0, (hipStream_t)stream, d_params, d_basis, ipe_groups, (float *)d_packed);
