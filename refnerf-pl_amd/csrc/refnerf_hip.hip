@@ -945,7 +945,9 @@ int refnerf_mlp_forward(const void *d_packed, const refnerf_level_cfg *cfg, cons
   const size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + 2 * rpw * (N + 1) +
                                               rn::NPS_TRAIN * rpw * N + 3 * rn::T_TILE + 8);
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n too large for the 160 KiB LDS budget%s");
-  LDS_ATTR_ONCE(lds_attr(rn::mlp_fwd_f32), lds_attr(rn::mlp_fwd_train_f32));
+  if (cfg->ipe_groups < 0 || cfg->ipe_groups > rn::IPE_MAX_GROUPS) return fail(REFNERF_EINVAL, "ipe_groups must be in [0,7]%s");
+  const bool gbasis = cfg->ipe_groups > 1;     /* d_packed then comes from refnerf_pack_weights_basis */
+  LDS_ATTR_ONCE(lds_attr(rn::mlp_fwd_f32), lds_attr(rn::mlp_fwd_train_f32), lds_attr(rn::mlp_fwd_f32_gb), lds_attr(rn::mlp_fwd_train_f32_gb));
   rn::LevelArgs a{};
   a.packed = d_packed;
   a.cfg = *cfg;
@@ -959,7 +961,9 @@ int refnerf_mlp_forward(const void *d_packed, const refnerf_level_cfg *cfg, cons
   a.g_covs = d_covs;
   a.cov_full = cov_is_full;
   const int grid = (R + rpw - 1) / rpw;
-  if (cfg->training) hipLaunchKernelGGL(rn::mlp_fwd_train_f32, dim3(grid), dim3(rn::NTHREADS), lds, (hipStream_t)stream, a);
+  if (gbasis && cfg->training) hipLaunchKernelGGL(rn::mlp_fwd_train_f32_gb, dim3(grid), dim3(rn::NTHREADS), lds, (hipStream_t)stream, a);
+  else if (gbasis) hipLaunchKernelGGL(rn::mlp_fwd_f32_gb, dim3(grid), dim3(rn::NTHREADS), lds, (hipStream_t)stream, a);
+  else if (cfg->training) hipLaunchKernelGGL(rn::mlp_fwd_train_f32, dim3(grid), dim3(rn::NTHREADS), lds, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(rn::mlp_fwd_f32, dim3(grid), dim3(rn::NTHREADS), lds, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return REFNERF_OK;

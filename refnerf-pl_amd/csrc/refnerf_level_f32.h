@@ -980,7 +980,7 @@ template <bool TRAIN, bool STAGE = false, bool BFC = false, bool SPC = false, bo
 __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   static_assert(!BFC || (TRAIN && !STAGE), "bf16 chains: training forward only");
   static_assert(!SPC || (TRAIN && !STAGE && !BFC), "split-f16 chains: training forward only");
-  static_assert(!GB || (!STAGE && !BFC), "general IPE basis: the fp32 skeleton with fp32 or split-f16 chains");
+  static_assert(!GB || (!BFC && !(STAGE && SPC)), "general IPE basis: the fp32 skeleton with fp32 or split-f16 chains");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   RN_STAMP(A, 0);
   const refnerf_level_cfg &cfg = A.cfg;
@@ -1047,14 +1047,24 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
     /* general basis: lifted mean / variance of this lane's sample on the three directions of group gq (recomputed from
      * the ray where it is needed: nothing of it stays live across the trunk) */
     auto lift_group = [&](int gq, float (&gm)[3], float (&gv)[3]) {
-      float og[3], dg[3], mean[3], cov[9];
+      float mean[3], cov[9];
+      if constexpr (STAGE) {
+        /* the caller's Gaussian: full covariance, or its diagonal (zeros elsewhere) */
+        const size_t sidx = valid ? (size_t)ray * N + si : 0;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        og[i] = A.rays.d_origins[(size_t)rayc * 3 + i];
-        dg[i] = A.rays.d_directions[(size_t)rayc * 3 + i];
+        for (int i = 0; i < 3; ++i) mean[i] = A.g_means[sidx * 3 + i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) cov[i] = A.cov_full ? A.g_covs[sidx * 9 + i] : ((i % 4 == 0) ? A.g_covs[sidx * 3 + i / 4] : 0.0f);
+      } else {
+        float og[3], dg[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          og[i] = A.rays.d_origins[(size_t)rayc * 3 + i];
+          dg[i] = A.rays.d_directions[(size_t)rayc * 3 + i];
+        }
+        const float *td = TD + (valid ? rl : 0) * (N + 1);
+        cast_sample_full(og, dg, A.rays.d_radii[rayc], td[valid ? si : 0], td[valid ? si + 1 : 1], cfg.ray_shape, mean, cov);
       }
-      const float *td = TD + (valid ? rl : 0) * (N + 1);
-      cast_sample_full(og, dg, A.rays.d_radii[rayc], td[valid ? si : 0], td[valid ? si + 1 : 1], cfg.ray_shape, mean, cov);
       const float *bs = reinterpret_cast<const float *>(A.packed) + PEXT_BASIS + 9 * gq;
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
@@ -1076,7 +1086,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         for (int b = 0; b < 3; ++b) {
           const float fe = ipe_feature(gm[b], gv[b], j, h);
           X[(48 * h + j * 3 + b) * T_TILE + col] = fe;
-          if constexpr (TRAIN) {
+          if constexpr (TRAIN && !STAGE) {
             if (keep && save) {
               if (gq == 0) store_row1(A.act, rpitch, ACT_IPE + 48 * h + j * 3 + b, rcol, fe);
               else store_row1(act_ext, rpitch, (gq - 1) * IPE_DIM + 48 * h + j * 3 + b, xcol, fe);
@@ -1362,5 +1372,8 @@ __global__ __launch_bounds__(NTHREADS) void level_fwd_f16x2c_gb(const LevelArgs 
 /* MLP.__call__ stage entry (eval / training) */
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_f32(const LevelArgs A) { level_fwd_f32_body<false, true>(A); }
 __global__ __launch_bounds__(NTHREADS) void mlp_fwd_train_f32(const LevelArgs A) { level_fwd_f32_body<true, true>(A); }
+/* ... with a general IPE basis */
+__global__ __launch_bounds__(NTHREADS) void mlp_fwd_f32_gb(const LevelArgs A) { level_fwd_f32_body<false, true, false, false, true>(A); }
+__global__ __launch_bounds__(NTHREADS) void mlp_fwd_train_f32_gb(const LevelArgs A) { level_fwd_f32_body<true, true, false, false, true>(A); }
 
 }  // namespace rn

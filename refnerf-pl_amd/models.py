@@ -348,9 +348,6 @@ class MLP(nn.Module):
         forward-only: gradients flow through Model.__call__ (refnerf_level_backward)."""
         del imageplane                                   # unused by the reference as well (models.py:536)
         _hip.require_device()
-        if self.ipe_groups:
-            raise ValueError("MLP.__call__ on caller-supplied Gaussians is built for the 'octahedron' / 1 basis; a general IPE basis "
-                             "runs through Model.__call__ (the fused level kernel)")
         means, covs = gaussians
         if viewdirs is None:
             raise ValueError("the fused Ref-NeRF MLP needs viewdirs (use_viewdirs / use_reflections)")
@@ -368,7 +365,7 @@ class MLP(nn.Module):
         cfg = _hip.default_cfg(
             n_samples=int(n), n_in=1, training=int(self.training), compute_extras=0,
             srgb_mapping=int(self.srgb_mapping), srgb_mapping_normalization=int(self.srgb_mapping_normalization),
-            precision=_PREC["f32"], dir_enc=self.kernel_dir_enc, density_bias=float(self.density_bias), roughness_bias=self.kernel_roughness_bias,
+            precision=_PREC["f32"], dir_enc=self.kernel_dir_enc, ipe_groups=self.ipe_groups, density_bias=float(self.density_bias), roughness_bias=self.kernel_roughness_bias,
             rgb_premultiplier=float(self.rgb_premultiplier), rgb_bias=float(self.rgb_bias),
             rgb_padding=float(self.rgb_padding))
         res = _hip.mlp_forward(self.packed_weights(cfg.precision), cfg, m, c, v)

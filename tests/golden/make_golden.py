@@ -176,6 +176,45 @@ def golden_mlp():
     save("mlp", **out)
 
 
+def golden_mlp_basis():
+    """MLP.__call__ on Gaussians with the constructor-default 'icosahedron' / 2 basis (full covariances AND their diagonals as
+    input), eval and training mode (density-gradient normals)."""
+    pk = dict(seed=8, bias_scale=0.1)
+    gin.clear_config()
+    gin.parse_config_files_and_bindings([REF_CFG], ["NerfMLP.basis_shape = 'icosahedron'", "NerfMLP.basis_subdivisions = 2"])
+    model = models.construct_model(utils.dummy_rays(), configs.Config())
+    specs, idx = layout.variant_layout(n_basis=21)
+    true = synthetic.make_basis_params(n_basis=21, **pk)[idx]
+    sd = model.nerf_mlp.state_dict()
+    for sp in specs:
+        sd[sp.name + ".weight"].copy_(torch.tensor(true[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim].reshape(sp.out_dim, sp.in_dim)))
+        sd[sp.name + ".bias"].copy_(torch.tensor(true[sp.b_off:sp.b_off + sp.out_dim]))
+    mlp = model.nerf_mlp
+    rays = synthetic.blender_rays(6, seed=19)
+    r = to_rays(rays)
+    n = 10
+    sdist = torch.linspace(0, 1, n + 1)[None].repeat(6, 1)
+    _, s_to_t = coord.construct_ray_warps(None, r.near, r.far)
+    tdist = s_to_t(sdist)
+    means, covs = render.cast_rays(tdist, r.origins, r.directions, r.radii, "cone", diag=False)
+    _, covs_diag = render.cast_rays(tdist, r.origins, r.directions, r.radii, "cone", diag=True)
+    out = {"param_kw": np.array([pk["seed"], pk["bias_scale"], 1.0, 0.0]), "means": means.numpy(), "covs": covs.numpy(),
+           "covs_diag": covs_diag.numpy(), "viewdirs": r.viewdirs.numpy()}
+    for tag, cv in (("full", covs), ("diag", torch.diag_embed(covs_diag))):       # a diagonal covariance = the full matrix with zeros
+        mlp.eval()
+        with torch.no_grad():
+            res = mlp((means, cv), viewdirs=r.viewdirs)
+        for k, v in res.items():
+            if v is not None:
+                out[f"{tag}_eval_{k}"] = v.numpy()
+        mlp.train()
+        res = mlp((means.clone(), cv), viewdirs=r.viewdirs)
+        for k, v in res.items():
+            if v is not None:
+                out[f"{tag}_train_{k}"] = v.detach().numpy()
+    save("mlp_basis", **out)
+
+
 def golden_render():
     out = {}
     rng = np.random.default_rng(13)
@@ -1023,6 +1062,6 @@ def golden_variants():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models", "posenc_models", "raydist_models", "basis_models"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models", "posenc_models", "raydist_models", "basis_models", "mlp_basis"]
     for w in which:
         globals()["golden_" + w]()

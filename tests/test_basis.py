@@ -315,3 +315,37 @@ def test_general_basis_ragged_shapes_vs_cpu_oracle(shape, subdiv, n_rays, n_prop
         nrm = hist_t[L]["normals"].detach()
         assert bool(torch.isfinite(nrm).all()) and float(((nrm * nrm).sum(-1) - 1).abs().max()) < 1e-3
     configs.clear_config()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("covform", ["full", "diag"])
+def test_mlp_call_stage_entry_with_general_basis(mode, covform):
+    """MLP.__call__(gaussians=(means, covs), viewdirs) with the constructor-default 'icosahedron' / 2 basis against the
+    reference MLP's own outputs (tests/golden/mlp_basis.npz): full covariances, and their diagonals handed over as [..., 3]"""
+    import torch
+    from refnerf_pl_amd import _hip, configs, models, synthetic, utils
+    _hip.require_device()
+    g = load_golden("mlp_basis")
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", "refnerf_blender.gin")],
+                                            ["NerfMLP.basis_shape = 'icosahedron'", "NerfMLP.basis_subdivisions = 2"])
+    model = models.construct_model(utils.dummy_rays(), configs.Config()).to(DEV)
+    pk = g["param_kw"]
+    model.nerf_mlp.load_flat_params(synthetic.make_basis_params(seed=int(pk[0]), n_basis=21, bias_scale=float(pk[1])))
+    mlp = model.nerf_mlp.train() if mode == "train" else model.nerf_mlp.eval()
+    covs = g["covs"] if covform == "full" else g["covs_diag"]
+    with torch.no_grad():
+        res = mlp((torch.tensor(g["means"]), torch.tensor(covs)), viewdirs=torch.tensor(g["viewdirs"]))
+    for k, v in res.items():
+        if k == "normals" and mode == "eval":
+            assert v is None
+            continue
+        want = g[f"{covform}_{mode}_{k}"]
+        assert tuple(v.shape) == want.shape, k
+        err = np.abs(v.cpu().numpy() - want)
+        if k == "normals":                              # ill-conditioned where the density gradient is tiny
+            assert np.median(err.max(-1)) < 1e-5 and np.mean(err.max(-1) < 1e-3) > 0.97
+        else:
+            assert err.max() <= (5e-6 if k == "normals_pred" else 3e-6), (k, err.max())
+    configs.clear_config()
