@@ -1084,7 +1084,10 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       for (int j = 0; j < 16; ++j)
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-          const float fe = ipe_feature(gm[b], gv[b], j, h);
+          /* split chains (this kernel is also the F16X2 inference mode of a general basis): the split eval kernel's feature
+           * (exact argument, 1.5-ulp reduced sine, hardware exp2: < 2e-7, below the 2^-22 of the operands it feeds) at a third of
+           * the libm cost; the octahedron training chains keep libm (their nine-term totals are pinned to 1e-5 of the oracle's) */
+          const float fe = SPC ? ipe_feature_split(gm[b], gv[b], j, h) : ipe_feature(gm[b], gv[b], j, h);
           X[(48 * h + j * 3 + b) * T_TILE + col] = fe;
           if constexpr (TRAIN && !STAGE) {
             if (keep && save) {
