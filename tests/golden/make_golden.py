@@ -682,6 +682,62 @@ def golden_trained(steps=400, n_rays=512, n_samples=32, lr=5e-4):
     golden_trained_models()
 
 
+TRAINED_LONG_BLOB = os.path.join(HERE, "trained_long_blob.npz")
+
+
+def golden_trained_long(steps=2500, n_rays=384, n_samples=48, lr=1e-3):
+    """A harsher "trained-like" weight set (the 400-step blob is gentle on 16-bit operands): the REFERENCE takes
+    `steps` Adam steps at twice the learning rate on the analytic shiny sphere; the blob is stored in FLOAT32 (weights off
+    every 16-bit grid).  Then its reference outputs: eval at C2's sample counts, one training step."""
+    pk = dict(seed=1, bias_scale=0.0)
+    model, cfg = build_model([f"Model.num_prop_samples = {n_samples}", f"Model.num_nerf_samples = {n_samples}"], pk)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=lr, eps=1e-6)
+    import time
+    t0 = time.time()
+    hist_loss = []
+    for it in range(steps):
+        rays = synthetic.blender_rays(n_rays, seed=5000 + it, center_frac=0.85)
+        gt = analytic_target(rays)
+        r = to_rays(rays)
+        opt.zero_grad()
+        rend, hist = model(r, 1.0, False)
+        batch = utils.Batch(rays=r, rgb=gt)
+        data_loss, stats = train_utils.compute_data_loss(batch, rend, r, cfg)
+        loss = data_loss + train_utils.orientation_loss(r, model, hist, cfg) + train_utils.predicted_normal_loss(model, hist, cfg)
+        loss.backward()
+        opt.step()
+        hist_loss.append(float(data_loss))
+        if it % 50 == 0:
+            print(f"step {it}: data loss {float(data_loss):.5f}  ({time.time() - t0:.0f} s)", flush=True)
+    blob = np.zeros(layout.NUM_PARAMS, np.float32)
+    sd = model.nerf_mlp.state_dict()
+    for spec in layout.PARAM_SPECS:
+        blob[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = sd[spec.name + ".weight"].numpy().reshape(-1)
+        blob[spec.b_off:spec.b_off + spec.out_dim] = sd[spec.name + ".bias"].numpy()
+    assert np.isfinite(blob).all()
+    np.savez_compressed(TRAINED_LONG_BLOB, blob_f32=blob, data_loss_curve=np.array(hist_loss, np.float32),
+                        recipe=np.array([steps, n_rays, n_samples, lr]))
+    print("wrote", TRAINED_LONG_BLOB, os.path.getsize(TRAINED_LONG_BLOB) // 1024, "KiB; final data loss", hist_loss[-1],
+          "| max |w|", float(np.abs(blob).max()))
+    golden_trained_long_models()
+
+
+def golden_trained_long_models():
+    blob = np.load(TRAINED_LONG_BLOB)["blob_f32"]
+    cases = {
+        "model_trained_long_eval": ([], synthetic.blender_rays(32, seed=41, center_frac=0.8), False),
+        "model_trained_long_train": (["Model.num_prop_samples = 64", "Model.num_nerf_samples = 96"],
+                                     synthetic.blender_rays(16, seed=42, center_frac=0.8), True),
+    }
+    for name, (bindings, rays, train) in cases.items():
+        model, cfg = build_model_blob(bindings, blob)
+        gt = analytic_target(rays)
+        res = run_model(model, cfg, rays, train, gt)
+        print(name, "density max", float(res["L1_h_density"].max()), "specular max", float(res["L1_h_specular"].max()))
+        _finish_model_fixture(name, res, bindings, rays, gt, param_kw=np.array([-2.0, 0.0, 1.0, 0.0]))   # seed -2: trained_long_blob.npz
+
+
 def _load_trained_blob():
     return np.load(TRAINED_BLOB)["blob_f16"].astype(np.float32)
 

@@ -209,3 +209,104 @@ def test_f16x2_chain_training_step_vs_reference(hip, name, bwd):
     assert rel < (1e-3 if trained else 2e-4), rel
     assert lrel < 1e-5 and rgb < 1e-4
     configs.clear_config()
+
+
+# ---------------------------------------------------------------- the harsher trained-like weights (2500 reference steps, fp32 blob)
+def _have_long():
+    import os
+    from helpers import GOLDEN
+    return os.path.exists(os.path.join(GOLDEN, "model_trained_long_eval.npz"))
+
+
+@pytest.mark.skipif(not _have_long(), reason="tests/golden/model_trained_long_*.npz not generated")
+def test_trained_long_eval_every_mode_vs_reference(hip, O):
+    """"a real network will be harsher on 16-bit operands".  Weights after 2500 of the reference's own Adam
+    steps (lr 1e-3, fp32 blob): the parity-grade modes hold north_star's 1e-4 RGB against the reference's outputs; the
+    plain 16-bit modes are recorded."""
+    g = load_golden("model_trained_long_eval")
+    P = params_from_golden(g)
+    rays = rays_from_golden(g)
+    kw, lv = cfg_from_bindings(g["bindings"])
+    ref = O.model_forward(P, rays, **lv, **kw)
+    rec = {"max_abs_weight": float(np.abs(P).max()), "max_density": float(g["L1_h_density"].max())}
+    for prec, tag in ((0, "f32"), (F16X2, "f16x2"), (1, "bf16"), (2, "f16")):
+        outs = run_hip_model(hip, P, rays, kw, lv, precision=prec)
+        for L, res in enumerate(outs):
+            rec[f"{tag}_L{L}_rgb_linf_vs_reference"] = float(np.abs(res["r_rgb"] - g[f"L{L}_r_rgb"]).max())
+            rec[f"{tag}_L{L}_bin_idx_vs_oracle"] = float(np.mean(res["bin_idx"] == ref[L]["bin_idx"]))
+    rec["oracle_L1_rgb_linf_vs_reference"] = float(np.abs(ref[1]["r_rgb"] - g["L1_r_rgb"]).max())
+    print(rec)
+    _record("trained_long_eval", rec)
+    for tag in ("f32", "f16x2"):
+        for L in range(2):
+            assert rec[f"{tag}_L{L}_rgb_linf_vs_reference"] <= RGB_TOL, (tag, L, rec)
+            assert rec[f"{tag}_L{L}_bin_idx_vs_oracle"] >= 0.999, (tag, L, rec)
+
+
+@pytest.mark.skipif(not _have_long(), reason="tests/golden/model_trained_long_*.npz not generated")
+@pytest.mark.parametrize("chains", ["f32", "f16x2"])
+def test_trained_long_training_step_vs_reference(hip, chains):
+    """one training step on the same weights: losses and autograd gradients of the reference, exact-fp32 and split-f16 chains.
+    On this sharp, trained surface the level-1 gradient is ill-conditioned in the SAMPLE POSITIONS: the 4e-7 differences of the
+    level-0 weights between two arithmetics move some level-1 positions by up to 5e-6 in s (f32 mode vs the reference: 137
+    of 1552 edges by > 1e-6), and un-damped IPE degrees turn that into 1e-3 of the level-1 gradient (scripts/dbg_trained_long_*.py;
+    level 0 alone: 3e-6).  Hence 5e-3 here, and the isolation test below for the arithmetic itself."""
+    import os
+    import torch
+    from refnerf_pl_amd import configs, models, train_utils, utils
+    g = load_golden("model_trained_long_train")
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                            [str(b) for b in g["bindings"] if str(b)] +
+                                            [f"Config.hip_train_precision = '{chains}'", f"Config.hip_bwd_precision = '{chains}'"])
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
+    model.nerf_mlp.load_flat_params(params_from_golden(g))
+    rays = utils.rays_from_dict(rays_from_golden(g), DEV)
+    batch = utils.Batch(rays=rays, rgb=np.asarray(g["gt_rgb"], np.float32))
+    rend, hist = model(rays, 1.0, False)
+    total, terms, _ = train_utils.compute_losses(model, batch, rays, rend, hist, cfg)
+    total.backward()
+    grads = torch.cat([p.grad.flatten() for p in model.nerf_mlp.ordered_parameters()]).cpu().numpy()
+    ref = g["grads_sub"]
+    rel = float(np.linalg.norm(grads[::97] - ref) / np.linalg.norm(ref))
+    lrel = abs(float(total.detach()) - float(g["loss_total"])) / abs(float(g["loss_total"]))
+    rgb = float(np.abs(rend[1]["rgb"].detach().cpu().numpy() - g["L1_r_rgb"]).max())
+    print(f"trained_long [{chains} chains]: gradient rel-L2 vs reference {rel:.2e}, loss rel {lrel:.2e}, RGB L-inf {rgb:.2e}")
+    _record("trained_long_train/" + chains, dict(grad_rel_l2=rel, loss_rel=lrel, rgb_linf=rgb))
+    assert rel < 5e-3 and lrel < 1e-5 and rgb < RGB_TOL
+    configs.clear_config()
+
+
+@pytest.mark.skipif(not _have_long(), reason="tests/golden/model_trained_long_*.npz not generated")
+def test_trained_long_split_chains_equal_f32_chains_from_the_same_step_function(hip):
+    """the arithmetic itself on the harsher weights: both levels run from IDENTICAL step functions in the exact-fp32 and the
+    split-f16 chain mode (forward and backward), same upstream gradients -> the 1.11 M gradients agree to 2e-5"""
+    import torch
+    g = load_golden("model_trained_long_train")
+    P = torch.tensor(params_from_golden(g), device=DEV)
+    rays = {k: torch.tensor(v, device=DEV) for k, v in rays_from_golden(g).items()}
+    for k in ("radii", "near", "far"):
+        rays[k] = rays[k].reshape(-1)
+    R = rays["origins"].shape[0]
+    packed = hip.pack_weights(P, precision=0)
+    gen = torch.Generator().manual_seed(3)
+    sd, w = torch.tensor([[0.0, 1.0]], device=DEV).repeat(R, 1), torch.ones((R, 1), device=DEV)
+    for N in (64, 96):
+        g_rgb = (torch.randn((R, 3), generator=gen) * 1e-2).to(DEV)
+        g_w = (torch.randn((R, N), generator=gen) * 1e-3).to(DEV)
+        g_np = (torch.randn((R, N, 3), generator=gen) * 1e-3).to(DEV)
+        grads, outs = {}, {}
+        for prec in (0, F16X2):
+            cfg = hip.default_cfg(n_samples=N, n_in=w.shape[1], training=1, compute_extras=0)
+            cfg.precision = prec
+            res = hip.level_forward(packed, cfg, rays, sd, w, history=True, save_activations=True)
+            out = torch.zeros(hip.NUM_PARAMS, device=DEV)
+            hip.level_backward(packed, cfg, rays, res, g_rgb, g_w, g_np, out)
+            grads[prec], outs[prec] = out.cpu().numpy(), res
+        assert torch.equal(outs[0]["sdist"], outs[F16X2]["sdist"])
+        rel = float(np.linalg.norm(grads[F16X2] - grads[0]) / np.linalg.norm(grads[0]))
+        drgb = float((outs[0]["r_rgb"] - outs[F16X2]["r_rgb"]).abs().max())
+        print(f"N = {N}, n_in = {w.shape[1]}: gradient rel diff between the chain modes {rel:.2e}, rendered RGB diff {drgb:.2e}")
+        assert rel < 2e-5 and drgb < 5e-6
+        sd, w = outs[0]["sdist"].contiguous(), outs[0]["weights"].contiguous()      # the next level's input: the f32 step function

@@ -453,3 +453,22 @@ def test_unfused_torch_path_matches_oracle(fam):
         for k in ("sdist", "weights", "rgb", "r_rgb", "r_diffuse", "r_specular", "r_acc", "r_distance", "r_distance_mean",
                   "r_roughness", "r_tint", "r_normals_pred", "r_percentiles"):
             np.testing.assert_allclose(b[L][k].reshape(a[L][k].shape), a[L][k], rtol=2e-6, atol=5e-6, err_msg=f"L{L} {k}")
+
+
+def test_oracle_on_the_long_trained_weights():
+    """the harsher trained-like fixture (2500 reference steps at lr 1e-3, fp32 blob; tests/golden/make_golden.py::
+    golden_trained_long): the oracle against the reference's eval outputs -- level-0 samples bit for bit, rendered RGB 2e-5
+    (the reference's BLAS summation order vs the oracle's sequential fp32 sums on activations up to 136)"""
+    import os
+    from helpers import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "model_trained_long_eval.npz")):
+        pytest.skip("fixture not generated")
+    g = load_golden("model_trained_long_eval")
+    P = params_from_golden(g)
+    kw, lv = cfg_from_bindings(g["bindings"])
+    out = O.model_forward(P, rays_from_golden(g), **lv, **kw)
+    assert np.array_equal(out[0]["sdist"], g["L0_h_sdist"].reshape(out[0]["sdist"].shape))
+    for L in range(2):
+        err = float(np.abs(out[L]["r_rgb"] - g[f"L{L}_r_rgb"]).max())
+        print(f"L{L}: oracle RGB L-inf vs reference {err:.2e}")
+        assert err <= 2e-5
