@@ -182,25 +182,27 @@ def cpu_baseline_and_parity(blob, spec, rays_np, hip_outputs):
     return base, parity
 
 
-def trained_like_parity(model, cfg, dev, spec, modes):
-    """The same check on the "trained-like" weights (tests/golden/trained_blob.npz: what the REFERENCE reached after 400
-    of its own Adam steps on an analytic shiny sphere): 256 Blender rays x this configuration's sample counts, every
-    arithmetic mode against the CPU oracle.  Random-init weights flatter 16-bit arithmetic; these do not."""
+def trained_like_parity(model, cfg, dev, spec, modes, which="trained_blob.npz"):
+    """The same check on "trained-like" weights -- tests/golden/trained_blob.npz: what the REFERENCE reached after 400 of
+    its own Adam steps on an analytic shiny sphere (stored as float16); trained_long_blob.npz: after 2500 steps at twice
+    the learning rate, stored in fp32 --: 256 Blender rays x this configuration's sample counts, every arithmetic mode
+    against the CPU oracle.  Random-init weights flatter 16-bit arithmetic; these do not."""
     import numpy as np
     import torch
     from oracle import oracle as O
     from refnerf_pl_amd import synthetic, utils
-    path = os.path.join(ROOT, "tests", "golden", "trained_blob.npz")
+    path = os.path.join(ROOT, "tests", "golden", which)
     if not os.path.exists(path):
         return None
-    blob = np.load(path)["blob_f16"].astype(np.float32)
+    z = np.load(path)
+    blob = z["blob_f32"] if "blob_f32" in z.files else z["blob_f16"].astype(np.float32)
     N = spec["samples"]
     rays_np = synthetic.blender_rays(256, seed=3, center_frac=0.8)
     ref = O.model_forward(blob, rays_np, num_prop_samples=N, num_nerf_samples=N, n_threads=os.cpu_count() or 1, history=True)
     keep = model.nerf_mlp.flat_params().clone()
     model.nerf_mlp.load_flat_params(blob)
     rays = utils.rays_from_dict(rays_np, dev)
-    res = {"rays_checked": 256, "weights": "tests/golden/trained_blob.npz"}
+    res = {"rays_checked": 256, "weights": "tests/golden/" + which}
     prev = cfg.hip_precision
     for m in modes:
         cfg.hip_precision = m
@@ -541,6 +543,7 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(blob, spec, rays_np, hip_outputs)
             line["parity"]["trained_like_weights"] = trained_like_parity(model, cfg, dev, spec, sorted(hip_outputs))
+            line["parity"]["trained_long_weights"] = trained_like_parity(model, cfg, dev, spec, sorted(hip_outputs), "trained_long_blob.npz")
             if args.config == "C2":
                 line["cpu_baseline_torch"] = torch_cpu_baseline(spec)
         if rank == 0 and world == 1 and args.config == "C2" and not args.no_other_configs:
