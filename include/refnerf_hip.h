@@ -52,7 +52,9 @@ enum {
                             v_mfma_f32_32x32x16_f16, fp32 accumulate), the directional trunk is plain f16; resampler,
                             encodings, activations and compositing are the fp32 parity code.  The 16-bit mode that holds
                             the reference's fp32 nn.Linear arithmetic (internal/models.py:576-580, 686-700) to 1e-4 RGB
-                            on trained weights; ~2.35x the MFMAs of REFNERF_PREC_F16.
+                            on trained weights; ~2.35x the MFMAs of REFNERF_PREC_F16.  Range: the hi halves are IEEE
+                            halves, so weights and hidden activations must stay below 65504 in magnitude (a trained
+                            Ref-NeRF's reach ~1e2; beyond the range the outputs are inf / NaN, not silently wrong).
                             refnerf_level_forward_train / refnerf_level_backward in this mode: the f32 kernels with every
                             256-wide contraction as W_hi x_hi + W_lo x_hi + W_hi x_lo on the same instruction (saved
                             activations stay REFNERF_ACT_F32; gradients 5e-5 rel-L2 from the reference's autograd). */
