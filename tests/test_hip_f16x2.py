@@ -310,3 +310,28 @@ def test_trained_long_split_chains_equal_f32_chains_from_the_same_step_function(
         print(f"N = {N}, n_in = {w.shape[1]}: gradient rel diff between the chain modes {rel:.2e}, rendered RGB diff {drgb:.2e}")
         assert rel < 2e-5 and drgb < 5e-6
         sd, w = outs[0]["sdist"].contiguous(), outs[0]["weights"].contiguous()      # the next level's input: the f32 step function
+
+
+def test_f16x2_operand_range(hip):
+    """include/refnerf_hip.h: the hi halves are IEEE halves.  Inside the range (hidden activations up to ~8e3 here, a trained
+    network's reach ~1e2) the mode holds its parity; beyond 65504 a unit overflows to inf and the ReLU's NaN-absorbing max drops
+    it -- finite but wrong outputs (recorded, so that the documentation stays honest about it)."""
+    from refnerf_pl_amd import layout, synthetic
+    rays = synthetic.blender_rays(64, seed=2, center_frac=0.6)
+    lv = dict(num_prop_samples=64, num_nerf_samples=64)
+    dev = {}
+    for scale in (30.0, 300.0, 3000.0):
+        P = synthetic.make_params(seed=0, bias_scale=0.05, sharpen=1.0)
+        for name in ("spatial_net.2", "spatial_net.3"):                    # two layers: hidden activations ~ 0.09 scale^2
+            sp = layout.SPEC_BY_NAME[name]
+            P[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim] *= scale
+        nxt = layout.SPEC_BY_NAME["spatial_net.4"]
+        P[nxt.w_off:nxt.w_off + nxt.out_dim * nxt.in_dim] /= scale * scale   # ... and back to O(1) for the rest of the network
+        f32 = run_hip_model(hip, P, rays, {}, lv, precision=0)
+        x2 = run_hip_model(hip, P, rays, {}, lv, precision=F16X2)
+        assert np.isfinite(f32[1]["r_rgb"]).all()
+        dev[scale] = float(np.nanmax(np.abs(x2[1]["r_rgb"] - f32[1]["r_rgb"])))
+        print(f"scale {scale:g} (activations up to ~{0.093 * scale * scale:.3g}): f16x2 vs f32 mode RGB {dev[scale]:.2e}")
+    _record("f16x2_operand_range", {str(k): v for k, v in dev.items()})
+    assert dev[30.0] <= 5e-6 and dev[300.0] <= 5e-6          # in range: parity
+    assert dev[3000.0] > 2e-5                                # out of range (8e5): the documented silent deviation
