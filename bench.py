@@ -197,8 +197,11 @@ def trained_like_parity(model, cfg, dev, spec, modes, which="trained_blob.npz"):
     z = np.load(path)
     blob = z["blob_f32"] if "blob_f32" in z.files else z["blob_f16"].astype(np.float32)
     N = spec["samples"]
-    rays_np = synthetic.blender_rays(256, seed=3, center_frac=0.8)
-    ref = O.model_forward(blob, rays_np, num_prop_samples=N, num_nerf_samples=N, n_threads=os.cpu_count() or 1, history=True)
+    llff = spec["family"] == "llff"
+    rays_np = synthetic.llff_rays(256, seed=3) if llff else synthetic.blender_rays(256, seed=3, center_frac=0.8)
+    okw = dict(srgb_mapping=int(model.nerf_mlp.srgb_mapping),
+               render_srgb_mode=cfg.srgb_mapping_type if cfg.srgb_mapping_when_rendering else "none")
+    ref = O.model_forward(blob, rays_np, num_prop_samples=N, num_nerf_samples=N, n_threads=os.cpu_count() or 1, history=True, **okw)
     keep = model.nerf_mlp.flat_params().clone()
     model.nerf_mlp.load_flat_params(blob)
     rays = utils.rays_from_dict(rays_np, dev)
@@ -543,7 +546,8 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity"] = cpu_baseline_and_parity(blob, spec, rays_np, hip_outputs)
             line["parity"]["trained_like_weights"] = trained_like_parity(model, cfg, dev, spec, sorted(hip_outputs))
-            line["parity"]["trained_long_weights"] = trained_like_parity(model, cfg, dev, spec, sorted(hip_outputs), "trained_long_blob.npz")
+            line["parity"]["trained_long_weights"] = trained_like_parity(model, cfg, dev, spec, sorted(hip_outputs),
+                                                                         "trained_llff_blob.npz" if spec["family"] == "llff" else "trained_long_blob.npz")
             if args.config == "C2":
                 line["cpu_baseline_torch"] = torch_cpu_baseline(spec)
         if rank == 0 and world == 1 and args.config == "C2" and not args.no_other_configs:

@@ -738,6 +738,80 @@ def golden_trained_long_models():
         _finish_model_fixture(name, res, bindings, rays, gt, param_kw=np.array([-2.0, 0.0, 1.0, 0.0]))   # seed -2: trained_long_blob.npz
 
 
+def analytic_target_ndc(rays):
+    """The same kind of ground truth for forward-facing NDC rays (synthetic.llff_rays: origins on z = -1, t in [0, 1] runs to
+    z = +1): a shaded sphere inside the NDC cube in front of a smooth two-tone backdrop (own code)."""
+    o, d = rays["origins"].astype(np.float64), rays["directions"].astype(np.float64)
+    c, rad = np.array([-0.15, 0.1, 0.25]), 0.5
+    oc = o - c
+    a = (d * d).sum(-1)
+    b = (oc * d).sum(-1)
+    disc = b * b - a * ((oc * oc).sum(-1) - rad * rad)
+    hit = disc > 0
+    t = (-b - np.sqrt(np.where(hit, disc, 0.0))) / a
+    hit &= (t > 0) & (t < 1)
+    p = o + t[:, None] * d
+    n = (p - c) / rad
+    light = np.array([0.4, 0.7, -0.6])
+    light /= np.linalg.norm(light)
+    v = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    refl = v - 2.0 * (v * n).sum(-1, keepdims=True) * n
+    spec = np.maximum(0.0, refl @ light) ** 24 * 0.7
+    col = (0.45 + 0.4 * n) * np.maximum(0.2, n @ light)[:, None] + spec[:, None]
+    end = o + d                                                      # where the ray leaves the cube (z = +1)
+    back = np.stack([0.55 + 0.25 * np.sin(2.0 * end[:, 0]), 0.5 + 0.2 * np.cos(1.5 * end[:, 1]), 0.6 + 0.0 * end[:, 0]], -1)
+    return np.where(hit[:, None], np.clip(col, 0.0, 1.0), back).astype(np.float32)
+
+
+TRAINED_LLFF_BLOB = os.path.join(HERE, "trained_llff_blob.npz")
+LLFF_BINDINGS = ["NerfMLP.srgb_mapping = False", "Config.srgb_mapping_when_rendering = True", "Config.srgb_mapping_type = 'norm_linear'",
+                 "Config.near = 0.", "Config.far = 1."]
+
+
+def golden_trained_llff(steps=1200, n_rays=384, n_samples=48, lr=1e-3):
+    """Trained-like weights for the forward-facing configurations (C4 / C5: NDC rays, linear colour, norm_linear render map):
+    the REFERENCE takes `steps` Adam steps on the analytic NDC scene above; fp32 blob; then its eval outputs at C4's sample
+    counts and one training step."""
+    pk = dict(seed=2, bias_scale=0.0)
+    model, cfg = build_model(LLFF_BINDINGS + [f"Model.num_prop_samples = {n_samples}", f"Model.num_nerf_samples = {n_samples}"], pk)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=lr, eps=1e-6)
+    import time
+    t0 = time.time()
+    hist_loss = []
+    for it in range(steps):
+        rays = synthetic.llff_rays(n_rays, seed=7000 + it)
+        gt = analytic_target_ndc(rays)
+        r = to_rays(rays)
+        opt.zero_grad()
+        rend, hist = model(r, 1.0, False)
+        batch = utils.Batch(rays=r, rgb=gt)
+        data_loss, stats = train_utils.compute_data_loss(batch, rend, r, cfg)
+        loss = data_loss + train_utils.orientation_loss(r, model, hist, cfg) + train_utils.predicted_normal_loss(model, hist, cfg)
+        loss.backward()
+        opt.step()
+        hist_loss.append(float(data_loss))
+        if it % 50 == 0:
+            print(f"step {it}: data loss {float(data_loss):.5f}  ({time.time() - t0:.0f} s)", flush=True)
+    blob = np.zeros(layout.NUM_PARAMS, np.float32)
+    sd = model.nerf_mlp.state_dict()
+    for spec in layout.PARAM_SPECS:
+        blob[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = sd[spec.name + ".weight"].numpy().reshape(-1)
+        blob[spec.b_off:spec.b_off + spec.out_dim] = sd[spec.name + ".bias"].numpy()
+    assert np.isfinite(blob).all()
+    np.savez_compressed(TRAINED_LLFF_BLOB, blob_f32=blob, data_loss_curve=np.array(hist_loss, np.float32),
+                        recipe=np.array([steps, n_rays, n_samples, lr]))
+    print("wrote", TRAINED_LLFF_BLOB, "final data loss", hist_loss[-1], "| max |w|", float(np.abs(blob).max()))
+    cases = {"model_trained_llff_eval": (LLFF_BINDINGS, synthetic.llff_rays(32, seed=51), False),
+             "model_trained_llff_train": (LLFF_BINDINGS + ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 96"], synthetic.llff_rays(16, seed=52), True)}
+    for name, (bindings, rays, train) in cases.items():
+        model, cfg = build_model_blob(bindings, blob)
+        gt = analytic_target_ndc(rays)
+        res = run_model(model, cfg, rays, train, gt)
+        print(name, "density max", float(res["L1_h_density"].max()))
+        _finish_model_fixture(name, res, bindings, rays, gt, param_kw=np.array([-3.0, 0.0, 1.0, 0.0]))   # seed -3: trained_llff_blob.npz
+
+
 def _load_trained_blob():
     return np.load(TRAINED_BLOB)["blob_f16"].astype(np.float32)
 

@@ -26,8 +26,16 @@ def trained_long_blob():
     return np.load(os.path.join(GOLDEN, "trained_long_blob.npz"))["blob_f32"]
 
 
+def trained_llff_blob():
+    """Trained-like weights of the forward-facing configurations: 1200 of the REFERENCE's Adam steps on an analytic NDC scene
+    (linear colour, norm_linear render map; tests/golden/make_golden.py::golden_trained_llff), float32."""
+    return np.load(os.path.join(GOLDEN, "trained_llff_blob.npz"))["blob_f32"]
+
+
 def params_from_golden(g):
     pk = g["param_kw"]
+    if int(pk[0]) == -3:
+        return trained_llff_blob()
     if int(pk[0]) == -2:
         return trained_long_blob()
     if int(pk[0]) < 0:

@@ -455,15 +455,17 @@ def test_unfused_torch_path_matches_oracle(fam):
             np.testing.assert_allclose(b[L][k].reshape(a[L][k].shape), a[L][k], rtol=2e-6, atol=5e-6, err_msg=f"L{L} {k}")
 
 
-def test_oracle_on_the_long_trained_weights():
+@pytest.mark.parametrize("tag", ["trained_long", "trained_llff"])
+def test_oracle_on_the_long_trained_weights(tag):
     """the harsher trained-like fixture (2500 reference steps at lr 1e-3, fp32 blob; tests/golden/make_golden.py::
-    golden_trained_long): the oracle against the reference's eval outputs -- level-0 samples bit for bit, rendered RGB 2e-5
+    golden_trained_long) and the forward-facing one (1200 steps on NDC rays, linear colour, norm_linear render map: the C4 / C5
+    family): the oracle against the reference's eval outputs -- level-0 samples bit for bit, rendered RGB 2e-5
     (the reference's BLAS summation order vs the oracle's sequential fp32 sums on activations up to 136)"""
     import os
     from helpers import GOLDEN
-    if not os.path.exists(os.path.join(GOLDEN, "model_trained_long_eval.npz")):
+    if not os.path.exists(os.path.join(GOLDEN, f"model_{tag}_eval.npz")):
         pytest.skip("fixture not generated")
-    g = load_golden("model_trained_long_eval")
+    g = load_golden(f"model_{tag}_eval")
     P = params_from_golden(g)
     kw, lv = cfg_from_bindings(g["bindings"])
     out = O.model_forward(P, rays_from_golden(g), **lv, **kw)
