@@ -48,14 +48,17 @@ def test_f16x2_vs_reference_fixtures(hip, name):
         assert rec[f"L{L}_bin_idx_vs_f32_mode"] >= 0.999, rec
 
 
-@pytest.mark.parametrize("case", ["C2_trained_like", "C2_trained_like_fp32_weights", "C2_bench_batch", "C3_shiny"])
+@pytest.mark.parametrize("case", ["C2_trained_like", "C2_trained_like_fp32_weights", "C2_bench_batch", "C3_shiny", "C2_trained_long", "C3_trained_long"])
 def test_f16x2_full_size_vs_oracle(hip, O, case):
     """BASELINE-sized batches on the HIP path, the first 512 rays through the CPU oracle: RGB L-inf <= 1e-4 and >= 99.9 %
     identical bin indices at every level -- on the trained-like weights (f16-exact as stored, and perturbed to full fp32
     precision) as on the bench batch (C2) and the shiny network (C3, the ring-of-records kernel variant)."""
     from refnerf_pl_amd import synthetic
-    R, N, n_or = (8192, 192, 512) if case == "C3_shiny" else (4096, 128, 512)
-    if case == "C2_trained_like":
+    R, N, n_or = (8192, 192, 512) if case.startswith("C3") else (4096, 128, 512)
+    if case.endswith("trained_long"):           # the 2500-step fp32 weight set, also through the ring-of-records variant (C3 shape)
+        from helpers import trained_long_blob
+        P, rk = trained_long_blob(), dict(seed=3, center_frac=0.8)
+    elif case == "C2_trained_like":
         P, rk = trained_blob(), dict(seed=3, center_frac=0.8)
     elif case == "C2_trained_like_fp32_weights":
         P, rk = perturbed_trained_blob(), dict(seed=3, center_frac=0.8)
