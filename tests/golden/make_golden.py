@@ -812,6 +812,45 @@ def golden_trained_llff(steps=1200, n_rays=384, n_samples=48, lr=1e-3):
         _finish_model_fixture(name, res, bindings, rays, gt, param_kw=np.array([-3.0, 0.0, 1.0, 0.0]))   # seed -3: trained_llff_blob.npz
 
 
+def golden_trajectory(steps=20, n_rays=256, n_samples=48, lr=5e-4):
+    """The first `steps` optimiser steps of the REFERENCE from the seeded init (its forward, its three Ref-NeRF losses, its
+    autograd, torch.optim.Adam) on fixed synthetic batches: the per-step losses and a subsample of the final parameters.
+    Checks the whole loop on the other side -- weight re-pack after every step, gradient accumulation into the flat blob,
+    optimiser coupling -- not just single steps."""
+    pk = dict(seed=3, bias_scale=0.0)
+    model, cfg = build_model([f"Model.num_prop_samples = {n_samples}", f"Model.num_nerf_samples = {n_samples}"], pk)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=lr, eps=1e-6)
+    out = {"total": [], "data": [], "orientation": [], "normal": []}
+    gts = []
+    for it in range(steps):
+        rays = synthetic.blender_rays(n_rays, seed=9100 + it, center_frac=0.85)
+        gt = analytic_target(rays)
+        gts.append(gt)
+        r = to_rays(rays)
+        opt.zero_grad()
+        rend, hist = model(r, 1.0, False)
+        batch = utils.Batch(rays=r, rgb=gt)
+        data_loss, _ = train_utils.compute_data_loss(batch, rend, r, cfg)
+        o_loss = train_utils.orientation_loss(r, model, hist, cfg)
+        n_loss = train_utils.predicted_normal_loss(model, hist, cfg)
+        loss = data_loss + o_loss + n_loss
+        loss.backward()
+        opt.step()
+        for k, v in (("total", loss), ("data", data_loss), ("orientation", o_loss), ("normal", n_loss)):
+            out[k].append(float(v))
+        print(it, float(loss), flush=True)
+    blob = np.zeros(layout.NUM_PARAMS, np.float32)
+    sd = model.nerf_mlp.state_dict()
+    for spec in layout.PARAM_SPECS:
+        blob[spec.w_off:spec.w_off + spec.out_dim * spec.in_dim] = sd[spec.name + ".weight"].numpy().reshape(-1)
+        blob[spec.b_off:spec.b_off + spec.out_dim] = sd[spec.name + ".bias"].numpy()
+    init = synthetic.make_params(**pk)
+    save("trajectory", recipe=np.array([steps, n_rays, n_samples, lr, 1e-6, pk["seed"]]), final_params_sub=blob[::97].copy(),
+         update_sub=(blob - init)[::97].copy(), gt_rgb=np.stack(gts),
+         **{"loss_" + k: np.array(v, np.float64) for k, v in out.items()})
+
+
 def _load_trained_blob():
     return np.load(TRAINED_BLOB)["blob_f16"].astype(np.float32)
 
