@@ -588,7 +588,14 @@ __device__ __forceinline__ float npk_total1(const v16f &a, int j) {
 /* totals 2e, 2e+1 (after ReLU) -> dword e of the next layer's two N-packed B fragments (hi + lo halves); same k order
  * as pack_acc */
 __device__ __forceinline__ void split_piece(const float (&s)[8], int e, v4uu &f0, v4uu &f1, float *dbg = nullptr, int lane = 0) {
+  /* ReLU that lets a NaN through (v_max_f32 would return the 0): a unit past the range of an IEEE half becomes hi = inf,
+   * lo = -inf, the next layer's accumulators inf - inf = NaN -- and the ray's colour comes out NaN instead of finite and
+   * wrong (include/refnerf_hip.h: REFNERF_PREC_F16X2 range) */
+#ifdef REFNERF_SPLIT_RELU_MAX
   const float x0 = fmaxf(s[2 * e], 0.0f), x1 = fmaxf(s[2 * e + 1], 0.0f);
+#else
+  const float x0 = (s[2 * e] < 0.0f) ? 0.0f : s[2 * e], x1 = (s[2 * e + 1] < 0.0f) ? 0.0f : s[2 * e + 1];
+#endif
 #ifdef REFNERF_SPLIT_DUMP
   if (dbg) {
 #pragma unroll

@@ -329,8 +329,9 @@ def test_trained_long_split_chains_equal_f32_chains_from_the_same_step_function(
 
 def test_f16x2_operand_range(hip):
     """include/refnerf_hip.h: the hi halves are IEEE halves.  Inside the range (hidden activations up to ~8e3 here, a trained
-    network's reach ~1e2) the mode holds its parity; beyond 65504 a unit overflows to inf and the ReLU's NaN-absorbing max drops
-    it -- finite but wrong outputs (recorded, so that the documentation stays honest about it)."""
+    network's reach ~1e2) the mode holds its parity; beyond 65504 a unit becomes hi = inf, lo = -inf, the next layer's
+    accumulators NaN, and the inference kernel's NaN-propagating ReLU carries that to the outputs: NaN, not a finite wrong
+    colour."""
     from refnerf_pl_amd import layout, synthetic
     rays = synthetic.blender_rays(64, seed=2, center_frac=0.6)
     lv = dict(num_prop_samples=64, num_nerf_samples=64)
@@ -345,11 +346,14 @@ def test_f16x2_operand_range(hip):
         f32 = run_hip_model(hip, P, rays, {}, lv, precision=0)
         x2 = run_hip_model(hip, P, rays, {}, lv, precision=F16X2)
         assert np.isfinite(f32[1]["r_rgb"]).all()
-        dev[scale] = float(np.nanmax(np.abs(x2[1]["r_rgb"] - f32[1]["r_rgb"])))
-        print(f"scale {scale:g} (activations up to ~{0.093 * scale * scale:.3g}): f16x2 vs f32 mode RGB {dev[scale]:.2e}")
-    _record("f16x2_operand_range", {str(k): v for k, v in dev.items()})
-    assert dev[30.0] <= 5e-6 and dev[300.0] <= 5e-6          # in range: parity
-    assert dev[3000.0] > 2e-5                                # out of range (8e5): the documented silent deviation
+        bad = ~np.isfinite(x2[1]["r_rgb"]).all(-1)
+        err = np.abs(x2[1]["r_rgb"] - f32[1]["r_rgb"]).max(-1)
+        dev[scale] = (float(bad.mean()), float(np.max(np.where(bad, 0.0, err))))
+        print(f"scale {scale:g} (activations up to ~{0.093 * scale * scale:.3g}): rays with NaN output {dev[scale][0]:.2f}, "
+              f"worst finite deviation from the f32 mode {dev[scale][1]:.2e}")
+    _record("f16x2_operand_range", {str(k): list(v) for k, v in dev.items()})
+    assert dev[30.0] == (0.0, dev[30.0][1]) and dev[30.0][1] <= 5e-6 and dev[300.0][0] == 0.0 and dev[300.0][1] <= 5e-6   # in range: parity
+    assert dev[3000.0][0] > 0.5 and dev[3000.0][1] <= 1e-4      # out of range (8e5): NaN, and whatever stays finite is right
 
 
 @pytest.mark.parametrize("chains,fused", [("f32", False), ("f16x2", False), ("f16x2", True)])
