@@ -55,9 +55,9 @@ enum {
                             on trained weights; ~2.35x the MFMAs of REFNERF_PREC_F16.  Range: the hi halves are IEEE
                             halves, so weights and hidden activations must stay below 65504 in magnitude (a trained
                             Ref-NeRF's reach ~1e2; checked up to 8e3: 1e-6).  Beyond it a unit becomes hi = inf, lo = -inf, the
-                            next layer's accumulators NaN; the inference kernel's ReLU lets the NaN through, so the ray's
-                            outputs are NaN (loud).  The chain kernels (training, general basis) use a NaN-absorbing integer
-                            max there: finite but wrong -- REFNERF_PREC_F32 has no such limit.
+                            next layer's accumulators NaN; the ReLUs of the split kernels (inference, training chains, general
+                            basis) let a NaN through, so the ray's outputs are NaN: loud, never a finite wrong colour.
+                            REFNERF_PREC_F32 has no such limit.
                             refnerf_level_forward_train / refnerf_level_backward in this mode: the f32 kernels with every
                             256-wide contraction as W_hi x_hi + W_lo x_hi + W_hi x_lo on the same instruction (saved
                             activations stay REFNERF_ACT_F32; gradients 5e-5 rel-L2 from the reference's autograd). */

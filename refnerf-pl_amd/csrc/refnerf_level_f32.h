@@ -522,9 +522,13 @@ __device__ __forceinline__ void gemm_chain_bf16_shared(__amdgpu_buffer_rsrc_t rs
 /* ReLU and its sign bit without a compare: as integers, x > 0 <=> max_i32(x, 0) != 0 (negative floats and -0 are
  * negative integers), so relu(x) = max_i32(x, 0) and the mask bit = min_u32(relu(x), 1) -- VALU only (see keep_if_bit),
  * bit-identical to `x > 0 ? x : 0` for every non-NaN x. */
+/* NANPROP (split-f16 chains): a NaN of either sign passes -- as signed integers the negative NaNs are the ones above -inf's
+ * pattern -- so that a unit beyond the range of an IEEE half (hi = inf, lo = -inf -> NaN accumulators) reaches the outputs as
+ * NaN instead of vanishing (include/refnerf_hip.h: REFNERF_PREC_F16X2 range) */
+template <bool NANPROP = false>
 __device__ __forceinline__ float relu_bit(float x, unsigned &mk, int bit) {
   const int xi = __builtin_bit_cast(int, x);
-  const unsigned v = (unsigned)(xi > 0 ? xi : 0);
+  const unsigned v = NANPROP ? (unsigned)(xi > (int)0xff800000 ? xi : 0) : (unsigned)(xi > 0 ? xi : 0);   /* (-inf = 0xff800000) */
   mk |= (v < 1u ? v : 1u) << bit;
   return __builtin_bit_cast(float, v);
 }
@@ -589,7 +593,7 @@ __device__ __forceinline__ void relu_mask_split(const v16f (&out)[8], unsigned (
   for (int ob = 0; ob < 8; ++ob) {
     float v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = relu_bit(out[ob][r], mk[ob >> 1], 16 * (ob & 1) + r);
+    for (int r = 0; r < 16; ++r) v[r] = relu_bit<true>(out[ob][r], mk[ob >> 1], 16 * (ob & 1) + r);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       unsigned h0, l0, h1, l1;

@@ -354,6 +354,17 @@ def test_f16x2_operand_range(hip):
     _record("f16x2_operand_range", {str(k): list(v) for k, v in dev.items()})
     assert dev[30.0] == (0.0, dev[30.0][1]) and dev[30.0][1] <= 5e-6 and dev[300.0][0] == 0.0 and dev[300.0][1] <= 5e-6   # in range: parity
     assert dev[3000.0][0] > 0.5 and dev[3000.0][1] <= 1e-4      # out of range (8e5): NaN, and whatever stays finite is right
+    # the split training chains (also the F16X2 path of a general basis) are loud in the same way
+    import torch
+    packed = hip.pack_weights(torch.tensor(P, device=DEV), precision=0)
+    r = {k: torch.tensor(v, device=DEV) for k, v in rays.items()}
+    for k in ("radii", "near", "far"):
+        r[k] = r[k].reshape(-1)
+    cfg = hip.default_cfg(n_samples=64, n_in=1, training=1, compute_extras=0)
+    cfg.precision = F16X2
+    res = hip.level_forward(packed, cfg, r, torch.tensor([[0.0, 1.0]], device=DEV).repeat(64, 1), torch.ones((64, 1), device=DEV),
+                            history=True, save_activations=True)
+    assert float(torch.isnan(res["r_rgb"]).float().mean()) > 0.5
 
 
 @pytest.mark.parametrize("chains,fused", [("f32", False), ("f16x2", False), ("f16x2", True)])
