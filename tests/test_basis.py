@@ -349,3 +349,43 @@ def test_mlp_call_stage_entry_with_general_basis(mode, covform):
         else:
             assert err.max() <= (5e-6 if k == "normals_pred" else 3e-6), (k, err.max())
     configs.clear_config()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chains", ["f32", "f16x2"])
+def test_general_basis_gradients_are_shard_invariant_at_ragged_sizes(chains):
+    """13 rays x 40 / 56 samples (sample counts that leave pad columns in the blocked ACT / DELTA / tail matrices) with a
+    21-direction basis: the gradient of a per-ray mean over the batch equals the ray-weighted mean of the gradients of its
+    6- and 7-ray shards -- pad columns (uninitialised memory made hostile first) contribute nothing, the tail job table and the
+    direction groups behave like the canonical path"""
+    import torch
+    from refnerf_pl_amd import _hip, configs, models, synthetic, utils
+    _hip.require_device()
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", "refnerf_blender.gin")], [
+        "NerfMLP.basis_shape = 'icosahedron'", "NerfMLP.basis_subdivisions = 2", "Model.num_prop_samples = 40", "Model.num_nerf_samples = 56",
+        f"Config.hip_train_precision = '{chains}'", f"Config.hip_bwd_precision = '{chains}'"])
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
+    model.nerf_mlp.load_flat_params(synthetic.make_basis_params(seed=12, n_basis=21, bias_scale=0.05, sharpen=10.0))
+    rd = synthetic.blender_rays(13, seed=8, center_frac=0.7)
+    tgt = torch.tensor(synthetic.target_rgb(13, seed=9), device=DEV)
+
+    def grad(b, e):
+        poison = torch.full((64 << 20,), float("nan"), device=DEV)     # whatever the allocator hands out next is hostile
+        del poison
+        for p in model.parameters():
+            p.grad = None
+        rays = utils.rays_from_dict({k: v[b:e] for k, v in rd.items()}, DEV)
+        rend, hist = model(rays, 1.0, False)
+        loss = (((rend[1]["rgb"] - tgt[b:e]) ** 2).sum(-1).mean() + 0.1 * ((rend[0]["rgb"] - tgt[b:e]) ** 2).sum(-1).mean()
+                + 1e-2 * (hist[1]["weights"] ** 2).sum(-1).mean())
+        loss.backward()
+        return torch.cat([p.grad.flatten() for p in model.nerf_mlp.ordered_parameters()]).double().cpu().numpy()
+    whole = grad(0, 13)
+    parts = (6 * grad(0, 6) + 7 * grad(6, 13)) / 13
+    assert np.isfinite(whole).all() and np.linalg.norm(whole) > 0
+    rel = float(np.linalg.norm(whole - parts) / np.linalg.norm(whole))
+    print(f"[{chains} chains] 13 rays vs 6 + 7: gradient rel-L2 {rel:.2e}")
+    assert rel < (1e-5 if chains == "f32" else 5e-5)
+    configs.clear_config()
