@@ -91,6 +91,143 @@ def parse():
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------ output
+INDEX_CONTRACT = ("sampler stage: CDF bin indices bit-exact vs the reference on identical inputs (test_sampler_*); end to end through "
+                  "Model.__call__: >= 99.999 % identical, the differing ones are CDF ties one ulp apart (SURVEY H1)")
+COMPACT_LIMIT = 4096       # bytes: the driver parses the tail of stdout it keeps (~8 KB); VERDICT r03 asks for <= 4 KB
+
+
+def _sig(x, digits=5):
+    """Numbers of the compact line at `digits` significant figures (bytes matter there)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _leg(d):
+    """{value, ms_per_step, frac} of one measured leg of the full record."""
+    if not isinstance(d, dict) or "value" not in d:
+        return None
+    out = _pick(d, ("value", "ms_per_step"))
+    if isinstance(d.get("roofline"), dict):
+        out["frac"] = d["roofline"].get("frac")
+    return out
+
+
+def _train_leg(d):
+    out = _leg(d)
+    if out is None:
+        return None
+    out.pop("frac", None)
+    for k, v in (d.get("kernels") or {}).items():        # per kernel family: launch ms and fraction of its roofline
+        out[k] = [v.get("avg_launch_ms"), v.get("frac")]
+    return out
+
+
+def _parity_pair(p, mode):
+    """(RGB L-inf vs the CPU oracle, identical-bin-index fraction, "k of n" differing indices) of one mode of a parity block."""
+    m = (p or {}).get(mode) if isinstance(p, dict) else None
+    if not isinstance(m, dict):
+        return None
+    out = {"rgb_linf": m.get("rgb_linf_vs_oracle"), "bin_idx_agreement": m.get("bin_idx_agreement")}
+    if "bin_idx_differing" in m:
+        out["bin_idx_differing"] = m["bin_idx_differing"]
+    if "rgb_p9999" in m:
+        out["rgb_p9999"] = m["rgb_p9999"]
+    if "rays_over_1e-4" in m:
+        out["rays_over_1e-4"] = m["rays_over_1e-4"]
+    return out
+
+
+def compact_line(full):
+    """The LAST stdout line: the contract's keys + roofline + cpu_baseline + one {value, ms_per_step, frac} per secondary
+    leg + four parity numbers, <= COMPACT_LIMIT bytes.  Everything else lives in the full record (`full_record`)."""
+    mode = full.get("dtype")
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data"))
+    cfgd = dict(full.get("config") or {})
+    if len(str(cfgd.get("workload", ""))) > 160:
+        cfgd["workload"] = cfgd["workload"][:157] + "..."
+    line["config"] = cfgd
+    if isinstance(full.get("roofline"), dict):
+        line["roofline"] = _pick(full["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches"))
+    if isinstance(full.get("cpu_baseline"), dict):
+        cb = dict(full["cpu_baseline"])
+        if len(str(cb.get("sample", ""))) > 140:
+            cb["sample"] = cb["sample"][:137] + "..."
+        line["cpu_baseline"] = cb
+    tb = [t for t in (full.get("cpu_baseline_torch") or []) if isinstance(t, dict) and t.get("value")]
+    if tb:
+        line["cpu_baseline_torch"] = {"value": tb[-1]["value"], "cores": tb[-1].get("cores")}
+    modes = {m: _leg(full.get(m + "_mode")) for m in EVAL_MODES if _leg(full.get(m + "_mode"))}
+    if modes:
+        line["other_modes"] = modes
+    train = {k[len("train_step_"):] or "f32": _train_leg(v) for k, v in full.items()
+             if k.startswith("train_step") and _train_leg(v)}
+    if "train_step" in full and _train_leg(full["train_step"]):
+        train[full["train_step"].get("dtype", "f32")] = _train_leg(full["train_step"])
+        train.pop("", None)
+    if train:
+        line["train_step"] = train
+    oc = {}
+    for name, leg in (full.get("other_configs") or {}).items():
+        if not isinstance(leg, dict):
+            continue
+        if "error" in leg:
+            oc[name] = {"error": str(leg["error"])[:60]}
+        elif "value" in leg:
+            oc[name] = dict(_train_leg(leg), dtype=leg.get("dtype"))
+        else:
+            oc[name] = {m: _leg(v) for m, v in leg.items() if _leg(v)}
+    if oc:
+        line["other_configs"] = oc
+    par = full.get("parity")
+    if isinstance(par, dict):
+        cp = {"rays_checked": par.get("rays_checked"), "bench_batch": _parity_pair(par, mode)}
+        for tag, key in (("trained_like", "trained_like_weights"), ("trained_long", "trained_long_weights")):
+            if _parity_pair(par.get(key), mode):
+                cp[tag] = _parity_pair(par[key], mode)
+        cp["index_contract"] = INDEX_CONTRACT
+        line["parity"] = cp
+    for k in ("full_image_render_ms", "llff_image_render_ms", "rccl"):
+        if k in full:
+            line[k] = full[k]
+    line["full_record"] = full.get("full_record", "gpurun_out/bench_full.json")
+    line = _sig(line)
+    # never exceed the limit: drop the optional blocks from the least important one
+    for victim in ("cpu_baseline_torch", "train_step", "other_modes", "other_configs", "llff_image_render_ms"):
+        if len(json.dumps(line)) <= COMPACT_LIMIT:
+            break
+        line.pop(victim, None)
+    return line
+
+
+def emit(full):
+    """Full record -> gpurun_out/bench_full.json and ONE stderr line (`BENCH_FULL {...}`); stdout carries exactly one line,
+    the compact one (BENCH_r03.json had parsed = null: the 20 KB line overflowed the ~8 KB stdout tail the driver parses)."""
+    full["full_record"] = "gpurun_out/bench_full.json"
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError as e:
+        full["full_record"] = f"stdout only ({type(e).__name__})"
+    print("BENCH_FULL " + json.dumps(full), file=sys.stderr)
+    sys.stderr.flush()
+    print(json.dumps(compact_line(full)))
+    sys.stdout.flush()
+
+
 # ------------------------------------------------------------------------------------------------ launcher
 def launch_ranks(args) -> int:
     """Parent of `--gpus N` (N > 1) outside torchrun: start one fresh child per GPU and relay rank 0's JSON line.
@@ -174,10 +311,12 @@ def cpu_baseline_and_parity(blob, spec, rays_np, hip_outputs):
         err = np.abs(rgb - ref[-1]["r_rgb"])
         mse = float(np.mean((rgb.astype(np.float64) - ref[-1]["r_rgb"]) ** 2))
         w_hip = out[1][-1]["weights"][:n].cpu().numpy()
+        same = bin_idx[-1][:n].cpu().numpy() == ref[-1]["bin_idx"]
         parity[tag] = {"rgb_linf_vs_oracle": float(err.max()), "psnr_vs_oracle_db": float(-10 * np.log10(max(mse, 1e-20))),
+                       "rgb_p9999": float(np.quantile(err.max(axis=-1), 0.9999)), "rays_over_1e-4": int((err.max(axis=-1) > 1e-4).sum()),
                        "weights_linf_vs_oracle": float(np.abs(w_hip - ref[-1]["weights"]).max()),
                        # north_star's "bit-exact sample indices": the CDF bin every sample of the final level was drawn from
-                       "bin_idx_agreement": float(np.mean(bin_idx[-1][:n].cpu().numpy() == ref[-1]["bin_idx"])),
+                       "bin_idx_agreement": float(np.mean(same)), "bin_idx_differing": f"{int(same.size - same.sum())} of {same.size}",
                        "sdist_max_abs_diff": float(np.abs(out[1][-1]["sdist"][:n].cpu().numpy() - ref[-1]["sdist"]).max())}
     return base, parity
 
@@ -213,12 +352,35 @@ def trained_like_parity(model, cfg, dev, spec, modes, which="trained_blob.npz"):
             out = model(rays, 1.0, True)
         rgb = out[0][-1]["rgb"].cpu().numpy()
         mse = float(np.mean((rgb.astype(np.float64) - ref[-1]["r_rgb"]) ** 2))
+        same = model.last_bin_idx[-1].cpu().numpy() == ref[-1]["bin_idx"]
         res[m] = {"rgb_linf_vs_oracle": float(np.abs(rgb - ref[-1]["r_rgb"]).max()),
                   "psnr_vs_oracle_db": float(-10 * np.log10(max(mse, 1e-20))),
-                  "bin_idx_agreement": float(np.mean(model.last_bin_idx[-1].cpu().numpy() == ref[-1]["bin_idx"]))}
+                  "bin_idx_agreement": float(np.mean(same)), "bin_idx_differing": f"{int(same.size - same.sum())} of {same.size}"}
     cfg.hip_precision = prev
     model.nerf_mlp.load_flat_params(keep)
     return res
+
+
+def cpu_baseline_train(model, cfg, blob, spec, rays_np, rank):
+    """cpu_baseline of the training configuration (C5): the CPU oracle's training step (`rn_level_train`: cached forward, the
+    data / orientation / predicted-normal losses, full backward into the gradient blob; the other six terms of the nine-term
+    set are elementwise on the level outputs and are not part of this timing) on a fixed prefix of rank 0's batch."""
+    from oracle import oracle as O
+    from refnerf_pl_amd import synthetic
+    cores = os.cpu_count() or 1
+    N = spec["samples"]
+    n = min(rays_np["origins"].shape[0], 2048 if cores >= 64 else 32)
+    sub = {k: v[:n] for k, v in rays_np.items()}
+    gt = synthetic.target_rgb(n, seed=7 + rank)
+    okw = dict(srgb_mapping=int(model.nerf_mlp.srgb_mapping),
+               render_srgb_mode=cfg.srgb_mapping_type if cfg.srgb_mapping_when_rendering else "none")
+    O.model_train(blob, {k: v[:16] for k, v in rays_np.items()}, gt[:16], num_prop_samples=N, num_nerf_samples=N, n_threads=cores, **okw)
+    t0 = time.time()
+    losses, _, _ = O.model_train(blob, sub, gt, num_prop_samples=N, num_nerf_samples=N, n_threads=cores, **okw)
+    dt = time.time() - t0
+    return {"value": n * N * 2 / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} rays x {N} samples x 2 levels, training forward + three Ref-NeRF losses + backward, fp32, "
+                      f"OpenMP over rays, {dt:.1f} s"}
 
 
 def torch_cpu_baseline(spec):
@@ -498,7 +660,7 @@ def main():
             for other in [m for m in EVAL_MODES if m != args.precision]:
                 cfg.hip_precision = other
                 n2 = max(3, args.steps // 5)
-                el2, k2, l2, out2 = timed(eager_step, n2, 1, True)
+                el2, k2, l2, out2 = timed(eager_step, n2, 3, True)      # 3 warm-up steps: a mode's first call re-packs / pages code in
                 line[other + "_mode"] = {"value": samples_per_step * n2 / el2, "unit": "ray-samples/s",
                                          "ms_per_step": 1e3 * el2 / n2, "dtype": other, "note": MODE_NOTES[other],
                                          "roofline": roofline_of(other, kernel_name(other), k2, l2, flop_per_launch)}
@@ -568,8 +730,10 @@ def main():
         line["ms_per_step"] = res["ms_per_step"]
         line["roofline"] = res.pop("roofline")
         line["train_step"] = res
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_train(model, cfg, blob, spec, rays_np, rank)
     if rank == 0:
-        print(json.dumps(line))
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -320,3 +320,42 @@ def test_train_ray_batcher_sampling_logic():
     assert d.rays.pix_x_int.reshape(-1)[:3].tolist() == [0, 1, 2] and int(d.rays.cam_idx.max()) == 0
     with pytest.raises(ValueError):
         make(batching="per_pixel")
+
+
+def test_bench_compact_line_fits_the_driver_tail():
+    """BENCH_r03.json had parsed = null because bench.py's one JSON line (20.6 KB) overflowed the ~8 KB
+    stdout tail the driver parses.  The LAST stdout line is now `bench.compact_line(full)`: <= 4 KB, with the contract's
+    keys, `roofline` and `cpu_baseline`; the full record goes to gpurun_out/bench_full.json + stderr.  Replayed here on the
+    full records of round 3 (the largest ones this repo ever printed)."""
+    import glob
+    import json
+    import bench
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "bench", "*.json")))
+    assert paths
+    for p in paths:
+        full = json.load(open(p))
+        # (round 3's C5 record predates the training configuration's cpu_baseline leg)
+        full.setdefault("cpu_baseline", {"value": 1.0e5, "unit": "ray-samples/s", "cores": 256, "kind": "port", "sample": "x" * 200})
+        line = bench.compact_line(full)
+        text = json.dumps(line)
+        assert len(text) < bench.COMPACT_LIMIT <= 4096, (p, len(text))
+        assert "\n" not in text
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in line, (p, k)
+        assert "workload" in line["config"] and "model" not in line["config"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in line["roofline"], (p, k)
+        assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-4
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in line["cpu_baseline"], (p, k)
+        assert abs(line["value"] / full["value"] - 1) < 1e-4
+        if "parity" in full:         # eval configurations: the oracle checks the timed batch
+            assert "index_contract" in line["parity"] and line["parity"]["bench_batch"]["rgb_linf"] is not None
+    # a pathological record (every optional block ten times its size) still fits: blocks are dropped, never the contract
+    full = json.load(open(paths[0]))
+    full["other_configs"] = {f"X{i}": v for i in range(10) for v in full["other_configs"].values()}
+    for i in range(40):
+        full[f"train_step_m{i}"] = full["train_step"]
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) < bench.COMPACT_LIMIT and "roofline" in line and "cpu_baseline" in line
