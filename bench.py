@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--no-image", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--no-graph", action="store_true", help="never replay the level loop from a HIP graph")
+    ap.add_argument("--no-rccl", action="store_true",
+                    help="single-GPU training legs: do not create the one-rank RCCL group (then the gradient all-reduce is skipped as "
+                         "torch.distributed is not initialised)")
     return ap.parse_args()
 
 
@@ -187,6 +190,8 @@ def compact_line(full):
             oc[name] = {"error": str(leg["error"])[:60]}
         elif "value" in leg:
             oc[name] = dict(_train_leg(leg), dtype=leg.get("dtype"))
+            if isinstance(leg.get("rccl"), dict):        # the step's gradient all-reduce ran through a one-rank RCCL group
+                oc[name]["rccl"] = "error" if "error" in leg["rccl"] else f"{leg['rccl'].get('backend')} x{leg['rccl'].get('world_size')}"
         else:
             oc[name] = {m: _leg(v) for m, v in leg.items() if _leg(v)}
     if oc:
@@ -257,6 +262,27 @@ def launch_ranks(args) -> int:
         return 1
     sys.stdout.write(out0)
     return 0
+
+
+def one_rank_rccl(dev):
+    """Single-GPU training legs: a ONE-rank RCCL ("nccl") group, so that the step includes the gradient all-reduce call and
+    `n_ranks_seen` comes from RCCL (the reference trains under DDP on NCCL/RCCL, train.py:84-88).
+    Returns (torch.distributed or None, info dict)."""
+    import datetime
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist, {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+    try:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        t0 = time.perf_counter()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev,
+                                timeout=datetime.timedelta(seconds=120))
+        return dist, {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "init_s": time.perf_counter() - t0}
+    except Exception as e:            # never lose the line over it: the step then runs without the collective, and says so
+        return None, {"error": repr(e)[:200]}
 
 
 # ------------------------------------------------------------------------------------------------ workload
@@ -535,8 +561,10 @@ def other_configs(args, dev, sync, max_over_ranks):
         spec = dict(CONFIGS["C5"], rays=2048)
         model, cfg, _ = build_model(a, spec, dev)
         rays = utils.rays_from_dict(make_rays(spec, spec["rays"], seed=1), dev)
-        res = train_step_bench(a, spec, model, cfg, rays, 0, 1, dev, None, sync, max_over_ranks, args.train_precision, n_steps=3, n_warm=1, geometry=True)
+        dist1, rccl = (None, None) if args.no_rccl else one_rank_rccl(dev)       # the step's all-reduce through a one-rank RCCL group
+        res = train_step_bench(a, spec, model, cfg, rays, 0, 1, dev, dist1, sync, max_over_ranks, args.train_precision, n_steps=3, n_warm=1, geometry=True)
         res["workload"] = spec["workload"] + " [2048 rays on this GPU: the per-GPU shard at 8 ranks]"
+        res["rccl"] = rccl
         out["C5_shard"] = res
         if args.train_precision != "f32":
             out["C5_shard_f32_chains"] = train_step_bench(a, spec, model, cfg, rays, 0, 1, dev, None, sync, max_over_ranks, "f32", n_steps=2, n_warm=1, geometry=True)
@@ -571,6 +599,9 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    rccl = None
+    if world == 1 and CONFIGS[args.config]["mode"] == "train" and not args.no_rccl:
+        dist, rccl = one_rank_rccl(dev)
     n_ranks_seen = dist.get_world_size() if dist is not None else 1
     assert n_ranks_seen == world
 
@@ -730,13 +761,17 @@ def main():
         line["ms_per_step"] = res["ms_per_step"]
         line["roofline"] = res.pop("roofline")
         line["train_step"] = res
+        if rccl is not None:
+            line["rccl"] = rccl
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_train(model, cfg, blob, spec, rays_np, rank)
     if rank == 0:
         emit(line)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+    import torch.distributed as _d
+    if _d.is_initialized():
+        _d.destroy_process_group()
 
 
 def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync, max_over_ranks, chains="f32",
@@ -772,7 +807,7 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
             renderings, history = model(rays, 1.0, False)
             total, _, _ = train_utils.compute_losses(model, batch, rays, renderings, history, cfg)
         total.backward()
-        distributed.allreduce_gradients(model)
+        distributed.allreduce_gradients(model, force=dist is not None)      # (one-rank RCCL group of the single-GPU legs: still issued)
         opt.step()
         for m in mlps:
             m.mark_updated()               # fused Adam leaves no trace in the version counters: tell the weight-image cache

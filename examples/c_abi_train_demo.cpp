@@ -29,7 +29,8 @@ static bool read_file(const char *path, std::vector<float> &v, size_t n) {
 template <typename T> static T *dmalloc(size_t n) { void *p = nullptr; return hipMalloc(&p, n * sizeof(T)) == hipSuccess ? (T *)p : nullptr; }
 
 int main(int argc, char **argv) {
-  if (argc != 8) { fprintf(stderr, "usage: %s weights.f32 c2w.f32 W H focal gt.f32 out_grads.f32\n", argv[0]); return 1; }
+  if (argc != 8 && argc != 9) { fprintf(stderr, "usage: %s weights.f32 c2w.f32 W H focal gt.f32 out_grads.f32 [chains 0 = f32 | 3 = split f16]\n", argv[0]); return 1; }
+  const int chains = argc == 9 ? atoi(argv[8]) : REFNERF_PREC_F32;   // cfg.precision of both directions: REFNERF_PREC_F32 | REFNERF_PREC_F16X2
   const int W = atoi(argv[3]), H = atoi(argv[4]);
   const float focal = (float)atof(argv[5]);
   const int R = W * H, N = 48;
@@ -86,6 +87,7 @@ int main(int argc, char **argv) {
     cfg[l].n_in = l == 0 ? 1 : N;
     cfg[l].training = 1;
     cfg[l].compute_extras = 0;
+    cfg[l].precision = chains;          // (fp32 ACT / DELTA rows in both chain modes: REFNERF_ACT_F32 below)
     refnerf_level_out out = {};
     out.d_sdist = d_sd[l]; out.d_weights = d_w[l]; out.d_density = d_dens[l]; out.d_rgb = d_hrgb[l];
     out.d_r_rgb = d_rgb[l]; out.d_r_diffuse = d_dif; out.d_r_specular = d_spc; out.d_r_distance = d_dist; out.d_r_acc = d_acc;

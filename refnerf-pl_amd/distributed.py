@@ -56,16 +56,36 @@ def _host_staged(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) != "nccl"
 
 
-def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = True, flat: bool = None) -> None:
+def _flat_leaves(module: torch.nn.Module) -> list:
+    """MLPs of `module` whose flat blob is a live autograd leaf (MLP.flat_parameter() was called and not released)."""
+    seen, out = set(), []
+    for m in module.modules():
+        f = getattr(m, "_flat", None)
+        if hasattr(m, "flat_parameter") and id(m) not in seen and f is not None and f.requires_grad:
+            seen.add(id(m))
+            out.append(m)
+    return out
+
+
+def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = True, flat: bool = None, force: bool = False) -> None:
     """Sum (or average) the gradients over the group with one all-reduce per blob.
-    `flat` (default: `module.config.hip_flat_grads` when the module is a Model, else False) selects WHERE the gradients
-    live: True = one tensor per MLP (MLP.flat_parameter().grad, reduced in place), False = the nn.Parameters' .grad
-    (flattened, reduced, scattered back).  The choice comes from the configuration, never from leftover tensor state, and
-    in either mode every rank issues the same collectives: a missing gradient contributes zeros."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    `flat` (default: `module.config.hip_flat_grads` when the module has a config, i.e. is a Model) selects WHERE the
+    gradients live: True = one tensor per MLP (MLP.flat_parameter().grad, reduced in place), False = the nn.Parameters'
+    .grad (flattened, reduced, scattered back).  In either mode every rank issues the same collectives: a missing gradient
+    contributes zeros.  A module WITHOUT a config (a bare MLP) is in flat mode iff its blob is a live flat leaf -- the state
+    flat_parameter() / release_flat_parameter() maintain, identical on every rank that runs the same script; asking such a
+    module for the per-parameter path while its flat leaf is live raises (its parameters are views with .grad None: the
+    reduction would sum zeros and leave the real gradient unreduced).
+    `force`: issue the collective even in a one-rank group (the RCCL smoke test on a one-GPU box)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
+    config = getattr(module, "config", None)
     if flat is None:
-        flat = bool(getattr(getattr(module, "config", None), "hip_flat_grads", False))
+        flat = bool(getattr(config, "hip_flat_grads", False)) if config is not None else bool(_flat_leaves(module))
+    if not flat and config is None and _flat_leaves(module):
+        raise RuntimeError("allreduce_gradients(flat=False) on a module whose MLP blob is a live flat leaf (Config.hip_flat_grads / "
+                           "MLP.flat_parameter()): the per-parameter .grad tensors are empty in that mode.  Pass flat=True, or call "
+                           "MLP.release_flat_parameter() first.")
     if flat:
         seen = set()
         for m in module.modules():
@@ -108,9 +128,9 @@ def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = Tru
         off += n
 
 
-def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
-    """Make every rank start from rank `src`'s parameters (DDP does this at wrap time)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None, force: bool = False) -> None:
+    """Make every rank start from rank `src`'s parameters (DDP does this at wrap time).  `force`: also in a one-rank group."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     with torch.no_grad():
         for p in module.parameters():

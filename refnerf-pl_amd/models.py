@@ -492,7 +492,9 @@ class _LevelFunction(torch.autograd.Function):
         if ctx.saved is None:
             raise RuntimeError("this level's saved activations were released by its first backward "
                                "(a second backward through the same graph / retain_graph is not supported)")
-        if mlp._packed_key != ctx.packed_key:
+        # (only the parameter-version part of the key: an inference call in ANOTHER precision between this level's forward
+        # and backward -- a validation hook, the noisy-ray pass -- changes key[0] but not the weights the backward reads)
+        if mlp._packed_key is None or mlp._packed_key[1:] != ctx.packed_key[1:]:
             raise _hip.HipLibraryError("parameters changed between the training forward and backward of a level")
         g = {k: v for k, v in zip(ctx.diff_keys, gouts) if v is not None}
         grads = torch.zeros(mlp.canon_size, dtype=torch.float32, device=ctx.saved["sdist"].device)
@@ -532,7 +534,6 @@ class PropMLP(MLP):
 
 _PREC = {"f32": _hip.PREC_F32, "bf16": _hip.PREC_BF16, "f16": _hip.PREC_F16, "f16x2": _hip.PREC_F16X2}
 _TRAIN_FWD_PREC = ("f32", "f16x2", "bf16")   # MLP chains of the training forward: exact fp32 | split f16 (parity-grade, fp32 ACT rows) | bf16
-_TRAIN_PREC = ("f32", "bf16")                # (kept for callers: the modes both directions share with the bf16-row format)
 
 
 class _Lean(threading.local):

@@ -68,6 +68,20 @@ def _worker(rank, world, port, tmp):
     assert all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in model.parameters())
     model.nerf_mlp.release_flat_parameter()
     assert not model.nerf_mlp.flat_params().requires_grad and model.nerf_mlp.flat_params().grad is None
+    # a bare MLP has no config: flat mode = "its blob is a live flat leaf" (it used to take the per-parameter
+    # path, all-reduce zeros and leave the real flat gradient unreduced)
+    mlp = model.nerf_mlp
+    blob = mlp.flat_parameter()
+    blob.grad = torch.full_like(blob, float(rank + 1))
+    distributed.allreduce_gradients(mlp, average=True)
+    assert torch.allclose(blob.grad, torch.full_like(blob, 1.5))
+    with pytest.raises(RuntimeError):
+        distributed.allreduce_gradients(mlp, average=True, flat=False)
+    mlp.release_flat_parameter()
+    for p in mlp.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))
+    distributed.allreduce_gradients(mlp, average=True)
+    assert all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in mlp.parameters())
     # ray sharding covers every ray exactly once, in order
     rd = synthetic.blender_rays(37, seed=3)
     rays = utils.rays_from_dict(rd)

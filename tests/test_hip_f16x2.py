@@ -45,19 +45,38 @@ def test_f16x2_vs_reference_fixtures(hip, name):
     for L in range(len(outs)):
         assert rec[f"L{L}_rgb_linf_vs_reference"] <= (2e-5 if "trained" not in name else RGB_TOL), rec
         assert rec[f"L{L}_weights_linf_vs_reference"] <= 1e-4, rec
-        assert rec[f"L{L}_bin_idx_vs_f32_mode"] >= 0.999, rec
+        assert rec[f"L{L}_bin_idx_vs_f32_mode"] >= 0.999, rec       # (fixtures of 16-64 rays: one tie is already 1e-4 of them)
 
 
-@pytest.mark.parametrize("case", ["C2_trained_like", "C2_trained_like_fp32_weights", "C2_bench_batch", "C3_shiny", "C2_trained_long", "C3_trained_long"])
+def _tail(err_per_ray):
+    """max / 99.99th percentile / count over north_star's 1e-4 of a per-ray RGB L-inf error"""
+    return float(err_per_ray.max()), float(np.quantile(err_per_ray, 0.9999)), int((err_per_ray > RGB_TOL).sum())
+
+
+INDEX_FLOOR = 0.9999     # end to end >= 99.99 % identical CDF bin indices (measured >= 99.999 %: the differing ones are CDF
+                         # ties one ulp apart, SURVEY H1; the sampler STAGE is bit-exact: test_sampler_*); r03 asserted 0.999
+
+
+@pytest.mark.parametrize("case", ["C2_trained_like", "C2_trained_like_fp32_weights", "C2_bench_batch", "C3_shiny", "C2_trained_long",
+                                  "C3_trained_long", "C4_trained_llff"])
 def test_f16x2_full_size_vs_oracle(hip, O, case):
-    """BASELINE-sized batches on the HIP path, the first 512 rays through the CPU oracle: RGB L-inf <= 1e-4 and >= 99.9 %
-    identical bin indices at every level -- on the trained-like weights (f16-exact as stored, and perturbed to full fp32
-    precision) as on the bench batch (C2) and the shiny network (C3, the ring-of-records kernel variant)."""
+    """BASELINE-sized batches on the HIP path against the CPU oracle: RGB L-inf <= 1e-4 and >= 99.99 % identical bin indices
+    at every level -- on the trained-like weights (f16-exact as stored, and perturbed to full fp32 precision) as on the
+    bench batch (C2) and the shiny network (C3, the ring-of-records kernel variant).  The harsher weight sets
+    (trained_long: 2500 reference steps; trained_llff: the forward-facing family of C4 / C5) go through the oracle as
+    WHOLE batches (the tail of the mode of record against the reference arithmetic, not against the
+    f32 mode): max, 99.99th percentile and the count of rays over 1e-4 are recorded."""
     from refnerf_pl_amd import synthetic
     R, N, n_or = (8192, 192, 512) if case.startswith("C3") else (4096, 128, 512)
+    kw = {}
     if case.endswith("trained_long"):           # the 2500-step fp32 weight set, also through the ring-of-records variant (C3 shape)
         from helpers import trained_long_blob
-        P, rk = trained_long_blob(), dict(seed=3, center_frac=0.8)
+        P, rk, n_or = trained_long_blob(), dict(seed=3, center_frac=0.8), R
+    elif case == "C4_trained_llff":             # forward-facing NDC rays, linear colour + norm_linear render map (llff_refnerf.gin)
+        from helpers import trained_llff_blob
+        g = load_golden("model_trained_llff_eval")
+        kw = cfg_from_bindings(g["bindings"])[0]
+        P, rk, n_or = trained_llff_blob(), None, R
     elif case == "C2_trained_like":
         P, rk = trained_blob(), dict(seed=3, center_frac=0.8)
     elif case == "C2_trained_like_fp32_weights":
@@ -66,12 +85,12 @@ def test_f16x2_full_size_vs_oracle(hip, O, case):
         P, rk = synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0), dict(seed=1, center_frac=0.5)
     else:
         P, rk = synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0, roughness_bias=-6.0), dict(seed=1, center_frac=0.5)
-    rays = synthetic.blender_rays(R, **rk)
+    rays = synthetic.llff_rays(R, seed=3) if rk is None else synthetic.blender_rays(R, **rk)
     lv = dict(num_prop_samples=N, num_nerf_samples=N)
-    out = run_hip_model(hip, P, rays, {}, lv, precision=F16X2)
-    again = run_hip_model(hip, P, rays, {}, lv, precision=F16X2)
-    f32 = run_hip_model(hip, P, rays, {}, lv, precision=0)
-    ref = O.model_forward(P, {k: v[:n_or] for k, v in rays.items()}, **lv)
+    out = run_hip_model(hip, P, rays, kw, lv, precision=F16X2)
+    again = run_hip_model(hip, P, rays, kw, lv, precision=F16X2)
+    f32 = run_hip_model(hip, P, rays, kw, lv, precision=0)
+    ref = O.model_forward(P, {k: v[:n_or] for k, v in rays.items()}, **lv, **kw)
     rec = {"rays": R, "samples": N, "oracle_rays": n_or}
     for L in range(2):
         a = out[L]
@@ -81,20 +100,28 @@ def test_f16x2_full_size_vs_oracle(hip, O, case):
         assert np.isfinite(a["r_rgb"]).all()
         assert w.min() >= 0 and np.all(w.sum(-1) <= 1 + 1e-5)
         assert np.all(np.diff(sd, axis=-1) >= 0) and sd.min() >= 0 and sd.max() <= 1
-        bg = np.maximum(0, 1 - a["r_acc"])[:, None]
-        np.testing.assert_allclose(a["r_rgb"], (w[..., None] * a["rgb"]).sum(1) + bg, rtol=0, atol=3e-5)
-        rec[f"L{L}_rgb_linf_vs_oracle"] = float(np.abs(a["r_rgb"][:n_or] - ref[L]["r_rgb"]).max())
-        rec[f"L{L}_f32_mode_rgb_linf_vs_oracle"] = float(np.abs(f32[L]["r_rgb"][:n_or] - ref[L]["r_rgb"]).max())
+        if not kw:
+            bg = np.maximum(0, 1 - a["r_acc"])[:, None]
+            np.testing.assert_allclose(a["r_rgb"], (w[..., None] * a["rgb"]).sum(1) + bg, rtol=0, atol=3e-5)
+        e16 = np.abs(a["r_rgb"][:n_or] - ref[L]["r_rgb"]).max(-1)
+        e32 = np.abs(f32[L]["r_rgb"][:n_or] - ref[L]["r_rgb"]).max(-1)
+        rec[f"L{L}_rgb_linf_vs_oracle"], rec[f"L{L}_rgb_p9999_vs_oracle"], rec[f"L{L}_rays_over_1e-4"] = _tail(e16)
+        rec[f"L{L}_f32_mode_rgb_linf_vs_oracle"], rec[f"L{L}_f32_mode_rgb_p9999_vs_oracle"], rec[f"L{L}_f32_mode_rays_over_1e-4"] = _tail(e32)
         rec[f"L{L}_weights_linf_vs_oracle"] = float(np.abs(a["weights"][:n_or] - ref[L]["weights"]).max())
-        rec[f"L{L}_bin_idx_agreement"] = float(np.mean(a["bin_idx"][:n_or] == ref[L]["bin_idx"]))
+        same = a["bin_idx"][:n_or] == ref[L]["bin_idx"]
+        rec[f"L{L}_bin_idx_agreement"] = float(np.mean(same))
+        rec[f"L{L}_bin_idx_differing"] = f"{int(same.size - same.sum())} of {same.size}"
+        same32 = f32[L]["bin_idx"][:n_or] == ref[L]["bin_idx"]
+        rec[f"L{L}_f32_mode_bin_idx_differing"] = f"{int(same32.size - same32.sum())} of {same32.size}"
         rec[f"L{L}_sdist_max_abs_diff"] = float(np.abs(a["sdist"][:n_or] - ref[L]["sdist"]).max())
         rec[f"L{L}_psnr_vs_oracle_db"] = _psnr(a["r_rgb"][:n_or], ref[L]["r_rgb"])
         rec[f"L{L}_rgb_linf_vs_f32_mode_full_batch"] = float(np.abs(a["r_rgb"] - f32[L]["r_rgb"]).max())
         rec[f"L{L}_density_max"] = float(a["density"].max())
+    print(case, rec)
     _record("f16x2_" + case, rec)
     for L in range(2):
         assert rec[f"L{L}_rgb_linf_vs_oracle"] <= RGB_TOL, rec
-        assert rec[f"L{L}_bin_idx_agreement"] >= 0.999, rec
+        assert rec[f"L{L}_bin_idx_agreement"] >= INDEX_FLOOR, rec
         assert rec[f"L{L}_rgb_linf_vs_f32_mode_full_batch"] <= RGB_TOL, rec
     assert rec["L0_bin_idx_agreement"] == 1.0, rec        # level 0 does not depend on the MLP: bit-exact resampler
 
@@ -252,7 +279,7 @@ def test_trained_long_eval_every_mode_vs_reference(hip, O, tag):
     for tag in ("f32", "f16x2"):
         for L in range(2):
             assert rec[f"{tag}_L{L}_rgb_linf_vs_reference"] <= RGB_TOL, (tag, L, rec)
-            assert rec[f"{tag}_L{L}_bin_idx_vs_oracle"] >= 0.999, (tag, L, rec)
+            assert rec[f"{tag}_L{L}_bin_idx_vs_oracle"] >= 0.999, (tag, L, rec)      # (32-ray fixtures: one tie = 2.4e-4)
 
 
 @pytest.mark.parametrize("tag", LONG_SETS)
@@ -409,4 +436,50 @@ def test_twenty_optimiser_steps_follow_the_reference(hip, chains, fused):
     print(f"[{chains} chains, fused={fused}] worst per-step loss deviation {worst:.2e}; accumulated update vs the reference's: rel-L2 {rel_u:.2e}")
     _record(f"trajectory/{chains}/fused={fused}", dict(worst_loss_rel=worst, update_rel_l2=rel_u))
     assert rel_u < 1e-2          # measured 7e-4 (f32 chains) / 1.3e-3 (split-f16 chains): Adam's 1 / sqrt(v) on tiny gradients
+    configs.clear_config()
+
+
+@pytest.mark.skipif(not _have("trained_long"), reason="tests/golden/model_trained_long_eval.npz missing")
+def test_render_from_a_reference_format_checkpoint(hip, tmp_path):
+    """SURVEY 8f-3 end to end on the GPU: the weights the reference reached after 2500 Adam steps, written as a Lightning
+    checkpoint with the reference's key names (`model.nerf_mlp.spatial_net.0.weight` ... -- nerf_system.py:22-33), loaded
+    through utils.load_reference_checkpoint into a Model on the device and rendered through the HIP path: the renderings
+    equal the ones the REFERENCE computed from those weights (tests/golden/model_trained_long_eval.npz)."""
+    import os
+    import torch
+    from refnerf_pl_amd import configs, models, utils
+    from helpers import trained_long_blob
+    g = load_golden("model_trained_long_eval")
+    gin = os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")
+    bindings = [str(b) for b in g["bindings"] if str(b)]
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([gin], bindings)
+    writer = models.construct_model(utils.dummy_rays(), configs.Config())            # (host side only: a CPU module)
+    writer.nerf_mlp.load_flat_params(trained_long_blob())
+    path = tmp_path / "last.ckpt"
+    torch.save(utils.reference_checkpoint(writer, epoch=0, global_step=2500), path)
+    keys = sorted(torch.load(path, weights_only=False)["state_dict"])
+    assert "model.nerf_mlp.spatial_net.0.weight" in keys and "model.prop_mlp.rgb.bias" in keys and len(keys) == 92
+    del writer
+
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([gin], bindings)
+    cfg = configs.Config()
+    torch.manual_seed(1)
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).eval()           # random init: every weight must come from the file
+    missing, unexpected = utils.load_reference_checkpoint(model, str(path))
+    assert missing == [] and unexpected == []
+    assert np.array_equal(model.nerf_mlp.flat_params().detach().cpu().numpy(), trained_long_blob())
+    rays = utils.rays_from_dict(rays_from_golden(g), DEV)
+    rec = {}
+    for prec in ("f16x2", "f32"):
+        cfg.hip_precision = prec
+        with torch.no_grad():
+            rend, hist = model(rays, 1.0, True)
+        for L in range(2):
+            rec[f"{prec}_L{L}_rgb_linf_vs_reference"] = float(np.abs(rend[L]["rgb"].cpu().numpy() - g[f"L{L}_r_rgb"]).max())
+            rec[f"{prec}_L{L}_acc_linf_vs_reference"] = float(np.abs(rend[L]["acc"].cpu().numpy() - g[f"L{L}_r_acc"]).max())
+    print(rec)
+    _record("reference_checkpoint_render", rec)
+    assert all(v <= RGB_TOL for v in rec.values()), rec
     configs.clear_config()

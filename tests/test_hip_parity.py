@@ -520,7 +520,7 @@ def test_device_ray_generation(hip, tag):
         assert float(rays.far.min()) == 6.0
 
 
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 3])        # REFNERF_PREC_F32, _BF16, _F16X2 (the mode of record)
 def test_c_abi_without_torch(hip, precision, tmp_path):
     """examples/c_abi_demo.cpp -- a C++ host that uses only include/refnerf_hip.h (hipMalloc'd buffers,
     no PyTorch) -- renders the same view as the Python host mirror, to the last few ulps."""
@@ -541,7 +541,7 @@ def test_c_abi_without_torch(hip, precision, tmp_path):
     configs.clear_config()
     configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
                                             ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 64",
-                                             f"Config.hip_precision = '{'bf16' if precision else 'f32'}'"])
+                                             f"Config.hip_precision = '{ {0: 'f32', 1: 'bf16', 3: 'f16x2'}[precision] }'"])
     cfg = configs.Config()
     model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).eval()
     model.nerf_mlp.load_flat_params(blob)
@@ -1231,7 +1231,7 @@ def test_full_size_batches_vs_oracle(hip, O, case):
     _record(case, rec)
     for L in range(2):
         assert rec[f"L{L}_f32_rgb_linf_vs_oracle"] <= tol32, rec
-        assert rec[f"L{L}_f32_bin_idx_agreement"] >= 0.999, rec
+        assert rec[f"L{L}_f32_bin_idx_agreement"] >= 0.9999, rec      # 65536+ indices: measured >= 99.997 % (CDF ties one ulp apart); 0.999 would hide a 250x regression
         if tol16 is not None:
             assert rec[f"L{L}_bf16_rgb_linf_vs_oracle"] <= tol16, rec
             assert rec[f"L{L}_f16_rgb_linf_vs_oracle"] <= tol16 / 5, rec
@@ -1363,7 +1363,8 @@ def test_wgrad_modes_agree(hip):
         _hip.level_backward(packed, bad, rays, res, g_rgb, g_w, g_np, torch.zeros(_hip.NUM_PARAMS, device=DEV))
 
 
-def test_c_abi_training_without_torch(hip, tmp_path):
+@pytest.mark.parametrize("chains", ["f32", "f16x2"])
+def test_c_abi_training_without_torch(hip, tmp_path, chains):
     """examples/c_abi_train_demo.cpp: a training step (two refnerf_level_forward_train calls, the data loss by hand,
     two refnerf_level_backward calls into one gradient blob) from a C++ host that links only the C ABI; loss and
     gradient equal the Python host's (Model.__call__ autograd nodes + train_utils.compute_data_loss)."""
@@ -1381,7 +1382,8 @@ def test_c_abi_training_without_torch(hip, tmp_path):
     c2w.astype(np.float32).tofile(tmp_path / "c2w.f32")
     gt.astype(np.float32).tofile(tmp_path / "gt.f32")
     out = subprocess.run([exe, str(tmp_path / "w.f32"), str(tmp_path / "c2w.f32"), str(W), str(H), str(focal),
-                          str(tmp_path / "gt.f32"), str(tmp_path / "g.f32")], capture_output=True, text=True, timeout=300)
+                          str(tmp_path / "gt.f32"), str(tmp_path / "g.f32"), {"f32": "0", "f16x2": "3"}[chains]],
+                         capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr + out.stdout
     g_c = np.fromfile(tmp_path / "g.f32", np.float32)
     loss_c = float(re.search(r"loss ([0-9.eE+-]+),", out.stdout).group(1))
@@ -1389,7 +1391,8 @@ def test_c_abi_training_without_torch(hip, tmp_path):
     configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
                                             ["Model.num_prop_samples = 48", "Model.num_nerf_samples = 48",
                                              "Config.orientation_loss_mult = 0.", "Config.orientation_coarse_loss_mult = 0.",
-                                             "Config.predicted_normal_loss_mult = 0.", "Config.predicted_normal_coarse_loss_mult = 0."])
+                                             "Config.predicted_normal_loss_mult = 0.", "Config.predicted_normal_coarse_loss_mult = 0.",
+                                             f"Config.hip_train_precision = '{chains}'", f"Config.hip_bwd_precision = '{chains}'"])
     cfg = configs.Config()
     model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
     model.nerf_mlp.load_flat_params(blob)

@@ -186,6 +186,21 @@ def test_two_rank_launcher_on_one_gpu(hip, config, extra):
     assert line["config"]["rays_per_gpu"] * 2 == line["config"]["total_rays"]
 
 
+def test_rccl_one_rank_group_runs_the_gradient_collectives(hip):
+    """RCCL itself on the box (the reference's DDP runs on it, train.py:84-88): ONE fresh child process
+    creates a one-rank "nccl" group on cuda:0 and runs distributed.allreduce_gradients (flat blob and per-parameter path,
+    forced past the world-size-1 early return) and broadcast_parameters on device tensors; the blob must come back
+    unchanged.  Reports the all-reduce latency of the 4.44 MB blob."""
+    worker = os.path.join(ROOT, "tests", "workers", "rccl_one_rank_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    print(f"RCCL one-rank group: {res}")
+    assert res["backend"] == "nccl" and res["world_size"] == 1
+    assert res["allreduce_blob_bytes"] == 4 * 1110158 and 0 < res["allreduce_ms"] < 50
+
+
 @pytest.mark.parametrize("chains,flat", [("f32", False), ("f16x2", True)])
 def test_two_rank_data_parallel_training_equals_single_process(hip, tmp_path, chains, flat):
     """The reference's DDP semantics end to end (train.py:84-88): two rank PROCESSES (gloo, sharing the device) train three
