@@ -263,7 +263,8 @@ int refnerf_level_forward_train(const void *d_packed, const refnerf_level_cfg *c
 size_t refnerf_backward_workspace_bytes(int32_t R, int32_t n_samples);
 /* ... and of both buffers for a level with a general IPE basis (cfg.ipe_groups > 1: the IPE features of the extra direction
  * groups behind the activations, the tail's partial sums behind the workspace; d_param_grads is then
- * REFNERF_NUM_PARAMS_EXT floats; f32 chains and the bf16x3 weight-gradient GEMM) */
+ * REFNERF_NUM_PARAMS_EXT floats, the gradient of the tail columns of groups the basis does not have -- group index >=
+ * ipe_groups -- is exactly 0; f32 / split-f16 chains and the bf16x3 weight-gradient GEMM) */
 size_t refnerf_backward_workspace_bytes_basis(int32_t R, int32_t n_samples, int32_t ipe_groups);
 size_t refnerf_activation_workspace_bytes_basis(int32_t R, int32_t n_samples, int32_t ipe_groups);
 

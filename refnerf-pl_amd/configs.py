@@ -216,8 +216,11 @@ class Config:
     render_spline_n_interp: int = 30
     render_spline_degree: int = 5
     render_spline_smoothness: float = .03
-    # build-side knob (not in the reference): arithmetic of the MLP contractions,
-    # 'f32' (exact fp32 MFMA, the parity mode) or 'bf16'.
+    # build-side knobs (not in the reference).  hip_precision = arithmetic of the MLP contractions of inference levels:
+    # 'f32' (exact fp32 MFMA chains: the strict parity mode and the DEFAULT -- no operand-range limit), 'f16x2' (split-operand
+    # f16 MFMA: the parity-grade fast mode of record of bench.py / README, <= 1e-4 RGB vs the reference also on trained weights,
+    # 3.5x faster; opt-in because hidden activations beyond 65504 turn into NaN outputs), 'bf16' / 'f16' (throughput modes:
+    # within 1e-4 on random-init networks only).
     hip_precision: str = 'f32'
     hip_train_precision: str = 'f32'  # MLP chains of the training forward: 'f32' (exact) | 'f16x2' (split f16: 22-bit products, parity-grade, ~3x faster) | 'bf16' (throughput mode)
     hip_bwd_precision: str = 'f32'  # transposed GEMM chains of the backward: 'f32' (exact) | 'f16x2' (split f16, parity-grade) | 'bf16' (throughput mode)

@@ -1113,6 +1113,11 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     we.part = (float *)(ws + plan.part_ext_off);
     if (plan.pitch > plan.S)
       hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(we.act), rn::ACT_EXT_ROWS, rn::ACT_EXT_UNITS, plan.pitch, plan.S);
+    /* fewer than 7 groups (icosahedron / 1, octahedron / 2): the forward wrote the rows of groups 1..G-1 only; the GEMM
+     * contracts all 576, so the others must read as zeros -- their gradient is then exactly 0, as the header promises */
+    if (cfg->ipe_groups - 1 < rn::EXT_GROUPS)
+      hipLaunchKernelGGL(rn::wgrad_zero_units, dim3(2048), dim3(256), 0, st, const_cast<float *>(we.act), (cfg->ipe_groups - 1) * rn::IPE_DIM,
+                         rn::ACT_EXT_ROWS, rn::ACT_EXT_UNITS, plan.pitch);
     hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<false, false, true>), dim3(8 * ((slices + 7) / 8) * rn::WJOBS_EXT.tiles), dim3(256), rn::wb_lds(false, false), st, we, slices);
     hipLaunchKernelGGL(rn::wgrad_reduce, dim3(256), dim3(256), 0, st, we.part, slices, d_param_grads + rn::NUM_PARAMS, (int)rn::EXT_PARAMS);
   }

@@ -137,8 +137,9 @@ __device__ __forceinline__ double wave_scan_incl(double v, int lane) {
 /* stepfun.sample_intervals (stepfun.py:209-258) for one ray, executed by one
  * wave.  t_in[M+1], logits in LDS scratch `lg[M]`; writes sdist[N+1] to `sd`
  * (LDS) and optional bin indices.  Scratch: e[M] (aliases lg), cw[M+1], c[N].
- * The softmax sum and the float64 cumsum run sequentially on lane 0 so that the
- * CDF is bit-identical to the oracle / torch's accumulation order. */
+ * The softmax sum and the float64 cumsum are SEQUENTIAL chains in the oracle's / torch's accumulation order, so that the
+ * CDF is bit-identical to theirs; the chain runs wave-uniformly on values fetched with v_readlane (no LDS round trip per
+ * term), every lane ends up with the same sums. */
 template <bool EXACT = true>
 __device__ __forceinline__ void sample_intervals_wave(const float *t_in, float *lg, float *cw, float *c, int M, int N,
                                       float smin, float smax, float *sd, int32_t *bin_idx_g, int lane) {

@@ -221,6 +221,14 @@ __global__ void wgrad_zero_tail(float *m, int rows, int units, long long pitch, 
     m[(i / tail) * RB + rb_col(S + (i % tail), units)] = 0.0f;
 }
 
+/* zero units [u0, u1) of a blocked matrix of `units` units over every sample column [0, pitch): the rows of the tail matrix
+ * that belong to direction groups a basis of fewer than 7 groups does not have (the training forward never writes them) */
+__global__ void wgrad_zero_units(float *m, int u0, int u1, int units, long long pitch) {
+  const long long n = (long long)(u1 - u0) * pitch;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m[(u0 + i / pitch) * RB + rb_col(i % pitch, units)] = 0.0f;
+}
+
 /* grads[i] += sum over slices (fixed order) of PART[slice][i] */
 __global__ void wgrad_reduce(const float *__restrict__ part, int slices, float *__restrict__ grads, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

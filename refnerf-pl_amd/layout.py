@@ -117,8 +117,9 @@ def _check_depth(name, d):
 
 def identity_fill(net_depth=DEPTH, net_depth_viewdirs=DEPTH, net_width=WIDTH, net_width_viewdirs=WIDTH):
     """Shallower trunks (net_depth / net_depth_viewdirs < 8) run as the canonical 8 layers with IDENTITY layers behind the
-    real ones: the activations are post-ReLU (>= 0), so relu(1 x + 0) = x exactly, in every arithmetic mode, and the backward
-    passes the deltas through unchanged.  -> int64 positions of the canonical blob that hold 1.0 (not parameters)."""
+    real ones: the activations are post-ReLU (>= 0), so relu(1 x + 0) = x -- exactly in the f32, bf16 and f16 modes (x is
+    already a value of the operand type); in the split-f16 modes each identity layer re-rounds x to its hi + lo pair (22
+    bits: <= 2^-22 relative per layer) -- and the backward passes the deltas through unchanged.  -> int64 positions of the canonical blob that hold 1.0 (not parameters)."""
     import numpy as np
     out = []
     for pre, d, w in (("spatial_net.", _check_depth("net_depth", net_depth), int(net_width)),

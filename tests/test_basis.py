@@ -389,3 +389,46 @@ def test_general_basis_gradients_are_shard_invariant_at_ragged_sizes(chains):
     print(f"[{chains} chains] 13 rays vs 6 + 7: gradient rel-L2 {rel:.2e}")
     assert rel < (1e-5 if chains == "f32" else 5e-5)
     configs.clear_config()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chains", ["f32", "f16x2"])
+def test_general_basis_gradient_of_absent_groups_is_exactly_zero(chains):
+    """C ABI contract of a basis with fewer than 7 direction groups ('icosahedron' / 1: 6 directions = 2 groups): the training
+    forward writes the tail-matrix rows of the groups that exist, the weight-gradient GEMM contracts all 576 tail rows --
+    the rows of the absent groups must read as zeros whatever the allocator left there (made hostile first), so that
+    d_param_grads[REFNERF_NUM_PARAMS ...] is finite, zero for groups >= ipe_groups and non-zero for the live group
+    (it came back as garbage / NaN; the Python host hid it behind its embedding index)."""
+    import torch
+    from refnerf_pl_amd import _hip, configs, layout, models, synthetic, utils
+    _hip.require_device()
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", "refnerf_blender.gin")], [
+        "NerfMLP.basis_shape = 'icosahedron'", "NerfMLP.basis_subdivisions = 1", "Model.num_prop_samples = 40", "Model.num_nerf_samples = 40",
+        f"Config.hip_train_precision = '{chains}'", f"Config.hip_bwd_precision = '{chains}'"])
+    cfg = configs.Config()
+    model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
+    mlp = model.nerf_mlp
+    assert mlp.ipe_groups == 2
+    mlp.load_flat_params(synthetic.make_basis_params(seed=12, n_basis=6, bias_scale=0.05, sharpen=10.0))
+    R, N = 13, 40
+    rd = synthetic.blender_rays(R, seed=8, center_frac=0.7)
+    r = {k: torch.tensor(v, device=DEV) for k, v in rd.items() if k != "lossmult"}
+    for k in ("radii", "near", "far"):
+        r[k] = r[k].reshape(-1)
+    poison = torch.full((96 << 20,), float("nan"), device=DEV)
+    del poison
+    packed = mlp.packed_weights(_hip.PREC_F32, force=True)
+    lcfg = model._level_cfg(mlp, N, 1, 1.0, False)
+    assert lcfg.training == 1 and lcfg.ipe_groups == 2
+    sd, w = torch.tensor([[0.0, 1.0]], device=DEV).repeat(R, 1), torch.ones((R, 1), device=DEV)
+    res = _hip.level_forward(packed, lcfg, r, sd, w, history=True, save_activations=True)
+    grads = torch.zeros(layout.NUM_PARAMS_EXT, device=DEV)
+    g_rgb = torch.tensor(synthetic.target_rgb(R, seed=9), device=DEV) * 1e-2
+    _hip.level_backward(packed, lcfg, r, res, g_rgb, None, None, grads)
+    g = grads.cpu().numpy()
+    assert np.isfinite(g).all()
+    tail = g[layout.NUM_PARAMS:].reshape(2, 256, 6, 96)          # [layer 0 | 5][row][group - 1][k]  (refnerf_layout.h ext_w_off)
+    assert np.abs(tail[:, :, 0]).max() > 0
+    assert not tail[:, :, 1:].any(), float(np.abs(tail[:, :, 1:]).max())
+    configs.clear_config()

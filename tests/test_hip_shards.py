@@ -137,6 +137,48 @@ def test_c5_shard_shape_training_step(hip, monkeypatch):
     _check_invariance(whole, halves, tol=2e-5)
 
 
+def test_c5_whole_batch_training_step_on_one_gpu(hip, monkeypatch):
+    """BASELINE config 5 as ONE batch on one MI355X (16384 LLFF rays x 256 samples x 2 levels, nine-term loss, the noisy-ray
+    pass at the gin's size with fixed rotations, split-f16 chains; ~150 GB of saved layer inputs / deltas resident in HBM):
+    the step is finite and bit-reproducible (fixed split-K order, no atomics), and -- rays being independent -- the
+    training-forward renderings of a 2048-ray slice of the batch equal those of the same rays run as their own 2048-ray
+    shard bit for bit (what a rank of the 8-GPU run computes)."""
+    from refnerf_pl_amd import sample_utils, synthetic, train_utils, utils
+    torch.cuda.empty_cache()
+    model, cfg = _model("refnerf_llff_geometry_losses.gin", ["Model.num_prop_samples = 256", "Model.num_nerf_samples = 256",
+                                                             "Config.hip_train_precision = 'f16x2'", "Config.hip_bwd_precision = 'f16x2'"])
+    R = 16384
+    rd = synthetic.llff_rays(R, seed=6)
+    gt = synthetic.target_rgb(R, seed=7)
+    rot = _rotations()
+    orig = sample_utils.sample_noisy_rays
+    monkeypatch.setattr(sample_utils, "sample_noisy_rays", lambda *a, **k: orig(*a, **dict(k, rotations=rot)))
+    rays = _slice_rays(rd, 0, R)
+    batch = utils.Batch(rays=rays, rgb=gt)
+    keep = {}
+
+    def loss():
+        total, terms, _, aux = train_utils.training_losses(model, batch, rays, cfg, global_step=200000)
+        keep["rgb"] = [r["rgb"].detach().clone() for r in aux["renderings"]]
+        return total, terms
+    first = _grad_of(model, loss)
+    rgb_whole = keep["rgb"]
+    again = _grad_of(model, loss)
+    assert len(first[1]) == 9, sorted(first[1])
+    assert np.isfinite(first[0]) and np.isfinite(first[2]).all() and np.linalg.norm(first[2]) > 0
+    assert first[0] == again[0] and np.array_equal(first[2], again[2]), "C5 whole-batch training step is not bit-reproducible"
+    del keep, batch, rays
+    torch.cuda.empty_cache()
+    b, e = 3 * 2048, 4 * 2048                     # rank 3's shard of the 8-GPU run
+    shard = _slice_rays(rd, b, e)
+    model.train()
+    with torch.no_grad():
+        rend, _ = model(shard, 1.0, True)
+    for L in range(2):
+        assert torch.equal(rend[L]["rgb"], rgb_whole[L][b:e]), L
+    print(f"C5 whole batch: total {first[0]:.6g}, |g| = {np.linalg.norm(first[2]):.4g}, peak HBM {torch.cuda.max_memory_allocated() / 2**30:.0f} GiB")
+
+
 def test_c4_shard_shape_eval_graph_replay(hip, O):
     """The per-GPU shard of BASELINE config 4 (512 LLFF rays x 128 samples x 2 levels): the HIP-graph replay of the level
     loop equals the eager call bit for bit in every arithmetic mode, on new rays too; the parity-grade modes match the
