@@ -237,7 +237,7 @@ def test_rccl_one_rank_group_runs_the_gradient_collectives(hip):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stderr[-3000:]
-    res = json.loads(r.stdout.strip().splitlines()[-1])
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])      # (RCCL prints its version banner on stdout at exit)
     print(f"RCCL one-rank group: {res}")
     assert res["backend"] == "nccl" and res["world_size"] == 1
     assert res["allreduce_blob_bytes"] == 4 * 1110158 and 0 < res["allreduce_ms"] < 50

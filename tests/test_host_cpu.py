@@ -359,3 +359,32 @@ def test_bench_compact_line_fits_the_driver_tail():
         full[f"train_step_m{i}"] = full["train_step"]
     line = bench.compact_line(full)
     assert len(json.dumps(line)) < bench.COMPACT_LIMIT and "roofline" in line and "cpu_baseline" in line
+
+
+def test_bench_stdout_carries_exactly_one_line(tmp_path):
+    """RCCL prints its version banner on stdout through C stdio, flushed at exit -- after bench.py's JSON line (seen on the
+    GPU box in round 4: the driver would have parsed "Librccl path : ..." as the last line).  bench.claim_stdout() points fd 1
+    at stderr for everyone else; only emit()'s compact line reaches the real stdout."""
+    import json
+    import subprocess
+    import sys
+    rec = os.path.join(ROOT, "profiles", "r03", "bench", "bench_C2.json")
+    code = (
+        "import ctypes, json, os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "bench.ROOT = sys.argv[2]\n"                                   # (the full record's file goes to the temp dir)
+        "bench.claim_stdout()\n"
+        "print('python-level noise')\n"
+        "os.write(1, b'fd-level noise\\n')\n"
+        "libc = ctypes.CDLL(None)\n"
+        "libc.printf(b'C stdio noise, flushed at exit\\n')\n"          # what RCCL's banner does
+        "bench.emit(json.load(open(sys.argv[1])))\n")
+    r = subprocess.run([sys.executable, "-c", code, rec, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert "roofline" in line and "cpu_baseline" in line and len(lines[0]) < 4096
+    assert "python-level noise" in r.stderr and "fd-level noise" in r.stderr and "C stdio noise" in r.stderr
+    assert "BENCH_FULL " in r.stderr and os.path.exists(tmp_path / "gpurun_out" / "bench_full.json")
