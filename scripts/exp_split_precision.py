@@ -69,7 +69,7 @@ def run(blob, rays, N, modes):
     old = TP.F
     TP.F = FShim()
     real_unpack = TP.unpack
-    TP.unpack = lambda _b: P
+    TP.unpack = lambda _b, _s=None: P
     try:
         out = TP.model_forward(blob, rays, num_prop_samples=N, num_nerf_samples=N)
     finally:

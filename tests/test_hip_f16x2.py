@@ -483,3 +483,49 @@ def test_render_from_a_reference_format_checkpoint(hip, tmp_path):
     _record("reference_checkpoint_render", rec)
     assert all(v <= RGB_TOL for v in rec.values()), rec
     configs.clear_config()
+
+
+@pytest.mark.skipif(not _have("trained_long"), reason="tests/golden/trained_long_blob.npz missing")
+def test_f16x2_image_crop_vs_oracle(hip, O):
+    """the tail of the mode of record against the REFERENCE ARITHMETIC over an image region, not against
+    the f32 mode.  A 200 x 200 crop of an 800 x 800 Blender-style view of the 2500-step weights -- rows 300..499, columns
+    560..759: the interior of the sphere, its silhouette (grazing rays: the worst-conditioned ones) and background -- cast on
+    the device, rendered through models.render_image (10 chunks of 4096 rays) in the f16x2 and the f32 mode, every one of
+    the 40,000 rays through the CPU oracle.  Recorded: max, 99.99th percentile, rays over 1e-4; asserted: north_star's bar."""
+    import os
+    import functools
+    import torch
+    from refnerf_pl_amd import camera_utils, configs, models, synthetic, utils
+    from helpers import trained_long_blob
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")], [])
+    cfg = configs.Config()
+    model = models.construct_model(None, cfg).to(DEV).eval()
+    blob = trained_long_blob()
+    model.nerf_mlp.load_flat_params(blob)
+    c2w, focal = synthetic.blender_camera(seed=1)
+    full = camera_utils.cast_pinhole_rays(c2w.astype(np.float32), 800, 800, focal, 2.0, 6.0, device=torch.device(DEV))
+    y0, x0, n = 300, 560, 200
+    crop = utils.Rays(**{k: getattr(full, k)[y0:y0 + n, x0:x0 + n].contiguous() for k in full.__dataclass_fields__})
+    rays_np = {k: getattr(crop, k).reshape(n * n, -1).cpu().numpy() for k in ("origins", "directions", "viewdirs", "radii", "near", "far", "lossmult")}
+    ref = O.model_forward(blob, rays_np, num_prop_samples=128, num_nerf_samples=128, history=False)
+    want = ref[-1]["r_rgb"].reshape(n, n, 3)
+    rec = {"pixels": n * n, "acc_range": [float(ref[-1]["r_acc"].min()), float(ref[-1]["r_acc"].max())]}
+    err = {}
+    for prec in ("f16x2", "f32"):
+        cfg.hip_precision = prec
+        with torch.no_grad():
+            img = models.render_image(functools.partial(model, train_frac=1.0, compute_extras=True), crop, cfg, verbose=False, device=torch.device(DEV))
+        e = np.abs(img["rgb"].cpu().numpy() - want).max(-1)
+        err[prec] = e
+        rec[prec + "_rgb_linf_vs_oracle"], rec[prec + "_rgb_p9999_vs_oracle"], rec[prec + "_pixels_over_1e-4"] = _tail(e.reshape(-1))
+        rec[prec + "_psnr_vs_oracle_db"] = _psnr(img["rgb"].cpu().numpy(), want)
+    worst = np.unravel_index(np.argmax(err["f16x2"]), err["f16x2"].shape)
+    rec["worst_pixel"] = [int(worst[0]) + y0, int(worst[1]) + x0]
+    rec["f32_mode_at_worst_f16x2_pixel"] = float(err["f32"][worst])
+    rec["acc_at_worst_pixel"] = float(ref[-1]["r_acc"].reshape(n, n)[worst])
+    print(rec)
+    _record("f16x2_image_crop_vs_oracle", rec)
+    assert 0.0 <= rec["acc_range"][0] < 0.05 and rec["acc_range"][1] > 0.95      # the crop holds background AND surface
+    assert rec["f16x2_rgb_linf_vs_oracle"] <= RGB_TOL and rec["f32_rgb_linf_vs_oracle"] <= RGB_TOL, rec
+    configs.clear_config()
