@@ -801,7 +801,7 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     from refnerf_pl_amd import _hip, distributed, synthetic, train_utils, utils
     model.train()
     fwd_chains = bwd_chains = chains                      # 'f32' | 'f16x2' (split-f16 chains both ways: parity-grade) | 'bf16'
-    if os.environ.get("REFNERF_BENCH_BWD"):               # A/B: e.g. f16x2 forward with the f32 backward
+    if os.environ.get("REFNERF_BENCH_BWD"):               # A/B: e.g. the f32 forward with the split-f16 backward (fp32 rows)
         bwd_chains = os.environ["REFNERF_BENCH_BWD"]
     cfg.hip_train_precision, cfg.hip_bwd_precision = fwd_chains, bwd_chains
     cfg.hip_fused_losses = True          # data + orientation + predicted-normal terms through the fused loss kernels
@@ -853,7 +853,8 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     samples_per_launch = (R + extra_rays) * N / passes
     kernels = {}
     names = {"fwd": "rn::level_fwd_train_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[fwd_chains],
-             "bwd": "rn::level_bwd_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[bwd_chains], "wgrad": "rn::wgrad_bf16x3_kernel"}
+             "bwd": "rn::level_bwd_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[bwd_chains],
+             "wgrad": "rn::wgrad_f16s_kernel" if (fwd_chains == "f16x2" and bwd_chains == "f16x2") else "rn::wgrad_bf16x3_kernel"}
     peak_of = {"fwd": PEAK_TFLOPS[fwd_chains], "bwd": PEAK_TFLOPS[bwd_chains]}
     for k, (ms, cnt) in fam.items():
         if not cnt:
@@ -862,7 +863,9 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
         if k == "wgrad":
             # algorithmic bytes: both operand matrices read once -- ACT (4396 rows) + DELTA (4244 rows) per sample,
             # fp32 rows in the f32 mode, bf16 rows with the bf16 chains
-            bytes_per_launch = samples_per_launch * (4396 + 4244) * (2 if chains == "bf16" else 4)
+            # (split-f16 formats, round 4: ACT hi / lo pair units = 4 B per element, DELTA one half per element + 18 factor words)
+            bytes_per_launch = samples_per_launch * ((4396 * 4 + 4244 * 2 + 18 * 4) if (fwd_chains == "f16x2" and bwd_chains == "f16x2")
+                                                     else (4396 + 4244) * (2 if chains == "bf16" else 4))
             ach = bytes_per_launch / (avg * 1e-3) / 1e9
             kernels[k] = {"kernel": names[k], "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": ach / PEAK_HBM_GBS, "avg_launch_ms": avg, "launches": cnt, "bytes_per_launch": bytes_per_launch}

@@ -87,7 +87,7 @@ int main(int argc, char **argv) {
     cfg[l].n_in = l == 0 ? 1 : N;
     cfg[l].training = 1;
     cfg[l].compute_extras = 0;
-    cfg[l].precision = chains;          // (fp32 ACT / DELTA rows in both chain modes: REFNERF_ACT_F32 below)
+    cfg[l].precision = chains;          // (the saved-activation format follows from it: refnerf_activations_format below)
     refnerf_level_out out = {};
     out.d_sdist = d_sd[l]; out.d_weights = d_w[l]; out.d_density = d_dens[l]; out.d_rgb = d_hrgb[l];
     out.d_r_rgb = d_rgb[l]; out.d_r_diffuse = d_dif; out.d_r_specular = d_spc; out.d_r_distance = d_dist; out.d_r_acc = d_acc;
@@ -121,7 +121,8 @@ int main(int argc, char **argv) {
   void *d_ws = nullptr;
   HIP_OK(hipMalloc(&d_ws, ws_bytes));
   for (int l = 1; l >= 0; --l) {
-    refnerf_level_saved saved = {d_sd[l], d_dens[l], d_hrgb[l], d_w[l], d_act[l], REFNERF_ACT_F32};
+    /* (the format refnerf_level_forward_train wrote for this cfg: fp32 rows, or the split-f16 pair units of REFNERF_PREC_F16X2) */
+    refnerf_level_saved saved = {d_sd[l], d_dens[l], d_hrgb[l], d_w[l], d_act[l], refnerf_activations_format(&cfg[l])};
     refnerf_level_grads seeds = {};
     seeds.d_g_r_rgb = d_g_rgb[l];
     RN_OK(refnerf_level_backward(d_packed, &cfg[l], &rays, R, &saved, &seeds, d_grads, d_ws, ws_bytes, nullptr));

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 8   /* v8: cfg.ipe_groups, refnerf_pack_weights_basis (general IPE bases: icosahedron); v7: REFNERF_PREC_F16X2 (split-operand f16: the parity-grade 16-bit inference mode); v6: cfg.dir_enc (REFNERF_DIRENC_*), cfg.raydist (REFNERF_RAYDIST_*), cfg.disable_integration; v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
+#define REFNERF_ABI_VERSION 9   /* v9: REFNERF_ACT_F16X2 (split-f16 ACT / DELTA formats of the split-f16 training chains), refnerf_activations_format; v8: cfg.ipe_groups, refnerf_pack_weights_basis (general IPE bases: icosahedron); v7: REFNERF_PREC_F16X2 (split-operand f16: the parity-grade 16-bit inference mode); v6: cfg.dir_enc (REFNERF_DIRENC_*), cfg.raydist (REFNERF_RAYDIST_*), cfg.disable_integration; v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {
@@ -59,8 +59,9 @@ enum {
                             basis) let a NaN through, so the ray's outputs are NaN: loud, never a finite wrong colour.
                             REFNERF_PREC_F32 has no such limit.
                             refnerf_level_forward_train / refnerf_level_backward in this mode: the f32 kernels with every
-                            256-wide contraction as W_hi x_hi + W_lo x_hi + W_hi x_lo on the same instruction (saved
-                            activations stay REFNERF_ACT_F32; gradients 5e-5 rel-L2 from the reference's autograd). */
+                            256-wide contraction as W_hi x_hi + W_lo x_hi + W_hi x_lo on the same instruction; saved
+                            activations REFNERF_ACT_F16X2 (built-in basis; then the backward must run in this mode too) or
+                            REFNERF_ACT_F32 (general basis); gradients <= 1e-4 rel-L2 from the reference's autograd. */
 };
 
 /* arithmetic of the weight-gradient GEMM of refnerf_level_backward (dW = DELTA x ACT^T over the samples) */
@@ -70,11 +71,16 @@ enum {
                                v_mfma_f32_32x32x16_bf16, fp32 accumulate: 2^-16 per product, HBM-bound (default) */
 };
 
-/* element type of the saved layer inputs: fp32 rows (f32 training forward) or bf16 rows (bf16-chain training forward,
- * whose activations are bf16-exact: half the stream; rows 2j and 2j+1 share the dwords of pair-row j, low / high half --
- * the buffer is opaque to the caller, only its size (rows x pitch x 4 bytes) is part of the ABI); the 128 rows of ReLU
- * mask words are 32-bit in both */
-enum { REFNERF_ACT_F32 = 0, REFNERF_ACT_BF16 = 1 };
+/* element type of the saved layer inputs: fp32 rows (f32 training forward; any forward with a general IPE basis), bf16 rows
+ * (bf16-chain training forward, whose activations are bf16-exact: half the stream; rows 2j and 2j+1 share the dwords of
+ * pair-row j, low / high half) or split-f16 pair units (REFNERF_ACT_F16X2, the split-f16 training forward on the built-in
+ * basis: per pair of rows one dword of packed hi halves and one of packed lo halves, x = hi + lo -- the chain kernels' own
+ * B fragments, stored without arithmetic; the split-f16 backward then writes its layer deltas as ONE half per element plus a
+ * power-of-two factor per (layer, sample), and the weight-gradient GEMM runs on v_mfma_f32_32x32x16_f16: 26 instead of
+ * 34.5 KB of operands per ray-sample).  The buffer is opaque to the caller, only its size is part of the ABI; the 128 rows of
+ * ReLU mask words are 32-bit in all three.  refnerf_activations_format(cfg) tells which one refnerf_level_forward_train
+ * writes for a configuration: pass it on in refnerf_level_saved.activations_format. */
+enum { REFNERF_ACT_F32 = 0, REFNERF_ACT_BF16 = 1, REFNERF_ACT_F16X2 = 2 };
 
 /* encoding of the (reflected) direction fed to the directional MLP (internal/models.py:484-492) */
 enum {
@@ -249,6 +255,7 @@ typedef struct refnerf_level_grads {
  * cfg->precision = REFNERF_PREC_BF16 runs the MLP chains (and the density-normal VJP) on bf16 MFMA with the
  * activations rounded to bf16 once per layer (RGB within 1e-4 of the f32 mode); REFNERF_PREC_F32 is the parity mode. */
 size_t refnerf_activation_workspace_bytes(int32_t R, int32_t n_samples);
+int refnerf_activations_format(const refnerf_level_cfg *cfg);   /* REFNERF_ACT_* of refnerf_level_forward_train(cfg), -1 for NULL */
 int refnerf_level_forward_train(const void *d_packed, const refnerf_level_cfg *cfg,
                                 const refnerf_rays *rays, int32_t R,
                                 const float *d_sdist_in, const float *d_weights_in,

@@ -15,7 +15,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
 
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X2 = 0, 1, 2, 3
-ABI_VERSION = 8   # REFNERF_ABI_VERSION
+ABI_VERSION = 9   # REFNERF_ABI_VERSION
 WGRAD_F32, WGRAD_BF16X3 = 0, 1
 DIRENC_IDE, DIRENC_POSENC = 0, 1   # REFNERF_DIRENC_*
 RAYDIST = {None: 0, "piecewise": 1, "reciprocal": 2, "log": 3, "exp": 4, "sqrt": 5, "square": 6}   # REFNERF_RAYDIST_*
@@ -93,6 +93,7 @@ def lib():
         L.refnerf_pack_weights_basis.argtypes = [_FP, _FP, C.c_int, _FP, C.c_int, _FP]
         L.refnerf_level_forward.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
                                             _FP, _FP, C.POINTER(LevelOut), _FP]
+        L.refnerf_activations_format.argtypes = [C.POINTER(LevelCfg)]
         L.refnerf_activation_workspace_bytes.restype = C.c_size_t
         L.refnerf_activation_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.refnerf_level_forward_train.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
@@ -242,8 +243,8 @@ def level_forward(packed, cfg: LevelCfg, rays: dict, sdist_in, weights_in, histo
         check(lib().refnerf_level_forward_train(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out),
                                                 ptr(act), act.numel(), stream_ptr()))
         res["activations"] = act
-        # REFNERF_ACT_F32 / REFNERF_ACT_BF16: only the bf16-chain forward writes bf16 rows (the split-f16 chains write fp32 rows)
-        res["activations_format"] = 1 if int(cfg.precision) == PREC_BF16 else 0
+        # REFNERF_ACT_*: what this forward wrote (f32 rows | bf16 pair-rows | split-f16 hi / lo pair units), as the library says
+        res["activations_format"] = int(lib().refnerf_activations_format(C.byref(cfg)))
     else:
         check(lib().refnerf_level_forward(ptr(packed), C.byref(cfg), C.byref(rs), R, ptr(sd), ptr(w), C.byref(out), stream_ptr()))
     return res

@@ -29,6 +29,7 @@
 #include "refnerf_level_bwd_f32.h"
 #include "refnerf_wgrad.h"
 #include "refnerf_wgrad_bf16x3.h"
+#include "refnerf_wgrad_f16.h"
 #include "refnerf_rays.h"
 
 namespace rn {
@@ -726,7 +727,7 @@ static int rays_per_wg(int N, int tile) {
 }
 
 namespace {
-struct BwdPlan { long long S, pitch; int slices, k_per_slice; size_t act_bytes, delta_off, part_off, seed_off, total, act_ext_off, part_ext_off; };
+struct BwdPlan { long long S, pitch; int slices, k_per_slice; size_t act_bytes, delta_off, part_off, seed_off, cmin_off, total, act_ext_off, part_ext_off; };
 /* groups > 1 (general IPE basis): the tail matrix of the groups' IPE features behind ACT, the tail's split-K partials behind the seeds */
 BwdPlan bwd_plan(int R, int N, int groups = 0) {
   BwdPlan p;
@@ -740,7 +741,8 @@ BwdPlan bwd_plan(int R, int N, int groups = 0) {
   p.delta_off = 0;
   p.part_off = p.delta_off + sizeof(float) * (size_t)rn::DEL_ALLOC_ROWS * p.pitch;
   p.seed_off = p.part_off + sizeof(float) * (size_t)p.slices * rn::NUM_PARAMS;
-  p.total = p.seed_off + sizeof(float) * (size_t)rn::NGS * p.pitch;
+  p.cmin_off = p.seed_off + sizeof(float) * (size_t)rn::NGS * p.pitch;      /* split-f16 formats: the smallest factor per layer id */
+  p.total = p.cmin_off + 128;
   p.act_ext_off = p.act_bytes;
   p.part_ext_off = p.total;
   if (groups > 1) {
@@ -990,6 +992,13 @@ size_t refnerf_activation_workspace_bytes_basis(int32_t R, int32_t n_samples, in
   return bwd_plan(R, n_samples, ipe_groups).act_bytes;
 }
 
+int refnerf_activations_format(const refnerf_level_cfg *cfg) {
+  if (!cfg) return -1;
+  if (cfg->precision == REFNERF_PREC_BF16) return REFNERF_ACT_BF16;
+  if (cfg->precision == REFNERF_PREC_F16X2 && cfg->ipe_groups <= 1) return REFNERF_ACT_F16X2;
+  return REFNERF_ACT_F32;
+}
+
 int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays, int32_t R,
                            const refnerf_level_saved *saved, const refnerf_level_grads *grads, float *d_param_grads,
                            void *d_workspace, size_t workspace_bytes, void *stream) {
@@ -1000,8 +1009,10 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   if (cfg->ray_shape != 0 && cfg->ray_shape != 1) return fail(REFNERF_EINVAL, "ray_shape must be 'cone' or 'cylinder'%s");
   if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16 && cfg->precision != REFNERF_PREC_F16X2)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown precision mode (REFNERF_PREC_F32, REFNERF_PREC_F16X2 or REFNERF_PREC_BF16)%s");
-  if (cfg->precision == REFNERF_PREC_F16X2 && saved->activations_format != REFNERF_ACT_F32)
-    return fail(REFNERF_EUNSUPPORTED, "the split-f16 backward chains read fp32 activation rows (forward with REFNERF_PREC_F32 or REFNERF_PREC_F16X2)%s");
+  if (cfg->precision == REFNERF_PREC_F16X2 && saved->activations_format != REFNERF_ACT_F32 && saved->activations_format != REFNERF_ACT_F16X2)
+    return fail(REFNERF_EUNSUPPORTED, "the split-f16 backward chains read split-f16 pair units (forward with REFNERF_PREC_F16X2) or fp32 rows (REFNERF_PREC_F32, or a general IPE basis)%s");
+  if (cfg->precision != REFNERF_PREC_F16X2 && saved->activations_format == REFNERF_ACT_F16X2)
+    return fail(REFNERF_EUNSUPPORTED, "activations written by the split-f16 training forward (REFNERF_ACT_F16X2) are read by the split-f16 backward: cfg->precision = REFNERF_PREC_F16X2%s");
   if (cfg->wgrad_mode != REFNERF_WGRAD_F32 && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown wgrad_mode%s");
   if (!saved->d_sdist || !saved->d_density || !saved->d_rgb || !saved->d_weights || !grads->d_g_r_rgb)
@@ -1023,7 +1034,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   const size_t ring_off = (lds + 15) / 16 * 16;
   if (cfg->precision == REFNERF_PREC_BF16) lds = ring_off + rn::RING_BYTES;       /* the chains' shared weight-stream ring */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget%s");
-  LDS_ATTR_ONCE(lds_attr(rn::level_bwd_f32), lds_attr(rn::level_bwd_bf16c), lds_attr(rn::level_bwd_f16x2c),
+  LDS_ATTR_ONCE(lds_attr(rn::level_bwd_f32), lds_attr(rn::level_bwd_bf16c), lds_attr(rn::level_bwd_f16x2c), lds_attr(rn::level_bwd_f16x2c_r32),
+                lds_attr(rn::wgrad_f16s_kernel, rn::WF_LDS),
                 lds_attr(rn::wgrad_kernel, (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4),
                 lds_attr(rn::wgrad_bf16x3_kernel<false, false>, rn::wb_lds(false, false)),
                 lds_attr(rn::wgrad_bf16x3_kernel<false, true>, rn::wb_lds(false, true)),
@@ -1047,9 +1059,12 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   a.seeds = (float *)(ws + plan.seed_off);
   a.pitch = plan.pitch;
   const bool act16 = saved->activations_format == REFNERF_ACT_BF16, del16 = cfg->precision == REFNERF_PREC_BF16 && (REFNERF_DELTA16 != 0);
-  if (saved->activations_format != REFNERF_ACT_F32 && saved->activations_format != REFNERF_ACT_BF16)
+  /* split-f16 formats (refnerf_layout.h): ACT as hi / lo pair units, DELTA as one half per element + factor rows */
+  const bool pairs = saved->activations_format == REFNERF_ACT_F16X2;
+  if (saved->activations_format != REFNERF_ACT_F32 && saved->activations_format != REFNERF_ACT_BF16 && !pairs)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown activations_format%s");
-  if ((act16 || del16) && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
+  if (pairs && gbasis) return fail(REFNERF_EUNSUPPORTED, "a general IPE basis keeps fp32 activation rows (REFNERF_ACT_F32)%s");
+  if ((act16 || del16 || pairs) && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
     return fail(REFNERF_EUNSUPPORTED, "bf16 activation / delta rows need wgrad_mode = REFNERF_WGRAD_BF16X3%s");
   a.act16 = act16 ? 1 : 0;
   a.ring_off = (int)ring_off;
@@ -1067,8 +1082,10 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   { int trc = timer_begin(st, &tslot, REFNERF_TIMER_BACKWARD); if (trc) return trc; }
   if (cfg->precision == REFNERF_PREC_BF16)
     hipLaunchKernelGGL(rn::level_bwd_bf16c, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
-  else if (cfg->precision == REFNERF_PREC_F16X2)
+  else if (cfg->precision == REFNERF_PREC_F16X2 && pairs)
     hipLaunchKernelGGL(rn::level_bwd_f16x2c, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
+  else if (cfg->precision == REFNERF_PREC_F16X2)
+    hipLaunchKernelGGL(rn::level_bwd_f16x2c_r32, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
   else
     hipLaunchKernelGGL(rn::level_bwd_f32, dim3((R + rpw - 1) / rpw), dim3(rn::NTHREADS), lds, st, a);
   HIP_TRY(hipGetLastError());
@@ -1084,17 +1101,25 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   }
   if (plan.pitch > plan.S) {   /* pad columns of both operand matrices must read as zero in the wgrad GEMM */
     hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(a.act), act16 ? rn::ACT_ROWS / 2 : rn::ACT_ROWS, rn::act_units(act16), plan.pitch, plan.S);
-    hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, del16 ? rn::DEL_ROWS / 2 : rn::DEL_ROWS, rn::del_units(del16), plan.pitch, plan.S);
+    hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, (del16 || pairs) ? rn::DEL_ROWS / 2 : rn::DEL_ROWS,
+                       pairs ? rn::DEL_UNITS_F16S : rn::del_units(del16), plan.pitch, plan.S);
   }
   rn::WgradArgs w;
-  w.act = a.act; w.delta = a.delta; w.a_units = rn::act_units(act16); w.d_units = rn::del_units(del16); w.pitch = plan.pitch; w.S = plan.S; w.k_per_slice = plan.k_per_slice;
+  w.act = a.act; w.delta = a.delta; w.a_units = rn::act_units(act16); w.d_units = pairs ? rn::DEL_UNITS_F16S : rn::del_units(del16); w.pitch = plan.pitch; w.S = plan.S; w.k_per_slice = plan.k_per_slice;
   w.part = (float *)(ws + plan.part_off);
   const int slices = (int)((plan.S + plan.k_per_slice - 1) / plan.k_per_slice);
   { int trc = timer_begin(st, &tslot, REFNERF_TIMER_WGRAD); if (trc) return trc; }
   if (cfg->wgrad_mode == REFNERF_WGRAD_BF16X3)
   {
     const dim3 wg_grid(8 * ((slices + 7) / 8) * rn::WJOBS.tiles);
-    if (del16 && act16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, true>), wg_grid, dim3(256), rn::wb_lds(true, true), st, w, slices);
+    if (pairs) {
+      /* the layers' smallest factors first (18 exact minima: +inf bits, then one atomicMin per block), then the f16 GEMM */
+      float *cmin = (float *)(ws + plan.cmin_off);
+      HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)cmin, 0x7f800000, 32, st));
+      hipLaunchKernelGGL(rn::delta_scale_min, dim3(rn::DSC_ROWS, 64), dim3(256), 0, st, a.delta, plan.S, cmin);
+      hipLaunchKernelGGL(rn::wgrad_f16s_kernel, wg_grid, dim3(256), rn::WF_LDS, st, w, slices, cmin);
+    }
+    else if (del16 && act16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, true>), wg_grid, dim3(256), rn::wb_lds(true, true), st, w, slices);
     else if (del16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, false>), wg_grid, dim3(256), rn::wb_lds(true, false), st, w, slices);
     else if (act16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<false, true>), wg_grid, dim3(256), rn::wb_lds(false, true), st, w, slices);
     else hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<false, false>), wg_grid, dim3(256), rn::wb_lds(false, false), st, w, slices);

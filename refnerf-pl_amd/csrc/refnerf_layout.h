@@ -259,6 +259,24 @@ constexpr int ACT_ALLOC_ROWS = ACT_ROWS_TOTAL + 1, DEL_ALLOC_ROWS = DEL_ROWS + 1
 static_assert((ACT_UNITS_F32 & ACT_UNITS_H16 & DEL_UNITS_F32 & DEL_UNITS_H16 & 1) == 1, "odd block strides");
 constexpr int act_units(bool h16) { return h16 ? ACT_UNITS_H16 : ACT_UNITS_F32; }
 constexpr int del_units(bool h16) { return h16 ? DEL_UNITS_H16 : DEL_UNITS_F32; }
+/* Split-f16 formats (REFNERF_ACT_F16X2: written by the split-f16 training forward, read by the split-f16 backward and its
+ * weight-gradient GEMM; round 4).  Same bytes per ACT element, half the bytes per DELTA element, and no arithmetic between the
+ * chain kernels' registers and HBM:
+ *   ACT   : the fp32 format's unit grid (ACT_UNITS_F32) with the rows taken in PAIRS -- unit 2j holds the packed HI halves of
+ *           rows (2j, 2j + 1), unit 2j + 1 their packed LO halves (x = hi + lo, 22 bits): exactly the dwords of the chain
+ *           kernels' packed B fragments, stored as they are; the mask rows keep their raw dwords;
+ *   DELTA : pair-rows of ONE IEEE half per element (DEL_ROWS / 2 units: the hi halves of the backward's packed deltas, i.e.
+ *           delta * c_s rounded to 11 bits, with c_s the power-of-two factor the chain carries for sample s in that layer),
+ *           followed by DSC_ROWS fp32 units holding c_s per (layer id, sample).  The weight-gradient GEMM brings every sample
+ *           of a layer to the layer's smallest factor (the largest deltas keep all their bits, the others shift down inside
+ *           the half's 40 binades) and divides the tile by it at the end.  Layer ids: spatial 0..7, heads 8, directional
+ *           9..16, rgb 17. */
+constexpr int DSC_ROWS = 18, DSC0 = DEL_ROWS / 2;
+constexpr int DEL_UNITS_F16S = DSC0 + DSC_ROWS + 1;
+static_assert((DEL_UNITS_F16S & 1) == 1 && DEL_UNITS_F16S <= DEL_ALLOC_ROWS, "odd block stride inside the fp32-sized allocation");
+constexpr int del_layer_id(int d_row) {
+  return d_row >= DEL_RGB ? 17 : (d_row >= DEL_VD ? 9 + (d_row - DEL_VD) / WIDTH : (d_row >= DEL_HEADS ? 8 : (d_row - DEL_SP) / WIDTH));
+}
 
 /* ---------------- bf16 MFMA operand image ----------------
  * Same 18 ops on v_mfma_f32_32x32x16_bf16 (K = 16 per step), two 32-sample

@@ -210,10 +210,15 @@ __device__ __forceinline__ void shift_masks(unsigned (&M)[8][4]) {
 
 /* BF: transposed chains on bf16 MFMA; SP: on split-f16 operands (22-bit deltas and weights, hi*hi + lo*hi + hi*lo on
  * v_mfma_f32_32x32x16_f16: the parity-grade fast chains, see refnerf_level_f32.h), fp32 ACT / DELTA rows */
-template <bool BF, bool SP = false>
+/* PF (split chains only): the split-f16 formats of refnerf_layout.h -- ACT read as hi / lo pair units (REFNERF_ACT_F16X2), DELTA
+ * written as ONE half per element (the hi halves of the packed deltas as they are: delta * c_s at 11 bits) plus the factor
+ * c_s per (layer id, sample) in the DSC units.  Half the DELTA bytes, and no arithmetic between the fragments and HBM. */
+template <bool BF, bool SP = false, bool PF = false>
 __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
   static_assert(!(BF && SP), "one chain arithmetic");
+  static_assert(!PF || SP, "pair formats belong to the split chains");
   constexpr bool D16 = BF && (REFNERF_DELTA16 != 0);
+  constexpr int DUNITS = PF ? DEL_UNITS_F16S : del_units(D16);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const refnerf_level_cfg &cfg = A.cfg;
   const int N = cfg.n_samples;
@@ -263,7 +268,16 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     const size_t gs = valid ? (size_t)ray * N + si : 0;
     /* this sample's column in the blocked rows of DELTA and (fp32 format) ACT; the sample-major block and the seed
      * rows keep (pitch, gs) */
-    const size_t dcol = (size_t)rb_col((long long)gs, del_units(D16)), acol = (size_t)rb_col((long long)gs, ACT_UNITS_F32);
+    const size_t dcol = (size_t)rb_col((long long)gs, DUNITS), acol = (size_t)rb_col((long long)gs, ACT_UNITS_F32);
+    /* PF: one packed pair (value0, value1) * c rounded to halves -> pair-row `row` / 2 of DELTA; the factor of layer `lid` */
+    auto store_dpair = [&](int row, float x0, float x1, float c) {
+      const v2hf pv = __builtin_convertvector((v2f){x0 * c, x1 * c}, v2hf);
+      stream_store_u(A.delta, (long long)(row >> 1) * rpitch + (long long)dcol, __builtin_bit_cast(unsigned, pv));
+    };
+    /* (0 for a sample without any gradient in that layer: it takes no part in the layer's smallest factor) */
+    auto store_dscale = [&](int lid, float c, bool live) {
+      if (valid && h == 0) stream_store(A.delta + (long long)(DSC0 + lid) * rpitch + (long long)dcol, live ? c : 0.0f);
+    };
     float v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) v[i] = A.rays.d_viewdirs[(size_t)rayc * 3 + i];
@@ -285,6 +299,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
       }
       if (!done) {
         if (A.act16) smb_load_rows(A.act, pitch, gs, h, SMB_X7, in);                  /* x7: input of the heads */
+        else if constexpr (PF) load_rows_split<8>(A.act, rpitch, ACT_SP + 7 * WIDTH, acol, h, in);
         else load_rows<8>(A.act, rpitch, ACT_SP + 7 * WIDTH, acol, h, in);
         heads_scalar_block_f32(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd4[0]);
       }
@@ -308,6 +323,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     }
     if (!rgb_bf) {
       if (A.act16) smb_load_rows(A.act, pitch, gs, h, SMB_V7, in);                  /* v7: input of the rgb layer */
+      else if constexpr (PF) load_rows_split<8>(A.act, rpitch, ACT_VD + 7 * WIDTH, acol, h, in);
       else load_rows<8>(A.act, rpitch, ACT_VD + 7 * WIDTH, acol, h, in);
     }
     wave_sync();
@@ -378,7 +394,13 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
         g_raw_diff[i] = g_dl[i] * dl[i] * (1.0f - dl[i]);
       }
     }
-    if (valid && h == 0) {
+    if constexpr (PF) {
+      /* (both half-waves hold the same three values) */
+      bool lr;
+      const float cr = pow2_scale_for(fmaxf(fmaxf(fabsf(g_raw_rgb[0]), fabsf(g_raw_rgb[1])), fabsf(g_raw_rgb[2])), &lr);
+      if (valid && h == 0) { store_dpair(DEL_RGB, g_raw_rgb[0], g_raw_rgb[1], cr); store_dpair(DEL_RGB + 2, g_raw_rgb[2], 0.0f, cr); }
+      store_dscale(17, cr, lr);
+    } else if (valid && h == 0) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) store_row1<D16>(A.delta, rpitch, DEL_RGB + i, dcol, g_raw_rgb[i]);
     }
@@ -394,7 +416,8 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     v4uu pk[(BF || SP) ? 16 : 1];                  /* packed delta (bf16 chains) / its hi halves (split chains) */
     v4uu pl[SP ? 16 : 1];                          /* lo halves (split chains) */
     float cs = 1.0f;                               /* split chains: this sample's power-of-two factor on the packed delta (mask_split) */
-    if constexpr (SP) mask_split(out, M[7], pk, pl, cs);
+    bool dlive = true;                             /* ... and whether the sample has any non-zero delta in the current layer */
+    if constexpr (SP) mask_split(out, M[7], pk, pl, cs, &dlive);
     else if constexpr (BF) mask_pack(out, M[7], pk);
     else masked_into(out, in, M[7]);
     /* ---- directional MLP, layers 7..0 ---- */
@@ -441,19 +464,26 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
           if (i == 7) RN_STAMP(A, 10);
         }
       } else if constexpr (SP) {
-        RowStoreHook sh_(A.delta, rpitch, DEL_VD + i * WIDTH, dcol, h, valid);
+        std::conditional_t<PF, PairStoreHook, RowStoreHook> sh_(A.delta, rpitch, DEL_VD + i * WIDTH, dcol, h, valid);
         const float inv = 1.0f / cs;
+        if constexpr (PF) store_dscale(9 + i, cs, dlive);  /* delta_i leaves as its packed hi halves, carrying cs */
         auto hook = [&](int t, int quarter = -1) {
+          if constexpr (PF) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (quarter < 0 || (e >> 1) == quarter) sh_(8 * t + e, split_elem(pk[t], pl[t], e) * inv);
+            for (int e = 0; e < 4; ++e)
+              if (quarter < 0 || e == quarter) sh_(4 * t + e, pk[t][e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (quarter < 0 || (e >> 1) == quarter) sh_(8 * t + e, split_elem(pk[t], pl[t], e) * inv);
+          }
         };
         if (i == 5) { gemm_op_split<DIN_BLOCKS, 16, 0, false>(rs, PACKED.ht_off[TOP_VD5_DIN], 0, lane, h, pk, pl, gd, nullptr); park_din(5); }
         if (i == 0) { gemm_op_split<DIN_BLOCKS, 16, 0, false>(rs, PACKED.ht_off[TOP_VD0], 0, lane, h, pk, pl, gd, nullptr, hook); park_din(0); }
         if (i > 0) {
           gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[TOP_VD1 + i - 1], 0, lane, h, pk, pl, out, nullptr, hook);
           shift_masks(M);
-          mask_split(out, M[7], pk, pl, cs);
+          mask_split(out, M[7], pk, pl, cs, &dlive);
         }
       } else {
         if (i == 5 || i == 0) {
@@ -472,7 +502,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     }
     RN_STAMP(A, 5);
     /* X rows 0..127: dL/d bottleneck (= head rows 0..127), rows 128..200: dL/d (IDE, n.v) */
-    store_rows<4, D16>(A.delta, rpitch, DEL_HEADS, dcol, h, valid, gd);
+    if constexpr (!PF) store_rows<4, D16>(A.delta, rpitch, DEL_HEADS, dcol, h, valid, gd);     /* (PF: from the tile, with the head block's factor, below) */
     wave_sync();
     /* ---- IDE, reflection, predicted normal, head activations (models.py:611-686) ---- */
     {
@@ -512,7 +542,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
 #pragma unroll
         for (int i = 0; i < 11; ++i) {
           X[tile_idx(HROW_DENSITY + i, col, xhi)] = hrow[i];
-          if (valid) store_row1<D16>(A.delta, rpitch, DEL_HEADS + HROW_DENSITY + i, dcol, hrow[i]);
+          if constexpr (!PF) { if (valid) store_row1<D16>(A.delta, rpitch, DEL_HEADS + HROW_DENSITY + i, dcol, hrow[i]); }
         }
       } else {
 #pragma unroll
@@ -558,22 +588,44 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
         for (int t = 0; t < BT_HEADS_STEPS; ++t)
 #pragma unroll
           for (int e = 0; e < 8; ++e) { const int row = 16 * t + 8 * h + e; m = fmaxf(m, fabsf(X[tile_idx(row, col, hi2)])); }
-        cs = pow2_scale_for(m);
+        cs = pow2_scale_for(m, &dlive);
+        if constexpr (PF) {
+          /* the 139 head rows (+ their zero pad row) leave from the tile with this factor: half h takes pairs h, h + 2, ... */
+          if (valid) {
+#pragma unroll 1
+            for (int j = h; j < (HROWS + 1) / 2; j += 2)
+              store_dpair(DEL_HEADS + 2 * j, X[tile_idx(2 * j, col, hi2)], (2 * j + 1 < HROWS) ? X[tile_idx(2 * j + 1, col, hi2)] : 0.0f, cs);
+          }
+          store_dscale(8, cs, dlive);
+        }
       }
       gemm_op_split<8, 0, BT_HEADS_STEPS, false>(rs, PACKED.ht_off[TOP_HEADS], 0, lane, h, pk, pl, out, X + col, NoStepHook(), cs);
-      mask_split(out, M[7], pk, pl, cs);
+      mask_split(out, M[7], pk, pl, cs, &dlive);
 #pragma unroll 1
       for (int i = 7; i >= 0; --i) {
+        if constexpr (PF) store_dscale(i, cs, dlive);
         if (i > 0) {
-          RowStoreHook sh_(A.delta, rpitch, DEL_SP + i * WIDTH, dcol, h, valid);
+          std::conditional_t<PF, PairStoreHook, RowStoreHook> sh_(A.delta, rpitch, DEL_SP + i * WIDTH, dcol, h, valid);
           const float inv = 1.0f / cs;
           gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[i - 1], 0, lane, h, pk, pl, out, nullptr, [&](int t, int quarter = -1) {
+            if constexpr (PF) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (quarter < 0 || (e >> 1) == quarter) sh_(8 * t + e, split_elem(pk[t], pl[t], e) * inv);
+              for (int e = 0; e < 4; ++e)
+                if (quarter < 0 || e == quarter) sh_(4 * t + e, pk[t][e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (quarter < 0 || (e >> 1) == quarter) sh_(8 * t + e, split_elem(pk[t], pl[t], e) * inv);
+            }
           });
           shift_masks(M);
-          mask_split(out, M[7], pk, pl, cs);
+          mask_split(out, M[7], pk, pl, cs, &dlive);
+        } else if constexpr (PF) {                                           /* no GEMM consumes delta_0: its hi halves as they are */
+          PairStoreHook sh_(A.delta, rpitch, DEL_SP, dcol, h, valid);
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sh_(4 * t + e, pk[t][e]);
         } else {                                                             /* no GEMM consumes delta_0 */
 #pragma unroll
           for (int blk = 0; blk < 8; ++blk)
@@ -612,6 +664,8 @@ __global__ __launch_bounds__(NTHREADS) void level_bwd_f32(const BwdArgs A) { lev
 /* bf16 chains (cfg.precision = REFNERF_PREC_BF16): gradients at bf16 accuracy */
 __global__ __launch_bounds__(NTHREADS) void level_bwd_bf16c(const BwdArgs A) { level_bwd_body<true>(A); }
 /* transposed chains on split-f16 operands (cfg.precision = REFNERF_PREC_F16X2 in refnerf_level_backward) */
-__global__ __launch_bounds__(NTHREADS) void level_bwd_f16x2c(const BwdArgs A) { level_bwd_body<false, true>(A); }
+__global__ __launch_bounds__(NTHREADS) void level_bwd_f16x2c(const BwdArgs A) { level_bwd_body<false, true, true>(A); }
+/* the same chains on fp32 ACT / DELTA rows (REFNERF_ACT_F32 activations: an f32 training forward, or a general IPE basis) */
+__global__ __launch_bounds__(NTHREADS) void level_bwd_f16x2c_r32(const BwdArgs A) { level_bwd_body<false, true>(A); }
 
 }  // namespace rn

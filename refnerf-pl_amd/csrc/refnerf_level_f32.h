@@ -127,6 +127,20 @@ struct RowStoreHookT {
 #endif
     soff += ((step & 3) == 3) ? p5 : p1;
   }
+  /* the same unit walk with a raw dword (REFNERF_ACT_F16X2: units 2j / 2j + 1 = the packed hi / lo halves of rows 2j, 2j + 1,
+   * i.e. step 8 t + e stores dword e >> 1 of the k-step's hi (e even) or lo (e odd) fragment -- no arithmetic, and no float
+   * register in between: a packed pair of halves is not a well-formed float) */
+  __device__ __forceinline__ void raw(int step, unsigned w) {
+    static_assert(!H16, "raw dwords go to 4-byte units");
+    if ((step & 15) == 0 && step > 0) {
+      rs = __builtin_amdgcn_make_buffer_rsrc(base + (unsigned long long)(step >> 4) * blk_bytes, 0, 0x80000000, 0x00020000);
+      soff = 0;
+    }
+#ifndef REFNERF_EXPERIMENT_NO_STREAM
+    __builtin_amdgcn_raw_buffer_store_b32(w, rs, voff, soff, REFNERF_STREAM_AUX);
+#endif
+    soff += ((step & 3) == 3) ? p5 : p1;
+  }
 };
 typedef RowStoreHookT<false> RowStoreHook;
 
@@ -608,21 +622,24 @@ __device__ __forceinline__ void relu_mask_split(const v16f (&out)[8], unsigned (
  * deltas of a backward chain are 1e-4 .. 1e-9 -- unscaled, their lo halves (and soon the hi halves) underflow and the
  * gradient dies down the chain (measured: 1.0 relative error at the first directional layers).  Columns of the B operand
  * are independent in W^T delta, so every SAMPLE carries its own factor through the chain. */
-__device__ __forceinline__ float pow2_scale_for(float m) {
+/* `live` (optional): whether the sample has any non-zero value at all -- a sample without gradient keeps factor 1, which
+ * must not be mistaken for "the sample with the largest deltas" when the layer's smallest factor is taken (refnerf_wgrad_f16.h) */
+__device__ __forceinline__ float pow2_scale_for(float m, bool *live = nullptr) {
   m = fmaxf(m, __shfl_xor(m, 32, 64));                    /* both half-waves hold values of the same sample */
   int e = 8 - __builtin_amdgcn_frexp_expf(m);
   e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  if (live) *live = m > 0.0f;
   return (m > 0.0f) ? __builtin_ldexpf(1.0f, e) : 1.0f;
 }
 /* delta through a recorded ReLU mask into the next transposed GEMM's packed hi / lo fragments, rescaled per sample:
  * on entry `out` carries the factor `c`, on exit the fragments carry the updated `c` (DELTA rows are stored as value / c) */
-__device__ __forceinline__ void mask_split(const v16f (&out)[8], const unsigned (&mk)[4], v4uu (&ph)[16], v4uu (&pl)[16], float &c) {
+__device__ __forceinline__ void mask_split(const v16f (&out)[8], const unsigned (&mk)[4], v4uu (&ph)[16], v4uu (&pl)[16], float &c, bool *live = nullptr) {
   float m = 0.0f;
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
     for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(keep_if_bit(out[ob][r], mk[ob >> 1], 16 * (ob & 1) + r)));
-  const float rs = pow2_scale_for(m);
+  const float rs = pow2_scale_for(m, live);
   c *= rs;
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) {
@@ -712,6 +729,57 @@ __device__ __forceinline__ void load_rows(const float *base, long long pitch, in
           x[blk][r + 1] = __builtin_bit_cast(float, w & 0xffff0000u);
         }
       } else x[blk][r] = load_e<false>(base, e0 + (long long)c * pitch);
+    }
+}
+
+/* ---- REFNERF_ACT_F16X2 (refnerf_layout.h): rows in pairs, unit 2j = packed hi halves of rows (2j, 2j + 1), unit 2j + 1 = packed
+ * lo halves.  `row` even. ---- */
+__device__ __forceinline__ void stream_store_u(float *base, long long idx, unsigned w) {
+#if REFNERF_STREAM_AUX
+  __builtin_nontemporal_store(w, reinterpret_cast<unsigned *>(base) + idx);
+#else
+  reinterpret_cast<unsigned *>(base)[idx] = w;
+#endif
+}
+__device__ __forceinline__ void store_pair_split(float *base, long long pitch, int row, size_t gs, float x0, float x1) {
+  unsigned hi, lo;
+  split_pair_h(x0, x1, hi, lo);
+  const long long e0 = (long long)row * pitch + (long long)gs;
+  stream_store_u(base, e0, hi);
+  stream_store_u(base, e0 + pitch, lo);
+}
+/* NB accumulator blocks (rows row0 + 32 blk + row(r, h)) as hi / lo pair units */
+template <int NB>
+__device__ __forceinline__ void store_rows_split(float *base, long long pitch, int row0, size_t gs, int h, bool valid, const v16f *x) {
+  const long long e0 = (long long)(row0 + 4 * h) * pitch + (long long)gs;
+  if (valid) {
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int c = blk * 32 + (r & 3) + 8 * (r >> 2);
+        unsigned hi, lo;
+        split_pair_h(x[blk][r], x[blk][r + 1], hi, lo);
+        stream_store_u(base, e0 + (long long)c * pitch, hi);
+        stream_store_u(base, e0 + (long long)(c + 1) * pitch, lo);
+      }
+  }
+}
+/* ... and read back as the fp32 accumulator image (hi + lo is exact in fp32) */
+template <int NB>
+__device__ __forceinline__ void load_rows_split(const float *base, long long pitch, int row0, size_t gs, int h, v16f *x) {
+  const long long e0 = (long long)(row0 + 4 * h) * pitch + (long long)gs;
+  const unsigned *u = reinterpret_cast<const unsigned *>(base);
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const int c = blk * 32 + (r & 3) + 8 * (r >> 2);
+      const unsigned wh = u[e0 + (long long)c * pitch], wl = u[e0 + (long long)(c + 1) * pitch];
+      const v2hf a = __builtin_bit_cast(v2hf, wh), b = __builtin_bit_cast(v2hf, wl);
+      const _Float16 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+      x[blk][r] = (float)a0 + (float)b0;
+      x[blk][r + 1] = (float)a1 + (float)b1;
     }
 }
 
@@ -985,6 +1053,9 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   static_assert(!BFC || (TRAIN && !STAGE), "bf16 chains: training forward only");
   static_assert(!SPC || (TRAIN && !STAGE && !BFC), "split-f16 chains: training forward only");
   static_assert(!GB || (!BFC && !(STAGE && SPC)), "general IPE basis: the fp32 skeleton with fp32 or split-f16 chains");
+  /* split chains on the built-in basis save the layer inputs as hi / lo pair units (REFNERF_ACT_F16X2); a general basis keeps
+   * fp32 rows (its tail matrix and tail job table are fp32) */
+  constexpr bool PAIRS = SPC && !GB;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   RN_STAMP(A, 0);
   const refnerf_level_cfg &cfg = A.cfg;
@@ -1120,12 +1191,20 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
         if (cfg.disable_integration) { lv[0] = 0.0f; lv[1] = 0.0f; lv[2] = 0.0f; }        /* models.py:228-231 */
       }
+      float fe_prev = 0.0f;
 #pragma unroll 1
       for (int j = 0; j < 16; ++j)
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
           const float fe = ipe_feature<BFC>(lm[b], lv[b], j, h);   /* bf16 chains: hardware sin / exp2, as the bf16 eval kernel (the MLP rounds its inputs to 8 bits) */
           X[(48 * h + j * 3 + b) * T_TILE + col] = fe;
+          if constexpr (PAIRS) {
+            /* features 3 j + b come in row order: every second one completes a pair (rows 48 h + q - 1, 48 h + q) */
+            const int q = j * 3 + b;
+            if (q & 1) { if (save) store_pair_split(A.act, rpitch, ACT_IPE + 48 * h + q - 1, rcol, fe_prev, fe); }
+            else fe_prev = fe;
+            continue;
+          }
           /* bf16 chains: (e sin, e cos) of every (j, b) once more as a bf16 pair in tile rows 128.. (free until P4): the
            * density-normal VJP needs exactly these as d feature / d mean (ipe_vjp_accum_lds) */
           if constexpr (BFC) reinterpret_cast<unsigned short *>(X)[((BNECK + j * 3 + b) * T_TILE + col) * 2 + h] = (unsigned short)cvt_pk_bf16(fe, fe);
@@ -1143,11 +1222,15 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         for (int e = 0; e < 4; ++e) hk(4 * t + e, pk[t][e]);       /* the k-step's B fragment as it is */
       };
     };
-    auto row_hook = [&](int row0) {              /* split chains: the layer input leaves as fp32 rows, 8 per k-step */
+    auto row_hook = [&](int row0) {              /* split chains: the layer input leaves 8 units per k-step: fp32 rows, or */
       return [&, hk = RowStoreHook(A.act, rpitch, row0, rcol, h, save)](int t, int quarter = -1) mutable {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (quarter < 0 || (e >> 1) == quarter) hk(8 * t + e, split_elem(pk[t], pl[t], e));
+          if (quarter < 0 || (e >> 1) == quarter) {
+            /* (REFNERF_ACT_F16X2) the fragment dwords themselves: unit 2j = hi halves, 2j + 1 = lo halves of rows (2j, 2j + 1) */
+            if constexpr (PAIRS) hk.raw(8 * t + e, (e & 1) ? pl[t][e >> 1] : pk[t][e >> 1]);
+            else hk(8 * t + e, split_elem(pk[t], pl[t], e));
+          }
       };
     };
     /* general basis: groups 1..G-1 of layer L (0: layer 0, 1: layer 5) accumulate into `out` through the same X rows */
@@ -1244,7 +1327,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < HD_ROWS) X[hdb + row * T_TILE] = hd[4][r];
       }
-      if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<4, BFC>(A.act, rpitch, ACT_DIN, rcol, h, save, hd); }
+      if constexpr (PAIRS) { if (A.act) store_rows_split<4>(A.act, rpitch, ACT_DIN, rcol, h, save, hd); }
+      else if constexpr (TRAIN && !STAGE) { if (A.act) store_rows<4, BFC>(A.act, rpitch, ACT_DIN, rcol, h, save, hd); }
     }
     wave_sync();
 
@@ -1274,16 +1358,29 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       float *xi = X + xhi + IDE_TERMS * h * T_TILE;   /* row BNECK (= 128) + 36 h */
       auto put = [&](int q, float val) {
         xi[q * T_TILE] = val;
+        if constexpr (PAIRS) return;             /* pair units: stored from the tile below (the encoders emit out of row order) */
         if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, rpitch, ACT_DIN + BNECK + IDE_TERMS * h + q, rcol, val); }
       };
       if (cfg.dir_enc == REFNERF_DIRENC_POSENC) posenc_eval(sh.refd[0], sh.refd[1], sh.refd[2], h, put);   /* models.py:487-492 */
       else ide_eval(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, put);
       if (h == 0) {
         X[tile_idx(BNECK + IDE_DIM, col, xhi)] = sh.dot;
-        if constexpr (TRAIN && !STAGE) { if (save) store_row1<BFC>(A.act, rpitch, ACT_DIN + BNECK + IDE_DIM, rcol, sh.dot); }
+        if constexpr (TRAIN && !STAGE && !PAIRS) { if (save) store_row1<BFC>(A.act, rpitch, ACT_DIN + BNECK + IDE_DIM, rcol, sh.dot); }
       } else {
 #pragma unroll
         for (int q = DIR_IN; q < DIR_PAD; ++q) X[tile_idx(q, col, xhi)] = 0.0f;
+      }
+      if constexpr (PAIRS) {
+        /* this lane's own 36 encoder outputs back from the tile, two rows per pair; half 0 adds (n.v, 0) and the (0, 0) pad pair */
+        if (save) {
+#pragma unroll 1
+          for (int q = 0; q < IDE_TERMS; q += 2)
+            store_pair_split(A.act, rpitch, ACT_DIN + BNECK + IDE_TERMS * h + q, rcol, xi[q * T_TILE], xi[(q + 1) * T_TILE]);
+          if (h == 0) {
+            store_pair_split(A.act, rpitch, ACT_DIN + BNECK + IDE_DIM, rcol, sh.dot, 0.0f);
+            store_pair_split(A.act, rpitch, ACT_DIN + BNECK + IDE_DIM + 2, rcol, 0.0f, 0.0f);
+          }
+        }
       }
     }
     wave_sync();

@@ -1,0 +1,200 @@
+/*
+ * refnerf_wgrad_f16.h -- the weight-gradient contraction on the split-f16 formats of refnerf_layout.h (round 4):
+ *   DELTA = ONE IEEE half per element (delta * c_s, 11 bits; c_s = the power-of-two factor the backward chain carried for
+ *           sample s in that layer, kept per (layer id, sample) in the DSC units),
+ *   ACT   = hi / lo pair units (22 bits), exactly as the chain kernels held them.
+ * dW[o][k] = sum_s DELTA[o][s] ACT[k][s] = (1 / c_min) sum_s (d16[o][s] * c_min / c_s) (a_hi[k][s] + a_lo[k][s]):
+ * every sample is brought to the layer's smallest factor c_min (taken over the samples that HAVE a gradient in that layer) with
+ * one packed multiply by a power of two (exact; a sample 2^29 below the layer's largest deltas starts to lose bits, 2^39 below
+ * it vanishes -- it carries that little of the sum),
+ * then TWO v_mfma_f32_32x32x16_f16 per product (d * a_hi + d * a_lo, fp32 accumulate) instead of the three of the split-bf16
+ * GEMM, no on-the-fly operand split (its 6 VALU per MFMA), and 26 KB instead of 34.5 KB of operands per ray-sample.
+ * Why 11 bits suffice for DELTA: scripts/exp_delta_precision.py (the reference's autograd with rounded weight-gradient
+ * operands on the three trained weight sets: gradient rel-L2 2e-5 .. 7e-5; bf16's 8 bits give 2e-4 .. 6e-4).
+ * Same job table, split-K slices, PART layout and fixed-order reduction as the other two GEMMs: bit-reproducible, no atomics
+ * (the min over the factors is exact in any order).
+ * Restates what autograd does for nn.Linear (internal/models.py:576-580,686-700): dW = delta^T x, db = sum delta.
+ */
+#pragma once
+#include "refnerf_wgrad_bf16x3.h"
+
+namespace rn {
+
+/* c_min[lid] = min over the valid samples of the factor row of layer id `lid`; cmin[] pre-set to +inf bits.
+ * grid = (DSC_ROWS, 64) x 256 threads; positive floats order like their bit patterns, so one atomicMin per block. */
+__global__ __launch_bounds__(256) void delta_scale_min(const float *__restrict__ delta, long long S, float *cmin) {
+  const int lid = blockIdx.x;
+  const float *row = delta + (long long)(DSC0 + lid) * RB;
+  float m = INFINITY;
+  for (long long s = (long long)blockIdx.y * blockDim.x + threadIdx.x; s < S; s += (long long)gridDim.y * blockDim.x) {
+    const float c = row[rb_col(s, DEL_UNITS_F16S)];
+    m = (c > 0.0f) ? fminf(m, c) : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m < INFINITY) atomicMin(reinterpret_cast<int *>(cmin) + lid, __builtin_bit_cast(int, m));
+}
+
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_mul_h(unsigned a, unsigned b) {
+  const v2h z = __builtin_bit_cast(v2h, a) * __builtin_bit_cast(v2h, b);
+  return __builtin_bit_cast(unsigned, z);
+}
+__device__ __forceinline__ float pk_sum_h(unsigned a) {
+  const v2h z = __builtin_bit_cast(v2h, a);
+  const _Float16 z0 = z[0], z1 = z[1];
+  return (float)z0 + (float)z1;
+}
+constexpr int WF_LDS = 3 * WB_TILE;            /* D, A_hi, A_lo: 54 KB */
+/* the backward scales a sample's largest delta into [2^7, 2^8) (pow2_scale_for); the sample(s) with the layer's smallest factor
+ * go up another 2^7 on load, to just below the largest half (2^15 < 65504), everything else follows: 29 binades at full
+ * precision below the layer's largest deltas, 10 more of gradual underflow */
+constexpr float TOP_SHIFT = 128.0f;
+
+/* grid = 8 * ceil(slices / 8) * WJOBS.tiles workgroups of 256 threads, decoded as in wgrad_bf16x3_kernel */
+__global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int slices, const float *__restrict__ cmin_all) {
+  constexpr const WJobs &JT = WJOBS;
+  extern __shared__ __attribute__((aligned(16))) char wbs[];
+  char *Dh = wbs, *Ah = wbs + WB_TILE, *Al = wbs + 2 * WB_TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, sl = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int tile = q % JT.tiles, slice = (q / JT.tiles) * 8 + xcd;
+  if (slice >= slices) return;
+  int ji = 0;
+#pragma unroll 1
+  for (int j = 1; j < JT.n; ++j) if (tile >= JT.job[j].tile0) ji = j;
+  const WJob J = JT.job[ji];
+  const int tl = tile - J.tile0;
+  const int tm = tl / J.tiles_n, tn = tl - tm * J.tiles_n;
+  const long long k_begin = (long long)slice * A.k_per_slice;
+  long long k_end = k_begin + A.k_per_slice;
+  const long long s_pad = (A.S + WB_KT - 1) / WB_KT * WB_KT;   /* <= pitch; columns >= S hold zeros */
+  if (k_end > s_pad) k_end = s_pad;
+  const int lid = del_layer_id(J.d_row);
+  const float cmin = cmin_all[lid];
+  const bool have = cmin < INFINITY;             /* (no valid sample wrote a factor: nothing to add) */
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  float bsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+
+  /* loader: the thread owns four PAIRS of rows of either tile (p = 2 pp + half, as the bf16 pair format of
+   * wgrad_bf16x3_kernel), 4 samples at lc4.  DELTA: one 16-B load per pair; ACT: the pair's hi unit and its lo unit. */
+  const int lrow = tid >> 4, lc4 = (tid & 15) * 4;
+  const int lpair = (lrow & 8) | ((lrow & 1) << 2) | ((lrow >> 1) & 3);
+  auto tile_row = [&](int p) { return 2 * lpair + 32 * (p >> 1) + (p & 1); };
+  const char *dp[8], *ap[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int orow = tm * WG_TM + tile_row(p), irow = tn * WG_TN + tile_row(p);
+    dp[p] = (orow < J.n_out) ? reinterpret_cast<const char *>(A.delta) + ((long long)((J.d_row + orow) >> 1) * RB + lc4) * 4 : nullptr;
+    /* ACT pair (rows 2j, 2j + 1): hi halves in unit 2j, lo halves in unit 2j + 1 -- both pointers of a pair address the hi unit */
+    ap[p] = (irow < J.n_in) ? reinterpret_cast<const char *>(A.act) + ((long long)((J.a_row + irow) & ~1) * RB + lc4) * 4 : nullptr;
+  }
+  const char *scp = reinterpret_cast<const char *>(A.delta) + ((long long)(DSC0 + lid) * RB + lc4) * 4;
+  const long long dstep = (long long)A.d_units * 4, astep = (long long)A.a_units * 4;   /* bytes per sample of k0 */
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  v4u dv[4], avh[4], avl[4];
+  v4f cv;
+  auto fetch = [&](long long k0) {
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      v4u x = {0u, 0u, 0u, 0u}, y = {0u, 0u, 0u, 0u}, z = {0u, 0u, 0u, 0u};
+      if (dp[2 * pp]) x = *reinterpret_cast<const v4u *>(dp[2 * pp] + k0 * dstep);
+      if (ap[2 * pp]) {
+        y = *reinterpret_cast<const v4u *>(ap[2 * pp] + k0 * astep);
+        z = *reinterpret_cast<const v4u *>(ap[2 * pp] + k0 * astep + RB * 4);
+      }
+      dv[pp] = x; avh[pp] = y; avl[pp] = z;
+    }
+    cv = *reinterpret_cast<const v4f *>(scp + k0 * dstep);
+  };
+  auto unpair = [](const v4u w, int half, bool live, unsigned &s01, unsigned &s23) {
+    const unsigned sel = half ? 0x07060302u : 0x05040100u;
+    s01 = live ? __builtin_amdgcn_perm(w[1], w[0], sel) : 0u;
+    s23 = live ? __builtin_amdgcn_perm(w[3], w[2], sel) : 0u;
+  };
+  if (k_begin < k_end) fetch(k_begin);
+  for (long long k0 = k_begin; k0 < k_end; k0 += WB_KT) {
+    __syncthreads();                                   /* previous tile fully consumed */
+    /* this thread's four samples to the layer's smallest factor: c_min / c_s, a power of two <= 1 (select, not multiply:
+     * the factor of a pad sample is whatever the allocator left there) */
+    unsigned f01, f23;
+    {
+      float f[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[i] = (have && k0 + lc4 + i < A.S && cv[i] > 0.0f) ? (cmin / cv[i]) * TOP_SHIFT : 0.0f;
+      f01 = pk_f16(f[0], f[1]);
+      f23 = pk_f16(f[2], f[3]);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int off = tile_row(p) * WB_ROW + lc4 * 2;
+      unsigned h0, h1, l0, l1;
+      unpair(dv[p >> 1], p & 1, dp[p] != nullptr, h0, h1);
+      h0 = pk_mul_h(h0, f01);
+      h1 = pk_mul_h(h1, f23);
+      bsum[p] += pk_sum_h(h0) + pk_sum_h(h1);
+      *reinterpret_cast<v2u *>(Dh + off) = (v2u){h0, h1};
+      unpair(avh[p >> 1], p & 1, ap[p] != nullptr, h0, h1);
+      unpair(avl[p >> 1], p & 1, ap[p] != nullptr, l0, l1);
+      *reinterpret_cast<v2u *>(Ah + off) = (v2u){h0, h1};
+      *reinterpret_cast<v2u *>(Al + off) = (v2u){l0, l1};
+    }
+    __syncthreads();
+    if (k0 + WB_KT < k_end) fetch(k0 + WB_KT);         /* next tile's loads fly under this tile's MFMAs */
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < WB_KT / 16; ++kk) {
+      v8h dh[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ro = (wm * 64 + i * 32 + sl) * WB_ROW + kk * 32 + h * 16;
+        const int co = (wn * 64 + i * 32 + sl) * WB_ROW + kk * 32 + h * 16;
+        dh[i] = *reinterpret_cast<const v8h *>(Dh + ro);
+        bh[i] = *reinterpret_cast<const v8h *>(Ah + co);
+        bl[i] = *reinterpret_cast<const v8h *>(Al + co);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float inv = have ? 1.0f / (cmin * TOP_SHIFT) : 0.0f;   /* (a power of two: exact) */
+  float *part = A.part + (size_t)slice * NUM_PARAMS;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int colk = tn * WG_TN + wn * 64 + j * 32 + sl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = tm * WG_TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (orow < J.n_out && colk < J.n_in) part[wjob_row_off(J, orow) + colk] = acc[i][j][r] * inv;
+      }
+    }
+  if (tn == 0 && J.b_off >= 0) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      float s = bsum[p];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+      const int orow = tm * WG_TM + tile_row(p);
+      if ((tid & 15) == 0 && orow < J.n_out) part[wjob_bias_off(J, orow)] = s * inv;
+    }
+  }
+}
+
+}  // namespace rn

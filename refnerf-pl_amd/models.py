@@ -710,8 +710,14 @@ class Model(nn.Module):
                     raise ValueError("Config.hip_bwd_precision must be 'f32', 'f16x2' or 'bf16'")
                 if mlp.ipe_groups and (bwd_prec not in ("f32", "f16x2") or cfg.wgrad_mode != _hip.WGRAD_BF16X3):
                     raise ValueError("a general IPE basis trains with Config.hip_bwd_precision = 'f32' or 'f16x2' and hip_wgrad_mode = 'bf16x3'")
-                if bwd_prec == "f16x2" and getattr(self.config, "hip_train_precision", "f32") == "bf16":
-                    raise ValueError("Config.hip_bwd_precision = 'f16x2' reads fp32 activation rows: use hip_train_precision 'f32' or 'f16x2'")
+                train_prec = getattr(self.config, "hip_train_precision", "f32")
+                if bwd_prec == "f16x2" and train_prec == "bf16":
+                    raise ValueError("Config.hip_bwd_precision = 'f16x2' reads split-f16 pair units or fp32 rows: use hip_train_precision 'f16x2' or 'f32'")
+                if train_prec == "f16x2" and bwd_prec != "f16x2" and not mlp.ipe_groups:
+                    # the split-f16 training forward saves its layer inputs as hi / lo pair units (REFNERF_ACT_F16X2), which the
+                    # split-f16 backward and its f16 weight-gradient GEMM consume (a general IPE basis keeps fp32 rows)
+                    raise ValueError("Config.hip_train_precision = 'f16x2' goes with hip_bwd_precision = 'f16x2' (its saved activations are "
+                                     "split-f16 pair units)")
                 flat_mode = bool(getattr(self.config, "hip_flat_grads", False))
                 if not flat_mode and mlp._flat is not None and (mlp._flat.requires_grad or mlp._flat.grad is not None):
                     mlp.release_flat_parameter()            # flat mode was switched off: no stale .grad on the blob

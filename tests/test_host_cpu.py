@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.lib()
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.refnerf_abi_version() == 8
+    assert lib.refnerf_abi_version() == 9
     assert _hip.packed_weights_bytes(_hip.PREC_F32) > 4 * layout.NUM_PARAMS
     c = _hip.default_cfg()
     assert (c.n_samples, c.resample_padding, c.density_bias) == (128, pytest.approx(0.01), pytest.approx(0.5))
