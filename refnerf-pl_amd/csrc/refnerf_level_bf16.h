@@ -369,7 +369,12 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
       if constexpr (RINGPS) {
         __syncthreads();
         const int end = (pass0 + BT < n_tot) ? pass0 + BT : n_tot;
-        composite_phase<BF_NW, true, NPS_EVAL, PSM>(A, TD, XP, PS, n_tot, ray0, wave, lane, nullptr, NRM, pass0 / N, end / N);
+        /* opaque copies: see level_fwd_split */
+        int td_o = (int)(TD - smem), xp_o = (int)(XP - smem), ps_o = (int)(PS - smem), nrm_o = (int)(NRM - smem), lane_e = lane, pass_e = pass0;
+        int ntot_e = n_tot, ray0_e = ray0, wave_e = wave;
+        asm volatile("" : "+s"(td_o), "+s"(xp_o), "+s"(ps_o), "+s"(nrm_o), "+v"(lane_e), "+s"(pass_e), "+s"(ntot_e), "+s"(ray0_e), "+s"(wave_e));
+        composite_phase<BF_NW, true, NPS_EVAL, PSM>(A, smem + td_o, smem + xp_o, smem + ps_o, ntot_e, ray0_e, wave_e, lane_e, nullptr, smem + nrm_o,
+                                                    pass_e / N, end / N);
       }
     };
     {
@@ -771,7 +776,13 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
       if constexpr (RINGPS) {
         __syncthreads();
         const int end = (pass0 + BT < n_tot) ? pass0 + BT : n_tot;
-        composite_phase<BF_NW, false, NPS_EVAL, PSM>(A, TD, XP, PS, n_tot, ray0, wave, lane, nullptr, NRM, pass0 / N, end / N);
+        /* opaque copies: the compositing's per-ray / per-lane addresses must be formed HERE, not hoisted in front of the
+         * pass loop and carried (spilled) across the MLP phases (ring variant: 44 B/lane of scratch in round 3) */
+        int td_o = (int)(TD - smem), xp_o = (int)(XP - smem), ps_o = (int)(PS - smem), nrm_o = (int)(NRM - smem), lane_e = lane, pass_e = pass0;
+        int ntot_e = n_tot, ray0_e = ray0, wave_e = wave;
+        asm volatile("" : "+s"(td_o), "+s"(xp_o), "+s"(ps_o), "+s"(nrm_o), "+v"(lane_e), "+s"(pass_e), "+s"(ntot_e), "+s"(ray0_e), "+s"(wave_e));
+        composite_phase<BF_NW, false, NPS_EVAL, PSM>(A, smem + td_o, smem + xp_o, smem + ps_o, ntot_e, ray0_e, wave_e, lane_e, nullptr, smem + nrm_o,
+                                                     pass_e / N, end / N);
       }
     };
     {

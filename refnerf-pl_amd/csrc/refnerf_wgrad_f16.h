@@ -102,9 +102,18 @@ __global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int 
   const char *scp = reinterpret_cast<const char *>(A.delta) + ((long long)(DSC0 + lid) * RB + lc4) * 4;
   const long long dstep = (long long)A.d_units * 4, astep = (long long)A.a_units * 4;   /* bytes per sample of k0 */
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
-  v4u dv[4], avh[4], avl[4];
-  v4f cv;
-  auto fetch = [&](long long k0) {
+  /* NST register sets of operand loads in flight (k-steps i, i + 1, ...): one k-step of MFMAs (~1 k cycles with the CU's
+   * second workgroup in between) does not cover an HBM round trip under load.  Measured (round 4, C2): a second set costs
+   * 52 VGPRs, the kernel drops to ONE workgroup per CU and takes 7.35 ms instead of 3.65 -- occupancy, not prefetch depth, is what
+   * hides the latency here; the default stays 1 */
+#ifndef REFNERF_WF_STAGES
+#define REFNERF_WF_STAGES 1
+#endif
+  constexpr int NST = REFNERF_WF_STAGES;
+  v4u dv[NST][4], avh[NST][4], avl[NST][4];
+  v4f cv[NST];
+  auto fetch = [&](auto SETC, long long k0) {
+    constexpr int st = decltype(SETC)::value;
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
       v4u x = {0u, 0u, 0u, 0u}, y = {0u, 0u, 0u, 0u}, z = {0u, 0u, 0u, 0u};
@@ -113,17 +122,17 @@ __global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int 
         y = *reinterpret_cast<const v4u *>(ap[2 * pp] + k0 * astep);
         z = *reinterpret_cast<const v4u *>(ap[2 * pp] + k0 * astep + RB * 4);
       }
-      dv[pp] = x; avh[pp] = y; avl[pp] = z;
+      dv[st][pp] = x; avh[st][pp] = y; avl[st][pp] = z;
     }
-    cv = *reinterpret_cast<const v4f *>(scp + k0 * dstep);
+    cv[st] = *reinterpret_cast<const v4f *>(scp + k0 * dstep);
   };
   auto unpair = [](const v4u w, int half, bool live, unsigned &s01, unsigned &s23) {
     const unsigned sel = half ? 0x07060302u : 0x05040100u;
     s01 = live ? __builtin_amdgcn_perm(w[1], w[0], sel) : 0u;
     s23 = live ? __builtin_amdgcn_perm(w[3], w[2], sel) : 0u;
   };
-  if (k_begin < k_end) fetch(k_begin);
-  for (long long k0 = k_begin; k0 < k_end; k0 += WB_KT) {
+  auto step = [&](auto SETC, long long k0) {
+    constexpr int st = decltype(SETC)::value;
     __syncthreads();                                   /* previous tile fully consumed */
     /* this thread's four samples to the layer's smallest factor: c_min / c_s, a power of two <= 1 (select, not multiply:
      * the factor of a pad sample is whatever the allocator left there) */
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int 
     {
       float f[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) f[i] = (have && k0 + lc4 + i < A.S && cv[i] > 0.0f) ? (cmin / cv[i]) * TOP_SHIFT : 0.0f;
+      for (int i = 0; i < 4; ++i) f[i] = (have && k0 + lc4 + i < A.S && cv[st][i] > 0.0f) ? (cmin / cv[st][i]) * TOP_SHIFT : 0.0f;
       f01 = pk_f16(f[0], f[1]);
       f23 = pk_f16(f[2], f[3]);
     }
@@ -139,18 +148,18 @@ __global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int 
     for (int p = 0; p < 8; ++p) {
       const int off = tile_row(p) * WB_ROW + lc4 * 2;
       unsigned h0, h1, l0, l1;
-      unpair(dv[p >> 1], p & 1, dp[p] != nullptr, h0, h1);
+      unpair(dv[st][p >> 1], p & 1, dp[p] != nullptr, h0, h1);
       h0 = pk_mul_h(h0, f01);
       h1 = pk_mul_h(h1, f23);
       bsum[p] += pk_sum_h(h0) + pk_sum_h(h1);
       *reinterpret_cast<v2u *>(Dh + off) = (v2u){h0, h1};
-      unpair(avh[p >> 1], p & 1, ap[p] != nullptr, h0, h1);
-      unpair(avl[p >> 1], p & 1, ap[p] != nullptr, l0, l1);
+      unpair(avh[st][p >> 1], p & 1, ap[p] != nullptr, h0, h1);
+      unpair(avl[st][p >> 1], p & 1, ap[p] != nullptr, l0, l1);
       *reinterpret_cast<v2u *>(Ah + off) = (v2u){h0, h1};
       *reinterpret_cast<v2u *>(Al + off) = (v2u){l0, l1};
     }
     __syncthreads();
-    if (k0 + WB_KT < k_end) fetch(k0 + WB_KT);         /* next tile's loads fly under this tile's MFMAs */
+    if (k0 + NST * WB_KT < k_end) fetch(SETC, k0 + NST * WB_KT);   /* this set's next tile flies under NST tiles of MFMAs */
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < WB_KT / 16; ++kk) {
@@ -172,6 +181,14 @@ __global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int 
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+  };
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, NST - 1> S1;
+  if (k_begin < k_end) fetch(S0(), k_begin);
+  if (NST > 1 && k_begin + WB_KT < k_end) fetch(S1(), k_begin + WB_KT);
+  for (long long k0 = k_begin; k0 < k_end; k0 += NST * WB_KT) {
+    step(S0(), k0);
+    if (NST > 1 && k0 + WB_KT < k_end) step(S1(), k0 + WB_KT);
   }
   const float inv = have ? 1.0f / (cmin * TOP_SHIFT) : 0.0f;   /* (a power of two: exact) */
   float *part = A.part + (size_t)slice * NUM_PARAMS;
