@@ -100,15 +100,23 @@ struct Pipe {
  * instruction's immediate offset cover both the global and the LDS side.
  * (Measured alternatives: all pieces issued by the prioritised waves 4-7, or
  * 2 pieces per wave with 16 KB chunks -- both slower in the full kernel.) */
+/* REFNERF_BF_SPREAD: the (up to) three pieces a wave moves per chunk are issued one at a time, two k-steps apart, instead of
+ * back to back right behind the rendezvous (an LDS-DMA piece costs its wave 100-185 issue cycles inside a burst, ~60 among
+ * MFMAs: MI355X_MICROARCH.md); `piece` = 0, 1, 2, or -1 for all three.  Measured (round 4, C2, same box): f16x2 4.865 -> 4.839 ms
+ * per step, bf16 2.105 -> 2.086, f16 2.175 -> 2.153, results bit-identical: on. */
+#ifndef REFNERF_BF_SPREAD
+#define REFNERF_BF_SPREAD 1
+#endif
 template <bool SPLIT = false>
-__device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off) {
+__device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off, int piece = -1) {
   if (p.dma_left > 0) {
     if (p.wave < 6) {
       lptr_t dst = (lptr_t)(p.wbuf + slot_off + p.wave * 3072);
-      __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 1024, 0);
-      if (p.wave < 5) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 2048, 0);
+      if (piece < 0 || piece == 0) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 0, 0);
+      if (piece < 0 || piece == 1) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 1024, 0);
+      if ((piece < 0 || piece == 2) && p.wave < 5) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 2048, 0);
     }
+    if (piece >= 0 && piece < 2) return;             /* the stream position moves on with the last piece */
     p.src += BF_CHUNK_BYTES;
     if constexpr (SPLIT) {
       /* a pass streams [spatial section][spatial section][directional section] */
@@ -225,7 +233,11 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], cons
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
 #endif
-      issue_chunk<SPLIT>(p, p.fil_off);
+      issue_chunk<SPLIT>(p, p.fil_off, REFNERF_BF_SPREAD ? 0 : -1);
+    }
+    if (REFNERF_BF_SPREAD) {
+      if (k == REFNERF_BF_RDV + 2) issue_chunk<SPLIT>(p, p.fil_off, 1);
+      if (k == REFNERF_BF_RDV + 4) issue_chunk<SPLIT>(p, p.fil_off, 2);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -976,6 +988,9 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   RN_STAMPW(A, 15);
+#ifdef REFNERF_PROF_WAITS
+  if (A.prof && blockIdx.x == (gridDim.x >> 1) && lane == 0) { A.prof[wave * 32 + 20] = p.t_vm; A.prof[wave * 32 + 21] = p.t_bar; }
+#endif
   if constexpr (!RINGPS) composite_phase<BF_NW, false, NPS_EVAL>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB), NRM);   /* P7 */
   RN_STAMPW(A, 16);
 }
