@@ -1035,7 +1035,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   if (cfg->precision == REFNERF_PREC_BF16) lds = ring_off + rn::RING_BYTES;       /* the chains' shared weight-stream ring */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget%s");
   LDS_ATTR_ONCE(lds_attr(rn::level_bwd_f32), lds_attr(rn::level_bwd_bf16c), lds_attr(rn::level_bwd_f16x2c), lds_attr(rn::level_bwd_f16x2c_r32),
-                lds_attr(rn::wgrad_f16s_kernel, rn::WF_LDS),
+                lds_attr(rn::wgrad_f16s_kernel<rn::WF_NW>, rn::WF_LDS),
                 lds_attr(rn::wgrad_kernel, (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4),
                 lds_attr(rn::wgrad_bf16x3_kernel<false, false>, rn::wb_lds(false, false)),
                 lds_attr(rn::wgrad_bf16x3_kernel<false, true>, rn::wb_lds(false, true)),
@@ -1117,7 +1117,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
       float *cmin = (float *)(ws + plan.cmin_off);
       HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)cmin, 0x7f800000, 32, st));
       hipLaunchKernelGGL(rn::delta_scale_min, dim3(rn::DSC_ROWS, 64), dim3(256), 0, st, a.delta, plan.S, cmin);
-      hipLaunchKernelGGL(rn::wgrad_f16s_kernel, wg_grid, dim3(256), rn::WF_LDS, st, w, slices, cmin);
+      hipLaunchKernelGGL((rn::wgrad_f16s_kernel<rn::WF_NW>), wg_grid, dim3(64 * rn::WF_NW), rn::WF_LDS, st, w, slices, cmin);
     }
     else if (del16 && act16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, true>), wg_grid, dim3(256), rn::wb_lds(true, true), st, w, slices);
     else if (del16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, false>), wg_grid, dim3(256), rn::wb_lds(true, false), st, w, slices);

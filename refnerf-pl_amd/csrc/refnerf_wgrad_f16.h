@@ -52,8 +52,21 @@ constexpr int WF_LDS = 3 * WB_TILE;            /* D, A_hi, A_lo: 54 KB */
  * precision below the layer's largest deltas, 10 more of gradual underflow */
 constexpr float TOP_SHIFT = 128.0f;
 
-/* grid = 8 * ceil(slices / 8) * WJOBS.tiles workgroups of 256 threads, decoded as in wgrad_bf16x3_kernel */
-__global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int slices, const float *__restrict__ cmin_all) {
+/* grid = 8 * ceil(slices / 8) * WJOBS.tiles workgroups of 64 NW threads, decoded as in wgrad_bf16x3_kernel.
+ * NW = 4 (default): waves 2 x 2 over the 128 x 128 tile (64 x 64 each), 8 rows of either operand tile per loader thread, two
+ * workgroups per CU;  NW = 8: waves 4 x 2 (32 x 64 each), 4 rows per loader thread, 116 registers -- measured 3.79 ms against
+ * 3.59 (round 4, C2): the same bytes are in flight per CU (LDS admits two workgroups either way), the narrower wave tiles read
+ * 1.7x the LDS bytes per MFMA.  What bounds this GEMM is bytes in flight per CU: one 4-wave workgroup per CU takes 7.35 ms. */
+#ifndef REFNERF_WF_WAVES
+#define REFNERF_WF_WAVES 4
+#endif
+constexpr int WF_NW = REFNERF_WF_WAVES;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void wgrad_f16s_kernel(const WgradArgs A, int slices, const float *__restrict__ cmin_all) {
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  constexpr int MI = 8 / NW;                     /* 32-row blocks of the D tile per wave */
+  constexpr int NPP = 16 / NW;                   /* row PAIRS of either tile per loader thread */
+  constexpr int NR = 2 * NPP;                    /* rows */
   constexpr const WJobs &JT = WJOBS;
   extern __shared__ __attribute__((aligned(16))) char wbs[];
   char *Dh = wbs, *Ah = wbs + WB_TILE, *Al = wbs + 2 * WB_TILE;
@@ -77,23 +90,26 @@ __global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int 
   const float cmin = cmin_all[lid];
   const bool have = cmin < INFINITY;             /* (no valid sample wrote a factor: nothing to add) */
 
-  v16f acc[2][2];
+  v16f acc[MI][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MI; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  float bsum[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-
-  /* loader: the thread owns four PAIRS of rows of either tile (p = 2 pp + half, as the bf16 pair format of
-   * wgrad_bf16x3_kernel), 4 samples at lc4.  DELTA: one 16-B load per pair; ACT: the pair's hi unit and its lo unit. */
-  const int lrow = tid >> 4, lc4 = (tid & 15) * 4;
-  const int lpair = (lrow & 8) | ((lrow & 1) << 2) | ((lrow >> 1) & 3);
-  auto tile_row = [&](int p) { return 2 * lpair + 32 * (p >> 1) + (p & 1); };
-  const char *dp[8], *ap[8];
+  float bsum[NR];
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
+  for (int p = 0; p < NR; ++p) bsum[p] = 0.0f;
+
+  /* loader: the thread owns NPP PAIRS of rows of either tile (p = 2 pp + half, as the bf16 pair format of
+   * wgrad_bf16x3_kernel), 4 samples at lc4.  DELTA: one 16-B load per pair; ACT: the pair's hi unit and its lo unit.
+   * The pair index is a bit permutation of the low four bits of lrow (two row groups of a half-wave 8 rows apart in LDS). */
+  const int lrow = tid >> 4, lc4 = (tid & 15) * 4;
+  const int lpair = (lrow & ~7) | ((lrow & 1) << 2) | ((lrow >> 1) & 3);
+  auto tile_row = [&](int p) { return 2 * lpair + 8 * NW * (p >> 1) + (p & 1); };
+  const char *dp[NR], *ap[NR];
+#pragma unroll
+  for (int p = 0; p < NR; ++p) {
     const int orow = tm * WG_TM + tile_row(p), irow = tn * WG_TN + tile_row(p);
     dp[p] = (orow < J.n_out) ? reinterpret_cast<const char *>(A.delta) + ((long long)((J.d_row + orow) >> 1) * RB + lc4) * 4 : nullptr;
     /* ACT pair (rows 2j, 2j + 1): hi halves in unit 2j, lo halves in unit 2j + 1 -- both pointers of a pair address the hi unit */
@@ -110,12 +126,12 @@ __global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int 
 #define REFNERF_WF_STAGES 1
 #endif
   constexpr int NST = REFNERF_WF_STAGES;
-  v4u dv[NST][4], avh[NST][4], avl[NST][4];
+  v4u dv[NST][NPP], avh[NST][NPP], avl[NST][NPP];
   v4f cv[NST];
   auto fetch = [&](auto SETC, long long k0) {
     constexpr int st = decltype(SETC)::value;
 #pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {
+    for (int pp = 0; pp < NPP; ++pp) {
       v4u x = {0u, 0u, 0u, 0u}, y = {0u, 0u, 0u, 0u}, z = {0u, 0u, 0u, 0u};
       if (dp[2 * pp]) x = *reinterpret_cast<const v4u *>(dp[2 * pp] + k0 * dstep);
       if (ap[2 * pp]) {
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int 
       f23 = pk_f16(f[2], f[3]);
     }
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < NR; ++p) {
       const int off = tile_row(p) * WB_ROW + lc4 * 2;
       unsigned h0, h1, l0, l1;
       unpair(dv[st][p >> 1], p & 1, dp[p] != nullptr, h0, h1);
@@ -163,17 +179,17 @@ __global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < WB_KT / 16; ++kk) {
-      v8h dh[2], bh[2], bl[2];
+      v8h dh[MI], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) dh[i] = *reinterpret_cast<const v8h *>(Dh + (wm * 32 * MI + i * 32 + sl) * WB_ROW + kk * 32 + h * 16);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int ro = (wm * 64 + i * 32 + sl) * WB_ROW + kk * 32 + h * 16;
         const int co = (wn * 64 + i * 32 + sl) * WB_ROW + kk * 32 + h * 16;
-        dh[i] = *reinterpret_cast<const v8h *>(Dh + ro);
         bh[i] = *reinterpret_cast<const v8h *>(Ah + co);
         bl[i] = *reinterpret_cast<const v8h *>(Al + co);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[i], bl[j], acc[i][j], 0, 0, 0);
@@ -193,19 +209,19 @@ __global__ __launch_bounds__(256) void wgrad_f16s_kernel(const WgradArgs A, int 
   const float inv = have ? 1.0f / (cmin * TOP_SHIFT) : 0.0f;   /* (a power of two: exact) */
   float *part = A.part + (size_t)slice * NUM_PARAMS;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int colk = tn * WG_TN + wn * 64 + j * 32 + sl;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int orow = tm * WG_TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int orow = tm * WG_TM + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (orow < J.n_out && colk < J.n_in) part[wjob_row_off(J, orow) + colk] = acc[i][j][r] * inv;
       }
     }
   if (tn == 0 && J.b_off >= 0) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < NR; ++p) {
       float s = bsum[p];
       s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
       const int orow = tm * WG_TM + tile_row(p);
