@@ -297,9 +297,17 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
           done = true;
         }
       }
+      if constexpr (PF) {
+        /* split-f16 pair units: x7 comes back as the very fragments the forward's heads GEMM consumed -- the same GEMM on them
+         * (block 4 of the split image, same product order) gives the forward's raw head values bit for bit, at 48 f16 MFMAs
+         * instead of 128 fp32 ones and without widening 256 values */
+        v4uu xh[16], xw[16];
+        load_frags_split(A.act, rpitch, ACT_SP + 7 * WIDTH, acol, h, xh, xw);
+        gemm_op_split<1, 16, 0, true>(rs, PACKED.hf_off[OP_HEADS] + 4 * 256, PACKED.op[OP_HEADS].b_off + 4 * 32, lane, h, xh, xw, hd4, nullptr);
+        done = true;
+      }
       if (!done) {
         if (A.act16) smb_load_rows(A.act, pitch, gs, h, SMB_X7, in);                  /* x7: input of the heads */
-        else if constexpr (PF) load_rows_split<8>(A.act, rpitch, ACT_SP + 7 * WIDTH, acol, h, in);
         else load_rows<8>(A.act, rpitch, ACT_SP + 7 * WIDTH, acol, h, in);
         heads_scalar_block_f32(rs, PACKED.op[OP_HEADS].a_off, PACKED.op[OP_HEADS].b_off, lane, h, in, hd4[0]);
       }
@@ -321,9 +329,14 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
         rgb_bf = true;
       }
     }
+    if constexpr (PF) {                              /* the forward's own rgb GEMM on its saved input fragments */
+      v4uu xh[16], xw[16];
+      load_frags_split(A.act, rpitch, ACT_VD + 7 * WIDTH, acol, h, xh, xw);
+      gemm_op_split<1, 16, 0, true>(rs, PACKED.hf_off[OP_RGB], PACKED.op[OP_RGB].b_off, lane, h, xh, xw, rgbv, nullptr);
+      rgb_bf = true;
+    }
     if (!rgb_bf) {
       if (A.act16) smb_load_rows(A.act, pitch, gs, h, SMB_V7, in);                  /* v7: input of the rgb layer */
-      else if constexpr (PF) load_rows_split<8>(A.act, rpitch, ACT_VD + 7 * WIDTH, acol, h, in);
       else load_rows<8>(A.act, rpitch, ACT_VD + 7 * WIDTH, acol, h, in);
     }
     wave_sync();

@@ -783,6 +783,21 @@ __device__ __forceinline__ void load_rows_split(const float *base, long long pit
     }
 }
 
+/* ... or as the packed hi / lo fragments of the 16 k-steps themselves (what the forward's GEMM consumed: dword e of k-step t = the
+ * pair units of accumulator rows 2 e, 2 e + 1 of that k-step's block) */
+__device__ __forceinline__ void load_frags_split(const float *base, long long pitch, int row0, size_t gs, int h, v4uu (&fh)[16], v4uu (&fl)[16]) {
+  const long long e0 = (long long)(row0 + 4 * h) * pitch + (long long)gs;
+  const unsigned *u = reinterpret_cast<const unsigned *>(base);
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 8 * (t & 1) + 2 * e, c = 32 * (t >> 1) + (r & 3) + 8 * (r >> 2);
+      fh[t][e] = u[e0 + (long long)c * pitch];
+      fl[t][e] = u[e0 + (long long)(c + 1) * pitch];
+    }
+}
+
 /* ReLU that also records the sign pattern: bit (16*(ob&1) + r) of mk[ob>>1]. */
 __device__ __forceinline__ void relu_mask_into(const v16f (&out)[8], v16f (&in)[8], unsigned (&mk)[4]) {
 #pragma unroll
