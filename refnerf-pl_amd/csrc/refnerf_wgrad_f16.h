@@ -89,6 +89,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_f16s_kernel(const WgradArgs A, 
   const int lid = del_layer_id(J.d_row);
   const float cmin = cmin_all[lid];
   const bool have = cmin < INFINITY;             /* (no valid sample wrote a factor: nothing to add) */
+  const bool need_bias = tn == 0 && J.b_off >= 0;
 
   v16f acc[MI][2];
 #pragma unroll
@@ -156,7 +157,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad_f16s_kernel(const WgradArgs A, 
     {
       float f[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) f[i] = (have && k0 + lc4 + i < A.S && cv[st][i] > 0.0f) ? (cmin / cv[st][i]) * TOP_SHIFT : 0.0f;
+      for (int i = 0; i < 4; ++i)      /* (factors are powers of two: v_rcp_f32 is exact on them) */
+        f[i] = (have && k0 + lc4 + i < A.S && cv[st][i] > 0.0f) ? (cmin * TOP_SHIFT) * __builtin_amdgcn_rcpf(cv[st][i]) : 0.0f;
       f01 = pk_f16(f[0], f[1]);
       f23 = pk_f16(f[2], f[3]);
     }
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_f16s_kernel(const WgradArgs A, 
       unpair(dv[st][p >> 1], p & 1, dp[p] != nullptr, h0, h1);
       h0 = pk_mul_h(h0, f01);
       h1 = pk_mul_h(h1, f23);
-      bsum[p] += pk_sum_h(h0) + pk_sum_h(h1);
+      if (need_bias) bsum[p] += pk_sum_h(h0) + pk_sum_h(h1);      /* (wave-uniform: only the first column tile of a job with a bias) */
       *reinterpret_cast<v2u *>(Dh + off) = (v2u){h0, h1};
       unpair(avh[st][p >> 1], p & 1, ap[p] != nullptr, h0, h1);
       unpair(avl[st][p >> 1], p & 1, ap[p] != nullptr, l0, l1);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_f16s_kernel(const WgradArgs A, 
         if (orow < J.n_out && colk < J.n_in) part[wjob_row_off(J, orow) + colk] = acc[i][j][r] * inv;
       }
     }
-  if (tn == 0 && J.b_off >= 0) {
+  if (need_bias) {
 #pragma unroll
     for (int p = 0; p < NR; ++p) {
       float s = bsum[p];

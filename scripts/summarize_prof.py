@@ -27,7 +27,8 @@ KERNELS = {"level_fwd_bf16": "rn::level_fwd_bf16", "level_fwd_f32": "rn::level_f
            "bwd_seed_kernel": "rn::bwd_seed_kernel", "wgrad_reduce": "rn::wgrad_reduce",
            "level_fwd_bf16_ring": "rn::level_fwd_bf16_ring", "level_fwd_f16_ring": "rn::level_fwd_f16_ring",
            "level_fwd_f16x2": "rn::level_fwd_f16x2", "level_fwd_f16x2_ring": "rn::level_fwd_f16x2_ring",
-           "level_fwd_train_f16x2c": "rn::level_fwd_train_f16x2c", "level_bwd_f16x2c": "rn::level_bwd_f16x2c"}
+           "level_fwd_train_f16x2c": "rn::level_fwd_train_f16x2c", "level_bwd_f16x2c": "rn::level_bwd_f16x2c",
+           "wgrad_f16s_kernel": "rn::wgrad_f16s_kernel", "delta_scale_min": "rn::delta_scale_min"}
 
 rows = list(csv.reader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
 with open(os.path.join(dst, f"kernel_stats{sfx}.csv"), "w", newline="") as f:
