@@ -798,8 +798,9 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     """One full training step on the batch: training forward (density-gradient normals + saved layer inputs),
     losses (the three Ref-NeRF terms, or with `geometry` the nine-term set of llff_refnerf_geometry_losses.gin incl.
     the noisy-ray second pass), HIP backward + weight-gradient GEMM, ONE all-reduce of the gradient blob over the
-    ranks, Adam step.  `chains` = arithmetic of the MLP chains of the training kernels ('f32' parity mode | 'bf16');
-    the weight-gradient GEMM runs on split-bf16 MFMA at fp32 accuracy in both (Config.hip_wgrad_mode)."""
+    ranks, Adam step.  `chains` = arithmetic of the MLP chains of the training kernels ('f32' strict parity | 'f16x2' split-f16,
+    the mode of record | 'bf16' throughput); the weight-gradient GEMM runs on split-bf16 MFMA at fp32 accuracy (f32 / bf16
+    chains) or on f16 MFMA over the split-f16 formats (f16x2 chains)."""
     import torch
     from refnerf_pl_amd import _hip, distributed, synthetic, train_utils, utils
     model.train()
@@ -886,8 +887,9 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
            "kernels_ms_per_step": sum(ms for ms, _ in fam.values()) / n,
            "mode": ("parity mode: f32 MLP chains (gradient rel-L2 <= 2e-4 vs the reference's autograd, 1e-3 on trained-like weights)"
                     if chains == "f32" else
-                    "parity-grade fast mode: forward and backward chains on split-f16 operands (22-bit products, fp32 ACT / DELTA rows); "
-                    "gradient rel-L2 5e-5 vs the reference's autograd also on trained-like weights"
+                    "parity-grade fast mode: forward and backward chains on split-f16 operands (22-bit products); ACT saved as hi / lo pair "
+                    "units, DELTA as one half per element + a per-sample factor, weight gradients on f16 MFMA; gradient rel-L2 5e-5 .. 1.1e-4 vs "
+                    "the reference's autograd, also on trained-like weights"
                     if chains == "f16x2" else
                     "throughput mode: bf16 MLP chains; gradient 1e-2 (random-init) / 1e-1 (trained-like weights) relative L2 from the "
                     "reference -- for from-scratch training, not a parity mode"),

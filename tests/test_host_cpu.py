@@ -330,7 +330,7 @@ def test_bench_compact_line_fits_the_driver_tail():
     import glob
     import json
     import bench
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "bench", "*.json")))
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "bench", "*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r04", "bench", "*.full.json")))
     assert paths
     for p in paths:
         full = json.load(open(p))
