@@ -370,6 +370,51 @@ __device__ void fill_chunk_split(const float *__restrict__ P, char *__restrict__
     reinterpret_cast<_Float16 *>(chunk + 1024)[idx] = part ? (_Float16)(v - (float)hi) : hi;
   }
 }
+/* REFNERF_SPLIT16: one chunk of the 16x16x32 spatial section (refnerf_layout.h) */
+__device__ void fill_chunk_sq(const float *__restrict__ P, char *__restrict__ chunk, int op, int ob, int kind, bool first, int base) {
+  for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+    float v = 0.0f;
+    if (e < 32 && first) {                       /* bias piece [T][b][4]: rows 16 T + 4 b + i of the slice */
+      const int T = e >> 4, b = (e >> 2) & 3, i = e & 3;
+      v = canon_b(P, op, ob * 32 + 16 * T + 4 * b + i);
+    }
+    reinterpret_cast<float *>(chunk)[e] = v;
+  }
+  for (int idx = threadIdx.x; idx < 16 * 512; idx += blockDim.x) {
+    const int e = idx & 7, lane = (idx >> 3) & 63, pi = idx >> 9;
+    const int bk = lane >> 4, r16 = lane & 15;
+    int T, part, col;
+    bool live = true;
+    if (kind == SQ_A || kind == SQ_B || kind == SQ_X) {
+      const int sl = pi >> 2, which = pi & 3;
+      T = which & 1; part = which >> 1;
+      if (kind == SQ_X) { live = sl < 3; col = base + 32 * sl + 8 * bk + e; }
+      else { const int st = (kind == SQ_B ? 4 : 0) + sl; col = 32 * st + 16 * (e >> 2) + 4 * bk + (e & 3); }
+    } else if (kind == SQ_BN) {
+      const int st = pi >> 1;
+      T = pi & 1; part = 0;
+      col = 32 * st + 16 * (e >> 2) + 4 * bk + (e & 3);
+    } else {                                     /* SQ_SC: tile T0 of the scalar block, [hi lo] per k-step */
+      const int st = pi >> 1;
+      T = 0; part = pi & 1;
+      col = 32 * st + 16 * (e >> 2) + 4 * bk + (e & 3);
+    }
+    const float v = live ? canon_w(P, op, ob * 32 + 16 * T + r16, col) : 0.0f;
+    const _Float16 hi = (_Float16)v;
+    reinterpret_cast<_Float16 *>(chunk + 1024)[idx] = part ? (_Float16)(v - (float)hi) : hi;
+  }
+}
+/* ... and a plain BNLDS chunk whose eight bottleneck k-steps follow the merged-run order of that section */
+__device__ void fill_chunk_bnlds_sq(const float *__restrict__ P, char *__restrict__ chunk, int op, int ob, bool first, int base) {
+  fill_chunk_plain<_Float16>(P, chunk, op, ob, BF_BNLDS, first, base);
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 8 * 512; idx += blockDim.x) {
+    const int e = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9;
+    const int h = lane >> 5, row = ob * 32 + (lane & 31);
+    const int feat = 32 * (t >> 1) + 16 * (e >> 2) + 8 * h + 4 * (t & 1) + (e & 3);
+    reinterpret_cast<_Float16 *>(chunk + 1024)[idx] = (_Float16)canon_w(P, op, row, base + feat);
+  }
+}
 __global__ void pack_weights_split(const float *__restrict__ P, char *__restrict__ out) {
   const int op = blockIdx.y, ob = blockIdx.x;
   const int nob = (op == OP_HEADS) ? 5 : (op == OP_RGB ? 1 : 8);
@@ -380,16 +425,26 @@ __global__ void pack_weights_split(const float *__restrict__ P, char *__restrict
   if (op > OP_HEADS) {
     const BfOp o = BFPACKED.op[op];
     const int base = (o.nchunk == 2) ? WIDTH : 0;
-    for (int j = 0; j < o.nchunk; ++j) fill_chunk_plain<_Float16>(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, o.kind[j], j == 0, base);
-  } else if (op == OP_HEADS && ob < 4) {
-    fill_chunk_plain<_Float16>(P, chunk, op, ob, BF_REG, true, 0);
-  } else {
-    const int n = sp_slice_chunks(op, ob);
-    for (int j = 0; j < n; ++j) {
-      const int kind = (op == 0 || j == 2) ? BF_SLDS : (j == 0 ? BF_SREG0 : BF_SREG1);
-      fill_chunk_split(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, kind, j == 0, op == 5 ? WIDTH : 0);
+    for (int j = 0; j < o.nchunk; ++j) {
+      if (REFNERF_SPLIT16 && o.kind[j] == BF_BNLDS) fill_chunk_bnlds_sq(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, j == 0, base);
+      else fill_chunk_plain<_Float16>(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, o.kind[j], j == 0, base);
     }
+    return;
   }
+  const int n = sp_slice_chunks(op, ob);
+#if REFNERF_SPLIT16
+  if (op == OP_HEADS) { fill_chunk_sq(P, chunk, op, ob, ob < 4 ? SQ_BN : SQ_SC, true, 0); return; }
+  for (int j = 0; j < n; ++j) {
+    const int kind = (op == 0 || j == 2) ? SQ_X : (j == 0 ? SQ_A : SQ_B);
+    fill_chunk_sq(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, kind, j == 0, op == 5 ? WIDTH : 0);
+  }
+#else
+  if (op == OP_HEADS && ob < 4) { fill_chunk_plain<_Float16>(P, chunk, op, ob, BF_REG, true, 0); return; }
+  for (int j = 0; j < n; ++j) {
+    const int kind = (op == 0 || j == 2) ? BF_SLDS : (j == 0 ? BF_SREG0 : BF_SREG1);
+    fill_chunk_split(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, kind, j == 0, op == 5 ? WIDTH : 0);
+  }
+#endif
 }
 
 /* ------------------------------------------------------------------ */

@@ -682,6 +682,125 @@ __device__ __forceinline__ void sp_layer(Pipe &p, typename MM::v8 (&a)[AF], bool
   }
 #endif
 }
+#if REFNERF_SPLIT16
+/* ---- the spatial section on v_mfma_f32_16x16x32_f16: three partial products into one accumulator (refnerf_layout.h) ---- */
+typedef _Float16 sq_v8 __attribute__((ext_vector_type(8)));
+constexpr int SQ_NF = 4;                         /* fragment ring: the four pieces of a k-step */
+struct SqAcc { v4f t0, t1; };                    /* the two 16-row tiles of a 32-row slice: lane (b, n) holds rows 4 b .. 4 b + 3 for sample n */
+template <int KIND> constexpr int sq_nm() { return KIND == SQ_X ? 18 : (KIND == SQ_BN ? 32 : 24); }      /* MFMAs of a chunk */
+template <int KIND> constexpr int sq_np() { return KIND == SQ_X ? 12 : 16; }                              /* pieces it consumes */
+/* static schedule of MFMA j of a chunk: k-step, piece, hi / lo input fragment, tile, and the piece whose last use it is.
+ * A / B / X, per k-step: [WhT0 H | WhT1 H | WlT0 H | WlT1 H | WhT0 L | WhT1 L] (per accumulator: hi*hi, lo*hi, hi*lo);
+ * BN: [WhT0 H | WhT1 H | WhT0 L | WhT1 L];  SC: [WhT0 H | WlT0 H | WhT0 L] */
+template <int KIND> constexpr int sq_step(int j) { return KIND == SQ_BN ? j / 4 : (KIND == SQ_SC ? j / 3 : j / 6); }
+template <int KIND> constexpr int sq_piece(int j) {
+  if (KIND == SQ_BN) return 2 * (j / 4) + (j & 1);
+  if (KIND == SQ_SC) return 2 * (j / 3) + ((j % 3) == 1 ? 1 : 0);
+  return 4 * (j / 6) + ((j % 6) < 4 ? (j % 6) : (j % 6) - 4);
+}
+template <int KIND> constexpr bool sq_lo(int j) { return KIND == SQ_BN ? (j & 3) >= 2 : (KIND == SQ_SC ? (j % 3) == 2 : (j % 6) >= 4); }
+template <int KIND> constexpr int sq_tile(int j) { return KIND == SQ_SC ? 0 : (KIND == SQ_BN ? (j & 1) : ((j % 6) & 1)); }
+template <int KIND> constexpr int sq_release(int j) {
+  if (KIND == SQ_BN) return (j & 3) >= 2 ? 2 * (j / 4) + ((j & 3) - 2) : -1;
+  if (KIND == SQ_SC) return (j % 3) == 1 ? 2 * (j / 3) + 1 : ((j % 3) == 2 ? 2 * (j / 3) : -1);
+  const int jj = j % 6, sl = j / 6;
+  return jj == 2 ? 4 * sl + 2 : (jj == 3 ? 4 * sl + 3 : (jj == 4 ? 4 * sl : (jj == 5 ? 4 * sl + 1 : -1)));
+}
+/* One chunk.  `fr` = the piece ring: on entry pieces 0..3 of this chunk, on exit those of the next one.  `in`: the layer input
+ * as [H(s) L(s)] x 8 k-steps (SQ_X: from the LDS planes instead).  hook(j): caller's VALU work behind MFMA j. */
+template <int KIND, bool FIRST, typename Hook = NoHook>
+__device__ __forceinline__ void sq_chunk(Pipe &p, sq_v8 (&fr)[SQ_NF], const v4uu (&in)[16], SqAcc &acc, Hook &&hook = Hook()) {
+  constexpr int NM = sq_nm<KIND>(), NP = sq_np<KIND>();
+  constexpr int RDV = NM / 2 - 1;
+  const char *w = p.wbuf + p.cur_off;
+  const char *cur = w + 1024 + p.lane * 16;
+  const char *nxt = p.wbuf + p.nxt_off + 1024 + p.lane * 16;
+  sq_v8 xb[2];
+  if (KIND == SQ_X) { xb[0] = lds_frag<MmF16>(p.xps); xb[1] = lds_frag<MmF16>(p.xps + (BT / 2) * 16); }
+  if (FIRST) {
+    const v4f *bp = reinterpret_cast<const v4f *>(w + (p.lane >> 4) * 16);      /* bias piece [T][b][4] */
+    acc.t0 = bp[0];
+    acc.t1 = bp[4];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < NM; ++j) {
+    constexpr int dummy = 0; (void)dummy;
+    const int sl = sq_step<KIND>(j);
+    sq_v8 b;
+    if (KIND == SQ_X) b = xb[sq_lo<KIND>(j) ? 1 : 0];
+    else b = __builtin_bit_cast(sq_v8, in[2 * ((KIND == SQ_B ? 4 : 0) + sl) + (sq_lo<KIND>(j) ? 1 : 0)]);
+    if (sq_tile<KIND>(j)) acc.t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[sq_piece<KIND>(j) % SQ_NF], b, acc.t1, 0, 0, 0);
+    else acc.t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[sq_piece<KIND>(j) % SQ_NF], b, acc.t0, 0, 0, 0);
+    const int rel = sq_release<KIND>(j);
+    if (rel >= 0) {
+      const int q = rel + SQ_NF;
+      fr[rel % SQ_NF] = (q < NP) ? lds_frag<MmF16>(cur + q * 1024) : lds_frag<MmF16>(nxt + (q - NP) * 1024);
+    }
+    hook(j);
+    if (KIND == SQ_X) {
+      /* the next k-step's H once this one's four H products are issued, its L behind the two L products */
+      if ((j % 6) == 3 && sl + 1 < 3) xb[0] = lds_frag<MmF16>(p.xps + (sl + 1) * (4 * BT * 16));
+      if ((j % 6) == 5 && sl + 1 < 3) xb[1] = lds_frag<MmF16>(p.xps + (sl + 1) * (4 * BT * 16) + (BT / 2) * 16);
+    }
+    if (j == RDV) {
+      /* mid-chunk rendezvous: chunk c+1 is complete for every wave, chunk c-1's slot is free */
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      issue_chunk<true>(p, p.fil_off, REFNERF_BF_SPREAD ? 0 : -1);
+    }
+    if (REFNERF_BF_SPREAD) {
+      if (j == RDV + 4) issue_chunk<true>(p, p.fil_off, 1);
+      if (j == RDV + 8) issue_chunk<true>(p, p.fil_off, 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const int t = p.cur_off;
+  p.cur_off = p.nxt_off;
+  p.nxt_off = p.fil_off;
+  p.fil_off = t;
+}
+/* piece q (0..3) of a slice's epilogue: accumulator values (2 q, 2 q + 1) of the eight a lane holds -> NaN-propagating ReLU,
+ * hi / lo split -> dword q of the next layer's H and L fragments of k-step `slice` */
+__device__ __forceinline__ void sq_epi_piece(const SqAcc &a, int q, v4uu &oh, v4uu &ol) {
+  const float y0 = q == 0 ? a.t0[0] : (q == 1 ? a.t0[2] : (q == 2 ? a.t1[0] : a.t1[2]));
+  const float y1 = q == 0 ? a.t0[1] : (q == 1 ? a.t0[3] : (q == 2 ? a.t1[1] : a.t1[3]));
+#ifdef REFNERF_SPLIT_RELU_MAX
+  const float x0 = fmaxf(y0, 0.0f), x1 = fmaxf(y1, 0.0f);
+#else
+  const float x0 = (y0 < 0.0f) ? 0.0f : y0, x1 = (y1 < 0.0f) ? 0.0f : y1;
+#endif
+  unsigned hi, lo;
+  split_pair_f16(x0, x1, hi, lo);
+  oh[q] = hi;
+  ol[q] = lo;
+}
+/* One spatial layer: slice ob's epilogue rides behind the first MFMAs of slice ob + 1 (all eight waves run the chunks in
+ * lockstep: VALU work between two slices idles the matrix pipe of every SIMD) */
+template <bool LAYER0>
+__device__ __forceinline__ void sq_layer(Pipe &p, sq_v8 (&fr)[SQ_NF], bool skip, const v4uu (&in)[16], v4uu (&out)[16]) {
+  SqAcc accs[2];
+#pragma unroll
+  for (int ob = 0; ob < 8; ++ob) {
+    SqAcc &acc = accs[ob & 1];
+    const SqAcc &prev = accs[(ob & 1) ^ 1];
+    auto hook = [&](int j) {
+      if (ob == 0 || j >= 8 || (j & 1)) return;
+      sq_epi_piece(prev, j >> 1, out[2 * ob - 2], out[2 * ob - 1]);
+    };
+    if constexpr (LAYER0) sq_chunk<SQ_X, true>(p, fr, in, acc, hook);
+    else {
+      sq_chunk<SQ_A, true>(p, fr, in, acc, hook);
+      sq_chunk<SQ_B, false>(p, fr, in, acc);
+      if (skip) sq_chunk<SQ_X, false>(p, fr, in, acc);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sq_epi_piece(accs[1], q, out[14], out[15]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+#endif
+
 /* directional layer of the split kernel: the plain layer on the split kernel's DMA schedule */
 template <typename MM, int KIND0, int REAL0>
 __device__ __forceinline__ void dir_layer(Pipe &p, typename MM::v8 (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16]) {
@@ -733,7 +852,12 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
   p.wbuf = WB;
   p.xp = Xb + (h * BT + col) * 16;
   /* N-packed IPE planes: [k-group][plane (hi | lo)][128 columns = wave * 16 + sample][16 B] */
+#if REFNERF_SPLIT16
+  /* lane (b = lane / 16, n = lane % 16) reads k-group 4 s + b of k-step s: hi plane, the lo plane (BT / 2) * 16 bytes behind */
+  p.xps = Xb + ((lane >> 4) * BT + wave * 16 + (lane & 15)) * 16;
+#else
   p.xps = Xb + (h * BT + (n >> 4) * (BT / 2) + wave * 16 + (n & 15)) * 16;
+#endif
   p.seq = 0;
   p.cur_off = 0; p.nxt_off = BF_CHUNK_BYTES; p.fil_off = 2 * BF_CHUNK_BYTES;
   p.dma_left = n_pass * SPPACKED.chunks_per_pass;
@@ -768,9 +892,17 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
   if (wave >= BF_NW / 2) __builtin_amdgcn_s_setprio(1);
 #endif
   v4uu R0[16], R1[16], bn[8];
+#if REFNERF_SPLIT16
+  /* one fragment ring for both sections: four pieces for the 16x16x32 spatial chunks; the plain directional chunks use its
+   * first AF entries (the ring always holds the leading pieces of the chunk about to run) */
+  sq_v8 ar[SQ_NF];
+#pragma unroll
+  for (int d = 0; d < SQ_NF; ++d) ar[d] = lds_frag<MM>(WB + 1024 + lane * 16 + d * 1024);
+#else
   v8mm ar[AF];
 #pragma unroll
   for (int d = 0; d < AF; ++d) ar[d] = lds_frag<MM>(WB + 1024 + lane * 16 + d * 1024);
+#endif
 
   for (int pass0 = 0; pass0 < n_tot; pass0 += BT) {
     int lane_v = lane;
@@ -885,6 +1017,54 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
         RN_STAMPW(A, 18);
         wave_sync();
         RN_STAMPW(A, 3 + phase * 4);
+#if REFNERF_SPLIT16
+        (void)dbgs;
+        /* the directional chunks keep AF fragments ahead: fetch the rest of the first spatial chunk's k-step (complete
+         * since the rendezvous in the middle of the chunk before it) */
+        if (phase == 0) {
+#pragma unroll
+          for (int d = AF; d < SQ_NF; ++d) ar[d] = lds_frag<MM>(p.wbuf + p.cur_off + 1024 + lane_v * 16 + d * 1024);
+        }
+        sq_layer<true>(p, ar, false, R0, R0);
+        RN_STAMPW(A, 4 + phase * 4);
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+          sq_layer<false>(p, ar, it == 2, R0, R1);
+          if (it < 3) sq_layer<false>(p, ar, false, R1, R0);
+        }
+        RN_STAMPW(A, 5 + phase * 4);
+        /* P3: heads.  Bottleneck slices: hi weights over the split input, kept as packed f16 (run 0) and merged with run 1's
+         * into the 32-sample B fragments of the directional trunk (refnerf_layout.h: the bottleneck k-steps of dir.0 / dir.4 are
+         * packed in the order this leaves).  Scalar block: all three products, to LDS HD. */
+#pragma unroll
+        for (int ob = 0; ob < 5; ++ob) {
+          SqAcc acc;
+          if (ob < 4) {
+            sq_chunk<SQ_BN, true>(p, ar, R1, acc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned pk = e == 0 ? pk_f16(acc.t0[0], acc.t0[1]) : (e == 1 ? pk_f16(acc.t0[2], acc.t0[3])
+                                : (e == 2 ? pk_f16(acc.t1[0], acc.t1[1]) : pk_f16(acc.t1[2], acc.t1[3])));
+              if (phase == 0) bn[2 * ob][e] = pk;
+              else {
+                const v2uu r = __builtin_amdgcn_permlane16_swap(bn[2 * ob][e], pk, false, false);
+                bn[2 * ob][e] = r[0];
+                bn[2 * ob + 1][e] = r[1];
+              }
+            }
+          } else {
+            sq_chunk<SQ_SC, true>(p, ar, R1, acc);
+            const int bq = lane_v >> 4;
+            int csl = cs + 4 * bq * BT;                  /* one laundered base: rows are immediate offsets from it */
+            asm volatile("" : "+v"(csl));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (4 * bq + i < HD_ROWS) HD[i * BT + csl] = acc.t0[i];
+          }
+        }
+        wave_sync();
+        RN_STAMPW(A, 6 + phase * 4);
+#else
         /* spatial trunk on the N-packed operands */
         sp_layer<MM, true>(p, ar, false, R0, bn, R0, dbgs);
         RN_STAMPW(A, 4 + phase * 4);
@@ -932,6 +1112,7 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
         }
         wave_sync();
         RN_STAMPW(A, 6 + phase * 4);
+#endif
       } else {
         /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
         char *xs = Xb + col * 16;
@@ -954,17 +1135,22 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
         }
         wave_sync();
         RN_STAMPW(A, 11);
-        dir_layer<MM, BF_BNLDS, BF_DIR_REAL_KS>(p, ar, 0, R0, bn, R0);
+#if REFNERF_SPLIT16
+        v8mm (&ad)[AF] = reinterpret_cast<v8mm (&)[AF]>(ar);     /* the ring's first AF entries */
+#else
+        v8mm (&ad)[AF] = ar;
+#endif
+        dir_layer<MM, BF_BNLDS, BF_DIR_REAL_KS>(p, ad, 0, R0, bn, R0);
         RN_STAMPW(A, 12);
 #pragma unroll 1
         for (int it = 0; it < 4; ++it) {
-          dir_layer<MM, BF_REG, 0>(p, ar, (it == 2) ? 2 : 0, R0, bn, R1);
-          if (it < 3) dir_layer<MM, BF_REG, 0>(p, ar, 0, R1, bn, R0);
+          dir_layer<MM, BF_REG, 0>(p, ad, (it == 2) ? 2 : 0, R0, bn, R1);
+          if (it < 3) dir_layer<MM, BF_REG, 0>(p, ad, 0, R1, bn, R0);
         }
         RN_STAMPW(A, 13);
         /* rgb: one slice */
         v16f acc;
-        bf_chunk<MM, BF_REG, 0, true, true>(p, ar, R1, bn, acc);
+        bf_chunk<MM, BF_REG, 0, true, true>(p, ad, R1, bn, acc);
         float raw_rgb[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n, 64);

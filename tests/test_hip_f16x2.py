@@ -162,7 +162,8 @@ def test_f16x2_level_options(hip, kw):
         assert np.abs(x[L]["r_rgb"] - y[L]["r_rgb"]).max() <= (RGB_TOL if loose else 2e-5), (kw, L)
         for k in ("r_diffuse", "r_specular", "r_acc", "r_distance_mean", "r_normals_pred", "r_roughness", "r_tint"):
             np.testing.assert_allclose(x[L][k], y[L][k], rtol=0, atol=5e-4 if loose else 5e-5, err_msg=k)
-        np.testing.assert_allclose(x[L]["r_percentiles"], y[L]["r_percentiles"], rtol=0, atol=5e-4 if loose else 1e-4)
+        # (distances of 2 .. 6: a percentile moves by the CDF knot's width times the relative weight difference)
+        np.testing.assert_allclose(x[L]["r_percentiles"], y[L]["r_percentiles"], rtol=0, atol=1e-3 if loose else 1e-4)
 
 
 def test_f16x2_through_the_model_api(hip):
