@@ -885,9 +885,11 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   }
   /* bf16 chains: the shared weight-stream ring comes on top; fewer rays per workgroup (a partly filled last pass)
    * when the whole-pass choice no longer fits */
-  while (train_bf && rpw > 1 && (lds + 15) / 16 * 16 + rn::RING_BYTES > 160 * 1024) { rpw /= 2; lds = lds_bytes(rpw); }
+  /* ... and so do the split-f16 chains of the built-in basis (REFNERF_SPLIT_SHARED: half steps through the same 8 KB slots) */
+  const bool train_ring = train_bf || (train_split && !gbasis && REFNERF_SPLIT_SHARED != 0);
+  while (train_ring && rpw > 1 && (lds + 15) / 16 * 16 + rn::RING_BYTES > 160 * 1024) { rpw /= 2; lds = lds_bytes(rpw); }
   const size_t ring_off = (lds + 15) / 16 * 16;
-  if (train_bf) lds = ring_off + rn::RING_BYTES;
+  if (train_ring) lds = ring_off + rn::RING_BYTES;
   lds += (size_t)rt().lds_pad;   /* debug (REFNERF_LDS_PAD): force 1 workgroup/CU */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget of this precision mode%s");
   LDS_ATTR_ONCE(lds_attr(rn::level_fwd_f32), lds_attr(rn::level_fwd_train_f32), lds_attr(rn::level_fwd_train_bf16c), lds_attr(rn::level_fwd_train_f16x2c),
@@ -945,7 +947,10 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
     for (int w = 0; w < nw; ++w) {
       fprintf(stderr, "[prof] wave %d:", w);
       for (int sl = 1; sl <= 18; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
-      fprintf(stderr, "  | dma-wait %lld barrier-wait %lld\n", hbuf[w * 32 + 20], hbuf[w * 32 + 21]);
+      fprintf(stderr, "  | dma-wait %lld barrier-wait %lld", hbuf[w * 32 + 20], hbuf[w * 32 + 21]);
+      if (hbuf[w * 32 + 23] > hbuf[w * 32 + 22])   /* -DREFNERF_PROF_WAITS builds: shader clock from the 100 MHz counter */
+        fprintf(stderr, " | clock %.0f MHz", 100.0 * (double)(hbuf[w * 32 + 15] - hbuf[w * 32]) / (double)(hbuf[w * 32 + 23] - hbuf[w * 32 + 22]));
+      fprintf(stderr, "\n");
     }
   }
   return REFNERF_OK;
@@ -1087,7 +1092,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   const int rpw = rays_per_wg(N, rn::T_TILE);
   size_t lds = sizeof(float) * (size_t)(rn::DIR_PAD * rn::T_TILE + rn::HD_ROWS * rn::T_TILE + rpw * (N + 1) + 8);
   const size_t ring_off = (lds + 15) / 16 * 16;
-  if (cfg->precision == REFNERF_PREC_BF16) lds = ring_off + rn::RING_BYTES;       /* the chains' shared weight-stream ring */
+  if (cfg->precision == REFNERF_PREC_BF16 || (cfg->precision == REFNERF_PREC_F16X2 && saved->activations_format == REFNERF_ACT_F16X2 && REFNERF_SPLIT_SHARED != 0))
+    lds = ring_off + rn::RING_BYTES;       /* the chains' shared weight-stream ring */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget%s");
   LDS_ATTR_ONCE(lds_attr(rn::level_bwd_f32), lds_attr(rn::level_bwd_bf16c), lds_attr(rn::level_bwd_f16x2c), lds_attr(rn::level_bwd_f16x2c_r32),
                 lds_attr(rn::wgrad_f16s_kernel<rn::WF_NW>, rn::WF_LDS),

@@ -107,14 +107,17 @@ struct Pipe {
 #ifndef REFNERF_BF_SPREAD
 #define REFNERF_BF_SPREAD 1
 #endif
+#ifndef REFNERF_DMA_AUX
+#define REFNERF_DMA_AUX 0   /* cache policy bits of the weight stream's LDS-DMA */
+#endif
 template <bool SPLIT = false>
 __device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off, int piece = -1) {
   if (p.dma_left > 0) {
     if (p.wave < 6) {
       lptr_t dst = (lptr_t)(p.wbuf + slot_off + p.wave * 3072);
-      if (piece < 0 || piece == 0) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 0, 0);
-      if (piece < 0 || piece == 1) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 1024, 0);
-      if ((piece < 0 || piece == 2) && p.wave < 5) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 2048, 0);
+      if (piece < 0 || piece == 0) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 0, REFNERF_DMA_AUX);
+      if (piece < 0 || piece == 1) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 1024, REFNERF_DMA_AUX);
+      if ((piece < 0 || piece == 2) && p.wave < 5) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 2048, REFNERF_DMA_AUX);
     }
     if (piece >= 0 && piece < 2) return;             /* the stream position moves on with the last piece */
     p.src += BF_CHUNK_BYTES;
@@ -745,8 +748,18 @@ __device__ __forceinline__ void sq_chunk(Pipe &p, sq_v8 (&fr)[SQ_NF], const v4uu
     }
     if (j == RDV) {
       /* mid-chunk rendezvous: chunk c+1 is complete for every wave, chunk c-1's slot is free */
+#ifdef REFNERF_PROF_WAITS
+      long long t0 = (long long)__builtin_readcyclecounter();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      long long t1 = (long long)__builtin_readcyclecounter();
+      __syncthreads();
+      long long t2 = (long long)__builtin_readcyclecounter();
+      p.t_vm += t1 - t0;
+      p.t_bar += t2 - t1;
+#else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+#endif
       issue_chunk<true>(p, p.fil_off, REFNERF_BF_SPREAD ? 0 : -1);
     }
     if (REFNERF_BF_SPREAD) {
@@ -864,6 +877,9 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
   p.lane = lane; p.wave = wave; p.h = h;
   p.t_vm = 0; p.t_bar = 0;
   RN_STAMPW(A, 0);
+#ifdef REFNERF_PROF_WAITS
+  if (A.prof && blockIdx.x == (gridDim.x >> 1) && lane == 0) A.prof[wave * 32 + 22] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   issue_chunk<true>(p, p.cur_off);                           /* overlaps with the resampler */
   issue_chunk<true>(p, p.nxt_off);
 
@@ -1175,7 +1191,10 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
   __syncthreads();
   RN_STAMPW(A, 15);
 #ifdef REFNERF_PROF_WAITS
-  if (A.prof && blockIdx.x == (gridDim.x >> 1) && lane == 0) { A.prof[wave * 32 + 20] = p.t_vm; A.prof[wave * 32 + 21] = p.t_bar; }
+  if (A.prof && blockIdx.x == (gridDim.x >> 1) && lane == 0) {
+    A.prof[wave * 32 + 20] = p.t_vm; A.prof[wave * 32 + 21] = p.t_bar;
+    A.prof[wave * 32 + 23] = (long long)__builtin_amdgcn_s_memrealtime();     /* 100 MHz: with slots 0 and 15, the shader clock */
+  }
 #endif
   if constexpr (!RINGPS) composite_phase<BF_NW, false, NPS_EVAL>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB), NRM);   /* P7 */
   RN_STAMPW(A, 16);

@@ -494,7 +494,8 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
         if (i == 5) { gemm_op_split<DIN_BLOCKS, 16, 0, false>(rs, PACKED.ht_off[TOP_VD5_DIN], 0, lane, h, pk, pl, gd, nullptr); park_din(5); }
         if (i == 0) { gemm_op_split<DIN_BLOCKS, 16, 0, false>(rs, PACKED.ht_off[TOP_VD0], 0, lane, h, pk, pl, gd, nullptr, hook); park_din(0); }
         if (i > 0) {
-          gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[TOP_VD1 + i - 1], 0, lane, h, pk, pl, out, nullptr, hook);
+          if constexpr (PF && REFNERF_SPLIT_SHARED != 0) gemm_chain_split_shared<false>(rs, PACKED.ht_off[TOP_VD1 + i - 1], 0, lane, h, wave, pk, pl, out, ring, hook);
+          else gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[TOP_VD1 + i - 1], 0, lane, h, pk, pl, out, nullptr, hook);
           shift_masks(M);
           mask_split(out, M[7], pk, pl, cs, &dlive);
         }
@@ -620,7 +621,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
         if (i > 0) {
           std::conditional_t<PF, PairStoreHook, RowStoreHook> sh_(A.delta, rpitch, DEL_SP + i * WIDTH, dcol, h, valid);
           const float inv = 1.0f / cs;
-          gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[i - 1], 0, lane, h, pk, pl, out, nullptr, [&](int t, int quarter = -1) {
+          auto hook = [&](int t, int quarter = -1) {
             if constexpr (PF) {
 #pragma unroll
               for (int e = 0; e < 4; ++e)
@@ -630,7 +631,9 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
               for (int e = 0; e < 8; ++e)
                 if (quarter < 0 || (e >> 1) == quarter) sh_(8 * t + e, split_elem(pk[t], pl[t], e) * inv);
             }
-          });
+          };
+          if constexpr (PF && REFNERF_SPLIT_SHARED != 0) gemm_chain_split_shared<false>(rs, PACKED.ht_off[i - 1], 0, lane, h, wave, pk, pl, out, ring, hook);
+          else gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[i - 1], 0, lane, h, pk, pl, out, nullptr, hook);
           shift_masks(M);
           mask_split(out, M[7], pk, pl, cs, &dlive);
         } else if constexpr (PF) {                                           /* no GEMM consumes delta_0: its hi halves as they are */

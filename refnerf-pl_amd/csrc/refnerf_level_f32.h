@@ -533,6 +533,102 @@ __device__ __forceinline__ void gemm_chain_bf16_shared(__amdgpu_buffer_rsrc_t rs
   rendezvous();
 }
 
+/* The same for the split-f16 chains.  A k-step of the split image is [8 hi fragments, 8 KB][8 lo fragments, 8 KB]; the ring
+ * keeps its 8 KB slots and works in HALF steps: the even half step brings the hi fragments (16 MFMAs: hi * hi, hi * lo),
+ * the odd one the lo fragments (8 MFMAs: lo * hi) -- gemm_op_split's products; an accumulator takes them as hi * hi, hi * lo,
+ * lo * hi per k-step instead of hi * hi, lo * hi, hi * lo (fp32 accumulation: results agree to rounding, not bit for bit).  Per-wave streams pull 4 x 16 KB per k-step through the CU's 64 B/clk vector-memory path (1024 cycles
+ * against 768 of matrix issue); shared, each wave fetches a quarter.  hook(step, quarter) as gemm_op_split's: quarters
+ * 0, 1 ride in the even half step, 2, 3 in the odd one.  Must be called by all four waves, the same number of times. */
+#ifndef REFNERF_SPLIT_SHARED
+#define REFNERF_SPLIT_SHARED 0   /* measured (round 4, C2): forward 6.03 -> 6.20 ms, backward 3.65 -> 3.67: off (docs/EXPERIMENTS.md section 9) */
+#endif
+template <bool BIAS, typename Hook>
+__device__ __forceinline__ void gemm_chain_split_shared(__amdgpu_buffer_rsrc_t rs, int a_off, int b_off, int lane, int h, int wave,
+                                                        const v4uu (&ih)[16], const v4uu (&il)[16], v16f (&out)[8], char *ring, Hook hook) {
+  constexpr int HSTEPS = 32;
+  constexpr int HB = BT_STEP_FLOATS * 4;                        /* 8 KB: [ob][lane][8 f16] */
+  const int voff = wave * 2048 + lane * 16;
+  const int soff = a_off * 4;
+  char *wr = ring + wave * 2048 + lane * 16;
+  const char *rd = ring + lane * 16;
+  auto fetch = [&](int u, v4u (&g)[2]) {
+    g[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + u * HB, 0);
+    g[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 1024, soff + u * HB, 0);
+  };
+  auto stage = [&](int u, const v4u (&g)[2]) {
+    *reinterpret_cast<v4u *>(wr + (u % RING_SLOTS) * HB) = g[0];
+    *reinterpret_cast<v4u *>(wr + (u % RING_SLOTS) * HB + 1024) = g[1];
+  };
+  auto frags = [&](int u, v8hf (&a)[8]) {
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob) a[ob] = *reinterpret_cast<const v8hf *>(rd + (u % RING_SLOTS) * HB + ob * 1024);
+  };
+  auto rendezvous = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  constexpr int GD = REFNERF_RING_FETCH;
+  v4u g[GD][2];
+  v8hf a[2][8];
+#pragma unroll
+  for (int d = 0; d < GD; ++d) fetch(d, g[d]);
+  if constexpr (BIAS) load_acc<8>(rs, b_off, h, out);
+  else {
+#pragma unroll
+    for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[ob][r] = 0.0f;
+  }
+  stage(0, g[0]);
+  fetch(GD, g[0]);
+  stage(1, g[1]);
+  fetch(GD + 1, g[1]);
+  rendezvous();
+  frags(0, a[0]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < HSTEPS; ++u) {
+    const int st = u >> 1;
+    if (u + 1 < HSTEPS) frags(u + 1, a[(u + 1) & 1]);
+    const v8hf bh = __builtin_bit_cast(v8hf, ih[st]), bl = __builtin_bit_cast(v8hf, il[st]);
+    if ((u & 1) == 0) {
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][ob], bh, out[ob], 0, 0, 0);
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][ob], bl, out[ob], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][ob], bh, out[ob], 0, 0, 0);
+    }
+    if (u + 2 < HSTEPS) {
+      stage(u + 2, g[(u + 2) % GD]);
+      if (u + 2 + GD < HSTEPS) fetch(u + 2 + GD, g[(u + 2) % GD]);
+    }
+    hook(st, 2 * (u & 1));
+    hook(st, 2 * (u & 1) + 1);
+    /* one wave per SIMD: the fragment reads of the next half step in the first gaps, then the stream's loads, its LDS
+     * writes and the row stores */
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);
+    if (u + 2 < HSTEPS) rendezvous();                 /* the last two half steps' slots are already complete */
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  /* the next call stages into slots 0 and 1 right away: their last readers must be done */
+  rendezvous();
+}
+
 /* ReLU and its sign bit without a compare: as integers, x > 0 <=> max_i32(x, 0) != 0 (negative floats and -0 are
  * negative integers), so relu(x) = max_i32(x, 0) and the mask bit = min_u32(relu(x), 1) -- VALU only (see keep_if_bit),
  * bit-identical to `x > 0 ? x : 0` for every non-NaN x. */
@@ -973,7 +1069,8 @@ __device__ __forceinline__ void density_normals_bf16(__amdgpu_buffer_rsrc_t rs, 
 
 /* density_normals on the split-f16 chains: the same VJP with 22-bit deltas; d feature / d mean recomputed exactly as in
  * the fp32 kernel (ipe_vjp_accum) */
-__device__ __forceinline__ void density_normals_split(__amdgpu_buffer_rsrc_t rs, int lane, int h, v16f (&out)[8], v4uu (&ph)[16], v4uu (&pl)[16],
+template <bool SHARED>
+__device__ __forceinline__ void density_normals_split(__amdgpu_buffer_rsrc_t rs, int lane, int h, int wave, char *ring, v16f (&out)[8], v4uu (&ph)[16], v4uu (&pl)[16],
                                                       unsigned (&M)[8][4], const float lm[3], const float lv[3], float nrm_out[3]) {
   load_acc<8>(rs, PACKED.wd_off, h, out);
   float c = 1.0f;                                /* per-sample power-of-two factor the chain carries (mask_split) */
@@ -992,7 +1089,8 @@ __device__ __forceinline__ void density_normals_split(__amdgpu_buffer_rsrc_t rs,
       ipe_vjp_accum(gi, lm, lv, h, gl);
     }
     if (i > 0) {
-      gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[i - 1], 0, lane, h, ph, pl, out, nullptr);
+      if constexpr (SHARED) gemm_chain_split_shared<false>(rs, PACKED.ht_off[i - 1], 0, lane, h, wave, ph, pl, out, ring, NoStepHook());
+      else gemm_op_split<8, 16, 0, false>(rs, PACKED.ht_off[i - 1], 0, lane, h, ph, pl, out, nullptr);
 #pragma unroll
       for (int l = 7; l > 0; --l)
 #pragma unroll
@@ -1071,6 +1169,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
   /* split chains on the built-in basis save the layer inputs as hi / lo pair units (REFNERF_ACT_F16X2); a general basis keeps
    * fp32 rows (its tail matrix and tail job table are fp32) */
   constexpr bool PAIRS = SPC && !GB;
+  constexpr bool SPLIT_RING = SPC && !GB && REFNERF_SPLIT_SHARED != 0;   /* 256 -> 256 chain layers through the shared weight-stream ring */
   extern __shared__ __attribute__((aligned(16))) float smem[];
   RN_STAMP(A, 0);
   const refnerf_level_cfg &cfg = A.cfg;
@@ -1287,6 +1386,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
         if constexpr (GB) { if (op == 5) { wave_sync(); ipe_group(0, false); wave_sync(); } }     /* X holds the last group of layer 0 */
         if (op == 5) gemm_op_split<8, 16, BF_IPE_STEPS, true>(rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, pk, pl, out, xc,
                                                              row_hook(ACT_SP + (op - 1) * WIDTH));
+        else if constexpr (SPLIT_RING) gemm_chain_split_shared<true>(rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, wave, pk, pl, out,
+                                                                     reinterpret_cast<char *>(smem) + A.ring_off, row_hook(ACT_SP + (op - 1) * WIDTH));
         else gemm_op_split<8, 16, 0, true>(rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, pk, pl, out, xc,
                                            row_hook(ACT_SP + (op - 1) * WIDTH));
         if constexpr (GB) { if (op == 5) more_groups(1); }
@@ -1353,7 +1454,7 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       /* (this kernel also serves cfg.precision = F16X2 in inference for a general basis: no normals then) */
       if (cfg.training) density_normals_split_gb(rs, lane, h, out, pk, pl, M, cfg.ipe_groups, reinterpret_cast<const float *>(A.packed) + PEXT_BASIS, lift_group, sh.normals);
       else { sh.normals[0] = 0.0f; sh.normals[1] = 0.0f; sh.normals[2] = 0.0f; }
-    } else if constexpr (SPC) density_normals_split(rs, lane, h, out, pk, pl, M, lm, lv, sh.normals);
+    } else if constexpr (SPC) density_normals_split<SPLIT_RING>(rs, lane, h, wave, reinterpret_cast<char *>(smem) + A.ring_off, out, pk, pl, M, lm, lv, sh.normals);
     else if constexpr (BFC) density_normals_bf16(rs, lane, h, wave, reinterpret_cast<char *>(smem) + A.ring_off, out, pk, M, X, col, sh.normals);
     else if constexpr (TRAIN && GB) density_normals_gb(rs, lane, h, in, out, M, xl, cfg.ipe_groups, reinterpret_cast<const float *>(A.packed) + PEXT_BASIS, lift_group, sh.normals);
     else if constexpr (TRAIN) density_normals(rs, lane, h, in, out, M, lm, lv, xl, sh.normals);
@@ -1425,6 +1526,8 @@ __device__ __forceinline__ void level_fwd_f32_body(const LevelArgs &A) {
       if constexpr (SPC) {
         if (op == 14) gemm_op_split<8, 16, BF_DIN_STEPS, true, decltype(row_hook(0)), DIR_PAD - 1>(
             rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, pk, pl, out, xc, row_hook(ACT_VD + (op - 10) * WIDTH));
+        else if constexpr (SPLIT_RING) gemm_chain_split_shared<true>(rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, wave, pk, pl, out,
+                                                                     reinterpret_cast<char *>(smem) + A.ring_off, row_hook(ACT_VD + (op - 10) * WIDTH));
         else gemm_op_split<8, 16, 0, true>(rs, PACKED.hf_off[op], PACKED.op[op].b_off, lane, h, pk, pl, out, xc,
                                            row_hook(ACT_VD + (op - 10) * WIDTH));
       } else if constexpr (BFC) {

@@ -46,7 +46,18 @@ __device__ __forceinline__ float pk_sum_h(unsigned a) {
   const _Float16 z0 = z[0], z1 = z[1];
   return (float)z0 + (float)z1;
 }
-constexpr int WF_LDS = 3 * WB_TILE;            /* D, A_hi, A_lo: 54 KB */
+/* LDS tiles of this kernel: 128 rows x 64 halves = 128 B per row, NO pad -- the 16-B chunk c of row r sits at chunk
+ * c ^ ((r >> 1) & 7): the sixteen lanes ds_read_b128 serves per cycle (consecutive rows, one chunk) then cover the sixteen
+ * 16-B slots of the 256-B bank window exactly once, as the 144-B pitch of the bf16 GEMM does -- and three tiles are 48 KB
+ * instead of 54 (bit-identical results, same time: 3.73 ms at C2).  Three workgroups per CU would now fit the LDS, but not the
+ * registers: see REFNERF_WF_OCC */
+constexpr int WF_ROW = WB_KT * 2;              /* 128 B */
+constexpr int WF_TILE = WG_TM * WF_ROW;        /* 16 KB */
+constexpr int WF_LDS = 3 * WF_TILE;            /* D, A_hi, A_lo: 48 KB */
+__device__ __forceinline__ int wf_off(int row, int byte) { return row * WF_ROW + ((((byte >> 4) ^ (row >> 1)) & 7) << 4) + (byte & 15); }
+#ifndef REFNERF_WF_OCC
+#define REFNERF_WF_OCC 2                       /* waves per SIMD the register allocation aims at (4-wave workgroups: workgroups per CU); 3: 168 VGPRs + 92 B/lane of scratch, 6.99 ms instead of 3.73 (round 4, C2) */
+#endif
 /* the backward scales a sample's largest delta into [2^7, 2^8) (pow2_scale_for); the sample(s) with the layer's smallest factor
  * go up another 2^7 on load, to just below the largest half (2^15 < 65504), everything else follows: 29 binades at full
  * precision below the layer's largest deltas, 10 more of gradual underflow */
@@ -62,14 +73,14 @@ constexpr float TOP_SHIFT = 128.0f;
 #endif
 constexpr int WF_NW = REFNERF_WF_WAVES;
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void wgrad_f16s_kernel(const WgradArgs A, int slices, const float *__restrict__ cmin_all) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? REFNERF_WF_OCC : 4))) void wgrad_f16s_kernel(const WgradArgs A, int slices, const float *__restrict__ cmin_all) {
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   constexpr int MI = 8 / NW;                     /* 32-row blocks of the D tile per wave */
   constexpr int NPP = 16 / NW;                   /* row PAIRS of either tile per loader thread */
   constexpr int NR = 2 * NPP;                    /* rows */
   constexpr const WJobs &JT = WJOBS;
   extern __shared__ __attribute__((aligned(16))) char wbs[];
-  char *Dh = wbs, *Ah = wbs + WB_TILE, *Al = wbs + 2 * WB_TILE;
+  char *Dh = wbs, *Ah = wbs + WF_TILE, *Al = wbs + 2 * WF_TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, sl = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_f16s_kernel(const WgradArgs A, 
     }
 #pragma unroll
     for (int p = 0; p < NR; ++p) {
-      const int off = tile_row(p) * WB_ROW + lc4 * 2;
+      const int off = wf_off(tile_row(p), lc4 * 2);
       unsigned h0, h1, l0, l1;
       unpair(dv[st][p >> 1], p & 1, dp[p] != nullptr, h0, h1);
       h0 = pk_mul_h(h0, f01);
@@ -183,10 +194,10 @@ __global__ __launch_bounds__(64 * NW) void wgrad_f16s_kernel(const WgradArgs A, 
     for (int kk = 0; kk < WB_KT / 16; ++kk) {
       v8h dh[MI], bh[2], bl[2];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) dh[i] = *reinterpret_cast<const v8h *>(Dh + (wm * 32 * MI + i * 32 + sl) * WB_ROW + kk * 32 + h * 16);
+      for (int i = 0; i < MI; ++i) dh[i] = *reinterpret_cast<const v8h *>(Dh + wf_off(wm * 32 * MI + i * 32 + sl, kk * 32 + h * 16));
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int co = (wn * 64 + i * 32 + sl) * WB_ROW + kk * 32 + h * 16;
+        const int co = wf_off(wn * 64 + i * 32 + sl, kk * 32 + h * 16);
         bh[i] = *reinterpret_cast<const v8h *>(Ah + co);
         bl[i] = *reinterpret_cast<const v8h *>(Al + co);
       }
