@@ -343,34 +343,8 @@ __global__ void pack_weights_16(const float *__restrict__ P, char *__restrict__ 
     fill_chunk_plain<E>(P, out + (size_t)(o.chunk0 + ob * o.nchunk + j) * BF_CHUNK_BYTES, op, ob, o.kind[j], j == 0, base);
 }
 
-/* Split-f16 image (REFNERF_PREC_F16X2, refnerf_layout.h): spatial ops + the scalar head block as [hi lo] piece pairs
- * (w = hi + lo, hi = fl16(w), lo = fl16(w - hi)), bottleneck blocks and the directional ops as plain f16 chunks. */
-__device__ void fill_chunk_split(const float *__restrict__ P, char *__restrict__ chunk, int op, int ob, int kind, bool first, int base) {
-  for (int e = threadIdx.x; e < 256; e += blockDim.x) {
-    float v = 0.0f;
-    if (e < 32 && first) {
-      int reg = e & 15, h = e >> 4;
-      v = canon_b(P, op, ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
-    }
-    reinterpret_cast<float *>(chunk)[e] = v;      /* floats 32..63 stay zero: the accumulator seed of the lo columns */
-  }
-  for (int idx = threadIdx.x; idx < 16 * 512; idx += blockDim.x) {
-    const int e = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9;
-    const int h = lane >> 5, row = ob * 32 + (lane & 31), part = t & 1;
-    float v = 0.0f;
-    if (kind == BF_SLDS) {
-      const int s = t >> 1;
-      if (s < BF_IPE_REAL_KS) v = canon_w(P, op, row, base + ipe_col_of_kprime(16 * s + 8 * h + e));
-    } else {
-      const int ks = (kind == BF_SREG1 ? 8 : 0) + (t >> 1);
-      const int r = 8 * (ks & 1) + e;
-      v = canon_w(P, op, row, 32 * (ks >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h);
-    }
-    const _Float16 hi = (_Float16)v;
-    reinterpret_cast<_Float16 *>(chunk + 1024)[idx] = part ? (_Float16)(v - (float)hi) : hi;
-  }
-}
-/* REFNERF_SPLIT16: one chunk of the 16x16x32 spatial section (refnerf_layout.h) */
+/* Split-f16 image (REFNERF_PREC_F16X2): one chunk of the 16x16x32 spatial section (refnerf_layout.h; w = hi + lo,
+ * hi = fl16(w), lo = fl16(w - hi)); the directional ops are plain f16 chunks */
 __device__ void fill_chunk_sq(const float *__restrict__ P, char *__restrict__ chunk, int op, int ob, int kind, bool first, int base) {
   for (int e = threadIdx.x; e < 256; e += blockDim.x) {
     float v = 0.0f;
@@ -426,25 +400,17 @@ __global__ void pack_weights_split(const float *__restrict__ P, char *__restrict
     const BfOp o = BFPACKED.op[op];
     const int base = (o.nchunk == 2) ? WIDTH : 0;
     for (int j = 0; j < o.nchunk; ++j) {
-      if (REFNERF_SPLIT16 && o.kind[j] == BF_BNLDS) fill_chunk_bnlds_sq(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, j == 0, base);
+      if (o.kind[j] == BF_BNLDS) fill_chunk_bnlds_sq(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, j == 0, base);
       else fill_chunk_plain<_Float16>(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, o.kind[j], j == 0, base);
     }
     return;
   }
   const int n = sp_slice_chunks(op, ob);
-#if REFNERF_SPLIT16
   if (op == OP_HEADS) { fill_chunk_sq(P, chunk, op, ob, ob < 4 ? SQ_BN : SQ_SC, true, 0); return; }
   for (int j = 0; j < n; ++j) {
     const int kind = (op == 0 || j == 2) ? SQ_X : (j == 0 ? SQ_A : SQ_B);
     fill_chunk_sq(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, kind, j == 0, op == 5 ? WIDTH : 0);
   }
-#else
-  if (op == OP_HEADS && ob < 4) { fill_chunk_plain<_Float16>(P, chunk, op, ob, BF_REG, true, 0); return; }
-  for (int j = 0; j < n; ++j) {
-    const int kind = (op == 0 || j == 2) ? BF_SLDS : (j == 0 ? BF_SREG0 : BF_SREG1);
-    fill_chunk_split(P, chunk + (size_t)j * BF_CHUNK_BYTES, op, ob, kind, j == 0, op == 5 ? WIDTH : 0);
-  }
-#endif
 }
 
 /* ------------------------------------------------------------------ */
@@ -808,12 +774,6 @@ BwdPlan bwd_plan(int R, int N, int groups = 0) {
 }
 }  // namespace
 
-#ifdef REFNERF_SPLIT_DUMP
-/* debug build only (scripts/dbg_split_dump.py): the split kernel dumps what its spatial trunk saw into this buffer */
-static float *g_split_dump = nullptr;
-extern "C" int refnerf_debug_set_dump(float *d_buf) { g_split_dump = d_buf; return 0; }
-#endif
-
 static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays,
                               int32_t R, const float *d_sdist_in, const float *d_weights_in,
                               const refnerf_level_out *out, float *d_act, long long act_pitch, void *stream) {
@@ -908,9 +868,6 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   a.g_means = nullptr; a.g_covs = nullptr; a.cov_full = 0;
   a.act = d_act; a.act_pitch = act_pitch;
   a.ring_off = (int)ring_off;
-#ifdef REFNERF_SPLIT_DUMP
-  a.dbg = g_split_dump;
-#endif
   if (rt().prof) {
     int prc = prof_buffer(&a.prof);
     if (prc) return prc;

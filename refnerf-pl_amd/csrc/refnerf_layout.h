@@ -328,43 +328,30 @@ constexpr BfPacked BFPACKED = make_bf_packed();
  * The parity-grade 16-bit mode: the spatial trunk and the scalar head block (density) take BOTH operands as
  * hi + lo pairs of IEEE halves (x = hi + lo exactly to 22 bits), the directional trunk stays plain f16 (measured on the
  * trained-like weights, scripts/exp_split_precision.py: only the density path needs more than 11 bits).
- * Activations are N-PACKED: a wave owns 16 samples per spatial run and the 32 B columns of an MFMA are
- * [hi of samples 0..15 | lo of samples 0..15]; MFMA(W_hi, B) + MFMA(W_lo, B) into ONE accumulator then hold the four
- * products hi*hi + lo*hi (columns 0..15) and hi*lo + lo*lo (columns 16..31), summed across the lane halves in the
- * epilogue.  Chunk kinds on top of the plain ones (same 17 KB chunks, same k maps as the plain image):
- *   SREG0 / SREG1 : register k-steps 0..7 / 8..15, pieces [hi(k) lo(k)] x 8 = 16 MFMAs
- *   SLDS          : the 6 real LDS k-steps of the IPE features, pieces [hi lo] x 6 = 12 MFMAs (4 pieces unused)
- * sp0: [SLDS]; sp1-4, 6, 7: [SREG0][SREG1]; sp5: [SREG0][SREG1][SLDS]; heads: bottleneck blocks [REG] (hi weights
- * only, over the N-packed input: w_hi (x_hi + x_lo)), scalar block [SREG0][SREG1]; directional ops as in the plain image.
- * A pass = the spatial section TWICE (two runs of 16 samples per wave), then the directional section once over all 32. */
-enum { BF_SREG0 = 3, BF_SREG1 = 4, BF_SLDS = 5 };
-constexpr int BF_SLDS_KS = 2 * BF_IPE_REAL_KS;   /* MFMAs of an SLDS chunk */
-/* REFNERF_SPLIT16 (round 4): the spatial section on v_mfma_f32_16x16x32_f16 with THREE partial products.  The N-packed form
- * above pays W_lo x [x_hi | x_lo] for the W_lo x_hi it needs (the lo x lo quarter rides along: 4 products); a K-concatenated
- * 3-product form on the 32x32 shape needs the hi AND lo halves of 32 samples resident (256 registers).  On the 16x16x32 shape a
+ * A pass = the spatial section TWICE (two runs of 16 samples per wave), then the directional section once over all 32.
+ * The spatial section runs on v_mfma_f32_16x16x32_f16 with THREE partial products (round 4; round 3's N-packed 32x32x16 form
+ * -- columns [hi of 16 samples | lo of 16 samples] -- paid W_lo x [x_hi | x_lo] for the W_lo x_hi it needs: 4 products; a
+ * K-concatenated 3-product form on the 32x32 shape needs the hi AND lo halves of 32 samples resident, 256 registers).  A
  * wave's 16 samples are the 16 columns: a layer's input is 8 k-steps of 32 as an H (hi halves) and an L (lo halves) fragment set
- * -- the same 64 registers -- and W_hi H + W_lo H + W_hi L go into ONE accumulator (no cross-lane sums in the epilogue).  A
+ * -- 64 registers -- and W_hi H + W_lo H + W_hi L go into ONE accumulator (no cross-lane sums in the epilogue).  A
  * 32-row slice = two 16-row tiles (T0, T1); lane (b = lane / 16, n = lane % 16) of an accumulator holds rows 4 b .. 4 b + 3 of
  * its tile for sample n, and those eight values of a slice are k-group b of the NEXT layer's k-step `slice`:
  *     feature of (k-step s, group b, element i) = 32 s + 16 (i / 4) + 4 b + i % 4.
  * Chunks (same 17 KB: bias piece [T][b][4] fp32 + 16 pieces of 1 KB, piece lane (b, r) = 8 halves W[16 T + r][k-group b]):
- *   SQ_A / SQ_B : k-steps 0..3 / 4..7, pieces [WhT0 WhT1 WlT0 WlT1] x 4, 24 MFMAs of 16.5 cycles (N-packed: 16 of 32)
+ *   SQ_A / SQ_B : k-steps 0..3 / 4..7, pieces [WhT0 WhT1 WlT0 WlT1] x 4, 24 MFMAs of 16.5 cycles
  *   SQ_X        : the 3 IPE k-steps (96 features, k' = 32 s + 8 b + i) from the LDS planes, 12 pieces, 18 MFMAs
  *   SQ_BN       : a bottleneck slice: hi weights only over H and L, pieces [WhT0 WhT1] x 8, 32 MFMAs
  *   SQ_SC       : the scalar head block (rows 128..139: tile T0 only), pieces [WhT0 WlT0] x 8, 24 MFMAs
  * sp0: [SQ_X]; sp1-4, 6, 7: [SQ_A][SQ_B]; sp5: [SQ_A][SQ_B][SQ_X]; heads: 4 x [SQ_BN] + [SQ_SC].  The two runs' bottlenecks
  * merge into the directional trunk's 32-sample fragments with one v_permlane16_swap per dword: slice ob becomes its k-steps
  * 2 ob, 2 ob + 1 with feature (t, h, e) = 32 (t / 2) + 16 (e / 4) + 8 h + 4 (t % 2) + e % 4 (the BNLDS chunks of this image). */
-#ifndef REFNERF_SPLIT16
-#define REFNERF_SPLIT16 1
-#endif
 enum { SQ_A = 6, SQ_B = 7, SQ_X = 8, SQ_BN = 9, SQ_SC = 10 };
 struct SpPacked { int chunk0[NUM_OPS]; int sp_chunks; int total_chunks; int chunks_per_pass; };
 constexpr int sp_slice_chunks(int op, int ob) {
   if (op == 0) return 1;
   if (op == 5) return 3;
   if (op < OP_HEADS) return 2;
-  if (op == OP_HEADS) return (ob < 4 || REFNERF_SPLIT16) ? 1 : 2;
+  if (op == OP_HEADS) return 1;
   return (op == 14) ? 2 : 1;
 }
 constexpr SpPacked make_sp_packed() {
@@ -381,7 +368,7 @@ constexpr SpPacked make_sp_packed() {
   return P;
 }
 constexpr SpPacked SPPACKED = make_sp_packed();
-static_assert(SPPACKED.sp_chunks == (REFNERF_SPLIT16 ? 133 : 134) && SPPACKED.total_chunks == (REFNERF_SPLIT16 ? 206 : 207), "split image layout");
+static_assert(SPPACKED.sp_chunks == 133 && SPPACKED.total_chunks == 206, "split image layout");
 
 /* head rows inside op 8 (5 blocks of 32): 0..127 bottleneck, then */
 constexpr int HROW_DENSITY = 128, HROW_GRAD = 129, HROW_ROUGH = 132, HROW_DIFFUSE = 133, HROW_TINT = 136, HROWS = 139;

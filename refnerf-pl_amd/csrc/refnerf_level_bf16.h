@@ -173,21 +173,18 @@ __device__ __forceinline__ typename MM::v8 lds_b(const Pipe &p, int kl) {
 }
 
 /* One chunk.  KIND: BF_REG (16 steps over `in`), BF_LDS8 (8 steps over LDS,
- * REAL_L real), BF_BNLDS (8 over `bn` + 8 over LDS, REAL_L real); split mode (refnerf_layout.h): BF_SREG0 / BF_SREG1
- * (k-steps 0..7 / 8..15 of `in`, each with the hi and the lo weight fragment), BF_SLDS (the 6 real IPE steps from the
- * N-packed LDS planes, hi and lo fragments).
- * FIRST: the chunk opens a slice (accumulator starts from the bias piece; NPK: N-packed columns -- the lo columns,
- * lanes 16-31 of each half, start from the zeros behind the bias).
+ * REAL_L real), BF_BNLDS (8 over `bn` + 8 over LDS, REAL_L real).  SPLIT: the chunk belongs to the split-f16 image (its
+ * stream position wraps differently: issue_chunk).
+ * FIRST: the chunk opens a slice (accumulator starts from the bias piece).
  * `a` is the A-fragment ring; on entry it holds fragments 0..AF-1 of this chunk,
  * on exit those of the next one. */
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 /* `hook(k)`: VALU work of the caller placed behind the MFMA of step k (the split kernel runs the epilogue of the previous
  * slice there, in the issue gaps of this slice's matrix instructions) */
-template <typename MM, int KIND, int REAL_L, bool FIRST, bool SPLIT = false, bool NPK = false, typename Hook = NoHook>
+template <typename MM, int KIND, int REAL_L, bool FIRST, bool SPLIT = false, typename Hook = NoHook>
 __device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc, Hook &&hook = Hook()) {
   typedef typename MM::v8 v8mm;
-  constexpr bool SK = (KIND == BF_SREG0 || KIND == BF_SREG1 || KIND == BF_SLDS);
-  constexpr int KS = (KIND == BF_LDS8) ? 8 : (KIND == BF_SLDS ? BF_SLDS_KS : 16);
+  constexpr int KS = (KIND == BF_LDS8) ? 8 : 16;
   constexpr int L0 = (KIND == BF_BNLDS) ? 8 : 0;      /* first LDS step (for the LDS kinds) */
   static_assert(KS % AF == 0, "ring phase");
   const char *w = p.wbuf + p.cur_off;
@@ -195,27 +192,20 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], cons
   const char *nxt = p.wbuf + p.nxt_off + 1024 + p.lane * 16;
   v8mm xr[2];
   if (KIND == BF_LDS8) { xr[0] = lds_b<MM, REAL_L>(p, 0); xr[1] = lds_b<MM, REAL_L>(p, 1); }
-  if (KIND == BF_SLDS) { xr[0] = lds_frag<MM>(p.xps); xr[1] = lds_frag<MM>(p.xps + 2 * BT * 16); }
-  if (FIRST) acc = bias16(w + ((SK || NPK) ? ((p.lane & 16) << 3) : 0), p.h);
+  if (FIRST) acc = bias16(w, p.h);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
     v8mm b;
     const bool lds_step = (KIND == BF_LDS8) || (KIND == BF_BNLDS && k >= 8);
-    if (KIND == BF_SLDS) b = xr[(k >> 1) & 1];
-    else if (KIND == BF_SREG0) b = __builtin_bit_cast(v8mm, in[k >> 1]);
-    else if (KIND == BF_SREG1) b = __builtin_bit_cast(v8mm, in[8 + (k >> 1)]);
-    else if (lds_step) b = xr[(k - L0) & 1];
+    if (lds_step) b = xr[(k - L0) & 1];
     else if (KIND == BF_REG) b = __builtin_bit_cast(v8mm, in[k]);
     else b = __builtin_bit_cast(v8mm, bn[k & 7]);
     acc = MM::mfma(a[k % AF], b, acc);
     /* A ring: fragment k+AF of this chunk, or the head of the next chunk (landed: k >= KS/2) */
     a[k % AF] = (k + AF < KS) ? lds_frag<MM>(cur + (k + AF) * 1024) : lds_frag<MM>(nxt + (k + AF - KS) * 1024);
     hook(k);
-    if (KIND == BF_SLDS) {
-      const int s2 = (k >> 1) + 2;                      /* after the lo MFMA of step s: fetch step s + 2 into its slot */
-      if ((k & 1) && s2 < BF_IPE_REAL_KS) xr[s2 & 1] = lds_frag<MM>(p.xps + (2 * s2) * BT * 16);
-    } else if (KIND == BF_LDS8 || KIND == BF_BNLDS) {
+    if (KIND == BF_LDS8 || KIND == BF_BNLDS) {
       const int kl2 = k + 2 - L0;                       /* LDS step to fetch now */
       if (kl2 >= 0 && kl2 < 8 && !(KIND == BF_LDS8 && kl2 < 2)) xr[kl2 & 1] = lds_b<MM, REAL_L>(p, kl2);
     }
@@ -571,26 +561,12 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16_ring(const LevelArg
  * ===================================================================================================================== */
 typedef unsigned v2uu __attribute__((ext_vector_type(2)));
 
-/* N-packed accumulator tile (columns 0-15: products with x_hi, 16-31: with x_lo) -> 8 fp32 totals: lanes 0-15 of each half
- * hold accumulator rows j, lanes 16-31 rows j + 8 (j = 0..7) of sample (lane & 15) */
-/* (by-value helpers: clang's __builtin_bit_cast applied directly to an ext-vector ELEMENT expression reads element 0) */
-__device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
-__device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
-__device__ __forceinline__ void npk_totals(const v16f &a, float (&s)[8]) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float lo = a[j], hi = a[j + 8];
-    const v2uu r = __builtin_amdgcn_permlane16_swap(f2u(lo), f2u(hi), false, false);
-    const unsigned r0 = r[0], r1 = r[1];
-    s[j] = u2f(r0) + u2f(r1);
-  }
-}
 __device__ __forceinline__ unsigned pk_f16(float lo, float hi) { return cvt_pk_mm<MmF16>(lo, hi); }
 /* (x0, x1) -> packed hi halves + packed lo halves, x = hi + lo.  The residual is formed from the BITS that get stored:
  * hipcc otherwise converts the same value twice with different instructions -- v_cvt_pk_f16_f32 of the fp32 product for the
  * stored half, v_fma_mixlo_f16 (the product rounded ONCE, to f16) for the copy the residual is taken from -- and the two
  * disagree by an ulp of the hi half for one value in ~10^5 (double rounding): 0.3 % of the samples then carried one IPE
- * feature that was off by 2^-11 (found with scripts/dbg_split_dump.py). */
+ * feature that was off by 2^-11 (found with a per-layer dump build in round 3). */
 __device__ __forceinline__ void split_pair_f16(float x0, float x1, unsigned &hi, unsigned &lo) {
   hi = pk_f16(x0, x1);
   asm("" : "+v"(hi));
@@ -598,94 +574,6 @@ __device__ __forceinline__ void split_pair_f16(float x0, float x1, unsigned &hi,
   const _Float16 h0 = hv[0], h1 = hv[1];
   lo = pk_f16(x0 - (float)h0, x1 - (float)h1);
 }
-/* one accumulator pair of an N-packed tile -> its fp32 total (see npk_totals) */
-__device__ __forceinline__ float npk_total1(const v16f &a, int j) {
-  const float lo = a[j], hi = a[j + 8];
-  const v2uu r = __builtin_amdgcn_permlane16_swap(f2u(lo), f2u(hi), false, false);
-  const unsigned r0 = r[0], r1 = r[1];
-  return u2f(r0) + u2f(r1);
-}
-/* totals 2e, 2e+1 (after ReLU) -> dword e of the next layer's two N-packed B fragments (hi + lo halves); same k order
- * as pack_acc */
-__device__ __forceinline__ void split_piece(const float (&s)[8], int e, v4uu &f0, v4uu &f1, float *dbg = nullptr, int lane = 0) {
-  /* ReLU that lets a NaN through (v_max_f32 would return the 0): a unit past the range of an IEEE half becomes hi = inf,
-   * lo = -inf, the next layer's accumulators inf - inf = NaN -- and the ray's colour comes out NaN instead of finite and
-   * wrong (include/refnerf_hip.h: REFNERF_PREC_F16X2 range) */
-#ifdef REFNERF_SPLIT_RELU_MAX
-  const float x0 = fmaxf(s[2 * e], 0.0f), x1 = fmaxf(s[2 * e + 1], 0.0f);
-#else
-  const float x0 = (s[2 * e] < 0.0f) ? 0.0f : s[2 * e], x1 = (s[2 * e + 1] < 0.0f) ? 0.0f : s[2 * e + 1];
-#endif
-#ifdef REFNERF_SPLIT_DUMP
-  if (dbg) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int jj = 2 * e + u + ((lane & 16) ? 8 : 0);
-      dbg[(jj & 3) + 8 * (jj >> 2) + 4 * (lane >> 5)] = u ? x1 : x0;
-    }
-  }
-#endif
-  unsigned hi, lo;
-  split_pair_f16(x0, x1, hi, lo);
-  const v2uu r = __builtin_amdgcn_permlane16_swap(hi, lo, false, false);
-  f0[e] = r[0];
-  f1[e] = r[1];
-}
-__device__ __forceinline__ void pack_acc_split(const v16f &a, v4uu &f0, v4uu &f1, float *dbg = nullptr, int lane = 0) {
-  float s[8];
-  npk_totals(a, s);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) split_piece(s, e, f0, f1, dbg, lane);
-}
-
-/* spatial slice: [SREG0][SREG1] (+ [SLDS] for the skip layer) */
-template <typename MM, typename Hook = NoHook>
-__device__ __forceinline__ void sp_slice(Pipe &p, typename MM::v8 (&a)[AF], bool skip, const v4uu (&in)[16], const v4uu (&bn)[8], v16f &acc, Hook &&hook = Hook()) {
-  bf_chunk<MM, BF_SREG0, 0, true, true>(p, a, in, bn, acc, hook);
-  bf_chunk<MM, BF_SREG1, 0, false, true>(p, a, in, bn, acc);
-  if (skip) bf_chunk<MM, BF_SLDS, 0, false, true>(p, a, in, bn, acc);
-}
-/* One spatial layer.  The epilogue of slice ob - 1 (column sums, ReLU, hi / lo split, swaps: ~60 VALU instructions) is
- * SOFTWARE-PIPELINED into the first chunk of slice ob: one piece behind each of its first 12 MFMAs, on the other
- * accumulator tile -- all eight waves run the chunks in lockstep, so an epilogue between two slices would idle the matrix
- * pipe of every SIMD. */
-#ifndef REFNERF_SPLIT_PIPE
-#define REFNERF_SPLIT_PIPE 1
-#endif
-template <typename MM, bool LAYER0>
-__device__ __forceinline__ void sp_layer(Pipe &p, typename MM::v8 (&a)[AF], bool skip, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16], float *dbg = nullptr) {
-#if REFNERF_SPLIT_PIPE
-  v16f accs[2];
-  float s[8];
-#pragma unroll
-  for (int ob = 0; ob < 8; ++ob) {
-    v16f &acc = accs[ob & 1];
-    const v16f &prev = accs[(ob & 1) ^ 1];
-    auto hook = [&](int k) {
-      /* 12 pieces behind MFMAs 0..11: (total 2e, total 2e+1, split e) for e = 0..3 -- two totals live at a time, and the
-       * accumulator registers of the previous tile die pair by pair */
-      if (ob == 0 || k >= 12) return;
-      const int e = k / 3, r = k - 3 * e;
-      if (r < 2) s[2 * e + r] = npk_total1(prev, 2 * e + r);
-      else split_piece(s, e, out[2 * ob - 2], out[2 * ob - 1], dbg ? dbg + 32 * (ob - 1) : nullptr, p.lane);
-    };
-    if constexpr (LAYER0) bf_chunk<MM, BF_SLDS, 0, true, true>(p, a, in, bn, acc, hook);
-    else sp_slice<MM>(p, a, skip, in, bn, acc, hook);
-  }
-  pack_acc_split(accs[1], out[14], out[15], dbg ? dbg + 32 * 7 : nullptr, p.lane);
-  __builtin_amdgcn_sched_barrier(0);
-#else
-#pragma unroll
-  for (int ob = 0; ob < 8; ++ob) {
-    v16f acc;
-    if constexpr (LAYER0) bf_chunk<MM, BF_SLDS, 0, true, true>(p, a, in, bn, acc);
-    else sp_slice<MM>(p, a, skip, in, bn, acc);
-    pack_acc_split(acc, out[2 * ob], out[2 * ob + 1], dbg ? dbg + 32 * ob : nullptr, p.lane);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#endif
-}
-#if REFNERF_SPLIT16
 /* ---- the spatial section on v_mfma_f32_16x16x32_f16: three partial products into one accumulator (refnerf_layout.h) ---- */
 typedef _Float16 sq_v8 __attribute__((ext_vector_type(8)));
 constexpr int SQ_NF = 4;                         /* fragment ring: the four pieces of a k-step */
@@ -812,7 +700,6 @@ __device__ __forceinline__ void sq_layer(Pipe &p, sq_v8 (&fr)[SQ_NF], bool skip,
   for (int q = 0; q < 4; ++q) sq_epi_piece(accs[1], q, out[14], out[15]);
   __builtin_amdgcn_sched_barrier(0);
 }
-#endif
 
 /* directional layer of the split kernel: the plain layer on the split kernel's DMA schedule */
 template <typename MM, int KIND0, int REAL0>
@@ -864,13 +751,9 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
   p.src_end = nullptr;
   p.wbuf = WB;
   p.xp = Xb + (h * BT + col) * 16;
-  /* N-packed IPE planes: [k-group][plane (hi | lo)][128 columns = wave * 16 + sample][16 B] */
-#if REFNERF_SPLIT16
-  /* lane (b = lane / 16, n = lane % 16) reads k-group 4 s + b of k-step s: hi plane, the lo plane (BT / 2) * 16 bytes behind */
+  /* IPE planes of a run: [k-group][plane (hi | lo)][128 columns = wave * 16 + sample][16 B].  Lane (b = lane / 16, n = lane % 16)
+   * reads k-group 4 s + b of k-step s: hi plane, the lo plane (BT / 2) * 16 bytes behind */
   p.xps = Xb + ((lane >> 4) * BT + wave * 16 + (lane & 15)) * 16;
-#else
-  p.xps = Xb + (h * BT + (n >> 4) * (BT / 2) + wave * 16 + (n & 15)) * 16;
-#endif
   p.seq = 0;
   p.cur_off = 0; p.nxt_off = BF_CHUNK_BYTES; p.fil_off = 2 * BF_CHUNK_BYTES;
   p.dma_left = n_pass * SPPACKED.chunks_per_pass;
@@ -907,18 +790,12 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
 #ifndef REFNERF_BF_NOPRIO
   if (wave >= BF_NW / 2) __builtin_amdgcn_s_setprio(1);
 #endif
-  v4uu R0[16], R1[16], bn[8];
-#if REFNERF_SPLIT16
+  v4uu R0[16], R1[16];
   /* one fragment ring for both sections: four pieces for the 16x16x32 spatial chunks; the plain directional chunks use its
    * first AF entries (the ring always holds the leading pieces of the chunk about to run) */
   sq_v8 ar[SQ_NF];
 #pragma unroll
   for (int d = 0; d < SQ_NF; ++d) ar[d] = lds_frag<MM>(WB + 1024 + lane * 16 + d * 1024);
-#else
-  v8mm ar[AF];
-#pragma unroll
-  for (int d = 0; d < AF; ++d) ar[d] = lds_frag<MM>(WB + 1024 + lane * 16 + d * 1024);
-#endif
 
   for (int pass0 = 0; pass0 < n_tot; pass0 += BT) {
     int lane_v = lane;
@@ -967,222 +844,169 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
       sample_heads<false>(cfg, HD[0 * BT + ci], gp, HD[4 * BT + ci], raw_dif, raw_tint, v, sh);
     };
 
+    /* P3 of a run: heads.  Bottleneck slices: hi weights over the split input -> packed f16.  Run 0 keeps them (bn0: the only
+     * registers that live across run 1); run 1 merges the two runs with one v_permlane16_swap per dword into the 32-sample B
+     * fragments of the directional trunk (refnerf_layout.h: the bottleneck k-steps of dir.0 / dir.4 are packed in the order
+     * this leaves).  Scalar block: all three products, to LDS HD.  (Run 1's heads sit behind the run loop, not in it: what a
+     * loop iteration assigns and a later one reads is live through the whole loop body for the register allocator -- with the
+     * merged fragments assigned inside, 16 registers were parked in scratch across every trunk.) */
+    v4uu bn0[4];
+    auto heads = [&](auto RUN, v4uu (&bn)[8]) {
+      constexpr int run = decltype(RUN)::value;
+      SqAcc acc;
+#pragma unroll
+      for (int ob = 0; ob < 5; ++ob) {
+        if (ob < 4) {
+          sq_chunk<SQ_BN, true>(p, ar, R1, acc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned pk = e == 0 ? pk_f16(acc.t0[0], acc.t0[1]) : (e == 1 ? pk_f16(acc.t0[2], acc.t0[3])
+                              : (e == 2 ? pk_f16(acc.t1[0], acc.t1[1]) : pk_f16(acc.t1[2], acc.t1[3])));
+            if (run == 0) bn0[ob][e] = pk;
+            else {
+              const v2uu r = __builtin_amdgcn_permlane16_swap(bn0[ob][e], pk, false, false);
+              bn[2 * ob][e] = r[0];
+              bn[2 * ob + 1][e] = r[1];
+            }
+          }
+        } else {
+          sq_chunk<SQ_SC, true>(p, ar, R1, acc);
+          const int bq = lane_v >> 4;
+          int csl = wave * 32 + 16 * run + (lane_v & 15) + 4 * bq * BT;   /* one laundered base: rows are immediate offsets from it */
+          asm volatile("" : "+v"(csl));
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (4 * bq + i < HD_ROWS) HD[i * BT + csl] = acc.t0[i];
+        }
+      }
+      wave_sync();
+    };
+    typedef std::integral_constant<int, 0> Run0;
+    typedef std::integral_constant<int, 1> Run1;
+
 #pragma unroll 1
-    for (int phase = 0; phase < 3; ++phase) {
+    for (int phase = 0; phase < 2; ++phase) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) { R0[e] = (v4uu){0, 0, 0, 0}; R1[e] = (v4uu){0, 0, 0, 0}; }
+      {
+      /* P1 of run `phase`: the wave's samples 16 * phase + (lane & 15); four lanes per sample, each 24 of the 96 IPE
+       * features: block hb = sin / "cos", degrees 8 qq .. 8 qq + 7 -- k-groups 6 hb + 3 qq + q, q = 0..2 */
+      const int i16 = lane_v & 15, part = lane_v >> 4;
+      const int hb = part >> 1, qq = part & 1;
+      const int cs = wave * 32 + 16 * phase + i16;          /* pass column of this lane's sample */
+      const int gs = pass0 + cs;
+      const int rls = gs / N, sis = gs - rls * N;
+      const bool vs = (gs < n_tot) && (ray0 + rls < A.R);
+      float o[3], d[3];
+      const float *ry = RY + (vs ? rls : 0) * 12;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { o[i] = ry[i]; d[i] = ry[3 + i]; }
+      const float radius = ry[9];
+      const float *td = TD + (vs ? rls : 0) * (N + 1);
+      const float t0 = td[vs ? sis : 0], t1 = td[vs ? sis + 1 : 1];
+      float lm[3], lv[3];
+      cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
+      if (cfg.disable_integration) { lv[0] = 0.0f; lv[1] = 0.0f; lv[2] = 0.0f; }        /* models.py:228-231 */
+      char *xw = Xb + (wave * 16 + i16) * 16;
+      RN_STAMPW(A, 17);
+      /* two features per trip (one dword of the hi plane, one of the lo plane): the libm sine is long, keep ONE copy pair */
+#pragma clang loop unroll(disable)
+      for (int t = 0; t < 12; ++t) {
+        unsigned whi, wlo;
+        {
+          float f[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int kk = 2 * t + u;                  /* 3 * (j - 8 qq) + b */
+            const int jj = kk / 3, b3 = kk - 3 * jj;
+            const float m = b3 == 0 ? lm[0] : (b3 == 1 ? lm[1] : lm[2]);
+            const float v = b3 == 0 ? lv[0] : (b3 == 1 ? lv[1] : lv[2]);
+            f[u] = ipe_feature_split(m, v, 8 * qq + jj, hb);
+          }
+          split_pair_f16(f[0], f[1], whi, wlo);
+        }
+        char *dst = xw + (6 * hb + 3 * qq + (t >> 2)) * BT * 16 + (t & 3) * 4;
+        *reinterpret_cast<unsigned *>(dst) = whi;
+        *reinterpret_cast<unsigned *>(dst + (BT / 2) * 16) = wlo;
+      }
+      }
+      RN_STAMPW(A, 18);
+      wave_sync();
+      RN_STAMPW(A, 3 + phase * 4);
+      /* the directional chunks keep AF fragments ahead: fetch the rest of the first spatial chunk's k-step (complete
+       * since the rendezvous in the middle of the chunk before it) */
       if (phase == 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bn[e] = (v4uu){0, 0, 0, 0};
+        for (int d = AF; d < SQ_NF; ++d) ar[d] = lds_frag<MM>(p.wbuf + p.cur_off + 1024 + lane_v * 16 + d * 1024);
       }
-      if (phase < 2) {
-        /* P1 of run `phase`: the wave's samples 16 * phase + (lane & 15); four lanes per sample, each 24 of the 96 IPE
-         * features: block hb = sin / "cos", degrees 8 qq .. 8 qq + 7 -- k-groups 6 hb + 3 qq + q, q = 0..2 */
-        const int i16 = lane_v & 15, part = lane_v >> 4;
-        const int hb = part >> 1, qq = part & 1;
-        const int cs = wave * 32 + 16 * phase + i16;          /* pass column of this lane's sample */
-        const int gs = pass0 + cs;
-        const int rls = gs / N, sis = gs - rls * N;
-        const bool vs = (gs < n_tot) && (ray0 + rls < A.R);
-        float o[3], d[3];
-        const float *ry = RY + (vs ? rls : 0) * 12;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { o[i] = ry[i]; d[i] = ry[3 + i]; }
-        const float radius = ry[9];
-        const float *td = TD + (vs ? rls : 0) * (N + 1);
-        const float t0 = td[vs ? sis : 0], t1 = td[vs ? sis + 1 : 1];
-        float lm[3], lv[3];
-        cast_sample(o, d, radius, t0, t1, cfg.ray_shape, lm, lv);
-        if (cfg.disable_integration) { lv[0] = 0.0f; lv[1] = 0.0f; lv[2] = 0.0f; }        /* models.py:228-231 */
-        char *xw = Xb + (wave * 16 + i16) * 16;
-        RN_STAMPW(A, 17);
-        /* two features per trip (one dword of the hi plane, one of the lo plane): the libm sine is long, keep ONE copy pair */
-#pragma clang loop unroll(disable)
-        for (int t = 0; t < 12; ++t) {
-          unsigned whi, wlo;
-          {
-            float f[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int kk = 2 * t + u;                  /* 3 * (j - 8 qq) + b */
-              const int jj = kk / 3, b3 = kk - 3 * jj;
-              const float m = b3 == 0 ? lm[0] : (b3 == 1 ? lm[1] : lm[2]);
-              const float v = b3 == 0 ? lv[0] : (b3 == 1 ? lv[1] : lv[2]);
-              f[u] = ipe_feature_split(m, v, 8 * qq + jj, hb);
-            }
-            split_pair_f16(f[0], f[1], whi, wlo);
-          }
-          char *dst = xw + (6 * hb + 3 * qq + (t >> 2)) * BT * 16 + (t & 3) * 4;
-          *reinterpret_cast<unsigned *>(dst) = whi;
-          *reinterpret_cast<unsigned *>(dst + (BT / 2) * 16) = wlo;
-#ifdef REFNERF_SPLIT_DUMP
-          if (A.dbg && vs) {
-            const MM::v2 vh = __builtin_bit_cast(MM::v2, whi), vl = __builtin_bit_cast(MM::v2, wlo);
-            float *dd = A.dbg + ((size_t)(ray0 + rls) * N + sis) * SPLIT_DUMP_STRIDE + 48 * hb + 24 * qq + 2 * t;
-            const mm_t a0 = vh[0], a1 = vh[1], b0 = vl[0], b1 = vl[1];
-            dd[0] = (float)a0 + (float)b0;
-            dd[1] = (float)a1 + (float)b1;
-          }
-#endif
-        }
-#ifdef REFNERF_SPLIT_DUMP
-        float *dbgs = (A.dbg && vs) ? A.dbg + ((size_t)(ray0 + rls) * N + sis) * SPLIT_DUMP_STRIDE + 96 : nullptr;
-#else
-        float *dbgs = nullptr;
-#endif
-        RN_STAMPW(A, 18);
-        wave_sync();
-        RN_STAMPW(A, 3 + phase * 4);
-#if REFNERF_SPLIT16
-        (void)dbgs;
-        /* the directional chunks keep AF fragments ahead: fetch the rest of the first spatial chunk's k-step (complete
-         * since the rendezvous in the middle of the chunk before it) */
-        if (phase == 0) {
-#pragma unroll
-          for (int d = AF; d < SQ_NF; ++d) ar[d] = lds_frag<MM>(p.wbuf + p.cur_off + 1024 + lane_v * 16 + d * 1024);
-        }
-        sq_layer<true>(p, ar, false, R0, R0);
-        RN_STAMPW(A, 4 + phase * 4);
+      sq_layer<true>(p, ar, false, R0, R0);
+      RN_STAMPW(A, 4 + phase * 4);
 #pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
-          sq_layer<false>(p, ar, it == 2, R0, R1);
-          if (it < 3) sq_layer<false>(p, ar, false, R1, R0);
-        }
-        RN_STAMPW(A, 5 + phase * 4);
-        /* P3: heads.  Bottleneck slices: hi weights over the split input, kept as packed f16 (run 0) and merged with run 1's
-         * into the 32-sample B fragments of the directional trunk (refnerf_layout.h: the bottleneck k-steps of dir.0 / dir.4 are
-         * packed in the order this leaves).  Scalar block: all three products, to LDS HD. */
-#pragma unroll
-        for (int ob = 0; ob < 5; ++ob) {
-          SqAcc acc;
-          if (ob < 4) {
-            sq_chunk<SQ_BN, true>(p, ar, R1, acc);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const unsigned pk = e == 0 ? pk_f16(acc.t0[0], acc.t0[1]) : (e == 1 ? pk_f16(acc.t0[2], acc.t0[3])
-                                : (e == 2 ? pk_f16(acc.t1[0], acc.t1[1]) : pk_f16(acc.t1[2], acc.t1[3])));
-              if (phase == 0) bn[2 * ob][e] = pk;
-              else {
-                const v2uu r = __builtin_amdgcn_permlane16_swap(bn[2 * ob][e], pk, false, false);
-                bn[2 * ob][e] = r[0];
-                bn[2 * ob + 1][e] = r[1];
-              }
-            }
-          } else {
-            sq_chunk<SQ_SC, true>(p, ar, R1, acc);
-            const int bq = lane_v >> 4;
-            int csl = cs + 4 * bq * BT;                  /* one laundered base: rows are immediate offsets from it */
-            asm volatile("" : "+v"(csl));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (4 * bq + i < HD_ROWS) HD[i * BT + csl] = acc.t0[i];
-          }
-        }
-        wave_sync();
-        RN_STAMPW(A, 6 + phase * 4);
-#else
-        /* spatial trunk on the N-packed operands */
-        sp_layer<MM, true>(p, ar, false, R0, bn, R0, dbgs);
-        RN_STAMPW(A, 4 + phase * 4);
-#pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
-          sp_layer<MM, false>(p, ar, it == 2, R0, bn, R1, dbgs ? dbgs + 256 * (2 * it + 1) : nullptr);
-          if (it < 3) sp_layer<MM, false>(p, ar, false, R1, bn, R0, dbgs ? dbgs + 256 * (2 * it + 2) : nullptr);
-        }
-        RN_STAMPW(A, 5 + phase * 4);
-        /* P3: heads.  Bottleneck blocks: hi weights over the N-packed input; kept as packed f16 (run 0), merged with
-         * run 1's into the plain 32-sample B fragments of the directional trunk.  Scalar block: split, to LDS HD. */
-#pragma unroll
-        for (int ob = 0; ob < 5; ++ob) {
-          v16f acc;
-          float s[8];
-          if (ob < 4) {
-            bf_chunk<MM, BF_REG, 0, true, true, true>(p, ar, R1, bn, acc);
-            npk_totals(acc, s);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const unsigned pk = pk_f16(s[2 * e], s[2 * e + 1]);
-              if (phase == 0) bn[2 * ob][e] = pk;
-              else {
-                const v2uu r = __builtin_amdgcn_permlane16_swap(bn[2 * ob][e], pk, false, false);
-                bn[2 * ob][e] = r[0];
-                bn[2 * ob + 1][e] = r[1];
-              }
-            }
-          } else {
-            sp_slice<MM>(p, ar, false, R1, bn, acc);
-            npk_totals(acc, s);
-            if ((lane_v & 16) == 0) {
-              int csl = cs + 4 * h * BT;                 /* one laundered base: rows are immediate offsets from it */
-              asm volatile("" : "+v"(csl));
-#pragma unroll
-              for (int rr = 0; rr < 8; ++rr) {
-                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * h;
-                if (row < HD_ROWS) HD[((rr & 3) + 8 * (rr >> 2)) * BT + csl] = s[rr];
-#ifdef REFNERF_SPLIT_DUMP
-                if (row < HD_ROWS && dbgs) dbgs[8 * 256 + row] = s[rr];
-#endif
-              }
-            }
-          }
-        }
-        wave_sync();
-        RN_STAMPW(A, 6 + phase * 4);
-#endif
-      } else {
-        /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
-        char *xs = Xb + col * 16;
-        {
-          SampleHeads sh;
-          load_heads(sh);
-          float ide[40];
-#pragma unroll
-          for (int q = 36; q < 40; ++q) ide[q] = 0.0f;
-          if (cfg.dir_enc == REFNERF_DIRENC_POSENC) posenc_eval<false, true>(sh.refd[0], sh.refd[1], sh.refd[2], h, [&](int q, float val) { ide[q] = val; });
-          else ide_eval<false>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { ide[q] = val; });
-          if (h == 0) ide[36] = sh.dot;
-#pragma unroll
-          for (int q = 0; q < 5; ++q) {
-            v8mm pk;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pk[e] = (mm_t)ide[q * 8 + e];
-            *reinterpret_cast<v8mm *>(xs + (5 * h + q) * BT * 16) = pk;
-          }
-        }
-        wave_sync();
-        RN_STAMPW(A, 11);
-#if REFNERF_SPLIT16
-        v8mm (&ad)[AF] = reinterpret_cast<v8mm (&)[AF]>(ar);     /* the ring's first AF entries */
-#else
-        v8mm (&ad)[AF] = ar;
-#endif
-        dir_layer<MM, BF_BNLDS, BF_DIR_REAL_KS>(p, ad, 0, R0, bn, R0);
-        RN_STAMPW(A, 12);
-#pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
-          dir_layer<MM, BF_REG, 0>(p, ad, (it == 2) ? 2 : 0, R0, bn, R1);
-          if (it < 3) dir_layer<MM, BF_REG, 0>(p, ad, 0, R1, bn, R0);
-        }
-        RN_STAMPW(A, 13);
-        /* rgb: one slice */
-        v16f acc;
-        bf_chunk<MM, BF_REG, 0, true, true>(p, ad, R1, bn, acc);
-        float raw_rgb[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n, 64);
-        int g_w, rl_w; bool valid;
-        locate(g_w, rl_w, valid);
-        int lane_w = lane, pass_w = pass0;
-        asm volatile("" : "+v"(lane_w), "+s"(pass_w));
-        if (valid && h == 0) {                                                            /* P6 */
-          SampleHeads sh;
-          load_heads(sh);
-          colour_store<false, NPS_EVAL, PSM, true>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
-        }
-        wave_sync();
-        history_flush<NPS_EVAL, PSM>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);
-        RN_STAMPW(A, 14);
+      for (int it = 0; it < 4; ++it) {
+        sq_layer<false>(p, ar, it == 2, R0, R1);
+        if (it < 3) sq_layer<false>(p, ar, false, R1, R0);
       }
+      RN_STAMPW(A, 5 + phase * 4);
+      if (phase == 0) {
+        v4uu none[8];
+        heads(Run0(), none);
+        RN_STAMPW(A, 6);
+      }
+    }
+    v4uu bn[8];
+    heads(Run1(), bn);
+    RN_STAMPW(A, 10);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { R0[e] = (v4uu){0, 0, 0, 0}; R1[e] = (v4uu){0, 0, 0, 0}; }
+    {
+    /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
+    char *xs = Xb + col * 16;
+    {
+      SampleHeads sh;
+      load_heads(sh);
+      float ide[40];
+#pragma unroll
+      for (int q = 36; q < 40; ++q) ide[q] = 0.0f;
+      if (cfg.dir_enc == REFNERF_DIRENC_POSENC) posenc_eval<false, true>(sh.refd[0], sh.refd[1], sh.refd[2], h, [&](int q, float val) { ide[q] = val; });
+      else ide_eval<false>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { ide[q] = val; });
+      if (h == 0) ide[36] = sh.dot;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        v8mm pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk[e] = (mm_t)ide[q * 8 + e];
+        *reinterpret_cast<v8mm *>(xs + (5 * h + q) * BT * 16) = pk;
+      }
+    }
+    wave_sync();
+    RN_STAMPW(A, 11);
+    v8mm (&ad)[AF] = reinterpret_cast<v8mm (&)[AF]>(ar);     /* the ring's first AF entries */
+    dir_layer<MM, BF_BNLDS, BF_DIR_REAL_KS>(p, ad, 0, R0, bn, R0);
+    RN_STAMPW(A, 12);
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+      dir_layer<MM, BF_REG, 0>(p, ad, (it == 2) ? 2 : 0, R0, bn, R1);
+      if (it < 3) dir_layer<MM, BF_REG, 0>(p, ad, 0, R1, bn, R0);
+    }
+    RN_STAMPW(A, 13);
+    /* rgb: one slice */
+    v16f acc;
+    bf_chunk<MM, BF_REG, 0, true, true>(p, ad, R1, bn, acc);
+    float raw_rgb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n, 64);
+    int g_w, rl_w; bool valid;
+    locate(g_w, rl_w, valid);
+    int lane_w = lane, pass_w = pass0;
+    asm volatile("" : "+v"(lane_w), "+s"(pass_w));
+    if (valid && h == 0) {                                                            /* P6 */
+      SampleHeads sh;
+      load_heads(sh);
+      colour_store<false, NPS_EVAL, PSM, true>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
+    }
+    wave_sync();
+    history_flush<NPS_EVAL, PSM>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);
+    RN_STAMPW(A, 14);
     }
     __builtin_amdgcn_wave_barrier();
     pass_epilogue();

@@ -60,13 +60,7 @@ struct LevelArgs {
   float *act;
   long long act_pitch;
   int ring_off;           /* bf16 chains: byte offset of the shared weight-stream ring (RING_BYTES) in dynamic LDS */
-#ifdef REFNERF_SPLIT_DUMP
-  float *dbg;             /* debug build only: [R*N][SPLIT_DUMP_STRIDE] what the split kernel's spatial trunk saw / produced */
-#endif
 };
-#ifdef REFNERF_SPLIT_DUMP
-constexpr int SPLIT_DUMP_STRIDE = 96 + 8 * 256 + 16;
-#endif
 
 #define RN_STAMP(A, slot) do { asm volatile("; RNMARK " #slot); if ((A).prof && blockIdx.x == (gridDim.x >> 1) && (threadIdx.x & 63) == 0) (A).prof[(threadIdx.x >> 6) * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 
