@@ -599,8 +599,14 @@ template <int KIND> constexpr int sq_release(int j) {
 }
 /* One chunk.  `fr` = the piece ring: on entry pieces 0..3 of this chunk, on exit those of the next one.  `in`: the layer input
  * as [H(s) L(s)] x 8 k-steps (SQ_X: from the LDS planes instead).  hook(j): caller's VALU work behind MFMA j. */
-template <int KIND, bool FIRST, typename Hook = NoHook>
-__device__ __forceinline__ void sq_chunk(Pipe &p, sq_v8 (&fr)[SQ_NF], const v4uu (&in)[16], SqAcc &acc, Hook &&hook = Hook()) {
+/* REFNERF_SQ_PREBIAS: a chunk that opens a slice finds its bias already in `acc` -- fetched by the chunk before it (PRE: this
+ * chunk fetches the bias piece of the NEXT chunk into `nacc` right behind its rendezvous) -- instead of loading it and waiting
+ * a full LDS round trip in front of its first MFMA */
+#ifndef REFNERF_SQ_PREBIAS
+#define REFNERF_SQ_PREBIAS 1
+#endif
+template <int KIND, bool FIRST, bool PRE, typename Hook = NoHook>
+__device__ __forceinline__ void sq_chunk(Pipe &p, sq_v8 (&fr)[SQ_NF], const v4uu (&in)[16], SqAcc &acc, SqAcc &nacc, Hook &&hook = Hook()) {
   constexpr int NM = sq_nm<KIND>(), NP = sq_np<KIND>();
   constexpr int RDV = NM / 2 - 1;
   const char *w = p.wbuf + p.cur_off;
@@ -608,7 +614,7 @@ __device__ __forceinline__ void sq_chunk(Pipe &p, sq_v8 (&fr)[SQ_NF], const v4uu
   const char *nxt = p.wbuf + p.nxt_off + 1024 + p.lane * 16;
   sq_v8 xb[2];
   if (KIND == SQ_X) { xb[0] = lds_frag<MmF16>(p.xps); xb[1] = lds_frag<MmF16>(p.xps + (BT / 2) * 16); }
-  if (FIRST) {
+  if (FIRST && !REFNERF_SQ_PREBIAS) {
     const v4f *bp = reinterpret_cast<const v4f *>(w + (p.lane >> 4) * 16);      /* bias piece [T][b][4] */
     acc.t0 = bp[0];
     acc.t1 = bp[4];
@@ -616,7 +622,6 @@ __device__ __forceinline__ void sq_chunk(Pipe &p, sq_v8 (&fr)[SQ_NF], const v4uu
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < NM; ++j) {
-    constexpr int dummy = 0; (void)dummy;
     const int sl = sq_step<KIND>(j);
     sq_v8 b;
     if (KIND == SQ_X) b = xb[sq_lo<KIND>(j) ? 1 : 0];
@@ -649,6 +654,11 @@ __device__ __forceinline__ void sq_chunk(Pipe &p, sq_v8 (&fr)[SQ_NF], const v4uu
       __syncthreads();
 #endif
       issue_chunk<true>(p, p.fil_off, REFNERF_BF_SPREAD ? 0 : -1);
+      if (PRE && REFNERF_SQ_PREBIAS) {
+        const v4f *bp = reinterpret_cast<const v4f *>(p.wbuf + p.nxt_off + (p.lane >> 4) * 16);
+        nacc.t0 = bp[0];
+        nacc.t1 = bp[4];
+      }
     }
     if (REFNERF_BF_SPREAD) {
       if (j == RDV + 4) issue_chunk<true>(p, p.fil_off, 1);
@@ -679,26 +689,34 @@ __device__ __forceinline__ void sq_epi_piece(const SqAcc &a, int q, v4uu &oh, v4
 /* One spatial layer: slice ob's epilogue rides behind the first MFMAs of slice ob + 1 (all eight waves run the chunks in
  * lockstep: VALU work between two slices idles the matrix pipe of every SIMD) */
 template <bool LAYER0>
-__device__ __forceinline__ void sq_layer(Pipe &p, sq_v8 (&fr)[SQ_NF], bool skip, const v4uu (&in)[16], v4uu (&out)[16]) {
-  SqAcc accs[2];
+__device__ __forceinline__ void sq_layer(Pipe &p, sq_v8 (&fr)[SQ_NF], SqAcc (&accs)[2], bool skip, const v4uu (&in)[16], v4uu (&out)[16]) {
+  /* slice ob accumulates in accs[(ob + 1) & 1]: on entry accs[1] holds the bias of slice 0, on exit that of the first slice
+   * behind this layer (REFNERF_SQ_PREBIAS) */
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) {
-    SqAcc &acc = accs[ob & 1];
-    const SqAcc &prev = accs[(ob & 1) ^ 1];
+    SqAcc &acc = accs[(ob + 1) & 1];
+    SqAcc &prev = accs[ob & 1];
     auto hook = [&](int j) {
       if (ob == 0 || j >= 8 || (j & 1)) return;
       sq_epi_piece(prev, j >> 1, out[2 * ob - 2], out[2 * ob - 1]);
     };
-    if constexpr (LAYER0) sq_chunk<SQ_X, true>(p, fr, in, acc, hook);
+    if constexpr (LAYER0) sq_chunk<SQ_X, true, true>(p, fr, in, acc, prev, hook);
     else {
-      sq_chunk<SQ_A, true>(p, fr, in, acc, hook);
-      sq_chunk<SQ_B, false>(p, fr, in, acc);
-      if (skip) sq_chunk<SQ_X, false>(p, fr, in, acc);
+      sq_chunk<SQ_A, true, false>(p, fr, in, acc, prev, hook);
+      sq_chunk<SQ_B, false, true>(p, fr, in, acc, prev);
+      if (skip) sq_chunk<SQ_X, false, true>(p, fr, in, acc, prev);
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) sq_epi_piece(accs[1], q, out[14], out[15]);
+  for (int q = 0; q < 4; ++q) sq_epi_piece(accs[0], q, out[14], out[15]);
   __builtin_amdgcn_sched_barrier(0);
+}
+/* the bias piece of the chunk in the `cur` slot (the first chunk of a run / of the heads: nothing ran ahead to fetch it) */
+__device__ __forceinline__ void sq_bias_now(const Pipe &p, SqAcc &acc) {
+  if (!REFNERF_SQ_PREBIAS) return;
+  const v4f *bp = reinterpret_cast<const v4f *>(p.wbuf + p.cur_off + (p.lane >> 4) * 16);
+  acc.t0 = bp[0];
+  acc.t1 = bp[4];
 }
 
 /* directional layer of the split kernel: the plain layer on the split kernel's DMA schedule */
@@ -853,11 +871,13 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
     v4uu bn0[4];
     auto heads = [&](auto RUN, v4uu (&bn)[8]) {
       constexpr int run = decltype(RUN)::value;
-      SqAcc acc;
+      SqAcc ha[2];
+      sq_bias_now(p, ha[1]);
 #pragma unroll
       for (int ob = 0; ob < 5; ++ob) {
+        SqAcc &acc = ha[(ob + 1) & 1];
         if (ob < 4) {
-          sq_chunk<SQ_BN, true>(p, ar, R1, acc);
+          sq_chunk<SQ_BN, true, true>(p, ar, R1, acc, ha[ob & 1]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const unsigned pk = e == 0 ? pk_f16(acc.t0[0], acc.t0[1]) : (e == 1 ? pk_f16(acc.t0[2], acc.t0[3])
@@ -870,7 +890,7 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
             }
           }
         } else {
-          sq_chunk<SQ_SC, true>(p, ar, R1, acc);
+          sq_chunk<SQ_SC, true, false>(p, ar, R1, acc, ha[ob & 1]);
           const int bq = lane_v >> 4;
           int csl = wave * 32 + 16 * run + (lane_v & 15) + 4 * bq * BT;   /* one laundered base: rows are immediate offsets from it */
           asm volatile("" : "+v"(csl));
@@ -939,12 +959,14 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
 #pragma unroll
         for (int d = AF; d < SQ_NF; ++d) ar[d] = lds_frag<MM>(p.wbuf + p.cur_off + 1024 + lane_v * 16 + d * 1024);
       }
-      sq_layer<true>(p, ar, false, R0, R0);
+      SqAcc accs[2];
+      sq_bias_now(p, accs[1]);
+      sq_layer<true>(p, ar, accs, false, R0, R0);
       RN_STAMPW(A, 4 + phase * 4);
 #pragma unroll 1
       for (int it = 0; it < 4; ++it) {
-        sq_layer<false>(p, ar, it == 2, R0, R1);
-        if (it < 3) sq_layer<false>(p, ar, false, R1, R0);
+        sq_layer<false>(p, ar, accs, it == 2, R0, R1);
+        if (it < 3) sq_layer<false>(p, ar, accs, false, R1, R0);
       }
       RN_STAMPW(A, 5 + phase * 4);
       if (phase == 0) {
