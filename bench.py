@@ -40,7 +40,7 @@ EVAL_MODES = ("f32", "f16x2", "bf16", "f16")
 MODE_NOTES = {
     "f16x2": "parity-grade 16-bit mode of record: split-operand f16 MFMA (hi + lo halves in the spatial trunk and the density head, "
              "plain f16 directional trunk), fp32 accumulate, fp32 resampler / encodings / compositing; <= 1e-4 RGB vs the reference "
-             "also on trained-like weights; executes 2.35x the algorithmic MFMAs (priced at the algorithmic FLOPs here)",
+             "also on trained-like weights; three partial products on v_mfma_f32_16x16x32_f16: 1.5x the algorithmic matrix cycles (priced at the algorithmic FLOPs here)",
     "f32": "strict parity mode: exact fp32 MFMA fma chains",
     "bf16": "throughput mode: bf16 operands, hardware transcendentals; within 1e-4 on random-init networks only (5e-2 on trained-like weights)",
     "f16": "throughput mode: f16 operands, hardware transcendentals; within 1e-4 on random-init networks only (1e-2 on trained-like weights)",

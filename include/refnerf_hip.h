@@ -48,11 +48,12 @@ enum {
                             with 11 instead of 8 significand bits -- 8-10x closer to REFNERF_PREC_F32 at ~3 % lower
                             throughput; hidden activations must stay below 65504.  refnerf_level_forward only. */
   REFNERF_PREC_F16X2 = 3 /* split-operand f16: in the spatial trunk and the density / scalar head block BOTH operands are
-                            hi + lo pairs of IEEE halves (22 significand bits; all four partial products on
-                            v_mfma_f32_32x32x16_f16, fp32 accumulate), the directional trunk is plain f16; resampler,
+                            hi + lo pairs of IEEE halves (22 significand bits; the partial products hi*hi + lo*hi + hi*lo
+                            on v_mfma_f32_16x16x32_f16, fp32 accumulate; lo*lo = 2^-22 of a product is dropped), the
+                            directional trunk is plain f16; resampler,
                             encodings, activations and compositing are the fp32 parity code.  The 16-bit mode that holds
                             the reference's fp32 nn.Linear arithmetic (internal/models.py:576-580, 686-700) to 1e-4 RGB
-                            on trained weights; ~2.35x the MFMAs of REFNERF_PREC_F16.  Range: the hi halves are IEEE
+                            on trained weights; ~1.5x the matrix cycles of REFNERF_PREC_F16.  Range: the hi halves are IEEE
                             halves, so weights and hidden activations must stay below 65504 in magnitude (a trained
                             Ref-NeRF's reach ~1e2; checked up to 8e3: 1e-6).  Beyond it a unit becomes hi = inf, lo = -inf, the
                             next layer's accumulators NaN; the ReLUs of the split kernels (inference, training chains, general
