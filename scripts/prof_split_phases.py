@@ -12,7 +12,7 @@ from test_hip_parity import dev_rays
 dev = "cuda:0"
 prec = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 P = synthetic.make_params(0, 0.05, 20.0)
-R = 4096
+R = int(os.environ.get("REFNERF_PROF_RAYS", "4096"))   # fewer rays = fewer busy CUs (R / 4 workgroups at 128 samples)
 rays = synthetic.blender_rays(R, seed=1, center_frac=0.5)
 packed = _hip.pack_weights(torch.tensor(P, device=dev), precision=prec)
 r = dev_rays(rays)
