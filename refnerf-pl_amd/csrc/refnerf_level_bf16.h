@@ -87,7 +87,7 @@ struct Pipe {
   const char *src_end;   /* end of one pass worth of chunks (wrap point) for this lane */
   char *wbuf;        /* LDS ring base (3 slots) */
   const char *xp;    /* LDS encodings, pre-offset to this lane's B fragment (sample n, half h) */
-  const char *xps;   /* split mode: the same for the N-packed IPE planes (lanes 0-15 hi, 16-31 lo of sample n & 15) */
+  const char *xps;   /* split mode: this lane's B fragment in the IPE planes of a run (hi plane; the lo plane (BT / 2) * 16 bytes behind) */
   int seq;           /* split mode: chunks issued so far in this pass (the spatial section is streamed twice) */
   int cur_off, nxt_off, fil_off;   /* ring slots: being consumed / landed next / free */
   int dma_left;      /* chunks still to be DMA'd by this workgroup */
@@ -548,16 +548,17 @@ __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16_ring(const LevelArg
  * REFNERF_PREC_F16X2 -- the parity-grade 16-bit mode (split operands, refnerf_layout.h "split-f16 operand image").
  *
  * Same skeleton as level_fwd_mm (8 waves, LDS-DMA chunk ring, one rendezvous per chunk, activations in registers), but
- *   * the spatial trunk runs TWICE per pass on 16 samples per wave with N-packed B operands [hi x16 | lo x16]: two MFMAs
- *     (W_hi, W_lo fragments) per k-step into one accumulator = all four partial products, fp32 accumulate; the epilogue
- *     adds the two column halves (v_permlane16_swap), applies ReLU in fp32, splits the result into hi + lo halves again
- *     and swaps them back into the N-packed layout -- 22 significand bits end to end;
+ *   * the spatial trunk runs TWICE per pass on 16 samples per wave, on v_mfma_f32_16x16x32_f16: a layer's input is an H and
+ *     an L fragment set (hi / lo halves of 8 k-steps x 32 features), and W_hi H + W_lo H + W_hi L accumulate into the two
+ *     16-row tiles of a 32-row slice (fp32; lo x lo = 2^-22 of a product is dropped).  The 8 values a lane holds after a slice
+ *     are -- after ReLU and the hi / lo split -- its 8 B elements of the next layer's k-step: no cross-lane traffic in the
+ *     epilogue, the weight image carries the feature permutation (refnerf_layout.h) -- 22 significand bits end to end;
  *   * the scalar head block (density, grad_pred, roughness, diffuse, tint) likewise; the bottleneck takes W_hi only;
  *   * the directional trunk is the plain f16 trunk over all 32 samples (the two runs' bottlenecks are merged with one
- *     more v_permlane16_swap per dword);
+ *     v_permlane16_swap per dword);
  *   * everything outside the contractions is the fp32 parity code: bit-exact resampler (sequential CDF), libm-accurate
  *     encodings / activations / compositing.
- * MFMA count per 32 samples: 2 x 2080 + 1168 = 5328 against 2272 of the plain kernel (2.35x).
+ * MFMAs per wave and pass: 2 x 3128 of 16.5 cycles + 1100 of 32 = 138 k matrix cycles (plain kernel: 2272 x 32 = 73 k).
  * ===================================================================================================================== */
 typedef unsigned v2uu __attribute__((ext_vector_type(2)));
 
@@ -722,7 +723,7 @@ __device__ __forceinline__ void sq_bias_now(const Pipe &p, SqAcc &acc) {
 /* directional layer of the split kernel: the plain layer on the split kernel's DMA schedule */
 template <typename MM, int KIND0, int REAL0>
 __device__ __forceinline__ void dir_layer(Pipe &p, typename MM::v8 (&a)[AF], int second, const v4uu (&in)[16], const v4uu (&bn)[8], v4uu (&out)[16]) {
-  /* (pipelining this plain epilogue into the next slice as in sp_layer measured no gain: 105.6 k -> 104.6 k cycles) */
+  /* (pipelining this plain epilogue into the next slice as in sq_layer measured no gain: 105.6 k -> 104.6 k cycles) */
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) {
     v16f acc;
