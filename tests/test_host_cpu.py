@@ -33,6 +33,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert lib.refnerf_abi_version() == 9
     assert _hip.packed_weights_bytes(_hip.PREC_F32) > 4 * layout.NUM_PARAMS
+    # 17 KB chunks (+ 2 chunks of tail pad the ring may prefetch into): 150 for the plain 16-bit images, 206 for the split-f16 one
+    # (133 spatial + heads chunks on the 16x16x32 layout, streamed twice per pass, + 73 directional: refnerf_layout.h)
+    assert _hip.packed_weights_bytes(_hip.PREC_BF16) == _hip.packed_weights_bytes(_hip.PREC_F16) == 152 * 17408
+    assert _hip.packed_weights_bytes(_hip.PREC_F16X2) == 208 * 17408
     c = _hip.default_cfg()
     assert (c.n_samples, c.resample_padding, c.density_bias) == (128, pytest.approx(0.01), pytest.approx(0.5))
     assert C.sizeof(_hip.LevelCfg) == 100 and c.ipe_groups == 0 and _hip.lib().refnerf_packed_weights_bytes_basis(_hip.PREC_F32, 7) > 4 * _hip.NUM_PARAMS_EXT and c.dir_enc == _hip.DIRENC_IDE and c.raydist == 0 and c.disable_integration == 0 and c.wgrad_mode == _hip.WGRAD_BF16X3 and C.sizeof(_hip.LevelOut) == 23 * 8
