@@ -750,12 +750,16 @@ static int rays_per_wg(int N, int tile) {
 namespace {
 struct BwdPlan { long long S, pitch; int slices, k_per_slice; size_t act_bytes, delta_off, part_off, seed_off, cmin_off, total, act_ext_off, part_ext_off; };
 /* groups > 1 (general IPE basis): the tail matrix of the groups' IPE features behind ACT, the tail's split-K partials behind the seeds */
+/* split-K slices of the weight-gradient GEMMs (one PART image of NUM_PARAMS floats each, reduced in a fixed order) */
+#ifndef REFNERF_MAX_SLICES
+#define REFNERF_MAX_SLICES 32
+#endif
 BwdPlan bwd_plan(int R, int N, int groups = 0) {
   BwdPlan p;
   p.S = (long long)R * N;
   p.pitch = (p.S + 127) / 128 * 128;
   long long sl = (p.S + 2047) / 2048;
-  p.slices = (int)(sl < 1 ? 1 : (sl > 32 ? 32 : sl));
+  p.slices = (int)(sl < 1 ? 1 : (sl > REFNERF_MAX_SLICES ? REFNERF_MAX_SLICES : sl));
   long long per = (p.S + p.slices - 1) / p.slices;
   p.k_per_slice = (int)((per + rn::WG_KT - 1) / rn::WG_KT * rn::WG_KT);
   p.act_bytes = sizeof(float) * (size_t)rn::ACT_ALLOC_ROWS * p.pitch;
@@ -1053,7 +1057,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     lds = ring_off + rn::RING_BYTES;       /* the chains' shared weight-stream ring */
   if (lds > 160 * 1024) return fail(REFNERF_EINVAL, "n_samples too large for the 160 KiB LDS budget%s");
   LDS_ATTR_ONCE(lds_attr(rn::level_bwd_f32), lds_attr(rn::level_bwd_bf16c), lds_attr(rn::level_bwd_f16x2c), lds_attr(rn::level_bwd_f16x2c_r32),
-                lds_attr(rn::wgrad_f16s_kernel<rn::WF_NW>, rn::WF_LDS),
+                lds_attr(rn::wgrad_f16s_kernel<rn::WF_NW>, rn::wf_lds(rn::WF_NW)),
                 lds_attr(rn::wgrad_kernel, (rn::WG_TM + rn::WG_TN) * rn::WG_LDK * 4),
                 lds_attr(rn::wgrad_bf16x3_kernel<false, false>, rn::wb_lds(false, false)),
                 lds_attr(rn::wgrad_bf16x3_kernel<false, true>, rn::wb_lds(false, true)),
@@ -1135,7 +1139,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
       float *cmin = (float *)(ws + plan.cmin_off);
       HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)cmin, 0x7f800000, 32, st));
       hipLaunchKernelGGL(rn::delta_scale_min, dim3(rn::DSC_ROWS, 64), dim3(256), 0, st, a.delta, plan.S, cmin);
-      hipLaunchKernelGGL((rn::wgrad_f16s_kernel<rn::WF_NW>), wg_grid, dim3(64 * rn::WF_NW), rn::WF_LDS, st, w, slices, cmin);
+      const dim3 wf_grid(8 * ((slices + 7) / 8) * (rn::wf_tm(rn::WF_NW) == 256 ? rn::WJOBS_M256.tiles : rn::WJOBS.tiles));
+      hipLaunchKernelGGL((rn::wgrad_f16s_kernel<rn::WF_NW>), wf_grid, dim3(64 * rn::WF_NW), rn::wf_lds(rn::WF_NW), st, w, slices, cmin);
     }
     else if (del16 && act16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, true>), wg_grid, dim3(256), rn::wb_lds(true, true), st, w, slices);
     else if (del16) hipLaunchKernelGGL((rn::wgrad_bf16x3_kernel<true, false>), wg_grid, dim3(256), rn::wb_lds(true, false), st, w, slices);

@@ -25,7 +25,9 @@ constexpr int WG_TM = 128, WG_TN = 128, WG_KT = 64, WG_LDK = 68;
 constexpr int MAX_WJOBS = 32;
 struct WJobs { WJob job[MAX_WJOBS]; int n; int tiles; };
 
-constexpr WJobs make_wjobs() {
+/* TM: rows of DELTA (output rows) per tile -- 128 for the fp32 / split-bf16 GEMMs and the 4-wave f16 GEMM, 256 for the 8-wave one */
+template <int TM>
+constexpr WJobs make_wjobs_t() {
   WJobs J{};
   int n = 0, t = 0;
   auto add = [&](int d_row, int n_out, int a_row, int n_in, int w_off, int ld, int b_off) {
@@ -33,7 +35,7 @@ constexpr WJobs make_wjobs() {
     j.d_row = d_row; j.n_out = n_out; j.a_row = a_row; j.n_in = n_in; j.w_off = w_off; j.ld = ld; j.b_off = b_off;
     j.tiles_n = (n_in + WG_TN - 1) / WG_TN;
     j.tile0 = t;
-    t += ((n_out + WG_TM - 1) / WG_TM) * j.tiles_n;
+    t += ((n_out + TM - 1) / TM) * j.tiles_n;
     J.job[n++] = j;
   };
   for (int i = 0; i < DEPTH; ++i) {            /* spatial MLP (models.py:576-580) */
@@ -60,7 +62,8 @@ constexpr WJobs make_wjobs() {
   J.n = n; J.tiles = t;
   return J;
 }
-constexpr WJobs WJOBS = make_wjobs();
+constexpr WJobs WJOBS = make_wjobs_t<WG_TM>();
+constexpr WJobs WJOBS_M256 = make_wjobs_t<256>();
 /* general IPE basis: the tail W_ext[L][256][EXT_K] (refnerf_layout.h) = deltas of layer 0 / 5 x the tail matrix's 576 rows;
  * offsets relative to the tail (its partials and its part of the gradient blob are addressed from NUM_PARAMS on) */
 constexpr WJobs make_wjobs_ext() {

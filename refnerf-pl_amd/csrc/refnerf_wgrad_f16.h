@@ -49,38 +49,57 @@ __device__ __forceinline__ float pk_sum_h(unsigned a) {
 /* LDS tiles of this kernel: 128 rows x 64 halves = 128 B per row, NO pad -- the 16-B chunk c of row r sits at chunk
  * c ^ ((r >> 1) & 7): the sixteen lanes ds_read_b128 serves per cycle (consecutive rows, one chunk) then cover the sixteen
  * 16-B slots of the 256-B bank window exactly once, as the 144-B pitch of the bf16 GEMM does -- and three tiles are 48 KB
- * instead of 54 (bit-identical results, same time: 3.73 ms at C2).  Three workgroups per CU would now fit the LDS, but not the
- * registers: see REFNERF_WF_OCC */
+ * instead of 54 (bit-identical results, same time).  Three workgroups per CU then fit the LDS: measured below. */
 constexpr int WF_ROW = WB_KT * 2;              /* 128 B */
-constexpr int WF_TILE = WG_TM * WF_ROW;        /* 16 KB */
-constexpr int WF_LDS = 3 * WF_TILE;            /* D, A_hi, A_lo: 48 KB */
 __device__ __forceinline__ int wf_off(int row, int byte) { return row * WF_ROW + ((((byte >> 4) ^ (row >> 1)) & 7) << 4) + (byte & 15); }
 #ifndef REFNERF_WF_OCC
-#define REFNERF_WF_OCC 2                       /* waves per SIMD the register allocation aims at (4-wave workgroups: workgroups per CU); 3: 168 VGPRs + 92 B/lane of scratch, 6.99 ms instead of 3.73 (round 4, C2) */
+#define REFNERF_WF_OCC 2                       /* waves per SIMD the register allocation aims at (4-wave workgroups: workgroups per CU) */
 #endif
 /* the backward scales a sample's largest delta into [2^7, 2^8) (pow2_scale_for); the sample(s) with the layer's smallest factor
  * go up another 2^7 on load, to just below the largest half (2^15 < 65504), everything else follows: 29 binades at full
  * precision below the layer's largest deltas, 10 more of gradual underflow */
 constexpr float TOP_SHIFT = 128.0f;
 
-/* grid = 8 * ceil(slices / 8) * WJOBS.tiles workgroups of 64 NW threads, decoded as in wgrad_bf16x3_kernel.
- * NW = 4 (default): waves 2 x 2 over the 128 x 128 tile (64 x 64 each), 8 rows of either operand tile per loader thread, two
- * workgroups per CU;  NW = 8: waves 4 x 2 (32 x 64 each), 4 rows per loader thread, 116 registers -- measured 3.79 ms against
- * 3.59 (round 4, C2): the same bytes are in flight per CU (LDS admits two workgroups either way), the narrower wave tiles read
- * 1.7x the LDS bytes per MFMA.  What bounds this GEMM is bytes in flight per CU: one 4-wave workgroup per CU takes 7.35 ms. */
+/* grid = 8 * ceil(slices / 8) * tiles workgroups of 64 NW threads, decoded as in wgrad_bf16x3_kernel.
+ * Default: NW = 4 waves, D (delta) tile of TM = 128 rows: waves 2 x 2 of 64 x 64 over a 128 x 128 output tile (job table WJOBS),
+ * 48 KB of LDS, 172 registers, two workgroups per CU: 3.6 ms per level at C2 = 20 GB actually fetched (13.7 GB of operands: the
+ * 2 x 2 tiles of a layer re-read either operand, L2 catches a third of that) at 5.5 TB/s.
+ * Measured alternatives (round 4, C2; bit-identical results, docs/EXPERIMENTS.md section 9):
+ *   TM = 256 (ALL output rows of a layer per tile, job table WJOBS_M256: ACT -- the larger operand -- is read once):
+ *     NW = 8 (waves 4 x 2 of 64 x 64), one workgroup per CU: 17.4 GB fetched, 3.80 ms; with two register sets of loads
+ *     (REFNERF_WF_STAGES8 = 2): 15.5 GB, 4.16 ms; two workgroups per CU need <= 128 registers: 120 B/lane of scratch, 6.5 ms;
+ *     NW = 4 (waves 2 x 2 of 128 x 64): 256 registers + 64 B/lane, 5.2 ms;
+ *   TM = 128, three workgroups per CU (REFNERF_WF_OCC = 3: 168 registers + 16 B/lane): 3.76 ms.
+ * Fewer bytes at lower occupancy, or more workgroups at the same bytes, both lose: the GEMM sits at the HBM rate of what it
+ * fetches, and fetching less needs the 256-row tile at two workgroups per CU -- 64 accumulator + 32 load registers leave no room. */
 #ifndef REFNERF_WF_WAVES
 #define REFNERF_WF_WAVES 4
 #endif
+#ifndef REFNERF_WF_STAGES8
+#define REFNERF_WF_STAGES8 1
+#endif
+constexpr bool wjobs_rows_even(const WJobs &T) {
+  for (int j = 0; j < T.n; ++j) if ((T.job[j].a_row | T.job[j].d_row) & 1) return false;
+  return true;
+}
+static_assert(wjobs_rows_even(WJOBS) && wjobs_rows_even(WJOBS_M256), "pair units: every job starts on an even row of ACT and DELTA");
 constexpr int WF_NW = REFNERF_WF_WAVES;
+#ifndef REFNERF_WF_TM
+#define REFNERF_WF_TM 128
+#endif
+constexpr int wf_tm(int nw) { return REFNERF_WF_TM; }                 /* rows of the D tile: 128, or 256 = all output rows of a layer */
+constexpr int wf_lds(int nw) { return (wf_tm(nw) + 2 * WG_TN) * WF_ROW; }
 template <int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? REFNERF_WF_OCC : 4))) void wgrad_f16s_kernel(const WgradArgs A, int slices, const float *__restrict__ cmin_all) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(REFNERF_WF_OCC))) void wgrad_f16s_kernel(const WgradArgs A, int slices, const float *__restrict__ cmin_all) {
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  constexpr int MI = 8 / NW;                     /* 32-row blocks of the D tile per wave */
-  constexpr int NPP = 16 / NW;                   /* row PAIRS of either tile per loader thread */
-  constexpr int NR = 2 * NPP;                    /* rows */
-  constexpr const WJobs &JT = WJOBS;
+  constexpr int TM = wf_tm(NW);                  /* 128 or 256 */
+  constexpr int MI = TM / (16 * NW);             /* 32-row blocks of the D tile per wave: waves (NW / 2) x 2 of (32 MI) x 64 */
+  constexpr int NPD = TM / (8 * NW);             /* row PAIRS of the D tile per loader thread: 4 */
+  constexpr int NPA = WG_TN / (8 * NW);          /* ... of the A tile: 4 or 2 */
+  constexpr int NRD = 2 * NPD, NRA = 2 * NPA;    /* rows */
+  constexpr const WJobs &JT = (TM == 256) ? WJOBS_M256 : WJOBS;
   extern __shared__ __attribute__((aligned(16))) char wbs[];
-  char *Dh = wbs, *Ah = wbs + WF_TILE, *Al = wbs + 2 * WF_TILE;
+  char *Dh = wbs, *Ah = wbs + TM * WF_ROW, *Al = Ah + WG_TN * WF_ROW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, sl = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -109,48 +128,46 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  float bsum[NR];
+  float bsum[NRD];
 #pragma unroll
-  for (int p = 0; p < NR; ++p) bsum[p] = 0.0f;
+  for (int p = 0; p < NRD; ++p) bsum[p] = 0.0f;
 
-  /* loader: the thread owns NPP PAIRS of rows of either tile (p = 2 pp + half, as the bf16 pair format of
+  /* loader: the thread owns NPD PAIRS of rows of the D tile and NPA of the A tile (p = 2 pp + half, as the bf16 pair format of
    * wgrad_bf16x3_kernel), 4 samples at lc4.  DELTA: one 16-B load per pair; ACT: the pair's hi unit and its lo unit.
    * The pair index is a bit permutation of the low four bits of lrow (two row groups of a half-wave 8 rows apart in LDS). */
   const int lrow = tid >> 4, lc4 = (tid & 15) * 4;
   const int lpair = (lrow & ~7) | ((lrow & 1) << 2) | ((lrow >> 1) & 3);
   auto tile_row = [&](int p) { return 2 * lpair + 8 * NW * (p >> 1) + (p & 1); };
-  const char *dp[NR], *ap[NR];
-#pragma unroll
-  for (int p = 0; p < NR; ++p) {
-    const int orow = tm * WG_TM + tile_row(p), irow = tn * WG_TN + tile_row(p);
-    dp[p] = (orow < J.n_out) ? reinterpret_cast<const char *>(A.delta) + ((long long)((J.d_row + orow) >> 1) * RB + lc4) * 4 : nullptr;
-    /* ACT pair (rows 2j, 2j + 1): hi halves in unit 2j, lo halves in unit 2j + 1 -- both pointers of a pair address the hi unit */
-    ap[p] = (irow < J.n_in) ? reinterpret_cast<const char *>(A.act) + ((long long)((J.a_row + irow) & ~1) * RB + lc4) * 4 : nullptr;
-  }
+  /* ONE address per operand: pair pp of this thread sits 4 NW pair units behind pair pp - 1 (the liveness of a row is a compare) */
+  const char *dp0 = reinterpret_cast<const char *>(A.delta) + ((long long)((J.d_row + tm * TM) / 2 + lpair) * RB + lc4) * 4;
+  const char *ap0 = reinterpret_cast<const char *>(A.act) + ((long long)(J.a_row + tn * WG_TN + 2 * lpair) * RB + lc4) * 4;
+  const long long dpp = (long long)(4 * NW) * RB * 4, app = (long long)(8 * NW) * RB * 4;   /* bytes between a thread's pairs */
+  auto d_live = [&](int p) { return tm * TM + tile_row(p) < J.n_out; };
+  auto a_live = [&](int p) { return tn * WG_TN + tile_row(p) < J.n_in; };
   const char *scp = reinterpret_cast<const char *>(A.delta) + ((long long)(DSC0 + lid) * RB + lc4) * 4;
   const long long dstep = (long long)A.d_units * 4, astep = (long long)A.a_units * 4;   /* bytes per sample of k0 */
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
-  /* NST register sets of operand loads in flight (k-steps i, i + 1, ...): one k-step of MFMAs (~1 k cycles with the CU's
-   * second workgroup in between) does not cover an HBM round trip under load.  Measured (round 4, C2): a second set costs
-   * 52 VGPRs, the kernel drops to ONE workgroup per CU and takes 7.35 ms instead of 3.65 -- occupancy, not prefetch depth, is what
-   * hides the latency here; the default stays 1 */
-#ifndef REFNERF_WF_STAGES
-#define REFNERF_WF_STAGES 1
-#endif
-  constexpr int NST = REFNERF_WF_STAGES;
-  v4u dv[NST][NPP], avh[NST][NPP], avl[NST][NPP];
+  /* NST register sets of operand loads in flight (k-steps i, i + 1, ...): ONE (a second set costs the 4-wave form its second
+   * workgroup per CU: 7.35 ms; the 8-wave form alone on its CU: 4.16 ms against 3.80) */
+  constexpr int NST = (NW == 8) ? REFNERF_WF_STAGES8 : 1;
+  v4u dv[NST][NPD], avh[NST][NPA], avl[NST][NPA];
   v4f cv[NST];
   auto fetch = [&](auto SETC, long long k0) {
     constexpr int st = decltype(SETC)::value;
 #pragma unroll
-    for (int pp = 0; pp < NPP; ++pp) {
-      v4u x = {0u, 0u, 0u, 0u}, y = {0u, 0u, 0u, 0u}, z = {0u, 0u, 0u, 0u};
-      if (dp[2 * pp]) x = *reinterpret_cast<const v4u *>(dp[2 * pp] + k0 * dstep);
-      if (ap[2 * pp]) {
-        y = *reinterpret_cast<const v4u *>(ap[2 * pp] + k0 * astep);
-        z = *reinterpret_cast<const v4u *>(ap[2 * pp] + k0 * astep + RB * 4);
+    for (int pp = 0; pp < NPD; ++pp) {
+      v4u x = {0u, 0u, 0u, 0u};
+      if (d_live(2 * pp)) x = *reinterpret_cast<const v4u *>(dp0 + pp * dpp + k0 * dstep);
+      dv[st][pp] = x;
+    }
+#pragma unroll
+    for (int pp = 0; pp < NPA; ++pp) {
+      v4u y = {0u, 0u, 0u, 0u}, z = {0u, 0u, 0u, 0u};
+      if (a_live(2 * pp)) {
+        y = *reinterpret_cast<const v4u *>(ap0 + pp * app + k0 * astep);
+        z = *reinterpret_cast<const v4u *>(ap0 + pp * app + k0 * astep + RB * 4);
       }
-      dv[st][pp] = x; avh[st][pp] = y; avl[st][pp] = z;
+      avh[st][pp] = y; avl[st][pp] = z;
     }
     cv[st] = *reinterpret_cast<const v4f *>(scp + k0 * dstep);
   };
@@ -174,16 +191,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
       f23 = pk_f16(f[2], f[3]);
     }
 #pragma unroll
-    for (int p = 0; p < NR; ++p) {
-      const int off = wf_off(tile_row(p), lc4 * 2);
-      unsigned h0, h1, l0, l1;
-      unpair(dv[st][p >> 1], p & 1, dp[p] != nullptr, h0, h1);
+    for (int p = 0; p < NRD; ++p) {
+      unsigned h0, h1;
+      unpair(dv[st][p >> 1], p & 1, d_live(p), h0, h1);
       h0 = pk_mul_h(h0, f01);
       h1 = pk_mul_h(h1, f23);
       if (need_bias) bsum[p] += pk_sum_h(h0) + pk_sum_h(h1);      /* (wave-uniform: only the first column tile of a job with a bias) */
-      *reinterpret_cast<v2u *>(Dh + off) = (v2u){h0, h1};
-      unpair(avh[st][p >> 1], p & 1, ap[p] != nullptr, h0, h1);
-      unpair(avl[st][p >> 1], p & 1, ap[p] != nullptr, l0, l1);
+      *reinterpret_cast<v2u *>(Dh + wf_off(tile_row(p), lc4 * 2)) = (v2u){h0, h1};
+    }
+#pragma unroll
+    for (int p = 0; p < NRA; ++p) {
+      const int off = wf_off(tile_row(p), lc4 * 2);
+      unsigned h0, h1, l0, l1;
+      unpair(avh[st][p >> 1], p & 1, a_live(p), h0, h1);
+      unpair(avl[st][p >> 1], p & 1, a_live(p), l0, l1);
       *reinterpret_cast<v2u *>(Ah + off) = (v2u){h0, h1};
       *reinterpret_cast<v2u *>(Al + off) = (v2u){l0, l1};
     }
@@ -192,22 +213,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < WB_KT / 16; ++kk) {
-      v8h dh[MI], bh[2], bl[2];
+      v8h dh[MI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) dh[i] = *reinterpret_cast<const v8h *>(Dh + wf_off(wm * 32 * MI + i * 32 + sl, kk * 32 + h * 16));
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int co = wf_off(wn * 64 + i * 32 + sl, kk * 32 + h * 16);
-        bh[i] = *reinterpret_cast<const v8h *>(Ah + co);
-        bl[i] = *reinterpret_cast<const v8h *>(Al + co);
-      }
+      for (int j = 0; j < 2; ++j) {
+        const int co = wf_off(wn * 64 + j * 32 + sl, kk * 32 + h * 16);
+        const v8h bh = *reinterpret_cast<const v8h *>(Ah + co), bl = *reinterpret_cast<const v8h *>(Al + co);
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MI; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[i], bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[i], bh, acc[i][j], 0, 0, 0);
         }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -228,16 +246,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 4
       const int colk = tn * WG_TN + wn * 64 + j * 32 + sl;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int orow = tm * WG_TM + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int orow = tm * TM + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (orow < J.n_out && colk < J.n_in) part[wjob_row_off(J, orow) + colk] = acc[i][j][r] * inv;
       }
     }
   if (need_bias) {
 #pragma unroll
-    for (int p = 0; p < NR; ++p) {
+    for (int p = 0; p < NRD; ++p) {
       float s = bsum[p];
       s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-      const int orow = tm * WG_TM + tile_row(p);
+      const int orow = tm * TM + tile_row(p);
       if ((tid & 15) == 0 && orow < J.n_out) part[wjob_bias_off(J, orow)] = s * inv;
     }
   }
