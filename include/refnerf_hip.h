@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 9   /* v9: REFNERF_ACT_F16X2 (split-f16 ACT / DELTA formats of the split-f16 training chains), refnerf_activations_format; v8: cfg.ipe_groups, refnerf_pack_weights_basis (general IPE bases: icosahedron); v7: REFNERF_PREC_F16X2 (split-operand f16: the parity-grade 16-bit inference mode); v6: cfg.dir_enc (REFNERF_DIRENC_*), cfg.raydist (REFNERF_RAYDIST_*), cfg.disable_integration; v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
+#define REFNERF_ABI_VERSION 10  /* v10: REFNERF_IMAGE_F16X2_TRAIN + REFNERF_ACT_SQ (training levels of REFNERF_PREC_F16X2 on the eval kernel's skeleton: d_packed of refnerf_level_forward_train / refnerf_level_backward is the train image then); v9: REFNERF_ACT_F16X2 (split-f16 ACT / DELTA formats of the split-f16 training chains), refnerf_activations_format; v8: cfg.ipe_groups, refnerf_pack_weights_basis (general IPE bases: icosahedron); v7: REFNERF_PREC_F16X2 (split-operand f16: the parity-grade 16-bit inference mode); v6: cfg.dir_enc (REFNERF_DIRENC_*), cfg.raydist (REFNERF_RAYDIST_*), cfg.disable_integration; v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {
@@ -81,7 +81,21 @@ enum {
  * 34.5 KB of operands per ray-sample).  The buffer is opaque to the caller, only its size is part of the ABI; the 128 rows of
  * ReLU mask words are 32-bit in all three.  refnerf_activations_format(cfg) tells which one refnerf_level_forward_train
  * writes for a configuration: pass it on in refnerf_level_saved.activations_format. */
-enum { REFNERF_ACT_F32 = 0, REFNERF_ACT_BF16 = 1, REFNERF_ACT_F16X2 = 2 };
+enum { REFNERF_ACT_F32 = 0, REFNERF_ACT_BF16 = 1, REFNERF_ACT_F16X2 = 2,
+       REFNERF_ACT_SQ = 3 /* v10: what the REFNERF_PREC_F16X2 training forward writes on the built-in basis: spatial layer inputs as
+                             hi / lo pair units, directional layer inputs as the ONE half their trunk multiplies, lane-local ReLU
+                             sign words, the raw scalar head rows and raw rgb (13.7 KB per ray-sample; the buffer keeps the size
+                             refnerf_activation_workspace_bytes reports); the backward writes its deltas as one half per element
+                             + two power-of-two factors per (layer, sample): 22 KB of weight-gradient operands per ray-sample */ };
+
+/* a weight image that is not an arithmetic mode of refnerf_level_forward: refnerf_pack_weights / refnerf_packed_weights_bytes
+ * take it in place of a REFNERF_PREC_* code */
+enum {
+  REFNERF_IMAGE_F16X2_TRAIN = 4 /* v10: forward + transposed operands of the REFNERF_PREC_F16X2 TRAINING kernels (built-in IPE
+                                   basis) as one stream of 17 KB chunks (11.5 MB): d_packed of refnerf_level_forward_train and
+                                   refnerf_level_backward when cfg.precision = REFNERF_PREC_F16X2 and cfg.ipe_groups <= 1
+                                   (a general basis and the other precisions keep the REFNERF_PREC_F32 image) */
+};
 
 /* encoding of the (reflected) direction fed to the directional MLP (internal/models.py:484-492) */
 enum {

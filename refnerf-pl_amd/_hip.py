@@ -15,7 +15,11 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
 
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X2 = 0, 1, 2, 3
-ABI_VERSION = 9   # REFNERF_ABI_VERSION
+IMAGE_F16X2_TRAIN = 4   # REFNERF_IMAGE_F16X2_TRAIN: the weight image of the REFNERF_PREC_F16X2 training kernels (built-in basis)
+ACT_F32, ACT_BF16, ACT_F16X2, ACT_SQ = 0, 1, 2, 3   # REFNERF_ACT_*
+ABI_VERSION = 10  # REFNERF_ABI_VERSION
+# debug knob, read once by the library as well: the round-4 training kernels of the f16x2 mode (REFNERF_ACT_F16X2, f32 image)
+LEGACY_F16X2_TRAIN = os.environ.get("REFNERF_LEGACY_F16X2_TRAIN", "0") not in ("", "0")
 WGRAD_F32, WGRAD_BF16X3 = 0, 1
 DIRENC_IDE, DIRENC_POSENC = 0, 1   # REFNERF_DIRENC_*
 RAYDIST = {None: 0, "piecewise": 1, "reciprocal": 2, "log": 3, "exp": 4, "sqrt": 5, "square": 6}   # REFNERF_RAYDIST_*

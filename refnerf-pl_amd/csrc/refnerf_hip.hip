@@ -31,6 +31,9 @@
 #include "refnerf_wgrad_bf16x3.h"
 #include "refnerf_wgrad_f16.h"
 #include "refnerf_rays.h"
+#include "refnerf_pack_common.h"
+#include "refnerf_sq_host.h"
+#include "refnerf_sq_layout.h"
 
 namespace rn {
 
@@ -38,41 +41,6 @@ namespace rn {
 /* weight packing                                                     */
 /* ------------------------------------------------------------------ */
 
-/* W[row][k] of GEMM op `op` in canonical storage; k = canonical input column. */
-__device__ float canon_w(const float *P, int op, int row, int k) {
-  if (op < 8) {
-    int in = CANON.sp_in[op];
-    return (k < in) ? P[CANON.sp_w[op] + row * in + k] : 0.0f;
-  }
-  if (op == OP_HEADS) {
-    if (row < BNECK) return P[CANON.bneck_w + row * WIDTH + k];
-    if (row == HROW_DENSITY) return P[CANON.density_w + k];
-    if (row < HROW_ROUGH) return P[CANON.gradpred_w + (row - HROW_GRAD) * WIDTH + k];
-    if (row == HROW_ROUGH) return P[CANON.rough_w + k];
-    if (row < HROW_TINT) return P[CANON.diffuse_w + (row - HROW_DIFFUSE) * WIDTH + k];
-    if (row < HROWS) return P[CANON.tint_w + (row - HROW_TINT) * WIDTH + k];
-    return 0.0f;
-  }
-  if (op < OP_RGB) {
-    int i = op - 9, in = CANON.vd_in[i];
-    return (k < in) ? P[CANON.vd_w[i] + row * in + k] : 0.0f;
-  }
-  return (row < 3) ? P[CANON.rgb_w + row * WIDTH + k] : 0.0f;
-}
-__device__ float canon_b(const float *P, int op, int row) {
-  if (op < 8) return P[CANON.sp_b[op] + row];
-  if (op == OP_HEADS) {
-    if (row < BNECK) return P[CANON.bneck_b + row];
-    if (row == HROW_DENSITY) return P[CANON.density_b];
-    if (row < HROW_ROUGH) return P[CANON.gradpred_b + row - HROW_GRAD];
-    if (row == HROW_ROUGH) return P[CANON.rough_b];
-    if (row < HROW_TINT) return P[CANON.diffuse_b + row - HROW_DIFFUSE];
-    if (row < HROWS) return P[CANON.tint_b + row - HROW_TINT];
-    return 0.0f;
-  }
-  if (op < OP_RGB) return P[CANON.vd_b[op - 9] + row];
-  return (row < 3) ? P[CANON.rgb_b + row] : 0.0f;
-}
 
 __global__ void pack_weights_f32(const float *__restrict__ P, float *__restrict__ out) {
   int op = blockIdx.y;
@@ -296,41 +264,6 @@ __global__ void pack_weights_ext(const float *__restrict__ P, const float *__res
   }
 }
 
-/* One plain 17 KB chunk of the 16-bit images (refnerf_layout.h): bias piece + 16 fragment pieces. */
-template <typename E>
-__device__ void fill_chunk_plain(const float *__restrict__ P, char *__restrict__ chunk, int op, int ob, int kind, bool first, int base) {
-  /* bias piece: fp32 [h][16] (first chunk of the slice), rest of the KB zero */
-  for (int e = threadIdx.x; e < 256; e += blockDim.x) {
-    float v = 0.0f;
-    if (e < 32 && first) {
-      int reg = e & 15, h = e >> 4;
-      v = canon_b(P, op, ob * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
-    }
-    reinterpret_cast<float *>(chunk)[e] = v;
-  }
-  for (int idx = threadIdx.x; idx < 16 * 512; idx += blockDim.x) {
-    int e = idx & 7, lane = (idx >> 3) & 63, t = idx >> 9;
-    int h = lane >> 5, row = ob * 32 + (lane & 31);
-    float v = 0.0f;
-    const bool reg_step = (kind == BF_REG) || (kind == BF_BNLDS && t < 8);
-    if (reg_step) {
-      int r = 8 * (t & 1) + e;
-      int feat = 32 * (t >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
-      v = canon_w(P, op, row, (kind == BF_REG) ? feat : base + feat);
-    } else if (kind == BF_LDS8) {
-      int kp = 16 * t + 8 * h + e;
-      if (t < BF_IPE_REAL_KS) v = canon_w(P, op, row, base + ipe_col_of_kprime(kp));
-    } else {
-      int kp = 16 * (t - 8) + 8 * h + e;
-      /* dir k': [Re x36 | n.v | 0 0 0 | Im x36 | 0 0 0 0] */
-      if (kp < IDE_TERMS) v = canon_w(P, op, row, base + BNECK + kp);
-      else if (kp == IDE_TERMS) v = canon_w(P, op, row, base + BNECK + IDE_DIM);
-      else if (kp >= 40 && kp < 40 + IDE_TERMS) v = canon_w(P, op, row, base + BNECK + IDE_TERMS + (kp - 40));
-    }
-    reinterpret_cast<E *>(chunk + 1024)[idx] = (E)v;
-  }
-}
-
 /* bf16 image: one block per (op, ob) slice, uniform 17 KB chunks in execution
  * order; see refnerf_layout.h. */
 template <typename E>   /* E = __bf16 (REFNERF_PREC_BF16) or _Float16 (REFNERF_PREC_F16): same image layout */
@@ -343,41 +276,6 @@ __global__ void pack_weights_16(const float *__restrict__ P, char *__restrict__ 
     fill_chunk_plain<E>(P, out + (size_t)(o.chunk0 + ob * o.nchunk + j) * BF_CHUNK_BYTES, op, ob, o.kind[j], j == 0, base);
 }
 
-/* Split-f16 image (REFNERF_PREC_F16X2): one chunk of the 16x16x32 spatial section (refnerf_layout.h; w = hi + lo,
- * hi = fl16(w), lo = fl16(w - hi)); the directional ops are plain f16 chunks */
-__device__ void fill_chunk_sq(const float *__restrict__ P, char *__restrict__ chunk, int op, int ob, int kind, bool first, int base) {
-  for (int e = threadIdx.x; e < 256; e += blockDim.x) {
-    float v = 0.0f;
-    if (e < 32 && first) {                       /* bias piece [T][b][4]: rows 16 T + 4 b + i of the slice */
-      const int T = e >> 4, b = (e >> 2) & 3, i = e & 3;
-      v = canon_b(P, op, ob * 32 + 16 * T + 4 * b + i);
-    }
-    reinterpret_cast<float *>(chunk)[e] = v;
-  }
-  for (int idx = threadIdx.x; idx < 16 * 512; idx += blockDim.x) {
-    const int e = idx & 7, lane = (idx >> 3) & 63, pi = idx >> 9;
-    const int bk = lane >> 4, r16 = lane & 15;
-    int T, part, col;
-    bool live = true;
-    if (kind == SQ_A || kind == SQ_B || kind == SQ_X) {
-      const int sl = pi >> 2, which = pi & 3;
-      T = which & 1; part = which >> 1;
-      if (kind == SQ_X) { live = sl < 3; col = base + 32 * sl + 8 * bk + e; }
-      else { const int st = (kind == SQ_B ? 4 : 0) + sl; col = 32 * st + 16 * (e >> 2) + 4 * bk + (e & 3); }
-    } else if (kind == SQ_BN) {
-      const int st = pi >> 1;
-      T = pi & 1; part = 0;
-      col = 32 * st + 16 * (e >> 2) + 4 * bk + (e & 3);
-    } else {                                     /* SQ_SC: tile T0 of the scalar block, [hi lo] per k-step */
-      const int st = pi >> 1;
-      T = 0; part = pi & 1;
-      col = 32 * st + 16 * (e >> 2) + 4 * bk + (e & 3);
-    }
-    const float v = live ? canon_w(P, op, ob * 32 + 16 * T + r16, col) : 0.0f;
-    const _Float16 hi = (_Float16)v;
-    reinterpret_cast<_Float16 *>(chunk + 1024)[idx] = part ? (_Float16)(v - (float)hi) : hi;
-  }
-}
 /* ... and a plain BNLDS chunk whose eight bottleneck k-steps follow the merged-run order of that section */
 __device__ void fill_chunk_bnlds_sq(const float *__restrict__ P, char *__restrict__ chunk, int op, int ob, bool first, int base) {
   fill_chunk_plain<_Float16>(P, chunk, op, ob, BF_BNLDS, first, base);
@@ -663,7 +561,24 @@ hipError_t lds_attr(K kernel, int bytes = 160 * 1024) {
     if (attr_err_ != hipSuccess) return fail(REFNERF_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(attr_err_)); \
   } while (0)
 
+/* REFNERF_LEGACY_F16X2_TRAIN (debug knob, read once): training levels in REFNERF_PREC_F16X2 on the built-in basis take the round-4
+ * kernels (fp32 skeleton with split-f16 chains, REFNERF_ACT_F16X2, d_packed = the REFNERF_PREC_F32 image) instead of the
+ * round-5 ones (refnerf_sq_train.hip, REFNERF_ACT_SQ, d_packed = the REFNERF_IMAGE_F16X2_TRAIN image) */
+bool legacy_f16x2_train() {
+  static const bool v = [] { const char *e = getenv("REFNERF_LEGACY_F16X2_TRAIN"); return e && *e && *e != '0'; }();
+  return v;
+}
+
 }  // namespace
+
+namespace rnh {
+int fail(int code, const char *fmt, const char *detail) { return ::fail(code, fmt, detail); }
+int timer_begin(hipStream_t st, long *slot, int fam) { return ::timer_begin(st, slot, fam); }
+int timer_end(hipStream_t st, long slot) { return ::timer_end(st, slot); }
+bool prof_on() { return rt().prof; }
+int prof_buffer(long long **out) { return ::prof_buffer(out); }
+int lds_pad() { return rt().lds_pad; }
+}  // namespace rnh
 
 extern "C" {
 
@@ -695,6 +610,7 @@ size_t refnerf_packed_weights_bytes(int precision) {
   if (precision == REFNERF_PREC_F32) return (size_t)rn::PACKED.total * sizeof(float);
   if (precision == REFNERF_PREC_BF16 || precision == REFNERF_PREC_F16) return ((size_t)rn::BFPACKED.chunks_per_pass + 2) * rn::BF_CHUNK_BYTES;
   if (precision == REFNERF_PREC_F16X2) return ((size_t)rn::SPPACKED.total_chunks + 2) * rn::BF_CHUNK_BYTES;
+  if (precision == REFNERF_IMAGE_F16X2_TRAIN) return rnsq::image_bytes();
   return 0;
 }
 
@@ -712,6 +628,8 @@ int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, v
   } else if (precision == REFNERF_PREC_F16X2) {
     dim3 grid(8, rn::NUM_OPS);
     hipLaunchKernelGGL(rn::pack_weights_split, grid, dim3(256), 0, (hipStream_t)stream, d_params, (char *)d_packed);
+  } else if (precision == REFNERF_IMAGE_F16X2_TRAIN) {
+    return rnsq::pack(d_params, d_packed, (hipStream_t)stream);
   } else {
     return fail(REFNERF_EINVAL, "refnerf_pack_weights: unknown precision%s");
   }
@@ -811,6 +729,10 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   /* training + F16X2: the same kernel with its chains on split-f16 operands (level_fwd_train_f16x2c), fp32 ACT rows */
   /* (a general basis in F16X2 takes that kernel in inference as well: level_fwd_f16x2c_gb) */
   const bool gb_split = gbasis && cfg->precision == REFNERF_PREC_F16X2;
+  /* training + F16X2 on the built-in basis: the round-5 kernels on the eval kernel's skeleton (refnerf_sq_train.hip);
+   * d_packed is the REFNERF_IMAGE_F16X2_TRAIN image, the activations REFNERF_ACT_SQ */
+  if (cfg->training && cfg->precision == REFNERF_PREC_F16X2 && !gbasis && d_act && !legacy_f16x2_train())
+    return rnsq::forward(d_packed, cfg, rays, R, d_sdist_in, d_weights_in, out, d_act, (hipStream_t)stream);
   const bool train_split = (cfg->training && cfg->precision == REFNERF_PREC_F16X2) || gb_split;
   const bool split = cfg->precision == REFNERF_PREC_F16X2 && !train_split;
   const bool bf = (cfg->precision == REFNERF_PREC_BF16 && !train_bf) || cfg->precision == REFNERF_PREC_F16 || split;     /* the LDS-ring 16-bit eval kernels */
@@ -1016,7 +938,7 @@ size_t refnerf_activation_workspace_bytes_basis(int32_t R, int32_t n_samples, in
 int refnerf_activations_format(const refnerf_level_cfg *cfg) {
   if (!cfg) return -1;
   if (cfg->precision == REFNERF_PREC_BF16) return REFNERF_ACT_BF16;
-  if (cfg->precision == REFNERF_PREC_F16X2 && cfg->ipe_groups <= 1) return REFNERF_ACT_F16X2;
+  if (cfg->precision == REFNERF_PREC_F16X2 && cfg->ipe_groups <= 1) return legacy_f16x2_train() ? REFNERF_ACT_F16X2 : REFNERF_ACT_SQ;
   return REFNERF_ACT_F32;
 }
 
@@ -1030,9 +952,10 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   if (cfg->ray_shape != 0 && cfg->ray_shape != 1) return fail(REFNERF_EINVAL, "ray_shape must be 'cone' or 'cylinder'%s");
   if (cfg->precision != REFNERF_PREC_F32 && cfg->precision != REFNERF_PREC_BF16 && cfg->precision != REFNERF_PREC_F16X2)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown precision mode (REFNERF_PREC_F32, REFNERF_PREC_F16X2 or REFNERF_PREC_BF16)%s");
-  if (cfg->precision == REFNERF_PREC_F16X2 && saved->activations_format != REFNERF_ACT_F32 && saved->activations_format != REFNERF_ACT_F16X2)
-    return fail(REFNERF_EUNSUPPORTED, "the split-f16 backward chains read split-f16 pair units (forward with REFNERF_PREC_F16X2) or fp32 rows (REFNERF_PREC_F32, or a general IPE basis)%s");
-  if (cfg->precision != REFNERF_PREC_F16X2 && saved->activations_format == REFNERF_ACT_F16X2)
+  if (cfg->precision == REFNERF_PREC_F16X2 && saved->activations_format != REFNERF_ACT_F32 && saved->activations_format != REFNERF_ACT_F16X2 &&
+      saved->activations_format != REFNERF_ACT_SQ)
+    return fail(REFNERF_EUNSUPPORTED, "the split-f16 backward chains read the REFNERF_PREC_F16X2 forward's activations (REFNERF_ACT_SQ) or fp32 rows (REFNERF_PREC_F32, or a general IPE basis)%s");
+  if (cfg->precision != REFNERF_PREC_F16X2 && (saved->activations_format == REFNERF_ACT_F16X2 || saved->activations_format == REFNERF_ACT_SQ))
     return fail(REFNERF_EUNSUPPORTED, "activations written by the split-f16 training forward (REFNERF_ACT_F16X2) are read by the split-f16 backward: cfg->precision = REFNERF_PREC_F16X2%s");
   if (cfg->wgrad_mode != REFNERF_WGRAD_F32 && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown wgrad_mode%s");
@@ -1083,11 +1006,17 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   const bool act16 = saved->activations_format == REFNERF_ACT_BF16, del16 = cfg->precision == REFNERF_PREC_BF16 && (REFNERF_DELTA16 != 0);
   /* split-f16 formats (refnerf_layout.h): ACT as hi / lo pair units, DELTA as one half per element + factor rows */
   const bool pairs = saved->activations_format == REFNERF_ACT_F16X2;
-  if (saved->activations_format != REFNERF_ACT_F32 && saved->activations_format != REFNERF_ACT_BF16 && !pairs)
+  const bool sq = saved->activations_format == REFNERF_ACT_SQ;
+  if (saved->activations_format != REFNERF_ACT_F32 && saved->activations_format != REFNERF_ACT_BF16 && !pairs && !sq)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown activations_format%s");
+  if (sq && gbasis) return fail(REFNERF_EUNSUPPORTED, "a general IPE basis keeps fp32 activation rows (REFNERF_ACT_F32)%s");
+  if (sq && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
+    return fail(REFNERF_EUNSUPPORTED, "REFNERF_ACT_SQ activations go with wgrad_mode = REFNERF_WGRAD_BF16X3 (the f16 weight-gradient GEMM on the saved halves; "
+                                      "fp32 weight-gradient products: the REFNERF_PREC_F32 chains)%s");
   if (pairs && gbasis) return fail(REFNERF_EUNSUPPORTED, "a general IPE basis keeps fp32 activation rows (REFNERF_ACT_F32)%s");
   if ((act16 || del16 || pairs) && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
-    return fail(REFNERF_EUNSUPPORTED, "bf16 activation / delta rows need wgrad_mode = REFNERF_WGRAD_BF16X3%s");
+    return fail(REFNERF_EUNSUPPORTED, "16-bit activation / delta rows (bf16 chains, split-f16 pair units) need wgrad_mode = REFNERF_WGRAD_BF16X3 "
+                                      "(fp32 weight-gradient products: the REFNERF_PREC_F32 chains)%s");
   a.act16 = act16 ? 1 : 0;
   a.ring_off = (int)ring_off;
   a.prof = nullptr;
@@ -1099,6 +1028,22 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   hipStream_t st = (hipStream_t)stream;
   /* per-ray seeds first (one wave per ray), then the per-sample backward */
   hipLaunchKernelGGL(rn::bwd_seed_kernel, dim3((R + 3) / 4), dim3(rn::NTHREADS), sizeof(float) * 4 * (size_t)(N + 1), st, a);
+  if (sq) {
+    /* round-5 kernels: the per-sample chains, then the f16 weight-gradient GEMM on (ACT_SQ, DELTA + factor units) */
+    int rc = rnsq::backward_chain(d_packed, cfg, rays, R, saved->d_sdist, grads, a.act, a.delta, a.seeds, plan.pitch, st);
+    if (rc) return rc;
+    if (plan.pitch > plan.S) {
+      hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, const_cast<float *>(a.act), rn::AQ_MASK, rn::AQ_UNITS, plan.pitch, plan.S);
+      hipLaunchKernelGGL(rn::wgrad_zero_tail, dim3(256), dim3(256), 0, st, a.delta, rn::DEL_ROWS / 2, rn::DQ_UNITS, plan.pitch, plan.S);
+    }
+    const int slices = (int)((plan.S + plan.k_per_slice - 1) / plan.k_per_slice);
+    float *part = (float *)(ws + plan.part_off);
+    rc = rnsq::wgrad(a.act, a.delta, plan.S, plan.pitch, plan.k_per_slice, slices, part, (float *)(ws + plan.cmin_off), st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rn::wgrad_reduce, dim3(1024), dim3(256), 0, st, part, slices, d_param_grads, (int)rn::NUM_PARAMS);
+    HIP_TRY(hipGetLastError());
+    return REFNERF_OK;
+  }
   /* d_packed is the f32 image in both modes (it carries the bf16 transposed ops behind the fp32 ones) */
   long tslot = -1;
   { int trc = timer_begin(st, &tslot, REFNERF_TIMER_BACKWARD); if (trc) return trc; }

@@ -538,11 +538,13 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
   RN_STAMPW(A, 16);
 }
 
+#ifndef REFNERF_SECONDARY_TU   /* (the second translation unit takes the device functions of this header, not its kernels) */
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16(const LevelArgs A) { level_fwd_mm<MmBf16>(A); }
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16(const LevelArgs A) { level_fwd_mm<MmF16>(A); }
 /* the same with the per-sample records in a ring (rays_per_wg * N > 640) */
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_bf16_ring(const LevelArgs A) { level_fwd_mm<MmBf16, true>(A); }
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16_ring(const LevelArgs A) { level_fwd_mm<MmF16, true>(A); }
+#endif
 
 /* =====================================================================================================================
  * REFNERF_PREC_F16X2 -- the parity-grade 16-bit mode (split operands, refnerf_layout.h "split-f16 operand image").
@@ -1047,8 +1049,10 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
   RN_STAMPW(A, 16);
 }
 
+#ifndef REFNERF_SECONDARY_TU
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16x2(const LevelArgs A) { level_fwd_split<false>(A); }
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_f16x2_ring(const LevelArgs A) { level_fwd_split<true>(A); }
+#endif
 
 /* ---------------- bf16 weight image ---------------- */
 __device__ __forceinline__ int ipe_col_of_kprime(int kp) { return kp; }   /* LDS order = canonical IPE order */

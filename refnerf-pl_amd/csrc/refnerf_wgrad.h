@@ -112,6 +112,7 @@ struct WgradArgs {
   float *part;            /* [slices][NUM_PARAMS] */
 };
 
+#ifndef REFNERF_SECONDARY_TU   /* (kernels of the first translation unit) */
 /* grid = (WJOBS.tiles, slices), 256 threads: waves 2x2 over the 128x128 tile. */
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs A) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];
@@ -240,5 +241,7 @@ __global__ void wgrad_reduce(const float *__restrict__ part, int slices, float *
     grads[i] += s;
   }
 }
+
+#endif
 
 }  // namespace rn

@@ -1,0 +1,253 @@
+/*
+ * refnerf_wgrad_sq.h -- the weight-gradient contraction on the round-5 formats (refnerf_sq_layout.h): wgrad_f16s_kernel of
+ * refnerf_wgrad_f16.h with
+ *   * ACT in REFNERF_ACT_SQ: spatial jobs read hi / lo pair units (two products d * a_hi + d * a_lo), directional jobs read the
+ *     ONE half the forward's trunk multiplied (one product, half the ACT bytes and half the MFMAs of those jobs);
+ *   * DELTA factors as (c, kappa) units: every sample of a layer is brought to the layer's smallest kappa K (the power of two that
+ *     puts the LARGEST delta of the layer at [2^14, 2^15)): d16 * (K / c_s), then the tile is divided by K.  The backward's
+ *     bound-based factors leave a sample's stored maximum anywhere in the half's range, so the common factor comes from kappa,
+ *     the multiplier from c.
+ * Same job geometry, split-K slices, PART layout and fixed-order reduction: bit-reproducible, no atomics.
+ * Restates what autograd does for nn.Linear (internal/models.py:576-580,686-700): dW = delta^T x, db = sum delta.
+ */
+#pragma once
+#include "refnerf_wgrad.h"
+#include "refnerf_sq_layout.h"
+
+namespace rn {
+
+/* the job table on the units of REFNERF_ACT_SQ: a_row = first UNIT of the job's input, `half` = one half per element */
+struct WJobSq { WJob j; int a_unit; int half; };
+struct WJobsSq { WJobSq job[MAX_WJOBS]; int n; int tiles; };
+constexpr WJobsSq make_wjobs_sq() {
+  WJobsSq T{};
+  for (int i = 0; i < WJOBS.n; ++i) {
+    WJobSq q{};
+    q.j = WJOBS.job[i];
+    const int a = q.j.a_row;
+    if (a < ACT_DIN) { q.a_unit = (a == ACT_IPE) ? AQ_IPE : AQ_SP + (a - ACT_SP); q.half = 0; }
+    else if (a == ACT_DIN) { q.a_unit = AQ_DIN; q.half = 1; }
+    else { q.a_unit = AQ_VD + (a - ACT_VD) / 2; q.half = 1; }
+    T.job[i] = q;
+  }
+  T.n = WJOBS.n;
+  T.tiles = WJOBS.tiles;
+  return T;
+}
+constexpr WJobsSq WJOBS_SQ = make_wjobs_sq();
+
+/* K[lid] = min over the valid samples of the kappa unit of layer id `lid`; kmin[] pre-set to +inf bits.
+ * grid = (DSC_ROWS, 64) x 256 threads; positive floats order like their bit patterns, so one atomicMin per block. */
+__global__ __launch_bounds__(256) void delta_kappa_min(const float *__restrict__ delta, long long S, float *kmin) {
+  const int lid = blockIdx.x;
+  const float *row = delta + (long long)(DQ_K + lid) * RB;
+  float m = INFINITY;
+  for (long long s = (long long)blockIdx.y * blockDim.x + threadIdx.x; s < S; s += (long long)gridDim.y * blockDim.x) {
+    const float c = row[rb_col(s, DQ_UNITS)];
+    m = (c > 0.0f) ? fminf(m, c) : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m < INFINITY) atomicMin(reinterpret_cast<int *>(kmin) + lid, __builtin_bit_cast(int, m));
+}
+
+typedef _Float16 sqw_v2h __attribute__((ext_vector_type(2)));
+typedef _Float16 sqw_v8h __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned sqw_pk_mul(unsigned a, unsigned b) {
+  const sqw_v2h z = __builtin_bit_cast(sqw_v2h, a) * __builtin_bit_cast(sqw_v2h, b);
+  return __builtin_bit_cast(unsigned, z);
+}
+__device__ __forceinline__ float sqw_pk_sum(unsigned a) {
+  const sqw_v2h z = __builtin_bit_cast(sqw_v2h, a);
+  const _Float16 z0 = z[0], z1 = z[1];
+  return (float)z0 + (float)z1;
+}
+__device__ __forceinline__ unsigned sqw_pk_f16(float lo, float hi) {
+  const sqw_v2h r = __builtin_convertvector((v2f){lo, hi}, sqw_v2h);
+  return __builtin_bit_cast(unsigned, r);
+}
+constexpr int SQW_KT = 64;                     /* samples per k-step = one block of the operand matrices */
+constexpr int SQW_ROW = SQW_KT * 2;            /* 128 B per LDS row, chunks swizzled as in refnerf_wgrad_f16.h */
+__device__ __forceinline__ int sqw_off(int row, int byte) { return row * SQW_ROW + ((((byte >> 4) ^ (row >> 1)) & 7) << 4) + (byte & 15); }
+constexpr int SQW_NW = 4, SQW_TM = 128;
+constexpr int SQW_LDS = (SQW_TM + 2 * WG_TN) * SQW_ROW;
+static_assert(SQW_KT == RB, "one k-step = one 64-sample block of the operand matrices");
+
+struct WgradSqArgs {
+  const float *act, *delta;
+  long long S;
+  int k_per_slice;
+  float *part;            /* [slices][NUM_PARAMS] */
+};
+
+/* grid = 8 * ceil(slices / 8) * tiles workgroups of 256 threads: waves 2 x 2 of 64 x 64 over a 128 x 128 output tile */
+__global__ __launch_bounds__(64 * SQW_NW) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_sq_kernel(const WgradSqArgs A, int slices, const float *__restrict__ kmin_all) {
+  constexpr int NW = SQW_NW, TM = SQW_TM;
+  constexpr int MI = TM / (16 * NW);             /* 2 */
+  constexpr int NPD = TM / (8 * NW);             /* row PAIRS of the D tile per loader thread: 4 */
+  constexpr int NPA = WG_TN / (8 * NW);          /* ... of the A tile: 4 */
+  constexpr int NRD = 2 * NPD, NRA = 2 * NPA;
+  extern __shared__ __attribute__((aligned(16))) char wbs[];
+  char *Dh = wbs, *Ah = wbs + TM * SQW_ROW, *Al = Ah + WG_TN * SQW_ROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, sl = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int tile = q % WJOBS_SQ.tiles, slice = (q / WJOBS_SQ.tiles) * 8 + xcd;
+  if (slice >= slices) return;
+  int ji = 0;
+#pragma unroll 1
+  for (int j = 1; j < WJOBS_SQ.n; ++j) if (tile >= WJOBS_SQ.job[j].j.tile0) ji = j;
+  const WJob J = WJOBS_SQ.job[ji].j;
+  const int a_unit = WJOBS_SQ.job[ji].a_unit;
+  const bool half = WJOBS_SQ.job[ji].half != 0;
+  const int tl = tile - J.tile0;
+  const int tm = tl / J.tiles_n, tn = tl - tm * J.tiles_n;
+  const long long k_begin = (long long)slice * A.k_per_slice;
+  long long k_end = k_begin + A.k_per_slice;
+  const long long s_pad = (A.S + SQW_KT - 1) / SQW_KT * SQW_KT;
+  if (k_end > s_pad) k_end = s_pad;
+  const int lid = del_layer_id(J.d_row);
+  const float kmin = kmin_all[lid];
+  const bool have = kmin < INFINITY;
+  const bool need_bias = tn == 0 && J.b_off >= 0;
+
+  v16f acc[MI][2];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  float bsum[NRD];
+#pragma unroll
+  for (int p = 0; p < NRD; ++p) bsum[p] = 0.0f;
+
+  const int lrow = tid >> 4, lc4 = (tid & 15) * 4;
+  const int lpair = (lrow & ~7) | ((lrow & 1) << 2) | ((lrow >> 1) & 3);
+  auto tile_row = [&](int p) { return 2 * lpair + 8 * NW * (p >> 1) + (p & 1); };
+  /* pair pp of this thread sits 4 NW pair rows behind pair pp - 1: DELTA one unit per pair row, ACT two (hi, lo) or one */
+  const int aup = half ? 1 : 2;                                     /* ACT units per pair row */
+  const char *dp0 = reinterpret_cast<const char *>(A.delta) + ((long long)((J.d_row + tm * TM) / 2 + lpair) * RB + lc4) * 4;
+  const char *ap0 = reinterpret_cast<const char *>(A.act) + ((long long)(a_unit + (tn * (WG_TN / 2) + lpair) * aup) * RB + lc4) * 4;
+  const long long dpp = (long long)(4 * NW) * RB * 4, app = (long long)(4 * NW * aup) * RB * 4;
+  auto d_live = [&](int p) { return tm * TM + tile_row(p) < J.n_out; };
+  auto a_live = [&](int p) { return tn * WG_TN + tile_row(p) < J.n_in; };
+  const char *scp = reinterpret_cast<const char *>(A.delta) + ((long long)(DQ_C + lid) * RB + lc4) * 4;
+  const long long dstep = (long long)DQ_UNITS * 4, astep = (long long)AQ_UNITS * 4;   /* bytes per sample of k0 */
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  v4u dv[NPD], avh[NPA], avl[NPA];
+  v4f cv;
+  auto fetch = [&](long long k0) {
+#pragma unroll
+    for (int pp = 0; pp < NPD; ++pp) {
+      v4u x = {0u, 0u, 0u, 0u};
+      if (d_live(2 * pp)) x = *reinterpret_cast<const v4u *>(dp0 + pp * dpp + k0 * dstep);
+      dv[pp] = x;
+    }
+#pragma unroll
+    for (int pp = 0; pp < NPA; ++pp) {
+      v4u y = {0u, 0u, 0u, 0u}, z = {0u, 0u, 0u, 0u};
+      if (a_live(2 * pp)) {
+        y = *reinterpret_cast<const v4u *>(ap0 + pp * app + k0 * astep);
+        if (!half) z = *reinterpret_cast<const v4u *>(ap0 + pp * app + k0 * astep + RB * 4);
+      }
+      avh[pp] = y; avl[pp] = z;
+    }
+    cv = *reinterpret_cast<const v4f *>(scp + k0 * dstep);
+  };
+  auto unpair = [](const v4u w, int hf, bool live, unsigned &s01, unsigned &s23) {
+    const unsigned sel = hf ? 0x07060302u : 0x05040100u;
+    s01 = live ? __builtin_amdgcn_perm(w[1], w[0], sel) : 0u;
+    s23 = live ? __builtin_amdgcn_perm(w[3], w[2], sel) : 0u;
+  };
+  auto step = [&](long long k0) {
+    __syncthreads();                                   /* previous tile fully consumed */
+    /* this thread's four samples to the layer's common factor: K / c_s, a power of two (factors are powers of two: v_rcp_f32 is
+     * exact on them; a pad sample's factor is whatever the allocator left there: select, not multiply) */
+    /* (K / c_s = 2^(15 - e(stored max)) x (K / kappa_s) passes the largest half only for a sample whose stored deltas are all
+     * below 1: applied as two powers of two then) */
+    unsigned f01, f23, g01, g23;
+    {
+      float f[4], g[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x = (have && k0 + lc4 + i < A.S && cv[i] > 0.0f) ? kmin * __builtin_amdgcn_rcpf(cv[i]) : 0.0f;
+        f[i] = fminf(x, 32768.0f);
+        g[i] = x > 32768.0f ? x * (1.0f / 32768.0f) : 1.0f;
+      }
+      f01 = sqw_pk_f16(f[0], f[1]);
+      f23 = sqw_pk_f16(f[2], f[3]);
+      g01 = sqw_pk_f16(g[0], g[1]);
+      g23 = sqw_pk_f16(g[2], g[3]);
+    }
+#pragma unroll
+    for (int p = 0; p < NRD; ++p) {
+      unsigned h0, h1;
+      unpair(dv[p >> 1], p & 1, d_live(p), h0, h1);
+      h0 = sqw_pk_mul(sqw_pk_mul(h0, f01), g01);
+      h1 = sqw_pk_mul(sqw_pk_mul(h1, f23), g23);
+      if (need_bias) bsum[p] += sqw_pk_sum(h0) + sqw_pk_sum(h1);
+      *reinterpret_cast<v2u *>(Dh + sqw_off(tile_row(p), lc4 * 2)) = (v2u){h0, h1};
+    }
+#pragma unroll
+    for (int p = 0; p < NRA; ++p) {
+      const int off = sqw_off(tile_row(p), lc4 * 2);
+      unsigned h0, h1, l0, l1;
+      unpair(avh[p >> 1], p & 1, a_live(p), h0, h1);
+      *reinterpret_cast<v2u *>(Ah + off) = (v2u){h0, h1};
+      if (!half) {
+        unpair(avl[p >> 1], p & 1, a_live(p), l0, l1);
+        *reinterpret_cast<v2u *>(Al + off) = (v2u){l0, l1};
+      }
+    }
+    __syncthreads();
+    if (k0 + SQW_KT < k_end) fetch(k0 + SQW_KT);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < SQW_KT / 16; ++kk) {
+      sqw_v8h dh[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) dh[i] = *reinterpret_cast<const sqw_v8h *>(Dh + sqw_off(wm * 32 * MI + i * 32 + sl, kk * 32 + h * 16));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int co = sqw_off(wn * 64 + j * 32 + sl, kk * 32 + h * 16);
+        const sqw_v8h bh = *reinterpret_cast<const sqw_v8h *>(Ah + co);
+        if (!half) {
+          const sqw_v8h bl = *reinterpret_cast<const sqw_v8h *>(Al + co);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[i], bl, acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[i], bh, acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (k_begin < k_end) fetch(k_begin);
+  for (long long k0 = k_begin; k0 < k_end; k0 += SQW_KT) step(k0);
+  const float inv = have ? 1.0f / kmin : 0.0f;   /* (a power of two: exact) */
+  float *part = A.part + (size_t)slice * NUM_PARAMS;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int colk = tn * WG_TN + wn * 64 + j * 32 + sl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = tm * TM + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (orow < J.n_out && colk < J.n_in) part[wjob_row_off(J, orow) + colk] = acc[i][j][r] * inv;
+      }
+    }
+  if (need_bias) {
+#pragma unroll
+    for (int p = 0; p < NRD; ++p) {
+      float s = bsum[p];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+      const int orow = tm * TM + tile_row(p);
+      if ((tid & 15) == 0 && orow < J.n_out) part[wjob_bias_off(J, orow)] = s * inv;
+    }
+  }
+}
+
+}  // namespace rn

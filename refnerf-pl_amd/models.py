@@ -468,7 +468,9 @@ class _LevelFunction(torch.autograd.Function):
         # training kernels read the f32 image (it carries the bf16 chain ops); a training forward re-packs
         # unconditionally -- an optimiser step always changes the weights, but not every optimiser bumps the tensors'
         # version counters (fused Adam does not), and the pack is 16 us
-        packed = mlp.packed_weights(_hip.PREC_F32, force=True)
+        # (the split-f16 chains on the built-in basis: their own image -- forward + transposed operands as one chunk stream)
+        image = _hip.IMAGE_F16X2_TRAIN if (cfg.precision == _hip.PREC_F16X2 and not mlp.ipe_groups and not _hip.LEGACY_F16X2_TRAIN) else _hip.PREC_F32
+        packed = mlp.packed_weights(image, force=True)
         res = _hip.level_forward(packed, cfg, rays, sdist_in, weights_in, history=True, save_activations=True)
         ctx.mlp, ctx.cfg, ctx.rays, ctx.packed = mlp, cfg, rays, packed
         ctx.packed_key = mlp._packed_key

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.lib()
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.refnerf_abi_version() == 9
+    assert lib.refnerf_abi_version() == 10
     assert _hip.packed_weights_bytes(_hip.PREC_F32) > 4 * layout.NUM_PARAMS
     # 17 KB chunks (+ 2 chunks of tail pad the ring may prefetch into): 150 for the plain 16-bit images, 206 for the split-f16 one
     # (133 spatial + heads chunks on the 16x16x32 layout, streamed twice per pass, + 73 directional: refnerf_layout.h)
