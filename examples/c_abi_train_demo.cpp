@@ -63,8 +63,10 @@ int main(int argc, char **argv) {
   float *d_params = dmalloc<float>(REFNERF_NUM_PARAMS);
   HIP_OK(hipMemcpy(d_params, params.data(), REFNERF_NUM_PARAMS * sizeof(float), hipMemcpyHostToDevice));
   void *d_packed = nullptr;
-  HIP_OK(hipMalloc(&d_packed, refnerf_packed_weights_bytes(REFNERF_PREC_F32)));
-  RN_OK(refnerf_pack_weights(d_params, d_packed, REFNERF_PREC_F32, nullptr));
+  // training levels read the f32 image; the split-f16 chains (built-in IPE basis) stream their own (ABI v10)
+  const int image = chains == REFNERF_PREC_F16X2 ? REFNERF_IMAGE_F16X2_TRAIN : REFNERF_PREC_F32;
+  HIP_OK(hipMalloc(&d_packed, refnerf_packed_weights_bytes(image)));
+  RN_OK(refnerf_pack_weights(d_params, d_packed, image, nullptr));
 
   // ---- training forward of both levels: outputs the loss needs + what the backward reads back
   std::vector<float> sd0(2 * R), w0(R, 1.0f);

@@ -168,6 +168,17 @@ def default_cfg(**kw) -> LevelCfg:
     return c
 
 
+def level_image(precision: int, training: bool = False, ipe_groups: int = 0) -> int:
+    """Which weight image refnerf_level_forward / _forward_train / _backward expect as `d_packed` for a level configuration:
+    inference levels the image of their precision mode (a general IPE basis: the f32 image), training levels the f32 image --
+    except REFNERF_PREC_F16X2 on the built-in basis, whose training kernels stream their own image (REFNERF_IMAGE_F16X2_TRAIN)."""
+    if ipe_groups > 1:
+        return PREC_F32
+    if training:
+        return IMAGE_F16X2_TRAIN if (precision == PREC_F16X2 and not LEGACY_F16X2_TRAIN) else PREC_F32
+    return precision
+
+
 def packed_weights_bytes(precision=PREC_F32) -> int:
     return int(lib().refnerf_packed_weights_bytes(precision))
 

@@ -731,6 +731,9 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   const bool gb_split = gbasis && cfg->precision == REFNERF_PREC_F16X2;
   /* training + F16X2 on the built-in basis: the round-5 kernels on the eval kernel's skeleton (refnerf_sq_train.hip);
    * d_packed is the REFNERF_IMAGE_F16X2_TRAIN image, the activations REFNERF_ACT_SQ */
+  if (cfg->training && cfg->precision == REFNERF_PREC_F16X2 && !gbasis && !d_act && !legacy_f16x2_train())
+    return fail(REFNERF_EINVAL, "a training level in REFNERF_PREC_F16X2 runs through refnerf_level_forward_train: its kernel keeps the ReLU sign words and "
+                                "the bottleneck rows in the activation buffer (d_packed: the REFNERF_IMAGE_F16X2_TRAIN image)%s");
   if (cfg->training && cfg->precision == REFNERF_PREC_F16X2 && !gbasis && d_act && !legacy_f16x2_train())
     return rnsq::forward(d_packed, cfg, rays, R, d_sdist_in, d_weights_in, out, d_act, (hipStream_t)stream);
   const bool train_split = (cfg->training && cfg->precision == REFNERF_PREC_F16X2) || gb_split;

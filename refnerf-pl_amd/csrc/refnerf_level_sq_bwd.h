@@ -307,7 +307,9 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
           for (int q = 0; q < 4; ++q) R0[t][q] = win_load(dw, voff_dh2, du + 16 * (t >> 1), 8 * (t & 1) + 4 * (q >> 1) + (q & 1));
       }
       const float bnd = KC[TRC_G + TRG_VD5_DIN] * (m5 / c5) + KC[TRC_G + TRG_VD0] * (m0 / c0);
-      c_bn = tq_bound_scale(bnd, 1.0f);
+      /* (a sample without any delta in the directional trunk -- zero weight, dead trunk -- puts no constraint on the head rows'
+       * common factor: the scalar rows then sit at the top of the half's range as in every other sample) */
+      c_bn = bnd > 0.0f ? tq_bound_scale(bnd, 1.0f) : 0x1p100f;
       const float ia = c_bn / c5, ib = c_bn / c0, ja = 1.0f / c5, jb = 1.0f / c0;
       const v4uu (&nobn)[8] = reinterpret_cast<const v4uu (&)[8]>(R0);
 #pragma unroll
@@ -394,7 +396,8 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
         for (int t = 0; t < 8; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const MM::v2 z = __builtin_bit_cast(MM::v2, hbn[t][q]) * __builtin_bit_cast(MM::v2, dn2);
+            const unsigned w = hbn[t][q];         /* (a scalar copy first: __builtin_bit_cast on an ext-vector ELEMENT reads element 0) */
+            const MM::v2 z = __builtin_bit_cast(MM::v2, w) * __builtin_bit_cast(MM::v2, dn2);
             hbn[t][q] = __builtin_bit_cast(unsigned, z);
           }
       }

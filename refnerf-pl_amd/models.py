@@ -729,8 +729,16 @@ class Model(nn.Module):
                 res = dict(zip(holder["keys"], outs))
             else:
                 lean = _LEAN.depth > 0 and not self.training
-                res = _hip.level_forward(mlp.packed_weights(_hip.PREC_F32 if (cfg.training or mlp.ipe_groups) else cfg.precision), cfg, r, sdist, weights,
-                                         history=(("rgb",) if compute_extras else ()) if lean else True)
+                image = _hip.level_image(cfg.precision, bool(cfg.training), mlp.ipe_groups)
+                # (a training-mode level without autograd -- torch.no_grad() around a model in train() mode: the noisy-ray pass, shard
+                #  checks -- runs the SAME kernel as the differentiable one, bit for bit; the f16x2 training kernel keeps its sign words
+                #  and bottleneck rows in the activation buffer, so it gets one and drops it)
+                scratch_act = image == _hip.IMAGE_F16X2_TRAIN
+                res = _hip.level_forward(mlp.packed_weights(image), cfg, r, sdist, weights,
+                                         history=(("rgb",) if compute_extras else ()) if lean else True, save_activations=scratch_act)
+                if scratch_act:
+                    res.pop("activations", None)
+                    res.pop("activations_format", None)
             sdist, weights = res["sdist"], res["weights"]
             self.last_bin_idx.append(res.get("bin_idx"))
 

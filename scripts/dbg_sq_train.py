@@ -74,6 +74,14 @@ def main():
             na = np.linalg.norm(a)
             rel = np.linalg.norm(a - b) / max(na, 1e-30)
             print(f"  {name + '.' + part:34s} |g| {na:.3e}  rel {rel:.3e}  nonfinite {int((~np.isfinite(b)).sum())}")
+    np.set_printoptions(linewidth=200, precision=4)
+    for nm in ("bottleneck",):
+        a, b = p32[nm][1], p16[nm][1]
+        print(nm, "bias grad f32  :", a[:24])
+        print(nm, "bias grad f16x2:", b[:24])
+        print(nm, "ratio          :", (b / a)[:48])
+        aw, bw = p32[nm][0].reshape(128, 256), p16[nm][0].reshape(128, 256)
+        print(nm, "per-row rel err of dW:", (np.linalg.norm(aw - bw, axis=1) / np.linalg.norm(aw, axis=1))[:48])
     try:
         from oracle import oracle as O
         tr = {k: v for k, v in rays_np.items()}

@@ -36,8 +36,8 @@ def dev_rays(rays):
 
 
 def run_hip_model(hip, P, rays, kw, lv, precision=0):
-    # training-mode levels read the f32 image in both arithmetic modes (it carries the bf16 chain ops)
-    packed = hip.pack_weights(torch.tensor(P, device=DEV), precision=0 if kw.get("training") else precision)
+    # training-mode levels read the f32 image (it carries the bf16 chain ops), the f16x2 chains of the built-in basis their own
+    packed = hip.pack_weights(torch.tensor(P, device=DEV), precision=hip.level_image(precision, bool(kw.get("training")), int(kw.get("ipe_groups", 0))))
     r = dev_rays(rays)
     R = rays["origins"].shape[0]
     sdist = torch.tensor([[0.0, 1.0]], device=DEV).repeat(R, 1)
