@@ -675,6 +675,8 @@ def test_nerfmlp_variants_vs_reference(hip, name, flat, chains):
         for k in hist_keys:
             a = g[f"L{L}_h_{k}"]
             tol = 2e-4 if k == "normals_pred" else (1e-4 if k == "density" else 2e-6)
+            if chains == "f16x2" and k in ("rgb", "specular"):
+                tol = 5e-6                                 # the f16x2 training forward's directional trunk takes x as ONE half (round 5): 2.1e-6
             if L > 0 and k not in ("sdist", "weights"):
                 tol = max(tol, 5e-5)                   # level-1 sample positions differ by an ulp
             np.testing.assert_allclose(history[L][k].detach().cpu().numpy().reshape(a.shape), a, rtol=0, atol=tol, err_msg=f"L{L} {k}")
