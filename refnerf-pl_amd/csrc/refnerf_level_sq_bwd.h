@@ -161,37 +161,43 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
     const unsigned voff_f = h_v == 0 ? voff_d : BLK_NONE;                    /* per-sample units: half 0 stores            */
     RN_STAMPW(A, 1);
 
-    /* ===== per-sample head: what the forward left in ACT, the colour head backward (models.py:699-729) ===== */
-    float g_raw_rgb[3], g_tint[3], g_raw_diff[3], gsv[SQ_NGS], v[3];
-    float raw_density, raw_rough;
-    SampleHeads sh;
-    {
+    /* ===== per-sample head: what the forward left in ACT, the colour head backward (models.py:699-729) =====
+     * Evaluated TWICE -- here for the seed of the directional chain (g_raw_rgb), and again in front of the IDE backward -- from
+     * 24 reloaded values (L2) and ~300 VALU, instead of ~45 registers carried across both trunks (at 256 registers per lane that
+     * was 330 spilled VGPRs and 0.9 KB / lane of scratch). */
+    struct HeadState { SampleHeads sh; float g_raw_rgb[3], g_tint[3], g_raw_diff[3], gsv[SQ_NGS], v[3], raw_density, raw_rough; };
+    auto head_state = [&](HeadState &H) {
+      int cv2 = col_v;
+      asm volatile("" : "+v"(cv2));
+      const long long gs2 = gs_pass + cv2;
+      const bool valid2 = gs2 < A.S;
+      const unsigned va = blk_voff(aw, gs2, AQ_UNITS, valid2);
       float gp[3], raw_dif[3], raw_tint[3], raw_rgb[3];
       const int as = opaque_s(AQ_RAW);
-      raw_density = __builtin_bit_cast(float, win_load(aw, voff_a, as, 0));
-      raw_rough = __builtin_bit_cast(float, win_load(aw, voff_a, as, 4));
+      H.raw_density = __builtin_bit_cast(float, win_load(aw, va, as, 0));
+      H.raw_rough = __builtin_bit_cast(float, win_load(aw, va, as, 4));
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        gp[i] = __builtin_bit_cast(float, win_load(aw, voff_a, as, 1 + i));
-        raw_dif[i] = __builtin_bit_cast(float, win_load(aw, voff_a, as, 5 + i));
-        raw_tint[i] = __builtin_bit_cast(float, win_load(aw, voff_a, as, 8 + i));
-        raw_rgb[i] = __builtin_bit_cast(float, win_load(aw, voff_a, as, 11 + i));
+        gp[i] = __builtin_bit_cast(float, win_load(aw, va, as, 1 + i));
+        raw_dif[i] = __builtin_bit_cast(float, win_load(aw, va, as, 5 + i));
+        raw_tint[i] = __builtin_bit_cast(float, win_load(aw, va, as, 8 + i));
+        raw_rgb[i] = __builtin_bit_cast(float, win_load(aw, va, as, 11 + i));
       }
-      const long long gsc = valid ? gs : 0;
+      const long long gsc = valid2 ? gs2 : 0;
       const long long ray = gsc / N;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) v[i] = A.viewdirs[ray * 3 + i];
+      for (int i = 0; i < 3; ++i) H.v[i] = A.viewdirs[ray * 3 + i];
 #pragma unroll
-      for (int i = 0; i < SQ_NGS; ++i) gsv[i] = valid ? A.seeds[(size_t)i * A.pitch + gsc] : 0.0f;
-      sample_heads(cfg, raw_density, gp, raw_rough, raw_dif, raw_tint, v, sh);
+      for (int i = 0; i < SQ_NGS; ++i) H.gsv[i] = valid2 ? A.seeds[(size_t)i * A.pitch + gsc] : 0.0f;
+      sample_heads(cfg, H.raw_density, gp, H.raw_rough, raw_dif, raw_tint, H.v, H.sh);
       float sg[3], dl[3], colr[3], g_col[3];
       const float pad_scale = (float)(1.0 + 2.0 * (double)cfg.rgb_padding);
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         sg[i] = sigmoid_t(cfg.rgb_premultiplier * raw_rgb[i] + cfg.rgb_bias);
-        dl[i] = sigmoid_t(sh.raw_dif[i] - LOG3_F);
-        colr[i] = sh.tint[i] * sg[i] + dl[i];
-        g_col[i] = gsv[1 + i] * pad_scale;
+        dl[i] = sigmoid_t(H.sh.raw_dif[i] - LOG3_F);
+        colr[i] = H.sh.tint[i] * sg[i] + dl[i];
+        g_col[i] = H.gsv[1 + i] * pad_scale;
       }
       if (cfg.srgb_mapping) colour_map_backward(colr, cfg.srgb_mapping_normalization != 0, true, g_col);
       float g_dl[3], g_sp[3];
@@ -201,9 +207,9 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
         float e_dl[3], e_sp[3], spl[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          e_dl[i] = (valid && A.g_s_diffuse) ? A.g_s_diffuse[gsc * 3 + i] : 0.0f;
-          e_sp[i] = (valid && A.g_s_specular) ? A.g_s_specular[gsc * 3 + i] : 0.0f;
-          spl[i] = sh.tint[i] * sg[i];
+          e_dl[i] = (valid2 && A.g_s_diffuse) ? A.g_s_diffuse[gsc * 3 + i] : 0.0f;
+          e_sp[i] = (valid2 && A.g_s_specular) ? A.g_s_specular[gsc * 3 + i] : 0.0f;
+          spl[i] = H.sh.tint[i] * sg[i];
         }
         if (cfg.srgb_mapping) {
           colour_map_backward(dl, false, true, e_dl);
@@ -214,10 +220,17 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        g_tint[i] = g_sp[i] * sg[i] + ((valid && A.g_s_tint) ? A.g_s_tint[gsc * 3 + i] : 0.0f);
-        g_raw_rgb[i] = (g_sp[i] * sh.tint[i]) * sg[i] * (1.0f - sg[i]) * cfg.rgb_premultiplier;
-        g_raw_diff[i] = g_dl[i] * dl[i] * (1.0f - dl[i]);
+        H.g_tint[i] = g_sp[i] * sg[i] + ((valid2 && A.g_s_tint) ? A.g_s_tint[gsc * 3 + i] : 0.0f);
+        H.g_raw_rgb[i] = (g_sp[i] * H.sh.tint[i]) * sg[i] * (1.0f - sg[i]) * cfg.rgb_premultiplier;
+        H.g_raw_diff[i] = g_dl[i] * dl[i] * (1.0f - dl[i]);
       }
+    };
+    float g_raw_rgb[3];
+    {
+      HeadState H;
+      head_state(H);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) g_raw_rgb[i] = H.g_raw_rgb[i];
     }
     RN_STAMPW(A, 2);
     float c, mx;
@@ -349,6 +362,14 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
     float c_h;
     {
       /* ===== IDE, reflection, predicted normal, head activations backward (models.py:611-686) ===== */
+      HeadState H;
+      head_state(H);
+      const SampleHeads &sh = H.sh;
+      const float (&v)[3] = H.v;
+      const float (&gsv)[SQ_NGS] = H.gsv;
+      const float (&g_tint)[3] = H.g_tint;
+      const float (&g_raw_diff)[3] = H.g_raw_diff;
+      const float raw_density = H.raw_density, raw_rough = H.raw_rough;
       float g_ref[3], g_rough;
       int ci = col_v;
       asm volatile("" : "+v"(ci));

@@ -49,12 +49,17 @@ __device__ __forceinline__ unsigned blk_voff(const BlkWin &w, long long gs, int 
 __device__ __forceinline__ unsigned blk_voff_add(unsigned voff, int lane_units) { return voff + (unsigned)lane_units * 256u; }
 /* unit `sunit` + `iunit`: sunit goes into the scalar offset (a wave-uniform run-time value: one s_add per store, nothing to
  * hoist), iunit (0..15) into the instruction's 12-bit immediate */
+/* (`voff` is laundered at every use: left visible, the loop-invariant sums voff + iunit * 256 are hoisted in front of the layer
+ * loops -- one VGPR per distinct immediate, 8 to 16 per window, live across every trunk -- and the instruction selector, which
+ * works block by block, then finds no add to fold into the immediate field) */
 __device__ __forceinline__ void win_store(const BlkWin &w, unsigned voff, int sunit, int iunit, unsigned dword) {
 #ifndef REFNERF_EXPERIMENT_NO_STREAM
+  asm volatile("" : "+v"(voff));
   __builtin_amdgcn_raw_buffer_store_b32(dword, w.rs, voff + (unsigned)iunit * 256u, sunit * 256, REFNERF_SQ_STREAM_AUX);
 #endif
 }
 __device__ __forceinline__ unsigned win_load(const BlkWin &w, unsigned voff, int sunit, int iunit) {
+  asm volatile("" : "+v"(voff));
   return __builtin_amdgcn_raw_buffer_load_b32(w.rs, voff + (unsigned)iunit * 256u, sunit * 256, 0);
 }
 /* a unit index the compiler must treat as a run-time scalar */

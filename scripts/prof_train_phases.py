@@ -12,7 +12,7 @@ dev = "cuda:0"; R, N = 4096, 128
 P = torch.tensor(synthetic.make_params(0, 0.05, 20.0), device=dev)
 rays = {k: torch.tensor(v, device=dev) for k, v in synthetic.blender_rays(R, seed=1, center_frac=0.5).items()}
 for k in ("radii", "near", "far"): rays[k] = rays[k].reshape(-1)
-packed = _hip.pack_weights(P, precision=0)
+packed = _hip.pack_weights(P, precision=_hip.level_image(prec, True))
 sd = torch.tensor([[0.0, 1.0]], device=dev).repeat(R, 1); w = torch.ones((R, 1), device=dev)
 g_rgb = torch.randn((R, 3), device=dev) * 1e-3; g_w = torch.randn((R, N), device=dev) * 1e-3; g_np = torch.randn((R, N, 3), device=dev) * 1e-3
 cfg = _hip.default_cfg(n_samples=N, n_in=1, training=1, compute_extras=0)
