@@ -110,6 +110,17 @@ struct Pipe {
 #ifndef REFNERF_DMA_AUX
 #define REFNERF_DMA_AUX 0   /* cache policy bits of the weight stream's LDS-DMA */
 #endif
+/* the rendezvous of a chunk: this wave's DMA pieces have landed, then every wave's.  REFNERF_BARE_BARRIER: s_barrier alone behind
+ * the wait -- __syncthreads() is a workgroup fence + barrier, and the fence is `s_waitcnt vmcnt(0) lgkmcnt(0)`: it also drains
+ * the A-fragment reads that were issued ahead for the MFMAs BEHIND the rendezvous */
+#ifndef REFNERF_BARE_BARRIER
+#define REFNERF_BARE_BARRIER 0
+#endif
+#if REFNERF_BARE_BARRIER
+#define RN_RENDEZVOUS() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define RN_RENDEZVOUS() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+#endif
 template <bool SPLIT = false>
 __device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off, int piece = -1) {
   if (p.dma_left > 0) {
@@ -223,8 +234,7 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], cons
       p.t_vm += t1 - t0;
       p.t_bar += t2 - t1;
 #else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      RN_RENDEZVOUS();
 #endif
       issue_chunk<SPLIT>(p, p.fil_off, REFNERF_BF_SPREAD ? 0 : -1);
     }
@@ -653,8 +663,7 @@ __device__ __forceinline__ void sq_chunk(Pipe &p, sq_v8 (&fr)[SQ_NF], const v4uu
       p.t_vm += t1 - t0;
       p.t_bar += t2 - t1;
 #else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      RN_RENDEZVOUS();
 #endif
       issue_chunk<true>(p, p.fil_off, REFNERF_BF_SPREAD ? 0 : -1);
       if (PRE && REFNERF_SQ_PREBIAS) {

@@ -51,6 +51,9 @@ __device__ __forceinline__ void sq_mask_pack(const v16f &a, v4uu &f0, v4uu &f1, 
     v[r] = keep(a[r], r) * rs;
     mx = fmaxf(mx, fabsf(v[r]));
   }
+  /* (pinned per slice: left to itself the optimiser re-associates the running maximum of a layer into ONE tree behind the last
+   * slice and keeps all 128 scaled values alive for it -- in scratch, and every reload drains the store queue) */
+  asm volatile("" : "+v"(mx));
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     f0[e] = pk_f16(v[2 * e], v[2 * e + 1]);
@@ -59,6 +62,18 @@ __device__ __forceinline__ void sq_mask_pack(const v16f &a, v4uu &f0, v4uu &f1, 
 }
 /* the eight dwords of k-steps 2 ob, 2 ob + 1 to their pair rows of DELTA (one half per element) */
 __device__ __forceinline__ void sq_store_delta(const BlkWin &dw, unsigned voff_h2, int unit, const v4uu &f0, const v4uu &f1) {
+#ifdef REFNERF_EXPERIMENT_NO_DELTA   /* timing experiment only: the chains run on real data, their deltas are not written */
+  return;
+#endif
+#ifdef REFNERF_EXPERIMENT_WIDE   /* timing experiment only (wrong layout): the same bytes as two 16-byte stores per lane */
+  {
+    unsigned vo = (voff_h2 & ~255u) + (voff_h2 & 255u) * 4u;
+    asm volatile("" : "+v"(vo));
+    __builtin_amdgcn_raw_buffer_store_b128(f0, dw.rs, vo, unit * 256, REFNERF_SQ_STREAM_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(f1, dw.rs, vo + 2048u, unit * 256, REFNERF_SQ_STREAM_AUX);
+    return;
+  }
+#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     win_store(dw, voff_h2, unit, 4 * (q >> 1) + (q & 1), f0[q]);
@@ -263,6 +278,7 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
             mx = fmaxf(mx, fabsf(x));
           }
         }
+        asm volatile("" : "+v"(mx));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           R0[2 * ob][e] = pk_f16(vv[2 * e], vv[2 * e + 1]);
@@ -339,6 +355,7 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
           float vv[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) { vv[r] = accA[r] * ia + accB[r] * ib; mxb = fmaxf(mxb, fabsf(vv[r])); }
+          asm volatile("" : "+v"(mxb));
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             hbn[2 * ob][e] = pk_f16(vv[2 * e], vv[2 * e + 1]);
@@ -507,6 +524,9 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   RN_STAMPW(A, 9);
+#ifdef REFNERF_PROF_WAITS
+  if (A.prof && blockIdx.x == (gridDim.x >> 1) && lane == 0) { A.prof[wave * 32 + 20] = p.t_vm; A.prof[wave * 32 + 21] = p.t_bar; }
+#endif
 }
 
 __global__ __launch_bounds__(BF_NTHREADS) void level_bwd_sq(const SqBwdArgs A) { level_bwd_sq_body(A); }

@@ -55,6 +55,9 @@ __device__ __forceinline__ unsigned blk_voff_add(unsigned voff, int lane_units) 
 __device__ __forceinline__ void win_store(const BlkWin &w, unsigned voff, int sunit, int iunit, unsigned dword) {
 #ifndef REFNERF_EXPERIMENT_NO_STREAM
   asm volatile("" : "+v"(voff));
+#ifdef REFNERF_EXPERIMENT_STORE_LOCAL   /* timing experiment only: every store of a lane lands on the same line (no HBM traffic) */
+  sunit &= REFNERF_EXPERIMENT_STORE_LOCAL;
+#endif
   __builtin_amdgcn_raw_buffer_store_b32(dword, w.rs, voff + (unsigned)iunit * 256u, sunit * 256, REFNERF_SQ_STREAM_AUX);
 #endif
 }
@@ -71,8 +74,23 @@ __device__ __forceinline__ int opaque_s(int x) {
 /* the rendezvous: chunk c + 1 is complete for every wave (every wave's DMA pieces have landed: they were issued before the
  * VMK newest vector-memory operations of this wave), chunk c - 1's slot is free */
 template <int VMK>
-__device__ __forceinline__ void tq_rendezvous() {
+__device__ __forceinline__ void tq_rendezvous(Pipe &p) {
+#ifdef REFNERF_PROF_WAITS   /* cycles in the counted wait / in the barrier (debug builds) */
+  const long long t0 = (long long)__builtin_readcyclecounter();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMK) : "memory");
+  const long long t1 = (long long)__builtin_readcyclecounter();
+  asm volatile("s_barrier" ::: "memory");
+  const long long t2 = (long long)__builtin_readcyclecounter();
+  p.t_vm += t1 - t0;
+  p.t_bar += t2 - t1;
+#elif defined(REFNERF_EXPERIMENT_TQ_SYNC)   /* timing experiment: the eval kernels' rendezvous (fence + barrier: drains stores and LDS reads) */
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#elif defined(REFNERF_EXPERIMENT_TQ_LGKM)   /* timing experiment: counted vmcnt, but the LDS reads drained as __syncthreads does */
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VMK) : "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VMK) : "memory");
+#endif
 }
 
 /* stream position of the training forward: [run section] x 2 + [directional section]; of the backward: linear */
@@ -107,7 +125,7 @@ template <bool BWD>
 __device__ __forceinline__ void tq_idle_pass(Pipe &p) {
 #pragma unroll 1
   for (int c = 0; c < (BWD ? TR_BWD : TR_FWD_PASS); ++c) {
-    tq_rendezvous<0>();
+    tq_rendezvous<0>(p);
     tq_issue<BWD>(p, p.fil_off);
     tq_rotate(p);
   }
@@ -144,7 +162,7 @@ __device__ __forceinline__ void tq_chunk(Pipe &p, sq_v8 (&fr)[SQ_NF], const v4uu
       if ((j % 6) == 5 && sl + 1 < 3) xb[1] = lds_frag<MmF16>(p.xps + (sl + 1) * (4 * BT * 16) + (BT / 2) * 16);
     }
     if (j == RDV) {
-      tq_rendezvous<VMK>();
+      tq_rendezvous<VMK>(p);
       tq_issue<false>(p, p.fil_off, 0);
       if (PRE) {
         const v4f *bp = reinterpret_cast<const v4f *>(p.wbuf + p.nxt_off + (p.lane >> 4) * 16);
@@ -177,6 +195,11 @@ __device__ __forceinline__ void tq_bf_chunk(Pipe &p, MmF16::v8 (&a)[AF], const v
   auto lds_bq = [&](int kl) { return REAL_L == 1 ? lds_frag<MM>(p.xp) : lds_b<MM, REAL_L>(p, kl); };
   if (KIND == BF_LDS8) { xr[0] = lds_bq(0); xr[1] = lds_bq(1); }
   if (FIRST) acc = bias16(w, p.h);
+#ifdef REFNERF_EXPERIMENT_ACC2
+  v16f acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
+#endif
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
@@ -185,6 +208,9 @@ __device__ __forceinline__ void tq_bf_chunk(Pipe &p, MmF16::v8 (&a)[AF], const v
     if (lds_step) b = xr[(k - L0) & 1];
     else if (KIND == BF_REG) b = __builtin_bit_cast(v8mm, in[k]);
     else b = __builtin_bit_cast(v8mm, bn[k & 7]);
+#ifdef REFNERF_EXPERIMENT_ACC2
+    if (k & 1) acc2 = MM::mfma(a[k % AF], b, acc2); else
+#endif
     acc = MM::mfma(a[k % AF], b, acc);
     a[k % AF] = (k + AF < KS) ? lds_frag<MM>(cur + (k + AF) * 1024) : lds_frag<MM>(nxt + (k + AF - KS) * 1024);
     if (KIND == BF_LDS8 || KIND == BF_BNLDS) {
@@ -192,13 +218,17 @@ __device__ __forceinline__ void tq_bf_chunk(Pipe &p, MmF16::v8 (&a)[AF], const v
       if (kl2 >= 0 && kl2 < 8 && !(KIND == BF_LDS8 && kl2 < 2)) xr[kl2 & 1] = lds_bq(kl2);
     }
     if (k == RDV) {
-      tq_rendezvous<VMK>();
+      tq_rendezvous<VMK>(p);
       tq_issue<BWD>(p, p.fil_off, 0);
     }
     if (k == RDV + 2) tq_issue<BWD>(p, p.fil_off, 1);
     if (k == RDV + 4) tq_issue<BWD>(p, p.fil_off, 2);
     __builtin_amdgcn_sched_barrier(0);
   }
+#ifdef REFNERF_EXPERIMENT_ACC2
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+#endif
   tq_rotate(p);
 }
 
@@ -290,6 +320,7 @@ __device__ __forceinline__ void tq_vjp_piece(const SqAcc &a, int q, v4uu &oh, v4
   const int bit = bit0 + 4 * (q >> 1) + 2 * (q & 1);
   const float x0 = tq_keep(y0, mk, bit) * rs, x1 = tq_keep(y1, mk, bit + 1) * rs;
   mx = fmaxf(mx, fmaxf(fabsf(x0), fabsf(x1)));
+  asm volatile("" : "+v"(mx));                   /* (pinned: the optimiser otherwise gathers a layer's maximum into one tree behind its last slice) */
   unsigned hi, lo;
   split_pair_f16(x0, x1, hi, lo);
   oh[q] = hi;

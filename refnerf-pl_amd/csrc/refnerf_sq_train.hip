@@ -313,7 +313,7 @@ int backward_chain(const void *d_packed, const refnerf_level_cfg *cfg, const ref
     for (int w = 0; w < 8; ++w) {
       fprintf(stderr, "[prof sq-bwd] wave %d:", w);
       for (int sl = 1; sl <= 9; ++sl) fprintf(stderr, " %lld", hbuf[w * 32 + sl] ? hbuf[w * 32 + sl] - hbuf[w * 32] : -1LL);
-      fprintf(stderr, "\n");
+      fprintf(stderr, "  | counted-wait %lld barrier-wait %lld\n", hbuf[w * 32 + 20], hbuf[w * 32 + 21]);
     }
   }
   return REFNERF_OK;

@@ -7,6 +7,8 @@ sys.path.insert(0, os.getcwd())
 import torch
 import refnerf_pl_amd
 from refnerf_pl_amd import _hip, synthetic
+if os.environ.get("REFNERF_LIB"):
+    _hip.LIB_PATH = os.path.join(os.getcwd(), os.environ["REFNERF_LIB"])
 prec = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dev = "cuda:0"; R, N = 4096, 128
 P = torch.tensor(synthetic.make_params(0, 0.05, 20.0), device=dev)
