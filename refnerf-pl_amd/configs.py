@@ -217,16 +217,21 @@ class Config:
     render_spline_degree: int = 5
     render_spline_smoothness: float = .03
     # build-side knobs (not in the reference).  hip_precision = arithmetic of the MLP contractions of inference levels:
-    # 'f32' (exact fp32 MFMA chains: the strict parity mode and the DEFAULT -- no operand-range limit), 'f16x2' (split-operand
-    # f16 MFMA: the parity-grade fast mode of record of bench.py / README, <= 1e-4 RGB vs the reference also on trained weights,
-    # 3.5x faster; opt-in because hidden activations beyond 65504 turn into NaN outputs), 'bf16' / 'f16' (throughput modes:
-    # within 1e-4 on random-init networks only).
+    # 'f32' (exact fp32 MFMA chains: the strict parity mode and the default of THIS CLASS -- no operand-range limit), 'f16x2'
+    # (split-operand f16 MFMA: the parity-grade fast mode of record, <= 1e-4 RGB vs the reference also on trained weights, 4x
+    # faster; hidden activations beyond 65504 turn into NaN outputs), 'bf16' / 'f16' (throughput modes: within 1e-4 on
+    # random-init networks only).  The shipped configs/refnerf_*.gin set all three knobs to 'f16x2' (INTEGRATION.md section A).
     hip_precision: str = 'f32'
     hip_train_precision: str = 'f32'  # MLP chains of the training forward: 'f32' (exact) | 'f16x2' (split f16: 22-bit products, parity-grade, ~3x faster) | 'bf16' (throughput mode)
     hip_bwd_precision: str = 'f32'  # transposed GEMM chains of the backward: 'f32' (exact) | 'f16x2' (split f16, parity-grade) | 'bf16' (throughput mode)
     hip_fused_losses: bool = False  # data (mse) + orientation + predicted-normal losses of a level as ONE fused kernel each way (train_utils.fused_refnerf_losses)
     hip_flat_grads: bool = False  # route the backward's gradient to MLP.flat_parameter().grad (one tensor) instead of the 46 nn.Parameters
-    hip_wgrad_mode: str = 'bf16x3'  # weight-gradient GEMM of the backward: 'bf16x3' (split-bf16 MFMA, fp32-level accuracy) | 'f32'
+    # weight-gradient GEMM of the backward.  'bf16x3' (default) = the 16-bit-MFMA GEMM that goes with the chains: after f32 chains
+    # (fp32 ACT / DELTA rows) operands split hi + lo into bf16 pairs, three products, fp32-level accuracy; after 'f16x2' chains
+    # the f16 GEMM on the saved halves themselves (ACT 22 / 11 bits, DELTA 11 bits + per-sample factors: gradient within 1e-4 ..
+    # 2e-4 of the f32 chains); after 'bf16' chains bf16 rows.  'f32' = fp32 MFMA products, with the f32 chains only (Model
+    # raises for 'f16x2' chains + 'f32': their operands are 16-bit).
+    hip_wgrad_mode: str = 'bf16x3'
 
 
 def load_config(gin_configs=None, gin_bindings=None) -> Config:

@@ -720,6 +720,11 @@ class Model(nn.Module):
                     # split-f16 backward and its f16 weight-gradient GEMM consume (a general IPE basis keeps fp32 rows)
                     raise ValueError("Config.hip_train_precision = 'f16x2' goes with hip_bwd_precision = 'f16x2' (its saved activations are "
                                      "split-f16 pair units)")
+                if train_prec == "f16x2" and not mlp.ipe_groups and cfg.wgrad_mode != _hip.WGRAD_BF16X3:
+                    #  the split-f16 chains hand the weight-gradient GEMM 16-bit operands (ACT hi / lo pair units and
+                    # one-half rows, DELTA one half per element + factors): there is no fp32-product GEMM on those
+                    raise ValueError("Config.hip_wgrad_mode = 'f32' goes with the exact-fp32 chains (hip_train_precision = hip_bwd_precision = 'f32'); "
+                                     "the 'f16x2' chains feed their own f16 weight-gradient GEMM (hip_wgrad_mode = 'bf16x3', the default)")
                 flat_mode = bool(getattr(self.config, "hip_flat_grads", False))
                 if not flat_mode and mlp._flat is not None and (mlp._flat.requires_grad or mlp._flat.grad is not None):
                     mlp.release_flat_parameter()            # flat mode was switched off: no stale .grad on the blob

@@ -12,8 +12,26 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "shipped_config: the test reads configs/*.gin as shipped (no f32 bindings injected)")
 
 
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _f32_unless_a_test_says_otherwise(request, monkeypatch):
+    """The shipped configs/*.gin select the mode of record ('f16x2' in all three hip_* knobs).  The parity tests were written
+    against the strict-parity default of `Config` ('f32'): every parse of a config file inside a test gets the three f32
+    bindings IN FRONT of the test's own (which override them), unless the test is marked `shipped_config`."""
+    if request.node.get_closest_marker("shipped_config"):
+        return
+    import refnerf_pl_amd  # noqa: F401
+    from refnerf_pl_amd import configs
+    real = configs.parse_config_files_and_bindings
+
+    def parse(config_files=None, bindings=None, *a, **kw):
+        pre = ["Config.hip_precision = 'f32'", "Config.hip_train_precision = 'f32'", "Config.hip_bwd_precision = 'f32'"]
+        return real(config_files, pre + list(bindings or []), *a, **kw)
+    monkeypatch.setattr(configs, "parse_config_files_and_bindings", parse)

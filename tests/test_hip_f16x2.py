@@ -617,3 +617,48 @@ def test_split_f16_activation_format_contract(hip):
         bad.precision = bad_prec
         with pytest.raises(hip.HipLibraryError, match="REFNERF_ACT_F16X2|REFNERF_ACT_SQ|split-f16"):
             hip.level_backward(packed, bad, rays, res, g_rgb, None, None, torch.zeros(hip.NUM_PARAMS, device=DEV))
+
+
+@pytest.mark.shipped_config
+def test_shipped_config_runs_the_mode_of_record(hip):
+    """a drop-in user who loads configs/refnerf_blender.gin WITHOUT bindings gets the mode of record -- the
+    split-f16 kernels in inference, training forward and backward -- not the strict-parity f32 kernels: the three hip_* knobs of
+    the shipped config, the precision Model hands the library, the kernel that then runs (bit-identical output to an explicit
+    'f16x2' binding, different from 'f32'), the activation format of a training level, and the timer family of its launches."""
+    import os
+    import torch
+    from refnerf_pl_amd import configs, models, synthetic, utils
+    gin = os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")
+    lv = ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 64"]
+    rays = utils.rays_from_dict(dict(synthetic.blender_rays(64, seed=1, center_frac=0.4)), DEV)
+    blob = synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0)
+    out = {}
+    for tag, extra in (("shipped", []), ("f16x2", ["Config.hip_precision = 'f16x2'"]), ("f32", ["Config.hip_precision = 'f32'"])):
+        configs.clear_config()
+        configs.parse_config_files_and_bindings([gin], lv + extra)
+        cfg = configs.Config()
+        if tag == "shipped":
+            assert (cfg.hip_precision, cfg.hip_train_precision, cfg.hip_bwd_precision) == ("f16x2", "f16x2", "f16x2")
+        model = models.construct_model(None, cfg).to(DEV).eval()
+        model.nerf_mlp.load_flat_params(blob)
+        if tag == "shipped":
+            assert model._level_cfg(model.nerf_mlp, 64, 1, 1.0, True).precision == hip.PREC_F16X2
+        with torch.no_grad():
+            rend, _ = model(rays, 1.0, True)
+        out[tag] = rend[1]["rgb"].clone()
+        if tag == "shipped":
+            # a training level of the shipped config: the round-5 kernels (their activation format), one forward + one backward launch
+            model.train()
+            hip.set_timing(True)
+            rend, hist = model(rays, 1.0, True)
+            rend[1]["rgb"].sum().backward()
+            torch.cuda.synchronize()
+            fams = {f: hip.get_timing(f)[1] for f in (hip.TIMER_FORWARD, hip.TIMER_BACKWARD, hip.TIMER_WGRAD)}
+            hip.set_timing(False)
+            assert fams[hip.TIMER_FORWARD] == 2 and fams[hip.TIMER_BACKWARD] == 2 and fams[hip.TIMER_WGRAD] == 2, fams
+            tcfg = model._level_cfg(model.nerf_mlp, 64, 1, 1.0, True)
+            import ctypes as C
+            assert tcfg.precision == hip.PREC_F16X2 and int(hip.lib().refnerf_activations_format(C.byref(tcfg))) == (hip.ACT_F16X2 if hip.LEGACY_F16X2_TRAIN else hip.ACT_SQ)
+    assert torch.equal(out["shipped"], out["f16x2"]) and not torch.equal(out["shipped"], out["f32"])
+    assert float((out["shipped"] - out["f32"]).abs().max()) < 1e-4
+    configs.clear_config()
