@@ -856,9 +856,10 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     passes = 2 if geometry else 1           # clean + noisy pass: two launches of each family per level and step
     samples_per_launch = (R + extra_rays) * N / passes
     kernels = {}
-    names = {"fwd": "rn::level_fwd_train_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[fwd_chains],
-             "bwd": "rn::level_bwd_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[bwd_chains],
-             "wgrad": "rn::wgrad_f16s_kernel" if (fwd_chains == "f16x2" and bwd_chains == "f16x2") else "rn::wgrad_bf16x3_kernel"}
+    sq = fwd_chains == "f16x2" and bwd_chains == "f16x2" and not _hip.LEGACY_F16X2_TRAIN      # the round-5 kernels (eval skeleton)
+    names = {"fwd": "rn::level_fwd_train_sq" if sq else "rn::level_fwd_train_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[fwd_chains],
+             "bwd": "rn::level_bwd_sq" if sq else "rn::level_bwd_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[bwd_chains],
+             "wgrad": "rn::wgrad_sq_kernel" if sq else ("rn::wgrad_f16s_kernel" if (fwd_chains == "f16x2" and bwd_chains == "f16x2") else "rn::wgrad_bf16x3_kernel")}
     peak_of = {"fwd": PEAK_TFLOPS[fwd_chains], "bwd": PEAK_TFLOPS[bwd_chains]}
     for k, (ms, cnt) in fam.items():
         if not cnt:
@@ -868,7 +869,11 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
             # algorithmic bytes: both operand matrices read once -- ACT (4396 rows) + DELTA (4244 rows) per sample,
             # fp32 rows in the f32 mode, bf16 rows with the bf16 chains
             # (split-f16 formats, round 4: ACT hi / lo pair units = 4 B per element, DELTA one half per element + 18 factor words)
-            bytes_per_launch = samples_per_launch * ((4396 * 4 + 4244 * 2 + 18 * 4) if (fwd_chains == "f16x2" and bwd_chains == "f16x2")
+            # (round 5, REFNERF_ACT_SQ: spatial ACT rows hi + lo = 4 B per element, directional ACT rows ONE half, DELTA one half
+            #  + two factor words per layer: (96 + 2048) * 4 + (204 + 2048) * 2 + 4244 * 2 + 36 * 4 = 21.7 KB per ray-sample)
+            act_sp = 2 if getattr(cfg, "hip_wgrad_mode", "bf16x3") == "f16" else 4       # 'f16': the spatial layer inputs at one half as well
+            bytes_per_launch = samples_per_launch * (((96 + 2048) * act_sp + (204 + 2048) * 2 + 4244 * 2 + 36 * 4) if sq
+                                                     else (4396 * 4 + 4244 * 2 + 18 * 4) if (fwd_chains == "f16x2" and bwd_chains == "f16x2")
                                                      else (4396 + 4244) * (2 if chains == "bf16" else 4))
             ach = bytes_per_launch / (avg * 1e-3) / 1e9
             kernels[k] = {"kernel": names[k], "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -68,8 +68,18 @@ enum {
 /* arithmetic of the weight-gradient GEMM of refnerf_level_backward (dW = DELTA x ACT^T over the samples) */
 enum {
   REFNERF_WGRAD_F32 = 0,    /* v_mfma_f32_32x32x2_f32: fp32 products                                     */
-  REFNERF_WGRAD_BF16X3 = 1  /* operands split hi + lo into bf16 pairs, hi*hi + hi*lo + lo*hi on
-                               v_mfma_f32_32x32x16_bf16, fp32 accumulate: 2^-16 per product, HBM-bound (default) */
+  REFNERF_WGRAD_BF16X3 = 1, /* the 16-bit-MFMA GEMM that goes with the chains (default).  After f32 chains: operands split hi + lo into
+                               bf16 pairs, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate: 2^-16 per product,
+                               HBM-bound.  After REFNERF_PREC_F16X2 chains (REFNERF_ACT_SQ): the f16 GEMM on the saved halves --
+                               spatial layer inputs hi + lo (22 bits), directional layer inputs and every delta ONE half.
+                               After bf16 chains: bf16 rows. */
+  REFNERF_WGRAD_F16 = 2     /* v10, REFNERF_PREC_F16X2 training levels on the built-in basis only (set it in the cfg of BOTH
+                               refnerf_level_forward_train and refnerf_level_backward): the spatial layer inputs at ONE half as
+                               well -- the forward does not write their lo halves, the GEMM does not read them: 17.4 instead of
+                               21.7 KB of weight-gradient operands per ray-sample, one MFMA product per tile.  A layer input's
+                               rounding is independent per sample, so it averages over the batch where a weight's does not:
+                               scripts/exp_train_sq_precision.py measures +1 .. 5 % on the gradient's distance from the
+                               reference's autograd (three trained weight sets). */
 };
 
 /* element type of the saved layer inputs: fp32 rows (f32 training forward; any forward with a general IPE basis), bf16 rows

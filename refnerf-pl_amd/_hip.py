@@ -20,7 +20,7 @@ ACT_F32, ACT_BF16, ACT_F16X2, ACT_SQ = 0, 1, 2, 3   # REFNERF_ACT_*
 ABI_VERSION = 10  # REFNERF_ABI_VERSION
 # debug knob, read once by the library as well: the round-4 training kernels of the f16x2 mode (REFNERF_ACT_F16X2, f32 image)
 LEGACY_F16X2_TRAIN = os.environ.get("REFNERF_LEGACY_F16X2_TRAIN", "0") not in ("", "0")
-WGRAD_F32, WGRAD_BF16X3 = 0, 1
+WGRAD_F32, WGRAD_BF16X3, WGRAD_F16 = 0, 1, 2
 DIRENC_IDE, DIRENC_POSENC = 0, 1   # REFNERF_DIRENC_*
 RAYDIST = {None: 0, "piecewise": 1, "reciprocal": 2, "log": 3, "exp": 4, "sqrt": 5, "square": 6}   # REFNERF_RAYDIST_*
 SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 4}

@@ -230,7 +230,9 @@ class Config:
     # (fp32 ACT / DELTA rows) operands split hi + lo into bf16 pairs, three products, fp32-level accuracy; after 'f16x2' chains
     # the f16 GEMM on the saved halves themselves (ACT 22 / 11 bits, DELTA 11 bits + per-sample factors: gradient within 1e-4 ..
     # 2e-4 of the f32 chains); after 'bf16' chains bf16 rows.  'f32' = fp32 MFMA products, with the f32 chains only (Model
-    # raises for 'f16x2' chains + 'f32': their operands are 16-bit).
+    # raises for 'f16x2' chains + 'f32': their operands are 16-bit).  'f16' ('f16x2' chains on the built-in basis; elsewhere it
+    # means 'bf16x3'): the spatial layer inputs at ONE half too -- 20 % fewer operand bytes, one product per tile; the gradient's
+    # distance from the reference's autograd grows by 1 .. 5 % (scripts/exp_train_sq_precision.py).
     hip_wgrad_mode: str = 'bf16x3'
 
 

@@ -734,6 +734,8 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   if (cfg->training && cfg->precision == REFNERF_PREC_F16X2 && !gbasis && !d_act && !legacy_f16x2_train())
     return fail(REFNERF_EINVAL, "a training level in REFNERF_PREC_F16X2 runs through refnerf_level_forward_train: its kernel keeps the ReLU sign words and "
                                 "the bottleneck rows in the activation buffer (d_packed: the REFNERF_IMAGE_F16X2_TRAIN image)%s");
+  if (cfg->wgrad_mode == REFNERF_WGRAD_F16 && !(cfg->training && cfg->precision == REFNERF_PREC_F16X2 && !gbasis && !legacy_f16x2_train()))
+    return fail(REFNERF_EUNSUPPORTED, "wgrad_mode = REFNERF_WGRAD_F16 belongs to training levels in REFNERF_PREC_F16X2 on the built-in IPE basis%s");
   if (cfg->training && cfg->precision == REFNERF_PREC_F16X2 && !gbasis && d_act && !legacy_f16x2_train())
     return rnsq::forward(d_packed, cfg, rays, R, d_sdist_in, d_weights_in, out, d_act, (hipStream_t)stream);
   const bool train_split = (cfg->training && cfg->precision == REFNERF_PREC_F16X2) || gb_split;
@@ -960,8 +962,10 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     return fail(REFNERF_EUNSUPPORTED, "the split-f16 backward chains read the REFNERF_PREC_F16X2 forward's activations (REFNERF_ACT_SQ) or fp32 rows (REFNERF_PREC_F32, or a general IPE basis)%s");
   if (cfg->precision != REFNERF_PREC_F16X2 && (saved->activations_format == REFNERF_ACT_F16X2 || saved->activations_format == REFNERF_ACT_SQ))
     return fail(REFNERF_EUNSUPPORTED, "activations written by the split-f16 training forward (REFNERF_ACT_F16X2) are read by the split-f16 backward: cfg->precision = REFNERF_PREC_F16X2%s");
-  if (cfg->wgrad_mode != REFNERF_WGRAD_F32 && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
+  if (cfg->wgrad_mode != REFNERF_WGRAD_F32 && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3 && cfg->wgrad_mode != REFNERF_WGRAD_F16)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown wgrad_mode%s");
+  if (cfg->wgrad_mode == REFNERF_WGRAD_F16 && saved->activations_format != REFNERF_ACT_SQ)
+    return fail(REFNERF_EUNSUPPORTED, "wgrad_mode = REFNERF_WGRAD_F16 belongs to the REFNERF_PREC_F16X2 training kernels (REFNERF_ACT_SQ activations, written with the same wgrad_mode)%s");
   if (!saved->d_sdist || !saved->d_density || !saved->d_rgb || !saved->d_weights || !grads->d_g_r_rgb)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: null saved tensor / rendering gradient%s");
   if (!saved->d_activations)
@@ -1013,7 +1017,7 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
   if (saved->activations_format != REFNERF_ACT_F32 && saved->activations_format != REFNERF_ACT_BF16 && !pairs && !sq)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown activations_format%s");
   if (sq && gbasis) return fail(REFNERF_EUNSUPPORTED, "a general IPE basis keeps fp32 activation rows (REFNERF_ACT_F32)%s");
-  if (sq && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3)
+  if (sq && cfg->wgrad_mode != REFNERF_WGRAD_BF16X3 && cfg->wgrad_mode != REFNERF_WGRAD_F16)
     return fail(REFNERF_EUNSUPPORTED, "REFNERF_ACT_SQ activations go with wgrad_mode = REFNERF_WGRAD_BF16X3 (the f16 weight-gradient GEMM on the saved halves; "
                                       "fp32 weight-gradient products: the REFNERF_PREC_F32 chains)%s");
   if (pairs && gbasis) return fail(REFNERF_EUNSUPPORTED, "a general IPE basis keeps fp32 activation rows (REFNERF_ACT_F32)%s");
@@ -1041,7 +1045,8 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     }
     const int slices = (int)((plan.S + plan.k_per_slice - 1) / plan.k_per_slice);
     float *part = (float *)(ws + plan.part_off);
-    rc = rnsq::wgrad(a.act, a.delta, plan.S, plan.pitch, plan.k_per_slice, slices, part, (float *)(ws + plan.cmin_off), st);
+    rc = rnsq::wgrad(a.act, a.delta, plan.S, plan.pitch, plan.k_per_slice, slices, part, (float *)(ws + plan.cmin_off),
+                     cfg->wgrad_mode == REFNERF_WGRAD_F16 ? 1 : 0, st);
     if (rc) return rc;
     hipLaunchKernelGGL(rn::wgrad_reduce, dim3(1024), dim3(256), 0, st, part, slices, d_param_grads, (int)rn::NUM_PARAMS);
     HIP_TRY(hipGetLastError());

@@ -247,6 +247,7 @@ __device__ __forceinline__ float tq_relu_bit(float y, unsigned &mk, int bit) {
 
 /* piece q of a spatial slice's epilogue in the training forward: ReLU, sign bits (bits `bit0` + 2 q, + 1 and + 4 for the T1
  * values), hi / lo split, and the two dwords to their pair units */
+template <bool ACT_LO>
 __device__ __forceinline__ void tq_epi_piece(const SqAcc &a, int q, v4uu &oh, v4uu &ol, unsigned &mk, int bit0, const BlkWin &aw, unsigned voff, int unit) {
   const float y0 = q == 0 ? a.t0[0] : (q == 1 ? a.t0[2] : (q == 2 ? a.t1[0] : a.t1[2]));
   const float y1 = q == 0 ? a.t0[1] : (q == 1 ? a.t0[3] : (q == 2 ? a.t1[1] : a.t1[3]));
@@ -258,12 +259,12 @@ __device__ __forceinline__ void tq_epi_piece(const SqAcc &a, int q, v4uu &oh, v4
   ol[q] = lo;
   /* rows 32 s + 16 (q / 2) + 4 b + 2 (q % 2), + 1: the pair's hi unit and its lo unit (4 b rows ride in voff) */
   win_store(aw, voff, unit + 16 * (q >> 1), 2 * (q & 1), hi);
-  win_store(aw, voff, unit + 16 * (q >> 1), 2 * (q & 1) + 1, lo);
+  if (ACT_LO) win_store(aw, voff, unit + 16 * (q >> 1), 2 * (q & 1) + 1, lo);    /* (REFNERF_WGRAD_F16: the weight-gradient GEMM reads the hi halves only) */
 }
 
 /* One spatial layer of the training forward: sq_layer + the ACT / mask stores of its OUTPUT (= the next layer's input).
  * `unit` = first unit of that input's pair units; VMK0 = vector-memory operations in front of the layer's first chunk. */
-template <bool LAYER0, int VMK0>
+template <bool LAYER0, int VMK0, bool ACT_LO>
 __device__ __forceinline__ void tq_layer(Pipe &p, sq_v8 (&fr)[SQ_NF], SqAcc (&accs)[2], bool skip, const v4uu (&in)[16], v4uu (&out)[16],
                                          const BlkWin &aw, unsigned voff_sp, unsigned voff_mk, int unit, int mask_unit) {
   unsigned mk0 = 0u, mk1 = 0u;
@@ -275,9 +276,9 @@ __device__ __forceinline__ void tq_layer(Pipe &p, sq_v8 (&fr)[SQ_NF], SqAcc (&ac
     SqAcc &prev = accs[ob & 1];
     auto hook = [&](int j) {
       if (ob == 0 || j >= 8 || (j & 1)) return;
-      tq_epi_piece(prev, j >> 1, out[2 * ob - 2], out[2 * ob - 1], (ob - 1) < 4 ? mk0 : mk1, 8 * ((ob - 1) & 3), aw, voff_sp, unit + 32 * (ob - 1));
+      tq_epi_piece<ACT_LO>(prev, j >> 1, out[2 * ob - 2], out[2 * ob - 1], (ob - 1) < 4 ? mk0 : mk1, 8 * ((ob - 1) & 3), aw, voff_sp, unit + 32 * (ob - 1));
     };
-    constexpr int VM = 8;
+    constexpr int VM = ACT_LO ? 8 : 4;
     if constexpr (LAYER0) {
       if (ob == 0) tq_chunk<SQ_X, true, true, VMK0>(p, fr, in, acc, prev, hook);
       else tq_chunk<SQ_X, true, true, VM>(p, fr, in, acc, prev, hook);
@@ -289,12 +290,13 @@ __device__ __forceinline__ void tq_layer(Pipe &p, sq_v8 (&fr)[SQ_NF], SqAcc (&ac
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) tq_epi_piece(accs[0], q, out[14], out[15], mk1, 24, aw, voff_sp, unit + 32 * 7);
+  for (int q = 0; q < 4; ++q) tq_epi_piece<ACT_LO>(accs[0], q, out[14], out[15], mk1, 24, aw, voff_sp, unit + 32 * 7);
   win_store(aw, voff_mk, mask_unit, 0, mk0);
   win_store(aw, voff_mk, mask_unit, 1, mk1);
   __builtin_amdgcn_sched_barrier(0);
 }
-constexpr int TQ_VM_LAYER = 10;      /* 8 tail stores + 2 mask words in front of the next layer's first chunk */
+/* 8 (4: hi halves only) tail stores + 2 mask words in front of the next layer's first chunk */
+template <bool ACT_LO> constexpr int tq_vm_layer() { return (ACT_LO ? 8 : 4) + 2; }
 
 /* ---- the density-gradient VJP (16-sample tiles, three products) ---- */
 /* power of two that keeps |W^T delta| below 2^15 for a sample whose largest |delta| is m: m rs G < 2^15 */
@@ -460,6 +462,8 @@ __device__ __forceinline__ void tq_dir_layer(Pipe &p, MmF16::v8 (&a)[AF], int se
 }
 constexpr int TQ_VM_DIR_LAYER = 12;  /* 8 fragment dwords + 4 mask words in front of the next layer's first chunk */
 
+/* ACT_LO: the lo halves of the spatial layer inputs (and of the IPE rows) are written to ACT (cfg.wgrad_mode != REFNERF_WGRAD_F16) */
+template <bool ACT_LO>
 __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
   typedef MmF16 MM;
   typedef MM::v8 v8mm;
@@ -623,7 +627,7 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
         *reinterpret_cast<unsigned *>(dst + (BT / 2) * 16) = wlo;
         /* canonical rows 48 hb + 24 qq + 2 t, + 1: the pair's hi and lo units */
         win_store(aw, voff_ipe, AQ_IPE + 2 * t, 0, whi);
-        win_store(aw, voff_ipe, AQ_IPE + 2 * t, 1, wlo);
+        if (ACT_LO) win_store(aw, voff_ipe, AQ_IPE + 2 * t, 1, wlo);
       }
       }
       RN_STAMPW(A, 18);
@@ -636,12 +640,12 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
       const unsigned voff_sp = blk_voff_add(voff_c, 4 * bq), voff_h = blk_voff_add(voff_c, 2 * bq);
       SqAcc accs[2];
       sq_bias_now(p, accs[1]);
-      tq_layer<true, 0>(p, ar, accs, false, R0, R0, aw, voff_sp, voff_h, AQ_SP, AQ_MASK);
+      tq_layer<true, 0, ACT_LO>(p, ar, accs, false, R0, R0, aw, voff_sp, voff_h, AQ_SP, AQ_MASK);
       RN_STAMPW(A, 4 + phase * 4);
 #pragma unroll 1
       for (int it = 0; it < 4; ++it) {
-        tq_layer<false, TQ_VM_LAYER>(p, ar, accs, it == 2, R0, R1, aw, voff_sp, voff_h, AQ_SP + (2 * it + 1) * WIDTH, AQ_MASK + 8 * (2 * it + 1));
-        if (it < 3) tq_layer<false, TQ_VM_LAYER>(p, ar, accs, false, R1, R0, aw, voff_sp, voff_h, AQ_SP + (2 * it + 2) * WIDTH, AQ_MASK + 8 * (2 * it + 2));
+        tq_layer<false, tq_vm_layer<ACT_LO>(), ACT_LO>(p, ar, accs, it == 2, R0, R1, aw, voff_sp, voff_h, AQ_SP + (2 * it + 1) * WIDTH, AQ_MASK + 8 * (2 * it + 1));
+        if (it < 3) tq_layer<false, tq_vm_layer<ACT_LO>(), ACT_LO>(p, ar, accs, false, R1, R0, aw, voff_sp, voff_h, AQ_SP + (2 * it + 2) * WIDTH, AQ_MASK + 8 * (2 * it + 2));
       }
       RN_STAMPW(A, 5 + phase * 4);
       {
@@ -653,7 +657,7 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
         for (int ob = 0; ob < 5; ++ob) {
           SqAcc &acc = ha[(ob + 1) & 1];
           if (ob < 4) {
-            if (ob == 0) tq_chunk<SQ_A, true, false, TQ_VM_LAYER>(p, ar, R1, acc, ha[ob & 1]);
+            if (ob == 0) tq_chunk<SQ_A, true, false, tq_vm_layer<ACT_LO>()>(p, ar, R1, acc, ha[ob & 1]);
             else tq_chunk<SQ_A, true, false, 4>(p, ar, R1, acc, ha[ob & 1]);
             tq_chunk<SQ_B, false, true, 0>(p, ar, R1, acc, ha[ob & 1]);
 #pragma unroll
@@ -854,6 +858,8 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
   composite_phase<BF_NW, false, NP>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB), NRM);   /* P7 */
 }
 
-__global__ __launch_bounds__(BF_NTHREADS) void level_fwd_train_sq(const LevelArgs A) { level_fwd_train_sq_body(A); }
+__global__ __launch_bounds__(BF_NTHREADS) void level_fwd_train_sq(const LevelArgs A) { level_fwd_train_sq_body<true>(A); }
+/* ... for the hi-halves-only weight-gradient GEMM (cfg.wgrad_mode = REFNERF_WGRAD_F16) */
+__global__ __launch_bounds__(BF_NTHREADS) void level_fwd_train_sq_h(const LevelArgs A) { level_fwd_train_sq_body<false>(A); }
 
 }  // namespace rn

@@ -30,5 +30,5 @@ int backward_chain(const void *d_packed, const refnerf_level_cfg *cfg, const ref
                    hipStream_t st);
 /* dW partials of the level: PART[slices][NUM_PARAMS] (the caller reduces them) */
 int wgrad(const float *d_act, const float *d_delta, long long S, long long pitch, int k_per_slice, int slices, float *d_part,
-          float *d_kmin, hipStream_t st);
+          float *d_kmin, int act11, hipStream_t st);
 }  // namespace rnsq

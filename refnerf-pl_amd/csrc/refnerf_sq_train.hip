@@ -236,7 +236,10 @@ int forward(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_ra
     const size_t scratch = sizeof(float) * (size_t)nw * (3 * (cfg->n_in + 4) + N + 3);
     if (scratch > (size_t)rn::BF_X_BYTES) return rnh::fail(REFNERF_EINVAL, "n_in / n_samples too large for the resampler scratch of this precision mode%s");
   }
-  static hipError_t attr = hipFuncSetAttribute((const void *)rn::level_fwd_train_sq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static hipError_t attr = [] {
+    hipError_t e = hipFuncSetAttribute((const void *)rn::level_fwd_train_sq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e != hipSuccess ? e : hipFuncSetAttribute((const void *)rn::level_fwd_train_sq_h, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }();
   if (attr != hipSuccess) return rnh::fail(REFNERF_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(attr));
   rn::LevelArgs a;
   a.packed = d_packed;
@@ -258,7 +261,8 @@ int forward(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_ra
   const int grid = (R + rpw - 1) / rpw;
   long tslot = -1;
   { int trc = rnh::timer_begin(st, &tslot, REFNERF_TIMER_FORWARD); if (trc) return trc; }
-  hipLaunchKernelGGL(rn::level_fwd_train_sq, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  if (cfg->wgrad_mode == REFNERF_WGRAD_F16) hipLaunchKernelGGL(rn::level_fwd_train_sq_h, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
+  else hipLaunchKernelGGL(rn::level_fwd_train_sq, dim3(grid), dim3(rn::BF_NTHREADS), lds, st, a);
   SQ_HIP_TRY(hipGetLastError());
   { int trc = rnh::timer_end(st, tslot); if (trc) return trc; }
   if (a.prof) {
@@ -320,7 +324,7 @@ int backward_chain(const void *d_packed, const refnerf_level_cfg *cfg, const ref
 }
 
 int wgrad(const float *d_act, const float *d_delta, long long S, long long pitch, int k_per_slice, int slices, float *d_part,
-          float *d_kmin, hipStream_t st) {
+          float *d_kmin, int act11, hipStream_t st) {
   (void)pitch;
   static hipError_t attr = hipFuncSetAttribute((const void *)rn::wgrad_sq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rn::SQW_LDS);
   if (attr != hipSuccess) return rnh::fail(REFNERF_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(attr));
@@ -331,7 +335,7 @@ int wgrad(const float *d_act, const float *d_delta, long long S, long long pitch
   const dim3 grid(8 * ((slices + 7) / 8) * rn::WJOBS_SQ.tiles);
   long tslot = -1;
   { int trc = rnh::timer_begin(st, &tslot, REFNERF_TIMER_WGRAD); if (trc) return trc; }
-  hipLaunchKernelGGL(rn::wgrad_sq_kernel, grid, dim3(64 * rn::SQW_NW), rn::SQW_LDS, st, w, slices, d_kmin);
+  hipLaunchKernelGGL(rn::wgrad_sq_kernel, grid, dim3(64 * rn::SQW_NW), rn::SQW_LDS, st, w, slices, d_kmin, act11);
   SQ_HIP_TRY(hipGetLastError());
   { int trc = rnh::timer_end(st, tslot); if (trc) return trc; }
   return REFNERF_OK;

@@ -81,7 +81,9 @@ struct WgradSqArgs {
 };
 
 /* grid = 8 * ceil(slices / 8) * tiles workgroups of 256 threads: waves 2 x 2 of 64 x 64 over a 128 x 128 output tile */
-__global__ __launch_bounds__(64 * SQW_NW) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_sq_kernel(const WgradSqArgs A, int slices, const float *__restrict__ kmin_all) {
+/* act11 (cfg.wgrad_mode = REFNERF_WGRAD_F16): the spatial jobs take the hi units of their pair units only (the forward did not
+ * write the lo units): one product per tile everywhere */
+__global__ __launch_bounds__(64 * SQW_NW) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_sq_kernel(const WgradSqArgs A, int slices, const float *__restrict__ kmin_all, int act11) {
   constexpr int NW = SQW_NW, TM = SQW_TM;
   constexpr int MI = TM / (16 * NW);             /* 2 */
   constexpr int NPD = TM / (8 * NW);             /* row PAIRS of the D tile per loader thread: 4 */
@@ -100,7 +102,8 @@ __global__ __launch_bounds__(64 * SQW_NW) __attribute__((amdgpu_waves_per_eu(2))
   for (int j = 1; j < WJOBS_SQ.n; ++j) if (tile >= WJOBS_SQ.job[j].j.tile0) ji = j;
   const WJob J = WJOBS_SQ.job[ji].j;
   const int a_unit = WJOBS_SQ.job[ji].a_unit;
-  const bool half = WJOBS_SQ.job[ji].half != 0;
+  const bool halfrows = WJOBS_SQ.job[ji].half != 0;          /* ONE half per element, rows in pairs: one unit per pair row */
+  const bool half = halfrows || act11 != 0;                  /* no lo operand */
   const int tl = tile - J.tile0;
   const int tm = tl / J.tiles_n, tn = tl - tm * J.tiles_n;
   const long long k_begin = (long long)slice * A.k_per_slice;
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(64 * SQW_NW) __attribute__((amdgpu_waves_per_eu(2))
   const int lpair = (lrow & ~7) | ((lrow & 1) << 2) | ((lrow >> 1) & 3);
   auto tile_row = [&](int p) { return 2 * lpair + 8 * NW * (p >> 1) + (p & 1); };
   /* pair pp of this thread sits 4 NW pair rows behind pair pp - 1: DELTA one unit per pair row, ACT two (hi, lo) or one */
-  const int aup = half ? 1 : 2;                                     /* ACT units per pair row */
+  const int aup = halfrows ? 1 : 2;                                 /* ACT units per pair row */
   const char *dp0 = reinterpret_cast<const char *>(A.delta) + ((long long)((J.d_row + tm * TM) / 2 + lpair) * RB + lc4) * 4;
   const char *ap0 = reinterpret_cast<const char *>(A.act) + ((long long)(a_unit + (tn * (WG_TN / 2) + lpair) * aup) * RB + lc4) * 4;
   const long long dpp = (long long)(4 * NW) * RB * 4, app = (long long)(4 * NW * aup) * RB * 4;

@@ -643,9 +643,13 @@ class Model(nn.Module):
             raise ValueError(f"IPE basis '{mlp.basis_shape}' / {mlp.basis_subdivisions} ({mlp.ipe_basis_dirs} directions): the fused kernels run a "
                              "general basis in the parity-grade modes (Config.hip_precision / hip_train_precision / hip_bwd_precision = 'f32' or "
                              "'f16x2'); the plain bf16 / f16 throughput modes are built for 'octahedron' / 1")
-        wgrad = {"f32": _hip.WGRAD_F32, "bf16x3": _hip.WGRAD_BF16X3}.get(getattr(cfg, "hip_wgrad_mode", "bf16x3"))
+        wgrad = {"f32": _hip.WGRAD_F32, "bf16x3": _hip.WGRAD_BF16X3, "f16": _hip.WGRAD_F16}.get(getattr(cfg, "hip_wgrad_mode", "bf16x3"))
         if wgrad is None:
-            raise ValueError("Config.hip_wgrad_mode must be 'bf16x3' or 'f32'")
+            raise ValueError("Config.hip_wgrad_mode must be 'bf16x3', 'f16' or 'f32'")
+        if wgrad == _hip.WGRAD_F16 and (not self.training or train_prec != "f16x2" or mlp.ipe_groups or _hip.LEGACY_F16X2_TRAIN):
+            # 'f16' = the weight-gradient GEMM of the split-f16 training kernels with every operand at ONE half: inference levels and
+            # the other chain modes (f32 / bf16 chains, a general IPE basis) run the GEMM that goes with them
+            wgrad = _hip.WGRAD_BF16X3
         return _hip.default_cfg(
             n_samples=int(n_samples), n_in=int(n_in), training=int(self.training),
             compute_extras=int(bool(compute_extras)), srgb_mapping=int(mlp.srgb_mapping),
@@ -720,11 +724,11 @@ class Model(nn.Module):
                     # split-f16 backward and its f16 weight-gradient GEMM consume (a general IPE basis keeps fp32 rows)
                     raise ValueError("Config.hip_train_precision = 'f16x2' goes with hip_bwd_precision = 'f16x2' (its saved activations are "
                                      "split-f16 pair units)")
-                if train_prec == "f16x2" and not mlp.ipe_groups and cfg.wgrad_mode != _hip.WGRAD_BF16X3:
+                if train_prec == "f16x2" and not mlp.ipe_groups and cfg.wgrad_mode == _hip.WGRAD_F32:
                     #  the split-f16 chains hand the weight-gradient GEMM 16-bit operands (ACT hi / lo pair units and
                     # one-half rows, DELTA one half per element + factors): there is no fp32-product GEMM on those
                     raise ValueError("Config.hip_wgrad_mode = 'f32' goes with the exact-fp32 chains (hip_train_precision = hip_bwd_precision = 'f32'); "
-                                     "the 'f16x2' chains feed their own f16 weight-gradient GEMM (hip_wgrad_mode = 'bf16x3', the default)")
+                                     "the 'f16x2' chains feed their own f16 weight-gradient GEMM (hip_wgrad_mode = 'bf16x3', the default, or 'f16')")
                 flat_mode = bool(getattr(self.config, "hip_flat_grads", False))
                 if not flat_mode and mlp._flat is not None and (mlp._flat.requires_grad or mlp._flat.grad is not None):
                     mlp.release_flat_parameter()            # flat mode was switched off: no stale .grad on the blob

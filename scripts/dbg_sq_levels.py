@@ -38,6 +38,8 @@ def main():
         for prec in (0, F16X2):
             cfg = hip.default_cfg(n_samples=N, n_in=w.shape[1], training=1, compute_extras=0, **cfg_from_bindings(g["bindings"])[0])
             cfg.precision = prec
+            if prec == F16X2 and os.environ.get("REFNERF_WGRAD_MODE") == "f16":
+                cfg.wgrad_mode = hip.WGRAD_F16
             res = hip.level_forward(packed[prec], cfg, rays, sd, w, history=True, save_activations=True)
             out = torch.zeros(hip.NUM_PARAMS, device=DEV)
             hip.level_backward(packed[prec], cfg, rays, res, g_rgb, g_w, None, out)

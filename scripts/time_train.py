@@ -12,6 +12,8 @@ if len(sys.argv) > 1 and sys.argv[1].isdigit():
     spec["rays"], spec["samples"] = int(sys.argv[1]), int(sys.argv[2]); sys.argv = sys.argv[:1] + sys.argv[3:]
 from refnerf_pl_amd import utils
 model, cfg, blob = bench.build_model(args, spec, dev)
+if os.environ.get("REFNERF_WGRAD_MODE"):
+    cfg.hip_wgrad_mode = os.environ["REFNERF_WGRAD_MODE"]
 rays = utils.rays_from_dict(bench.make_rays(spec, spec["rays"], seed=1), dev)
 sync = torch.cuda.synchronize
 for mode in (sys.argv[1:] or ["f32", "f16x2", "bf16"]):

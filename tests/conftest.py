@@ -33,5 +33,7 @@ def _f32_unless_a_test_says_otherwise(request, monkeypatch):
 
     def parse(config_files=None, bindings=None, *a, **kw):
         pre = ["Config.hip_precision = 'f32'", "Config.hip_train_precision = 'f32'", "Config.hip_bwd_precision = 'f32'"]
+        if os.environ.get("REFNERF_TEST_WGRAD"):      # e.g. 'f16': run the suite's f16x2-chain tests with the one-half weight-gradient GEMM
+            pre.append(f"Config.hip_wgrad_mode = '{os.environ['REFNERF_TEST_WGRAD']}'")
         return real(config_files, pre + list(bindings or []), *a, **kw)
     monkeypatch.setattr(configs, "parse_config_files_and_bindings", parse)

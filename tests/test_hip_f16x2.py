@@ -651,7 +651,7 @@ def test_shipped_config_runs_the_mode_of_record(hip):
             model.train()
             hip.set_timing(True)
             rend, hist = model(rays, 1.0, True)
-            rend[1]["rgb"].sum().backward()
+            (rend[0]["rgb"].sum() + rend[1]["rgb"].sum()).backward()
             torch.cuda.synchronize()
             fams = {f: hip.get_timing(f)[1] for f in (hip.TIMER_FORWARD, hip.TIMER_BACKWARD, hip.TIMER_WGRAD)}
             hip.set_timing(False)
