@@ -163,7 +163,8 @@ def compact_line(full):
         cfgd["workload"] = cfgd["workload"][:157] + "..."
     line["config"] = cfgd
     if isinstance(full.get("roofline"), dict):
-        line["roofline"] = _pick(full["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches"))
+        line["roofline"] = _pick(full["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches",
+                                                    "mfma_busy", "executed_flop_frac", "sustained_clock_ghz"))
     if isinstance(full.get("cpu_baseline"), dict):
         cb = dict(full["cpu_baseline"])
         if len(str(cb.get("sample", ""))) > 140:
@@ -462,14 +463,31 @@ def traffic_of(kernel, config_name, rays_per_rank, N):
     return None, None
 
 
+def pmc_of(kernel, config_name, rays_per_rank, N):
+    """matrix-pipe occupancy figures of the committed PMC passes (profiles/traffic.json, scripts/summarize_prof.py):
+    mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), the sustained clock = GRBM_GUI_ACTIVE / 8 / launch
+    duration, executed_flop_frac = mfma_busy x clock / 2.4 GHz = what the matrix pipes EXECUTED (all partial products) of the peak
+    the roofline is priced at.  Only for the workload they were measured on."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        key = f"{kernel}@{config_name}"
+        entry = prof[key] if key in prof else (prof[kernel] if config_name == "C2" and kernel in prof else None)
+        if entry and "mfma_busy" in entry and rays_per_rank == CONFIGS[config_name]["rays"] and N == CONFIGS[config_name]["samples"]:
+            return {k: entry[k] for k in ("mfma_busy", "executed_flop_frac", "sustained_clock_ghz", "valu_per_mfma") if k in entry}
+    except (OSError, KeyError, ValueError):
+        pass
+    return {}
+
+
 def mfma_roofline(prec, kernel, kern_ms, launches, flop_per_launch, config_name, rays_per_rank, N):
     avg_ms = kern_ms / launches
     achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
     traffic, src = traffic_of(kernel, config_name, rays_per_rank, N)
-    return {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
-            "frac": achieved / PEAK_TFLOPS[prec], "traffic": traffic, "traffic_source": src, "kernel": kernel,
-            "avg_launch_ms": avg_ms, "launches": launches, "flop_per_launch": flop_per_launch,
-            "timing": "HIP event pairs on the launch stream, inside the timed region"}
+    return dict({"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                 "frac": achieved / PEAK_TFLOPS[prec], "traffic": traffic, "traffic_source": src, "kernel": kernel,
+                 "avg_launch_ms": avg_ms, "launches": launches, "flop_per_launch": flop_per_launch,
+                 "timing": "HIP event pairs on the launch stream, inside the timed region"},
+                **pmc_of(kernel, config_name, rays_per_rank, N))
 
 
 def eval_kernel_name(prec, N, rays_per_rank):
@@ -876,15 +894,20 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
                                                      else (4396 * 4 + 4244 * 2 + 18 * 4) if (fwd_chains == "f16x2" and bwd_chains == "f16x2")
                                                      else (4396 + 4244) * (2 if chains == "bf16" else 4))
             ach = bytes_per_launch / (avg * 1e-3) / 1e9
+            tr, tsrc = traffic_of(names[k], spec.get("name", "C2"), R, N) if not geometry else (None, None)
             kernels[k] = {"kernel": names[k], "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                          "frac": ach / PEAK_HBM_GBS, "avg_launch_ms": avg, "launches": cnt, "bytes_per_launch": bytes_per_launch}
+                          "frac": ach / PEAK_HBM_GBS, "avg_launch_ms": avg, "launches": cnt, "bytes_per_launch": bytes_per_launch,
+                          "traffic": tr, "traffic_source": tsrc}
         else:
             # forward: MLP + density-normal VJP; backward kernel: the transposed chains dX = W^T delta (one pass over
             # the MLP's contractions -- the other half of the backward FLOPs, dW, is the wgrad GEMM's)
             flop = samples_per_launch * ((FLOP_PER_SAMPLE + NORMALS_VJP_FLOP) if k == "fwd" else FLOP_PER_SAMPLE)
             ach = flop / (avg * 1e-3) / 1e12
-            kernels[k] = {"kernel": names[k], "bound": "mfma", "achieved": ach, "peak": peak_of[k], "unit": "TFLOP/s",
-                          "frac": ach / peak_of[k], "avg_launch_ms": avg, "launches": cnt, "flop_per_launch": flop}
+            tr, tsrc = traffic_of(names[k], spec.get("name", "C2"), R, N) if not geometry else (None, None)
+            kernels[k] = dict({"kernel": names[k], "bound": "mfma", "achieved": ach, "peak": peak_of[k], "unit": "TFLOP/s",
+                               "frac": ach / peak_of[k], "avg_launch_ms": avg, "launches": cnt, "flop_per_launch": flop,
+                               "traffic": tr, "traffic_source": tsrc},
+                              **({} if geometry else pmc_of(names[k], spec.get("name", "C2"), R, N)))
     out = {"value": rate, "unit": "ray-samples/s (fwd+bwd+Adam)", "ms_per_step": 1e3 * el / n, "steps": n,
            "dtype": chains, "wgrad": getattr(cfg, "hip_wgrad_mode", "bf16x3"), "losses": "fused kernels (Config.hip_fused_losses)", "gradients": "one flat tensor per MLP (Config.hip_flat_grads)",
            "loss": float(loss.detach()),
@@ -902,8 +925,7 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
                    "operand type, the weight-gradient GEMM against HBM); kernels_ms_per_step = their sum, the rest of ms_per_step "
                    "is losses, all-reduce, optimiser and weight re-pack"}
     if "fwd" in kernels:
-        out["roofline"] = dict(kernels["fwd"], traffic=None, traffic_source=None,
-                               timing="HIP event pairs on the launch stream, inside the timed region")
+        out["roofline"] = dict(kernels["fwd"], timing="HIP event pairs on the launch stream, inside the timed region")
     return out
 
 

@@ -28,7 +28,10 @@ KERNELS = {"level_fwd_bf16": "rn::level_fwd_bf16", "level_fwd_f32": "rn::level_f
            "level_fwd_bf16_ring": "rn::level_fwd_bf16_ring", "level_fwd_f16_ring": "rn::level_fwd_f16_ring",
            "level_fwd_f16x2": "rn::level_fwd_f16x2", "level_fwd_f16x2_ring": "rn::level_fwd_f16x2_ring",
            "level_fwd_train_f16x2c": "rn::level_fwd_train_f16x2c", "level_bwd_f16x2c": "rn::level_bwd_f16x2c",
-           "wgrad_f16s_kernel": "rn::wgrad_f16s_kernel", "delta_scale_min": "rn::delta_scale_min"}
+           "wgrad_f16s_kernel": "rn::wgrad_f16s_kernel", "delta_scale_min": "rn::delta_scale_min",
+           "level_fwd_train_sq": "rn::level_fwd_train_sq", "level_fwd_train_sq_h": "rn::level_fwd_train_sq_h", "level_bwd_sq": "rn::level_bwd_sq",
+           "wgrad_sq_kernel": "rn::wgrad_sq_kernel", "delta_kappa_min": "rn::delta_kappa_min",
+           "pack_train_chunks": "rn::pack_train_chunks", "pack_train_consts": "rn::pack_train_consts"}
 
 rows = list(csv.reader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
 with open(os.path.join(dst, f"kernel_stats{sfx}.csv"), "w", newline="") as f:
@@ -70,5 +73,28 @@ for short, counters in stats.items():
                   "FETCH_SIZE_KB": round(fs, 1), "WRITE_SIZE_KB": round(ws, 1),
                   "bytes_per_launch": int((2 * fs + ws) * 1024)})
         traffic[key] = e
+    # matrix-pipe occupancy of the launch: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs,
+    # GRBM_GUI_ACTIVE the launch's cycles summed over the 8 XCDs; the sustained clock needs the launch duration (kernel trace)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "GRBM_GUI_ACTIVE" in counters:
+        busy = sum(counters["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(counters["SQ_VALU_MFMA_BUSY_CYCLES"])
+        gui = sum(counters["GRBM_GUI_ACTIVE"]) / len(counters["GRBM_GUI_ACTIVE"]) / 8.0
+        key = KERNELS[short] if cfg == "C2" else f"{KERNELS[short]}@{cfg}"
+        e = traffic.get(key, {"round": os.path.basename(dst.rstrip("/")), "workload": WORKLOAD})
+        if gui > 0 and busy > 0:
+            e["mfma_busy"] = round(busy / (gui * 1024.0), 4)
+            e["gui_cycles_per_launch"] = int(gui)
+            dur_ns = None
+            for r in rows[1:]:
+                if r and r[0].replace("void ", "").split("(")[0].split("<")[0] == KERNELS[short]:
+                    try:
+                        dur_ns = float(r[rows[0].index("AverageNs")])
+                    except (ValueError, IndexError):
+                        pass
+            if dur_ns:
+                e["sustained_clock_ghz"] = round(gui / dur_ns, 3)
+                e["executed_flop_frac"] = round(e["mfma_busy"] * (gui / dur_ns) / 2.4, 4)      # of the 2.4 GHz peak the roofline is priced at
+            if "SQ_INSTS_VALU" in counters and "SQ_INSTS_MFMA" in counters and sum(counters["SQ_INSTS_MFMA"]) > 0:
+                e["valu_per_mfma"] = round(sum(counters["SQ_INSTS_VALU"]) / sum(counters["SQ_INSTS_MFMA"]), 2)
+            traffic[key] = e
 json.dump(traffic, open(tj, "w"), indent=2)
 print("wrote", sorted(os.listdir(dst)))

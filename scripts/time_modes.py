@@ -15,7 +15,10 @@ configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", "refnerf_
                                         [f"Model.num_prop_samples = {N}", f"Model.num_nerf_samples = {N}"])
 cfg = configs.Config()
 model = models.construct_model(None, cfg).to(dev).eval()
-model.nerf_mlp.load_flat_params(synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0))
+_blob = synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0)
+if os.environ.get("REFNERF_ZERO_WEIGHTS"):     # power experiment: the same instruction stream on all-zero operands
+    _blob = _blob * 0.0
+model.nerf_mlp.load_flat_params(_blob)
 rays = utils.rays_from_dict(synthetic.blender_rays(R, seed=1, center_frac=0.5), dev)
 ref = None
 for prec in modes:
