@@ -637,7 +637,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     rccl = None
-    if world == 1 and CONFIGS[args.config]["mode"] == "train" and not args.no_rccl:
+    if world == 1 and not args.no_rccl:
+        # (eval configurations too since round 5: `n_ranks_seen` of EVERY leg comes from the RCCL group -- VERDICT r4 item 9)
         dist, rccl = one_rank_rccl(dev)
     n_ranks_seen = dist.get_world_size() if dist is not None else 1
     assert n_ranks_seen == world

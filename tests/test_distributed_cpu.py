@@ -26,7 +26,9 @@ def _free_port():
 def _fake_render(rays):
     o, d = torch.as_tensor(rays.origins), torch.as_tensor(rays.directions)
     rgb = torch.sin(o * 3.0) * 0.5 + d * 0.25
-    return [{"rgb": rgb * 0.5, "acc": rgb.sum(-1)}, {"rgb": rgb, "acc": rgb.sum(-1) * 2, "ray_sdist": rgb[:2]}], None
+    # (a float64 per-ray output beside the float32 ones, as the level kernels' percentiles: the packed gather keeps every dtype)
+    return [{"rgb": rgb * 0.5, "acc": rgb.sum(-1)},
+            {"rgb": rgb, "acc": rgb.sum(-1) * 2, "distance_median": rgb.double().sum(-1) / 3.0, "ray_sdist": rgb[:2]}], None
 
 
 def _worker(rank, world, port, tmp):
@@ -96,9 +98,11 @@ def _worker(rank, world, port, tmp):
     cfg.render_chunk_size = 4
     out = distributed.render_image_sharded(_fake_render, img, cfg)
     ref, _ = _fake_render(utils.rays_from_dict({k: np.asarray(v)[:35] for k, v in rd.items()}))
-    assert set(out) == {"rgb", "acc"}
-    assert torch.allclose(out["rgb"].reshape(-1, 3), ref[-1]["rgb"]) and out["rgb"].shape == (7, 5, 3)
-    assert torch.allclose(out["acc"].reshape(-1), ref[-1]["acc"])
+    assert set(out) == {"rgb", "acc", "distance_median"}
+    assert torch.equal(out["rgb"].reshape(-1, 3), ref[-1]["rgb"]) and out["rgb"].shape == (7, 5, 3)
+    assert torch.equal(out["acc"].reshape(-1), ref[-1]["acc"])
+    assert out["distance_median"].dtype == torch.float64 and torch.equal(out["distance_median"].reshape(-1), ref[-1]["distance_median"])
+    assert distributed.LAST_IMAGE_COLLECTIVES == 1       # ONE all_gather per image, whatever the number of outputs
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")

@@ -58,7 +58,10 @@ INDEX_FLOOR = 0.9999     # end to end >= 99.99 % identical CDF bin indices (meas
 
 
 @pytest.mark.parametrize("case", ["C2_trained_like", "C2_trained_like_fp32_weights", "C2_bench_batch", "C3_shiny", "C2_trained_long",
-                                  "C3_trained_long", "C4_trained_llff"])
+                                  "C3_trained_long", "C4_trained_llff",
+                                  # round 5 (one seeded batch per weight set is thin evidence for a 4 % margin):
+                                  # two more views of the 2500-step weights at C3's shape, the LLFF weights at C5's sample count
+                                  "C3_trained_long_view2", "C3_trained_long_view3", "C5_trained_llff"])
 def test_f16x2_full_size_vs_oracle(hip, O, case):
     """BASELINE-sized batches on the HIP path against the CPU oracle: RGB L-inf <= 1e-4 and >= 99.99 % identical bin indices
     at every level -- on the trained-like weights (f16-exact as stored, and perturbed to full fp32 precision) as on the
@@ -67,16 +70,19 @@ def test_f16x2_full_size_vs_oracle(hip, O, case):
     WHOLE batches (the tail of the mode of record against the reference arithmetic, not against the
     f32 mode): max, 99.99th percentile and the count of rays over 1e-4 are recorded."""
     from refnerf_pl_amd import synthetic
-    R, N, n_or = (8192, 192, 512) if case.startswith("C3") else (4096, 128, 512)
+    R, N, n_or = (8192, 192, 512) if case.startswith("C3") else ((2048, 256, 2048) if case.startswith("C5") else (4096, 128, 512))
     kw = {}
-    if case.endswith("trained_long"):           # the 2500-step fp32 weight set, also through the ring-of-records variant (C3 shape)
+    llff_seed = 3
+    if "trained_long" in case:                  # the 2500-step fp32 weight set, also through the ring-of-records variant (C3 shape)
         from helpers import trained_long_blob
-        P, rk, n_or = trained_long_blob(), dict(seed=3, center_frac=0.8), R
-    elif case == "C4_trained_llff":             # forward-facing NDC rays, linear colour + norm_linear render map (llff_refnerf.gin)
+        view = {"": 3, "_view2": 11, "_view3": 23}[case.split("trained_long")[1]]
+        P, rk, n_or = trained_long_blob(), dict(seed=view, center_frac=0.8), R
+    elif case.endswith("trained_llff"):         # forward-facing NDC rays, linear colour + norm_linear render map (llff_refnerf.gin)
         from helpers import trained_llff_blob
         g = load_golden("model_trained_llff_eval")
         kw = cfg_from_bindings(g["bindings"])[0]
         P, rk, n_or = trained_llff_blob(), None, R
+        llff_seed = 7 if case.startswith("C5") else 3
     elif case == "C2_trained_like":
         P, rk = trained_blob(), dict(seed=3, center_frac=0.8)
     elif case == "C2_trained_like_fp32_weights":
@@ -85,7 +91,7 @@ def test_f16x2_full_size_vs_oracle(hip, O, case):
         P, rk = synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0), dict(seed=1, center_frac=0.5)
     else:
         P, rk = synthetic.make_params(seed=0, bias_scale=0.05, sharpen=20.0, roughness_bias=-6.0), dict(seed=1, center_frac=0.5)
-    rays = synthetic.llff_rays(R, seed=3) if rk is None else synthetic.blender_rays(R, **rk)
+    rays = synthetic.llff_rays(R, seed=llff_seed) if rk is None else synthetic.blender_rays(R, **rk)
     lv = dict(num_prop_samples=N, num_nerf_samples=N)
     out = run_hip_model(hip, P, rays, kw, lv, precision=F16X2)
     again = run_hip_model(hip, P, rays, kw, lv, precision=F16X2)
