@@ -878,7 +878,7 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     sq = fwd_chains == "f16x2" and bwd_chains == "f16x2" and not _hip.LEGACY_F16X2_TRAIN      # the round-5 kernels (eval skeleton)
     names = {"fwd": "rn::level_fwd_train_sq" if sq else "rn::level_fwd_train_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[fwd_chains],
              "bwd": "rn::level_bwd_sq" if sq else "rn::level_bwd_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[bwd_chains],
-             "wgrad": "rn::wgrad_sq_kernel" if sq else ("rn::wgrad_f16s_kernel" if (fwd_chains == "f16x2" and bwd_chains == "f16x2") else "rn::wgrad_bf16x3_kernel")}
+             "wgrad": "rn::wgrad_sq256_kernel" if sq else ("rn::wgrad_f16s_kernel" if (fwd_chains == "f16x2" and bwd_chains == "f16x2") else "rn::wgrad_bf16x3_kernel")}
     peak_of = {"fwd": PEAK_TFLOPS[fwd_chains], "bwd": PEAK_TFLOPS[bwd_chains]}
     for k, (ms, cnt) in fam.items():
         if not cnt:

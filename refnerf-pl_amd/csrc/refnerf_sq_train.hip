@@ -328,14 +328,22 @@ int wgrad(const float *d_act, const float *d_delta, long long S, long long pitch
   (void)pitch;
   static hipError_t attr = hipFuncSetAttribute((const void *)rn::wgrad_sq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rn::SQW_LDS);
   if (attr != hipSuccess) return rnh::fail(REFNERF_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(attr));
+  static hipError_t attr2 = hipFuncSetAttribute((const void *)rn::wgrad_sq256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rn::SQ2_LDS);
+  if (attr2 != hipSuccess) return rnh::fail(REFNERF_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(attr2));
+  /* REFNERF_WGRAD_SQ_TILE=128: the four-wave 128 x 128 tiles (measurement aid; the default 256 x 256 tile fetches every operand once) */
+  static const bool tile128 = [] { const char *e = getenv("REFNERF_WGRAD_SQ_TILE"); return e && atoi(e) == 128; }();
   SQ_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_kmin, 0x7f800000, 32, st));
   hipLaunchKernelGGL(rn::delta_kappa_min, dim3(rn::DSC_ROWS, 64), dim3(256), 0, st, d_delta, S, d_kmin);
   rn::WgradSqArgs w;
   w.act = d_act; w.delta = d_delta; w.S = S; w.k_per_slice = k_per_slice; w.part = d_part;
-  const dim3 grid(8 * ((slices + 7) / 8) * rn::WJOBS_SQ.tiles);
   long tslot = -1;
   { int trc = rnh::timer_begin(st, &tslot, REFNERF_TIMER_WGRAD); if (trc) return trc; }
-  hipLaunchKernelGGL(rn::wgrad_sq_kernel, grid, dim3(64 * rn::SQW_NW), rn::SQW_LDS, st, w, slices, d_kmin, act11);
+  if (tile128) {
+    const dim3 grid(8 * ((slices + 7) / 8) * rn::WJOBS_SQ.tiles);
+    hipLaunchKernelGGL(rn::wgrad_sq_kernel, grid, dim3(64 * rn::SQW_NW), rn::SQW_LDS, st, w, slices, d_kmin, act11);
+  } else {
+    hipLaunchKernelGGL(rn::wgrad_sq256_kernel, dim3(rn::WJOBS_SQ.n * slices), dim3(512), rn::SQ2_LDS, st, w, slices, d_kmin, act11);
+  }
   SQ_HIP_TRY(hipGetLastError());
   { int trc = rnh::timer_end(st, tslot); if (trc) return trc; }
   return REFNERF_OK;

@@ -253,4 +253,260 @@ __global__ __launch_bounds__(64 * SQW_NW) __attribute__((amdgpu_waves_per_eu(2))
   }
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * The 256 x 256 tile: ONE workgroup of eight waves owns a whole layer's dW for its slice of the sample axis, so every DELTA and
+ * ACT byte of the slice is fetched exactly once (the 128 x 128 tiles above read each operand twice and the four sibling tiles
+ * drift apart faster than one XCD's L2 can hold the 3 MB a k-step of its 64 workgroups streams: 19 % hits, 18.9 GB fetched
+ * for 11.6 GB of operands at 4096 x 128).  Waves 4 x 2 of 64 x 128 (128 accumulator registers); 32-sample k-steps.
+ *
+ * One workgroup per CU has nobody to hide its HBM latency behind, and 128 accumulators + fragments leave no room for a second
+ * register set of operands in flight (two sets: 280-1300 spilled registers in every arrangement tried, also as four waves
+ * with 512 registers each).  So the operands travel HBM -> LDS by LDS-DMA into a ring of RAW k-steps -- every lane DMAs the 7 x
+ * 16 B it will itself convert, so a ring slot is a per-lane FIFO and needs no barrier, only the wave's own vmcnt -- and two
+ * k-steps (2 x 56 KB per CU) are in flight while a third is converted (unpair, common factor, transpose) into the fragment
+ * layout T and multiplied.  LDS: T 48 KB + 2 x 56 KB = 160 KB.  Jobs issued heaviest first (grid = jobs x slices).
+ * Same arithmetic and slice order as wgrad_sq_kernel (the bias sums add in another order).
+ * ------------------------------------------------------------------------------------------------------------------------- */
+constexpr int SQ2_KT = 32, SQ2_T = 256, SQ2_ROWB = SQ2_KT * 2;
+constexpr int SQ2_REG = SQ2_T * SQ2_ROWB;                      /* one operand of T: 16 KB */
+constexpr int SQ2_TB = 3 * SQ2_REG;                            /* T = [D | A_hi | A_lo] */
+constexpr int SQ2_RG = 512 * 16;                               /* one 16 B piece per thread: 8 KB */
+constexpr int SQ2_SLOT = 7 * SQ2_RG;                           /* D x 2, A_hi x 2, A_lo x 2, factors */
+constexpr int SQ2_NS = 2;
+constexpr int SQ2_LDS = SQ2_TB + SQ2_NS * SQ2_SLOT;
+static_assert(SQ2_LDS <= 160 * 1024, "LDS of one CU");
+static_assert(WIDTH <= SQ2_T && DIR_IN <= SQ2_T && IPE_DIM <= SQ2_T && HROWS <= SQ2_T, "one tile per job");
+struct Sq2Order { int o[MAX_WJOBS]; };
+constexpr Sq2Order make_sq2_order() {
+  Sq2Order O{};
+  int cost[MAX_WJOBS] = {};
+  for (int i = 0; i < WJOBS_SQ.n; ++i) {
+    O.o[i] = i;
+    cost[i] = ((WJOBS_SQ.job[i].j.n_out + 1) / 2) * 4 + WJOBS_SQ.job[i].j.n_in * (WJOBS_SQ.job[i].half ? 2 : 4);
+  }
+  for (int i = 1; i < WJOBS_SQ.n; ++i)
+    for (int k = i; k > 0 && cost[O.o[k]] > cost[O.o[k - 1]]; --k) { const int t = O.o[k]; O.o[k] = O.o[k - 1]; O.o[k - 1] = t; }
+  return O;
+}
+constexpr Sq2Order SQ2_ORDER = make_sq2_order();
+__device__ __forceinline__ long long sq2_koff(long long k, int units) { return ((k >> 6) * (long long)units * RB + (k & 63)) * 4; }
+typedef __attribute__((address_space(1))) const void *sq2_gptr;
+typedef __attribute__((address_space(3))) void *sq2_lptr;
+
+/* HALF: no lo operand (directional jobs: one half per element; every job under cfg.wgrad_mode = REFNERF_WGRAD_F16) -- a template
+ * parameter, so that each flavour is straight-line code */
+template <bool HALF>
+__device__ __forceinline__ void wgrad_sq256_body(const WgradSqArgs &A, int slice, int ji, const float *__restrict__ kmin_all) {
+  extern __shared__ __attribute__((aligned(16))) char wbs[];
+  constexpr int VM = HALF ? 5 : 7;                 /* VMEM operations (all LDS-DMA) of one k-step and wave */
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, sl = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const WJob J = WJOBS_SQ.job[ji].j;
+  const int a_unit = WJOBS_SQ.job[ji].a_unit;
+  const bool halfrows = WJOBS_SQ.job[ji].half != 0;
+  const long long k_begin = (long long)slice * A.k_per_slice;
+  long long k_end = k_begin + A.k_per_slice;
+  const long long s_pad = (A.S + RB - 1) / RB * RB;
+  if (k_end > s_pad) k_end = s_pad;
+  const int nsteps = (int)((k_end - k_begin + SQ2_KT - 1) / SQ2_KT);    /* >= 2: the caller's slice count leaves no slice empty */
+  const int lid = del_layer_id(J.d_row);
+  const float kmin = kmin_all[lid];
+  const bool have = kmin < INFINITY;
+
+  v16f acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+  /* this lane's pieces: pair rows p0 = tid / 8 and p0 + 64 of both tiles, samples c4 .. c4 + 3 of the k-step.  A pair row past
+   * the job's last one re-reads the last one (same cache lines; the conversion zeroes it) */
+  const int p0 = tid >> 3, c4 = (tid & 7) * 4;
+  const int aup = halfrows ? 1 : 2;
+  const int dlast = (J.n_out - 1) / 2, alast = (J.n_in - 1) / 2;
+  const char *dp[2], *ap[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pd = min(p0 + 64 * q, dlast), pa = min(p0 + 64 * q, alast);
+    dp[q] = reinterpret_cast<const char *>(A.delta) + ((long long)(J.d_row / 2 + pd) * RB + c4) * 4;
+    ap[q] = reinterpret_cast<const char *>(A.act) + ((long long)(a_unit + pa * aup) * RB + c4) * 4;
+  }
+  const char *scp = reinterpret_cast<const char *>(A.delta) + ((long long)(DQ_C + lid) * RB + c4) * 4;
+  auto kof = [&](int s) { return k_begin + (long long)(s < nsteps ? s : nsteps - 1) * SQ2_KT; };   /* (past the end: the last one again) */
+  /* k-step s -> ring slot: VM LDS-DMA instructions per wave, lane l of wave w lands at region + (64 w + l) 16 = region + 16 tid */
+  auto issue = [&](int s, int slot) {
+    const long long k = kof(s);
+    const long long dk = sq2_koff(k, DQ_UNITS), ak = sq2_koff(k, AQ_UNITS);
+    char *base = wbs + SQ2_TB + slot * SQ2_SLOT + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      __builtin_amdgcn_global_load_lds((sq2_gptr)(dp[q] + dk), (sq2_lptr)(base + q * SQ2_RG), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((sq2_gptr)(ap[q] + ak), (sq2_lptr)(base + (2 + q) * SQ2_RG), 16, 0, 0);
+      if (!HALF) __builtin_amdgcn_global_load_lds((sq2_gptr)(ap[q] + ak + RB * 4), (sq2_lptr)(base + (4 + q) * SQ2_RG), 16, 0, 0);
+    }
+    __builtin_amdgcn_global_load_lds((sq2_gptr)(scp + dk), (sq2_lptr)(base + 6 * SQ2_RG), 16, 0, 0);
+  };
+  auto unpair = [](const v4u w, int hf, bool live, unsigned &s01, unsigned &s23) {
+    const unsigned sel = hf ? 0x07060302u : 0x05040100u;
+    s01 = live ? __builtin_amdgcn_perm(w[1], w[0], sel) : 0u;
+    s23 = live ? __builtin_amdgcn_perm(w[3], w[2], sel) : 0u;
+  };
+  /* T: 64 B rows of four 16 B chunks, chunk ^ (row / 4) -- the 16 rows a quarter wave reads at one chunk sit on 16 bank groups.
+   * Every address = a lane register + an immediate (the swizzle term depends on the lane and on kk only); the registers are
+   * made opaque once per k-step, or LICM parks the precomputed sums in VGPRs across the loop */
+  const int xs = (sl >> 2) & 3;
+  int rdD[2], rdA[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int ch = (((kk << 1) | h) ^ xs) << 4;
+    rdD[kk] = (wm * 64 + sl) * SQ2_ROWB + ch;
+    rdA[kk] = SQ2_REG + (wn * 128 + sl) * SQ2_ROWB + ch;
+  }
+  int wrT = (2 * p0) * SQ2_ROWB + ((((c4 >> 3) ^ (p0 >> 1)) & 3) << 4) + ((c4 * 2) & 15);
+  int mine = SQ2_TB + tid * 16;
+  auto opaque = [&] { asm volatile("" : "+v"(rdD[0]), "+v"(rdD[1]), "+v"(rdA[0]), "+v"(rdA[1]), "+v"(wrT), "+v"(mine)); };
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  /* k-step s (arrived in `slot`) -> T; the slot is re-armed with k-step s + SQ2_NS as soon as its pieces sit in registers */
+  auto stage = [&](int s, int slot) {
+    const long long k = kof(s);
+    const bool fresh = s < nsteps;             /* (past the end the last k-step comes again: not into the bias sums) */
+    const char *src = wbs + mine + slot * SQ2_SLOT;
+    v4u dv[2], avh[2], avl[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      dv[q] = *reinterpret_cast<const v4u *>(src + q * SQ2_RG);
+      avh[q] = *reinterpret_cast<const v4u *>(src + (2 + q) * SQ2_RG);
+      if (!HALF) avl[q] = *reinterpret_cast<const v4u *>(src + (4 + q) * SQ2_RG);
+    }
+    const v4f cv = *reinterpret_cast<const v4f *>(src + 6 * SQ2_RG);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef REFNERF_EXPERIMENT_SQ2_NODMA
+    issue(s + SQ2_NS, slot);
+#endif
+#ifdef REFNERF_EXPERIMENT_SQ2_NOSTAGE
+    if (dv[0][0] == 0x12345678u && avh[1][2] == 77u && avl[0][1] == 3u && cv[2] == 1.5f) bsum[0] += 1.0f;
+    return;
+#endif
+    unsigned f01, f23, g01, g23;
+    {
+      float f[4], g[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        /* (selects, not branches.  K / c_s, both powers of two: v_rcp_f32 is exact on them; passed as two factors when above the
+         * half's range; a pad sample's c is whatever the allocator left there) */
+        const float r = kmin * __builtin_amdgcn_rcpf(cv[i]);
+        const bool ok = have & (k + c4 + i < A.S) & (cv[i] > 0.0f);
+        const float x = ok ? r : 0.0f;
+        f[i] = fminf(x, 32768.0f);
+        g[i] = x > 32768.0f ? x * (1.0f / 32768.0f) : 1.0f;
+      }
+      f01 = sqw_pk_f16(f[0], f[1]);
+      f23 = sqw_pk_f16(f[2], f[3]);
+      g01 = sqw_pk_f16(g[0], g[1]);
+      g23 = sqw_pk_f16(g[2], g[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int row = 2 * (p0 + 64 * q) + e;
+        const int imm = (128 * q + e) * SQ2_ROWB;
+        unsigned h0, h1;
+        unpair(dv[q], e, row < J.n_out, h0, h1);
+        h0 = sqw_pk_mul(sqw_pk_mul(h0, f01), g01);
+        h1 = sqw_pk_mul(sqw_pk_mul(h1, f23), g23);
+        bsum[2 * q + e] += fresh ? sqw_pk_sum(h0) + sqw_pk_sum(h1) : 0.0f;   /* (a select: a branch would split the k-step into blocks) */
+        *reinterpret_cast<v2u *>(wbs + wrT + imm) = (v2u){h0, h1};
+        unpair(avh[q], e, row < J.n_in, h0, h1);
+        *reinterpret_cast<v2u *>(wbs + wrT + SQ2_REG + imm) = (v2u){h0, h1};
+        if (!HALF) {
+          unpair(avl[q], e, row < J.n_in, h0, h1);
+          *reinterpret_cast<v2u *>(wbs + wrT + 2 * SQ2_REG + imm) = (v2u){h0, h1};
+        }
+      }
+  };
+  auto compute = [&] {
+#ifdef REFNERF_EXPERIMENT_SQ2_NOCOMPUTE
+    return;
+#endif
+#pragma unroll
+    for (int kk = 0; kk < SQ2_KT / 16; ++kk) {
+      sqw_v8h dh[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dh[i] = *reinterpret_cast<const sqw_v8h *>(wbs + rdD[kk] + i * 32 * SQ2_ROWB);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const sqw_v8h bh = *reinterpret_cast<const sqw_v8h *>(wbs + rdA[kk] + j * 32 * SQ2_ROWB);
+        if (!HALF) {
+          const sqw_v8h bl = *reinterpret_cast<const sqw_v8h *>(wbs + rdA[kk] + SQ2_REG + j * 32 * SQ2_ROWB);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[i], bl, acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh[i], bh, acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  /* this wave's VM oldest DMA instructions (= the k-step about to be converted) have landed; the younger k-step stays in flight */
+#ifdef REFNERF_EXPERIMENT_SQ2_NODMA
+  auto arrived = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+#else
+  auto arrived = [] { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory"); };
+#endif
+  auto t_written = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto t_consumed = [] { asm volatile("s_barrier" ::: "memory"); };   /* (a wave's T reads are behind its MFMAs: done) */
+#pragma unroll
+  for (int s = 0; s < SQ2_NS; ++s) issue(s, s);
+  arrived();
+  stage(0, 0);
+  t_written();
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    opaque();
+    compute();
+    t_consumed();
+    arrived();
+    stage(s + 1, (s + 1) & 1);       /* (past the last k-step: the last one again, into a T nobody reads) */
+    t_written();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* (the re-armed slots' DMA before the workgroup gives its LDS back) */
+  const bool need_bias = J.b_off >= 0;
+  const float inv = have ? 1.0f / kmin : 0.0f;
+  float *part = A.part + (size_t)slice * NUM_PARAMS;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int colk = wn * 128 + j * 32 + sl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (orow < J.n_out && colk < J.n_in) part[wjob_row_off(J, orow) + colk] = acc[i][j][r] * inv;
+      }
+    }
+  if (need_bias) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float sum = bsum[p];
+      sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+      const int orow = 2 * (p0 + 64 * (p >> 1)) + (p & 1);
+      if ((tid & 7) == 0 && orow < J.n_out) part[wjob_bias_off(J, orow)] = sum * inv;
+    }
+  }
+}
+
+/* grid = jobs x slices workgroups of 512 threads, the heaviest jobs first.  (Slices per job in proportion to the job's bytes --
+ * two even rounds of ~495 workgroups -- measured SLOWER, 3.9 against 3.3 ms: a k-step of a light job costs the same MFMA and
+ * conversion time as a heavy one's, so its few long workgroups became the tail: docs/EXPERIMENTS.md section 10.) */
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_sq256_kernel(const WgradSqArgs A, int slices, const float *__restrict__ kmin_all, int act11) {
+  const int tix = blockIdx.x / slices, slice = blockIdx.x - tix * slices;
+  const int ji = SQ2_ORDER.o[tix];
+  if (WJOBS_SQ.job[ji].half != 0 || act11 != 0) wgrad_sq256_body<true>(A, slice, ji, kmin_all);
+  else wgrad_sq256_body<false>(A, slice, ji, kmin_all);
+}
+
 }  // namespace rn

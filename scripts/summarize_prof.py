@@ -30,7 +30,7 @@ KERNELS = {"level_fwd_bf16": "rn::level_fwd_bf16", "level_fwd_f32": "rn::level_f
            "level_fwd_train_f16x2c": "rn::level_fwd_train_f16x2c", "level_bwd_f16x2c": "rn::level_bwd_f16x2c",
            "wgrad_f16s_kernel": "rn::wgrad_f16s_kernel", "delta_scale_min": "rn::delta_scale_min",
            "level_fwd_train_sq": "rn::level_fwd_train_sq", "level_fwd_train_sq_h": "rn::level_fwd_train_sq_h", "level_bwd_sq": "rn::level_bwd_sq",
-           "wgrad_sq_kernel": "rn::wgrad_sq_kernel", "delta_kappa_min": "rn::delta_kappa_min",
+           "wgrad_sq_kernel": "rn::wgrad_sq_kernel", "wgrad_sq256_kernel": "rn::wgrad_sq256_kernel", "delta_kappa_min": "rn::delta_kappa_min",
            "pack_train_chunks": "rn::pack_train_chunks", "pack_train_consts": "rn::pack_train_consts"}
 
 rows = list(csv.reader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))

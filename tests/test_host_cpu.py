@@ -334,8 +334,9 @@ def test_bench_compact_line_fits_the_driver_tail():
     import glob
     import json
     import bench
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "bench", "*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r04", "bench", "*.full.json")))
-    assert paths
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "bench", "*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r04", "bench", "*.full.json"))
+                   + glob.glob(os.path.join(ROOT, "profiles", "r05", "bench", "*.full.json")))
+    assert paths and any("r05" in p for p in paths)
     for p in paths:
         full = json.load(open(p))
         # (round 3's C5 record predates the training configuration's cpu_baseline leg)
@@ -351,6 +352,12 @@ def test_bench_compact_line_fits_the_driver_tail():
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
             assert k in line["roofline"], (p, k)
         assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-4
+        if os.sep + "r05" + os.sep in p:
+            # what the kernel is actually bound by travels with the number -- the matrix pipe's busy fraction,
+            # the flops it executes as a fraction of the dense f16 peak, and the clock it sustained (profiles/traffic.json)
+            for k in ("mfma_busy", "executed_flop_frac", "sustained_clock_ghz"):
+                assert isinstance(line["roofline"].get(k), float) and 0 < line["roofline"][k] < 3, (p, k)
+            assert line["roofline"]["traffic"] is not None
         for k in ("value", "unit", "cores", "kind", "sample"):
             assert k in line["cpu_baseline"], (p, k)
         assert abs(line["value"] / full["value"] - 1) < 1e-4
