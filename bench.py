@@ -876,7 +876,8 @@ def train_step_bench(args, spec, model, cfg, rays, rank, world, dev, dist, sync,
     samples_per_launch = (R + extra_rays) * N / passes
     kernels = {}
     sq = fwd_chains == "f16x2" and bwd_chains == "f16x2" and not _hip.LEGACY_F16X2_TRAIN      # the round-5 kernels (eval skeleton)
-    names = {"fwd": "rn::level_fwd_train_sq" if sq else "rn::level_fwd_train_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[fwd_chains],
+    half_act = getattr(cfg, "hip_wgrad_mode", "bf16x3") == "f16"      # the forward that does not write the lo units of the spatial layer inputs
+    names = {"fwd": ("rn::level_fwd_train_sq_h" if half_act else "rn::level_fwd_train_sq") if sq else "rn::level_fwd_train_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[fwd_chains],
              "bwd": "rn::level_bwd_sq" if sq else "rn::level_bwd_" + {"bf16": "bf16c", "f16x2": "f16x2c", "f32": "f32"}[bwd_chains],
              "wgrad": "rn::wgrad_sq256_kernel" if sq else ("rn::wgrad_f16s_kernel" if (fwd_chains == "f16x2" and bwd_chains == "f16x2") else "rn::wgrad_bf16x3_kernel")}
     peak_of = {"fwd": PEAK_TFLOPS[fwd_chains], "bwd": PEAK_TFLOPS[bwd_chains]}

@@ -1045,10 +1045,11 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     }
     const int slices = (int)((plan.S + plan.k_per_slice - 1) / plan.k_per_slice);
     float *part = (float *)(ws + plan.part_off);
+    int used = slices;
     rc = rnsq::wgrad(a.act, a.delta, plan.S, plan.pitch, plan.k_per_slice, slices, part, (float *)(ws + plan.cmin_off),
-                     cfg->wgrad_mode == REFNERF_WGRAD_F16 ? 1 : 0, st);
+                     cfg->wgrad_mode == REFNERF_WGRAD_F16 ? 1 : 0, &used, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(rn::wgrad_reduce, dim3(1024), dim3(256), 0, st, part, slices, d_param_grads, (int)rn::NUM_PARAMS);
+    hipLaunchKernelGGL(rn::wgrad_reduce, dim3(1024), dim3(256), 0, st, part, used, d_param_grads, (int)rn::NUM_PARAMS);
     HIP_TRY(hipGetLastError());
     return REFNERF_OK;
   }

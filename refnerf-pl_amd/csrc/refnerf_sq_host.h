@@ -28,7 +28,7 @@ int forward(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_ra
 int backward_chain(const void *d_packed, const refnerf_level_cfg *cfg, const refnerf_rays *rays, int R, const float *d_sdist,
                    const refnerf_level_grads *grads, const float *d_act, float *d_delta, const float *d_seeds, long long pitch,
                    hipStream_t st);
-/* dW partials of the level: PART[slices][NUM_PARAMS] (the caller reduces them) */
+/* dW partials of the level: PART[*slices_used][NUM_PARAMS], *slices_used <= slices (the caller reduces them) */
 int wgrad(const float *d_act, const float *d_delta, long long S, long long pitch, int k_per_slice, int slices, float *d_part,
-          float *d_kmin, int act11, hipStream_t st);
+          float *d_kmin, int act11, int *slices_used, hipStream_t st);
 }  // namespace rnsq

@@ -324,8 +324,9 @@ int backward_chain(const void *d_packed, const refnerf_level_cfg *cfg, const ref
 }
 
 int wgrad(const float *d_act, const float *d_delta, long long S, long long pitch, int k_per_slice, int slices, float *d_part,
-          float *d_kmin, int act11, hipStream_t st) {
+          float *d_kmin, int act11, int *slices_used, hipStream_t st) {
   (void)pitch;
+  *slices_used = slices;
   static hipError_t attr = hipFuncSetAttribute((const void *)rn::wgrad_sq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rn::SQW_LDS);
   if (attr != hipSuccess) return rnh::fail(REFNERF_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(attr));
   static hipError_t attr2 = hipFuncSetAttribute((const void *)rn::wgrad_sq256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, rn::SQ2_LDS);
@@ -342,7 +343,16 @@ int wgrad(const float *d_act, const float *d_delta, long long S, long long pitch
     const dim3 grid(8 * ((slices + 7) / 8) * rn::WJOBS_SQ.tiles);
     hipLaunchKernelGGL(rn::wgrad_sq_kernel, grid, dim3(64 * rn::SQW_NW), rn::SQW_LDS, st, w, slices, d_kmin, act11);
   } else {
-    hipLaunchKernelGGL(rn::wgrad_sq256_kernel, dim3(rn::WJOBS_SQ.n * slices), dim3(512), rn::SQ2_LDS, st, w, slices, d_kmin, act11);
+    /* one workgroup per CU: jobs x slices workgroups run in rounds of #CUs.  REFNERF_WGRAD_SQ_SLICES: measurement aid */
+    static const int want = [] { const char *e = getenv("REFNERF_WGRAD_SQ_SLICES"); return e ? atoi(e) : 0; }();
+    int se = slices;
+    if (want > 0 && want < se) se = want;
+    const long long blocks = (S + rn::RB - 1) / rn::RB;
+    const long long per = (blocks + se - 1) / se;
+    se = (int)((blocks + per - 1) / per);
+    w.k_per_slice = (int)(per * rn::RB);
+    *slices_used = se;
+    hipLaunchKernelGGL(rn::wgrad_sq256_kernel, dim3(rn::WJOBS_SQ.n * se), dim3(512), rn::SQ2_LDS, st, w, se, d_kmin, act11);
   }
   SQ_HIP_TRY(hipGetLastError());
   { int trc = rnh::timer_end(st, tslot); if (trc) return trc; }
