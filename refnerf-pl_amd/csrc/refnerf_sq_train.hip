@@ -343,10 +343,15 @@ int wgrad(const float *d_act, const float *d_delta, long long S, long long pitch
     const dim3 grid(8 * ((slices + 7) / 8) * rn::WJOBS_SQ.tiles);
     hipLaunchKernelGGL(rn::wgrad_sq_kernel, grid, dim3(64 * rn::SQW_NW), rn::SQW_LDS, st, w, slices, d_kmin, act11);
   } else {
-    /* one workgroup per CU: jobs x slices workgroups run in rounds of #CUs.  REFNERF_WGRAD_SQ_SLICES: measurement aid */
+    /* One workgroup per CU (160 KB of LDS), so jobs x slices workgroups run in rounds of #CUs and a partial last round leaves
+     * most of the chip idle behind compute-bound stragglers: the slice count is cut to whole rounds (20 jobs x 32 slices =
+     * 2.5 rounds on 256 CUs -> 25 slices = 500 workgroups: 2.52 -> 2.10 ms at 4096 x 128; 24: 2.23, 28: 2.85, 19: 2.80).
+     * REFNERF_WGRAD_SQ_SLICES overrides (measurement aid). */
+    static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     static const int want = [] { const char *e = getenv("REFNERF_WGRAD_SQ_SLICES"); return e ? atoi(e) : 0; }();
     int se = slices;
-    if (want > 0 && want < se) se = want;
+    if (rn::WJOBS_SQ.n * se > cus) se = (rn::WJOBS_SQ.n * se / cus) * cus / rn::WJOBS_SQ.n;
+    if (want > 0 && want <= slices) se = want;
     const long long blocks = (S + rn::RB - 1) / rn::RB;
     const long long per = (blocks + se - 1) / se;
     se = (int)((blocks + per - 1) / per);

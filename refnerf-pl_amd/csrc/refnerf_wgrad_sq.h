@@ -264,16 +264,20 @@ __global__ __launch_bounds__(64 * SQW_NW) __attribute__((amdgpu_waves_per_eu(2))
  * with 512 registers each).  So the operands travel HBM -> LDS by LDS-DMA into a ring of RAW k-steps -- every lane DMAs the 7 x
  * 16 B it will itself convert, so a ring slot is a per-lane FIFO and needs no barrier, only the wave's own vmcnt -- and two
  * k-steps (2 x 56 KB per CU) are in flight while a third is converted (unpair, common factor, transpose) into the fragment
- * layout T and multiplied.  LDS: T 48 KB + 2 x 56 KB = 160 KB.  Jobs issued heaviest first (grid = jobs x slices).
+ * layout T and multiplied.  LDS: T 48 KB + 2 x 56 KB = 160 KB (no lo operand: T 32 KB + 3 x 40 KB).  Jobs issued heaviest first.
  * Same arithmetic and slice order as wgrad_sq_kernel (the bias sums add in another order).
  * ------------------------------------------------------------------------------------------------------------------------- */
 constexpr int SQ2_KT = 32, SQ2_T = 256, SQ2_ROWB = SQ2_KT * 2;
 constexpr int SQ2_REG = SQ2_T * SQ2_ROWB;                      /* one operand of T: 16 KB */
 constexpr int SQ2_TB = 3 * SQ2_REG;                            /* T = [D | A_hi | A_lo] */
 constexpr int SQ2_RG = 512 * 16;                               /* one 16 B piece per thread: 8 KB */
-constexpr int SQ2_SLOT = 7 * SQ2_RG;                           /* D x 2, A_hi x 2, A_lo x 2, factors */
-constexpr int SQ2_NS = 2;
-constexpr int SQ2_LDS = SQ2_TB + SQ2_NS * SQ2_SLOT;
+/* ring slot = D x 2, A_hi x 2, (A_lo x 2,) factors; two slots beside the three operands of T, or -- no lo operand -- three slots
+ * beside two */
+constexpr int sq2_regions(bool half) { return half ? 5 : 7; }
+constexpr int sq2_slots(bool half) { return half ? 3 : 2; }
+constexpr int sq2_tbytes(bool half) { return (half ? 2 : 3) * SQ2_REG; }
+constexpr int sq2_lds(bool half) { return sq2_tbytes(half) + sq2_slots(half) * sq2_regions(half) * SQ2_RG; }
+constexpr int SQ2_LDS = sq2_lds(false) > sq2_lds(true) ? sq2_lds(false) : sq2_lds(true);
 static_assert(SQ2_LDS <= 160 * 1024, "LDS of one CU");
 static_assert(WIDTH <= SQ2_T && DIR_IN <= SQ2_T && IPE_DIM <= SQ2_T && HROWS <= SQ2_T, "one tile per job");
 struct Sq2Order { int o[MAX_WJOBS]; };
@@ -298,7 +302,9 @@ typedef __attribute__((address_space(3))) void *sq2_lptr;
 template <bool HALF>
 __device__ __forceinline__ void wgrad_sq256_body(const WgradSqArgs &A, int slice, int ji, const float *__restrict__ kmin_all) {
   extern __shared__ __attribute__((aligned(16))) char wbs[];
-  constexpr int VM = HALF ? 5 : 7;                 /* VMEM operations (all LDS-DMA) of one k-step and wave */
+  constexpr int VM = sq2_regions(HALF);            /* VMEM operations (all LDS-DMA) of one k-step and wave */
+  constexpr int NS = sq2_slots(HALF), SLOT = sq2_regions(HALF) * SQ2_RG, TB = sq2_tbytes(HALF);
+  constexpr int G_AH = 2, G_AL = 4, G_CV = HALF ? 4 : 6;      /* region numbers within a slot */
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, sl = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -341,14 +347,14 @@ __device__ __forceinline__ void wgrad_sq256_body(const WgradSqArgs &A, int slice
   auto issue = [&](int s, int slot) {
     const long long k = kof(s);
     const long long dk = sq2_koff(k, DQ_UNITS), ak = sq2_koff(k, AQ_UNITS);
-    char *base = wbs + SQ2_TB + slot * SQ2_SLOT + wave * 1024;
+    char *base = wbs + TB + slot * SLOT + wave * 1024;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       __builtin_amdgcn_global_load_lds((sq2_gptr)(dp[q] + dk), (sq2_lptr)(base + q * SQ2_RG), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((sq2_gptr)(ap[q] + ak), (sq2_lptr)(base + (2 + q) * SQ2_RG), 16, 0, 0);
-      if (!HALF) __builtin_amdgcn_global_load_lds((sq2_gptr)(ap[q] + ak + RB * 4), (sq2_lptr)(base + (4 + q) * SQ2_RG), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((sq2_gptr)(ap[q] + ak), (sq2_lptr)(base + (G_AH + q) * SQ2_RG), 16, 0, 0);
+      if (!HALF) __builtin_amdgcn_global_load_lds((sq2_gptr)(ap[q] + ak + RB * 4), (sq2_lptr)(base + (G_AL + q) * SQ2_RG), 16, 0, 0);
     }
-    __builtin_amdgcn_global_load_lds((sq2_gptr)(scp + dk), (sq2_lptr)(base + 6 * SQ2_RG), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((sq2_gptr)(scp + dk), (sq2_lptr)(base + G_CV * SQ2_RG), 16, 0, 0);
   };
   auto unpair = [](const v4u w, int hf, bool live, unsigned &s01, unsigned &s23) {
     const unsigned sel = hf ? 0x07060302u : 0x05040100u;
@@ -367,25 +373,25 @@ __device__ __forceinline__ void wgrad_sq256_body(const WgradSqArgs &A, int slice
     rdA[kk] = SQ2_REG + (wn * 128 + sl) * SQ2_ROWB + ch;
   }
   int wrT = (2 * p0) * SQ2_ROWB + ((((c4 >> 3) ^ (p0 >> 1)) & 3) << 4) + ((c4 * 2) & 15);
-  int mine = SQ2_TB + tid * 16;
+  int mine = TB + tid * 16;
   auto opaque = [&] { asm volatile("" : "+v"(rdD[0]), "+v"(rdD[1]), "+v"(rdA[0]), "+v"(rdA[1]), "+v"(wrT), "+v"(mine)); };
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
   /* k-step s (arrived in `slot`) -> T; the slot is re-armed with k-step s + SQ2_NS as soon as its pieces sit in registers */
   auto stage = [&](int s, int slot) {
     const long long k = kof(s);
     const bool fresh = s < nsteps;             /* (past the end the last k-step comes again: not into the bias sums) */
-    const char *src = wbs + mine + slot * SQ2_SLOT;
+    const char *src = wbs + mine + slot * SLOT;
     v4u dv[2], avh[2], avl[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       dv[q] = *reinterpret_cast<const v4u *>(src + q * SQ2_RG);
-      avh[q] = *reinterpret_cast<const v4u *>(src + (2 + q) * SQ2_RG);
-      if (!HALF) avl[q] = *reinterpret_cast<const v4u *>(src + (4 + q) * SQ2_RG);
+      avh[q] = *reinterpret_cast<const v4u *>(src + (G_AH + q) * SQ2_RG);
+      if (!HALF) avl[q] = *reinterpret_cast<const v4u *>(src + (G_AL + q) * SQ2_RG);
     }
-    const v4f cv = *reinterpret_cast<const v4f *>(src + 6 * SQ2_RG);
+    const v4f cv = *reinterpret_cast<const v4f *>(src + G_CV * SQ2_RG);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef REFNERF_EXPERIMENT_SQ2_NODMA
-    issue(s + SQ2_NS, slot);
+    issue(s + NS, slot);
 #endif
 #ifdef REFNERF_EXPERIMENT_SQ2_NOSTAGE
     if (dv[0][0] == 0x12345678u && avh[1][2] == 77u && avl[0][1] == 3u && cv[2] == 1.5f) bsum[0] += 1.0f;
@@ -455,22 +461,24 @@ __device__ __forceinline__ void wgrad_sq256_body(const WgradSqArgs &A, int slice
 #ifdef REFNERF_EXPERIMENT_SQ2_NODMA
   auto arrived = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 #else
-  auto arrived = [] { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory"); };
+  auto arrived = [] { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM * (NS - 1)) : "memory"); };
 #endif
   auto t_written = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   auto t_consumed = [] { asm volatile("s_barrier" ::: "memory"); };   /* (a wave's T reads are behind its MFMAs: done) */
 #pragma unroll
-  for (int s = 0; s < SQ2_NS; ++s) issue(s, s);
+  for (int s = 0; s < NS; ++s) issue(s, s);
   arrived();
   stage(0, 0);
   t_written();
+  int slot = 1;
 #pragma unroll 1
   for (int s = 0; s < nsteps; ++s) {
     opaque();
     compute();
     t_consumed();
     arrived();
-    stage(s + 1, (s + 1) & 1);       /* (past the last k-step: the last one again, into a T nobody reads) */
+    stage(s + 1, slot);              /* (past the last k-step: the last one again, into a T nobody reads) */
+    slot = slot + 1 == NS ? 0 : slot + 1;
     t_written();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* (the re-armed slots' DMA before the workgroup gives its LDS back) */
