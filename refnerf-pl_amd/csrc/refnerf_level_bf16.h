@@ -125,10 +125,12 @@ template <bool SPLIT = false>
 __device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off, int piece = -1) {
   if (p.dma_left > 0) {
     if (p.wave < 6) {
+#ifndef REFNERF_EXP_NODMA
       lptr_t dst = (lptr_t)(p.wbuf + slot_off + p.wave * 3072);
       if (piece < 0 || piece == 0) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 0, REFNERF_DMA_AUX);
       if (piece < 0 || piece == 1) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 1024, REFNERF_DMA_AUX);
       if ((piece < 0 || piece == 2) && p.wave < 5) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 2048, REFNERF_DMA_AUX);
+#endif
     }
     if (piece >= 0 && piece < 2) return;             /* the stream position moves on with the last piece */
     p.src += BF_CHUNK_BYTES;
@@ -144,8 +146,19 @@ __device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off, int piece = -
   }
 }
 
+/* TIMING-ONLY builds (wrong results; scripts/build_main_variant.sh, docs/EXPERIMENTS.md section 10): -DREFNERF_EXP_NOFRAG takes the A
+ * fragments as whatever their registers hold (no LDS fragment traffic, same MFMAs), -DREFNERF_EXP_NODMA
+ * leaves the weight stream's LDS-DMA instructions out (the ring keeps what the first chunks brought). */
 template <typename MM>
-__device__ __forceinline__ typename MM::v8 lds_frag(const char *q) { return *reinterpret_cast<const typename MM::v8 *>(q); }
+__device__ __forceinline__ typename MM::v8 lds_frag(const char *q) {
+#ifdef REFNERF_EXP_NOFRAG
+  typename MM::v8 u;                              /* whatever the registers hold: no instruction at all */
+  asm volatile("" : "=v"(u) : "v"(q));
+  return u;
+#else
+  return *reinterpret_cast<const typename MM::v8 *>(q);
+#endif
+}
 
 __device__ __forceinline__ v16f bias16(const char *w, int h) {
   const v4f *bp = reinterpret_cast<const v4f *>(w + h * 64);

@@ -6,6 +6,8 @@ import torch
 import refnerf_pl_amd  # noqa: F401
 from refnerf_pl_amd import _hip, configs, models, synthetic, utils
 
+if os.environ.get("REFNERF_LIB"):              # an A/B build (scripts/build_main_variant.sh) instead of the in-tree library
+    _hip.LIB_PATH = os.path.join(ROOT, os.environ["REFNERF_LIB"])
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 modes = sys.argv[3:] or ["f16x2", "f16", "bf16", "f32"]
