@@ -524,7 +524,7 @@ def test_twenty_optimiser_steps_follow_the_reference(hip, chains, fused):
     rel_u = float(np.linalg.norm(upd - g["update_sub"]) / np.linalg.norm(g["update_sub"]))
     print(f"[{chains} chains, fused={fused}] worst per-step loss deviation {worst:.2e}; accumulated update vs the reference's: rel-L2 {rel_u:.2e}")
     _record(f"trajectory/{chains}/fused={fused}", dict(worst_loss_rel=worst, update_rel_l2=rel_u))
-    assert rel_u < 1e-2          # measured 7e-4 (f32 chains) / 1.3e-3 (split-f16 chains): Adam's 1 / sqrt(v) on tiny gradients
+    assert rel_u < 1e-2          # measured 7e-4 (f32 chains) / 4.6e-3 (split-f16 chains of round 5; round 4: 1.3e-3): Adam's 1 / sqrt(v) on tiny gradients
     configs.clear_config()
 
 
