@@ -59,10 +59,17 @@ enum {
                             next layer's accumulators NaN; the ReLUs of the split kernels (inference, training chains, general
                             basis) let a NaN through, so the ray's outputs are NaN: loud, never a finite wrong colour.
                             REFNERF_PREC_F32 has no such limit.
-                            refnerf_level_forward_train / refnerf_level_backward in this mode: the f32 kernels with every
-                            256-wide contraction as W_hi x_hi + W_lo x_hi + W_hi x_lo on the same instruction; saved
-                            activations REFNERF_ACT_F16X2 (built-in basis; then the backward must run in this mode too) or
-                            REFNERF_ACT_F32 (general basis); gradients <= 1e-4 rel-L2 from the reference's autograd. */
+                            refnerf_level_forward_train / refnerf_level_backward in this mode, built-in IPE basis (v10):
+                            the eval kernel's skeleton on the REFNERF_IMAGE_F16X2_TRAIN image -- spatial trunk and
+                            density-normal VJP W_hi x_hi + W_lo x_hi + W_hi x_lo, directional trunk [W_hi | W_lo] x on one
+                            half of x, backward W^T (22 bits) x delta (11 bits); saved activations REFNERF_ACT_SQ (then the
+                            backward must run in this mode too).  General basis: the f32 skeleton with three-product
+                            contractions, REFNERF_ACT_F32.  MEASURED gradient rel-L2 from the reference's autograd (GPU
+                            fixtures, tests/test_hip_f16x2.py): 3.5e-5 (shiny) .. 8.1e-5 (llff) .. 1.1e-4 (trained-like),
+                            1.6e-4 (icosahedron basis); trained_long 1.5e-3 in EVERY chain mode incl. f32 (level-1 sample
+                            positions on a sharp surface, not arithmetic); between the chain modes from identical step
+                            functions 7e-5 .. 2.7e-4.  Strict gradient parity = REFNERF_PREC_F32 chains; 22-bit deltas on
+                            fp32 rows = f32 forward + this mode's backward (level_bwd_f16x2c_r32: 2e-6 between the modes). */
 };
 
 /* arithmetic of the weight-gradient GEMM of refnerf_level_backward (dW = DELTA x ACT^T over the samples) */
