@@ -1,6 +1,10 @@
 #!/bin/bash
 # FETCH_SIZE / TCC hit counters of the weight-gradient GEMM for several library builds: bash scripts/pmc_wgrad_ab.sh ab/a.so ab/b.so ...
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+# the variants are copied over the in-tree library (rocprofv3 must start python itself: no env / wrapper hop): the original comes
+# back when the script ends, however it ends
+cp refnerf-pl_amd/csrc/librefnerf_hip.so /tmp/librefnerf_hip.intree.so
+trap 'cp /tmp/librefnerf_hip.intree.so refnerf-pl_amd/csrc/librefnerf_hip.so' EXIT
 for lib in "$@"; do
   cp $lib refnerf-pl_amd/csrc/librefnerf_hip.so
   tag=$(basename $lib .so)
