@@ -154,32 +154,49 @@ __device__ __forceinline__ float safe_arg(float x) {
   return m;
 }
 
-/* sin(a) for |a| < 1000 (safe_arg's range is |a| < 100 pi): quadrant reduction in float64 (two instructions, error 1e-13),
- * 4-term minimax kernels in fp32; <= 9.2e-8 absolute (1.5 ulp) over |a| < 315 (checked against float64 on 2e8 arguments).
- * The library's sinf carries its large-argument (Payne-Hanek) path through every call: ~150 instructions against ~25. */
+/* a = k pi/2 + r, |r| <= pi/4 (+ 1e-5), for |a| < 400: k = rint(a 2/pi) in fp32 and a three-constant Cody-Waite subtraction --
+ * k < 2^8, pi/2 = 1.5703125 (8 bits) + 4.8375e-4 (11 bits) + 7.5498e-8: the first two products are exact, the reduction's error
+ * is the last FMA's rounding (6e-8 r) + 2e-15 k.  Rounds 3-4 did this in float64 (rint + fma, two half-rate instructions plus
+ * three conversions per feature): the 96 IPE features were 15 k of a spatial run's 250 k cycles; in fp32 the same kernels measure
+ * the same 9.2e-8 maximum error against float64 over 4e6 IPE arguments, 6 results per million differ from the float64 reduction
+ * by one ulp (where k itself differs: r a hair past pi/4, inside the kernels' range). */
+__device__ __forceinline__ void quadrant_reduce(float a, float &r, int &q) {
+  const float k = __builtin_rintf(a * 0.636619772367581343f);
+  r = fmaf(-k, 7.54978995489188216e-8f, fmaf(-k, 4.837512969970703125e-4f, fmaf(-k, 1.5703125f, a)));
+  q = (int)k;
+}
+/* sin(a) for |a| < 400 (safe_arg's range is |a| < 100 pi): 4-term minimax kernels in fp32; <= 9.2e-8 absolute (1.5 ulp) over
+ * |a| < 315 (checked against float64).  The library's sinf carries its large-argument (Payne-Hanek) path through every call:
+ * ~150 instructions against ~20. */
 __device__ __forceinline__ float sin_reduced(float a) {
-  const double k = __builtin_rint((double)a * 0.63661977236758134308);
-  const float r = (float)__builtin_fma(-k, 1.57079632679489661923, (double)a);
-  const int q = (int)k;
+  float r; int q;
+  quadrant_reduce(a, r, q);
   const float r2 = r * r;
   const float s = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f) * r2, r, r);
   const float c = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f) * r2, r2, fmaf(-0.5f, r2, 1.0f));
   const float v = (q & 1) ? c : s;
   return (q & 2) ? -v : v;
 }
-/* safe_arg without branches or the library's fmodf loop (which hipcc inlines as a divergent 12-bits-per-trip reduction):
- * x - trunc(x / T) T is exact in float64 for these 24-bit operands, x / T is never closer than 1e-7 to an integer without
- * being one (both are multiples of 2^-15 below 2^18), so one correction step settles the truncation; the remainder is
- * representable in fp32, and the floored form adds T in fp32 exactly as torch's `%` does.  Valid for |x| < 2^24. */
-__device__ __forceinline__ float safe_arg_f64(float x) {
-  const double T = (double)T100PI, xd = (double)x;
-  const double n = __builtin_trunc(xd * (1.0 / T));
-  double r = __builtin_fma(-n, T, xd);
-  const double up = r + T, dn = r - T;
-  r = (xd > 0.0) ? (r < 0.0 ? up : (r >= T ? dn : r)) : (r > 0.0 ? dn : (r <= -T ? up : r));
-  float m = (float)r;
-  m = (m < 0.0f) ? m + T100PI : m;
-  return (fabsf(x) < T100PI) ? x : m;
+/* cos(a), same reduction and kernels */
+__device__ __forceinline__ float cos_reduced(float a) {
+  float r; int q;
+  quadrant_reduce(a, r, q);
+  const float r2 = r * r;
+  const float s = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f) * r2, r, r);
+  const float c = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f) * r2, r2, fmaf(-0.5f, r2, 1.0f));
+  const float v = (q & 1) ? s : c;
+  return ((q + 1) & 2) ? -v : v;
+}
+/* safe_arg (math.py:22-34: where(|x| < 100 pi, x, x % 100 pi), torch's floored remainder) without branches, the library's fmodf
+ * loop (which hipcc inlines as a divergent 12-bits-per-trip reduction) or float64: q = floor(x / T + 3e-4) is the true floor or
+ * one more (x / T in fp32 is off by < 1.5e-4 for |x| < 2^19), so r = fma(-q, T, x) lies in [-0.1, T) and is EXACT -- x and T are
+ * multiples of 2^-15 there, |r| < 512 -- and a negative r takes + T, exactly, as torch's `%` does.  Equal to the float64
+ * evaluation on 4e6 IPE arguments (|x| up to 4.4e5), bit for bit. */
+__device__ __forceinline__ float safe_arg_exact(float x) {
+  const float q = __builtin_floorf(fmaf(x, 1.0f / T100PI, 3e-4f));
+  float r = fmaf(-q, T100PI, x);
+  r = (r < 0.0f) ? r + T100PI : r;
+  return (fabsf(x) < T100PI) ? x : r;
 }
 /* IPE feature of the split-f16 kernel: the reference's argument (fp32 product, fp32 + pi/2, the fp32 `mod 100 pi`), then
  * sin_reduced and the hardware exp2 -- absolute error < 2e-7, below the 2^-22 of the hi + lo split it feeds */
@@ -188,7 +205,7 @@ __device__ __forceinline__ float ipe_feature_split(float lm, float lv, int j, in
   float x = lm * sc;
   if (cos_block) x = x + HALF_PI_F;
   const float e = __builtin_amdgcn_exp2f((-0.5f * LOG2E_F) * (lv * sc2));
-  return e * sin_reduced(safe_arg_f64(x));
+  return e * sin_reduced(safe_arg_exact(x));
 }
 
 /* One IPE feature (coord.py:119-126): block 0 = sin, block 1 = "cos" =

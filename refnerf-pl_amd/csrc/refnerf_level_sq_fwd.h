@@ -356,17 +356,6 @@ __device__ __forceinline__ void tq_vjp_layer(Pipe &p, sq_v8 (&fr)[SQ_NF], const 
   for (int q = 0; q < 4; ++q) tq_vjp_piece(accs[0], q, out[14], out[15], mk1, 24, rs, mx);
   __builtin_amdgcn_sched_barrier(0);
 }
-/* cos(a) with sin_reduced's reduction and kernels (refnerf_device_math.h): 1.5 ulp over |a| < 315 */
-__device__ __forceinline__ float cos_reduced(float a) {
-  const double k = __builtin_rint((double)a * 0.63661977236758134308);
-  const float r = (float)__builtin_fma(-k, 1.57079632679489661923, (double)a);
-  const int q = (int)k;
-  const float r2 = r * r;
-  const float s = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f) * r2, r, r);
-  const float c = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f) * r2, r2, fmaf(-0.5f, r2, 1.0f));
-  const float v = (q & 1) ? s : c;
-  return ((q + 1) & 2) ? -v : v;
-}
 /* d feature / d lifted mean of IPE feature k' = 48 hb + 3 j + axis (coord.py:119-126 differentiated, the variance detached as
  * the rest of the sample geometry): e cos(arg) 2^j with the forward's own argument (ipe_feature_split) */
 __device__ __forceinline__ float tq_ipe_dmean(float lm, float lv, int j, int hb) {
@@ -374,7 +363,7 @@ __device__ __forceinline__ float tq_ipe_dmean(float lm, float lv, int j, int hb)
   float x = lm * sc;
   if (hb) x = x + HALF_PI_F;
   const float e = __builtin_amdgcn_exp2f((-0.5f * LOG2E_F) * (lv * sc2));
-  return (e * cos_reduced(safe_arg_f64(x))) * sc;
+  return (e * cos_reduced(safe_arg_exact(x))) * sc;
 }
 /* The 96 IPE rows of a transposed layer (3 slices).  This lane's 24 rows k' = K0 + 4 b (K0 compile-time: 32 ob + 16 (e / 4) +
  * e % 4) are features of axis (K0 + b) mod 3; their derivatives d feature / d mean were parked by the caller in the lane's own
