@@ -352,7 +352,7 @@ def test_bench_compact_line_fits_the_driver_tail():
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
             assert k in line["roofline"], (p, k)
         assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-4
-        if os.sep + "r05" + os.sep in p:
+        if os.sep + "r05" + os.sep in p and os.path.basename(p).startswith("bench_C2"):   # (the PMC passes are collected at C2)
             # what the kernel is actually bound by travels with the number -- the matrix pipe's busy fraction,
             # the flops it executes as a fraction of the dense f16 peak, and the clock it sustained (profiles/traffic.json)
             for k in ("mfma_busy", "executed_flop_frac", "sustained_clock_ghz"):
