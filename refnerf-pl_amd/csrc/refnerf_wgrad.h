@@ -234,7 +234,26 @@ __global__ void wgrad_zero_units(float *m, int u0, int u1, int units, long long 
 }
 
 /* grads[i] += sum over slices (fixed order) of PART[slice][i] */
+/* (two parameters per thread as one 8-byte load per slice -- n and every slice offset are even -- and four slices' loads in
+ * flight: 111 MB in 76 -> 27 us; the order of the additions per parameter is unchanged: slice 0, 1, 2, ...) */
 __global__ void wgrad_reduce(const float *__restrict__ part, int slices, float *__restrict__ grads, int n) {
+  typedef float rv2 __attribute__((ext_vector_type(2)));
+  const int n2 = n >> 1;
+  if (((n & 1) == 0) && ((reinterpret_cast<size_t>(part) | reinterpret_cast<size_t>(grads)) & 7) == 0) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += gridDim.x * blockDim.x) {
+      const rv2 *p = reinterpret_cast<const rv2 *>(part) + i;
+      rv2 s = {0.0f, 0.0f};
+      int c = 0;
+      for (; c + 4 <= slices; c += 4) {
+        const rv2 a0 = p[(size_t)c * n2], a1 = p[(size_t)(c + 1) * n2], a2 = p[(size_t)(c + 2) * n2], a3 = p[(size_t)(c + 3) * n2];
+        s = s + a0; s = s + a1; s = s + a2; s = s + a3;
+      }
+      for (; c < slices; ++c) s = s + p[(size_t)c * n2];
+      rv2 *gp = reinterpret_cast<rv2 *>(grads) + i;
+      *gp = *gp + s;
+    }
+    return;
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float s = 0.0f;
     for (int c = 0; c < slices; ++c) s += part[(size_t)c * n + i];

@@ -470,7 +470,13 @@ class _LevelFunction(torch.autograd.Function):
         # version counters (fused Adam does not), and the pack is 16 us
         # (the split-f16 chains on the built-in basis: their own image -- forward + transposed operands as one chunk stream)
         image = _hip.IMAGE_F16X2_TRAIN if (cfg.precision == _hip.PREC_F16X2 and not mlp.ipe_groups and not _hip.LEGACY_F16X2_TRAIN) else _hip.PREC_F32
-        packed = mlp.packed_weights(image, force=True)
+        # (the levels of ONE Model.__call__ share the image of their MLP: no optimiser step can fall between them)
+        reuse = holder.get("call_images")
+        packed = reuse.get((id(mlp), image)) if reuse is not None else None
+        if packed is None:
+            packed = mlp.packed_weights(image, force=True)
+            if reuse is not None:
+                reuse[(id(mlp), image)] = packed
         res = _hip.level_forward(packed, cfg, rays, sdist_in, weights_in, history=True, save_activations=True)
         ctx.mlp, ctx.cfg, ctx.rays, ctx.packed = mlp, cfg, rays, packed
         ctx.packed_key = mlp._packed_key
@@ -687,6 +693,7 @@ class Model(nn.Module):
         # north_star's "sample indices"; bench.py and the parity tests compare them between arithmetic modes
         self.last_bin_idx = []
         prod_num_samples = 1
+        call_images = {}                       # weight images packed by this call's training levels: (MLP, image kind) -> buffer
         for i_level in range(self.num_levels):
             is_prop = i_level < (self.num_levels - 1)
             num_samples = self.num_prop_samples if is_prop else self.num_nerf_samples
@@ -732,7 +739,7 @@ class Model(nn.Module):
                 flat_mode = bool(getattr(self.config, "hip_flat_grads", False))
                 if not flat_mode and mlp._flat is not None and (mlp._flat.requires_grad or mlp._flat.grad is not None):
                     mlp.release_flat_parameter()            # flat mode was switched off: no stale .grad on the blob
-                holder = {"bwd_precision": _PREC[bwd_prec], "flat_mode": flat_mode}
+                holder = {"bwd_precision": _PREC[bwd_prec], "flat_mode": flat_mode, "call_images": call_images}
                 diff_inputs = (mlp.flat_parameter(),) if flat_mode else tuple(mlp.ordered_parameters())
                 outs = _LevelFunction.apply(mlp, cfg, r, holder, sdist.detach(), weights.detach(), *diff_inputs)
                 res = dict(zip(holder["keys"], outs))
