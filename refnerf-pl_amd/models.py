@@ -108,6 +108,8 @@ class MLP(nn.Module):
                  for i in range(self.net_depth)]
         self.spatial_net = nn.ModuleList([_linear(sp_in[i], W) for i in range(self.net_depth)])
         self.raw_density = _linear(W, 1)
+        if self.enable_pred_specular_density:                  # models.py:502-503 (same place in the construction order)
+            self.raw_specular_density = _linear(W, 1)
         self.grad_pred = _linear(W, 3)
         # the variants the reference runs and the fused kernels serve by embedding (layout.variant_layout): same module
         # names and TRUE shapes as the reference gives them (models.py:509-531)
@@ -156,8 +158,7 @@ class MLP(nn.Module):
             dead["enable_pred_normals"] = "False: TypeError in ref_utils.reflect at internal/ref_utils.py:37 in the reference"
         if dead:
             raise ValueError(f"MLP flags the reference itself cannot run (so there is nothing to match): {dead}")
-        want = dict(skip_layer=4, num_rgb_channels=3,
-                    enable_pred_specular_density=False, bottleneck_noise=0.0,
+        want = dict(skip_layer=4, num_rgb_channels=3, bottleneck_noise=0.0,
                     density_noise=0., disable_rgb=False, warp_fn=None)
         bad = {k: getattr(self, k) for k, v in want.items() if getattr(self, k) != v}
         for k, top in (("net_width_viewdirs", layout.WIDTH), ("net_width", layout.WIDTH), ("bottleneck_width", layout.BNECK)):
@@ -337,6 +338,31 @@ class MLP(nn.Module):
         self._packed_key = key
         return buf
 
+    def packed_specular_weights(self, precision: int) -> torch.Tensor:
+        """`enable_pred_specular_density` (models.py:502-503,583-584,624-625): the extra head is a second Linear(net_width, 1) on
+        the trunk's output with the density head's bias and activation, and nothing downstream reads it (the reference computes
+        `specular_weights` from it and drops them, models.py:250-258).  The fused kernels have no 140th head row; the value comes
+        from a SECOND launch on a weight image whose density head IS the specular-density head -- same trunk, same samples (the
+        level's samples depend on the incoming step function only), its `density` output = softplus(raw_specular + density_bias).
+        Re-packed on every call (the parameters may have moved; 20-60 us), into one cached buffer per image kind."""
+        if not self.enable_pred_specular_density:
+            raise ValueError("enable_pred_specular_density is off")
+        blob = self.canonical_blob().detach().clone()
+        spec = next(sp for sp in self.specs if sp.name == "raw_density")
+        wpos = torch.arange(spec.w_off, spec.w_off + spec.out_dim * spec.in_dim, device=blob.device)
+        bpos = torch.arange(spec.b_off, spec.b_off + spec.out_dim, device=blob.device)
+        if self._embed_index_np is not None:
+            idx = self.embed_index()
+            wpos, bpos = idx[wpos], idx[bpos]
+        with torch.no_grad():
+            blob[wpos] = self.raw_specular_density.weight.detach().reshape(-1).to(blob.dtype)
+            blob[bpos] = self.raw_specular_density.bias.detach().reshape(-1).to(blob.dtype)
+        if getattr(self, "_packed_spec", None) is None:
+            self._packed_spec = {}
+        buf = _hip.pack_weights(blob, self._packed_spec.get(precision), precision, basis=self.kernel_basis())
+        self._packed_spec[precision] = buf
+        return buf
+
     def __call__(self, gaussians, viewdirs=None, imageplane=None):
         """Evaluate the MLP on caller-supplied Gaussians (models.py:533-750).
 
@@ -381,6 +407,9 @@ class MLP(nn.Module):
             ray_results["tint"] = rs(res["tint"], 3)
         ray_results["diffuse"] = rs(res["diffuse"], 3)
         ray_results["specular"] = rs(res["specular"], 3)
+        if self.enable_pred_specular_density:                  # models.py:745-746 (key order as in the reference)
+            res2 = _hip.mlp_forward(self.packed_specular_weights(cfg.precision), cfg, m, c, v)
+            ray_results["specular_density"] = rs(res2["density"])
         if self.enable_pred_roughness:
             ray_results["roughness"] = rs(res["roughness"], 1)
         return ray_results
@@ -621,12 +650,28 @@ class Model(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
+    def _specular_density(self, mlp: MLP, cfg, r, sdist_in, weights_in):
+        """ray_results['specular_density'] of one level (MLP.packed_specular_weights): the level's inference kernel in
+        Config.hip_precision on the image whose density head is the specular-density head, same incoming step function -> same
+        samples; its `density` output.  Detached: no loss of the reference reads it (the head's gradient is None there too)."""
+        import ctypes
+        cfg2 = type(cfg)()
+        ctypes.memmove(ctypes.byref(cfg2), ctypes.byref(cfg), ctypes.sizeof(cfg))
+        cfg2.training, cfg2.compute_extras, cfg2.wgrad_mode = 0, 0, _hip.WGRAD_BF16X3
+        cfg2.precision = _PREC[getattr(self.config, "hip_precision", "f32")]
+        image = _hip.level_image(cfg2.precision, False, mlp.ipe_groups)
+        with torch.no_grad():
+            res = _hip.level_forward(mlp.packed_specular_weights(image), cfg2, r, sdist_in.detach(), weights_in.detach(), history=("density",))
+        return res["density"]
+
     def _level_cfg(self, mlp: MLP, n_samples, n_in, train_frac, compute_extras):
         cfg = self.config
         if self.ray_shape not in ('cone', 'cylinder'):
             raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')      # render.py:126
-        if cfg.render_with_specular_density:
+        if cfg.render_with_specular_density and not mlp.enable_pred_specular_density:
             raise ValueError('Specular density prediction from mlps should be enabled.')  # models.py:250-252
+        # (with the head enabled the reference computes `specular_weights` here and never reads them, models.py:253-258:
+        #  nothing to compute)
         if self.anneal_slope > 0:                                               # models.py:190-195
             s = self.anneal_slope
             anneal = (s * train_frac) / ((s - 1) * train_frac + 1)
@@ -715,6 +760,7 @@ class Model(nn.Module):
                                      'takes at most 512 (num_samples <= 171 per level with dilation)')
             mlp = self.prop_mlp if is_prop else self.nerf_mlp
             cfg = self._level_cfg(mlp, num_samples, weights.shape[-1], train_frac, compute_extras)
+            sd_in, w_in = sdist, weights                     # this level's incoming step function (the specular-density launch re-reads it)
             if self.training and torch.is_grad_enabled():
                 # one autograd node per level; sdist / resampling inputs are detached (models.py:205-216)
                 mlp.flat_params()
@@ -789,9 +835,12 @@ class Model(nn.Module):
                            "normals": hist("normals", N, 3) if self.training else None,
                            "normals_pred": hist("normals_pred", N, 3),
                            "grad_pred": hist("grad_pred", N, 3), "tint": hist("tint", N, 3),
-                           "diffuse": hist("diffuse", N, 3), "specular": hist("specular", N, 3),
-                           "roughness": hist("roughness", N, 1),
-                           "sdist": rs(sdist, N + 1), "weights": rs(weights, N)}      # (read-only for the next level: no copies)
+                           "diffuse": hist("diffuse", N, 3), "specular": hist("specular", N, 3)}
+            if mlp.enable_pred_specular_density:            # models.py:745-746: between 'specular' and 'roughness'
+                ray_results["specular_density"] = None if (_LEAN.depth > 0 and not self.training) else \
+                    rs(self._specular_density(mlp, cfg, r, sd_in, w_in), N)
+            ray_results.update({"roughness": hist("roughness", N, 1),
+                                "sdist": rs(sdist, N + 1), "weights": rs(weights, N)})      # (read-only for the next level: no copies)
             # the reference's dict only has the keys its flags produce (models.py:735-748)
             if mlp.disable_density_normals:
                 del ray_results["normals"]

@@ -1230,7 +1230,55 @@ def golden_variants():
         print(f"  {k}: {v}")
 
 
+SPECDENS_FLAGS = ["NerfMLP.enable_pred_specular_density = True", "Config.render_with_specular_density = True"]
+
+
+def specdens_head(seed=77):
+    """the extra head's parameters (not part of the canonical 46-tensor blob): seeded, stored in the fixture"""
+    rng = np.random.default_rng(seed)
+    return (rng.uniform(-1, 1, (1, layout.WIDTH)) / np.sqrt(layout.WIDTH) * 12.0).astype(np.float32), np.array([0.3], np.float32)
+
+
+def golden_specdens_models():
+    """`NerfMLP.enable_pred_specular_density` + `Config.render_with_specular_density` (internal/models.py:250-258,502-503,583-584,
+    624-625,745-746): the extra `specular_density` entry of ray_history, the unchanged renderings, and -- training -- that the head
+    receives no gradient (nothing reads `specular_weights`)."""
+    small = ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 64"]
+    cases = {
+        "model_specdens_eval": (SPECDENS_FLAGS, synthetic.blender_rays(16, seed=61, center_frac=0.4), False),
+        "model_specdens_train": (SPECDENS_FLAGS + small, synthetic.blender_rays(12, seed=62, center_frac=0.4), True),
+    }
+    pk = dict(seed=0, bias_scale=0.05, sharpen=20.0)
+    w, b = specdens_head()
+    for name, (bindings, rays, train) in cases.items():
+        model, cfg = build_model(bindings, pk)
+        sd = model.nerf_mlp.state_dict()
+        assert tuple(sd["raw_specular_density.weight"].shape) == w.shape
+        sd["raw_specular_density.weight"].copy_(torch.tensor(w))
+        sd["raw_specular_density.bias"].copy_(torch.tensor(b))
+        gt = synthetic.target_rgb(rays["origins"].shape[0], seed=2)
+        res = run_model(model, cfg, rays, train, gt)
+        assert "L1_h_specular_density" in res
+        res["hist_keys"] = np.array(list(model(to_rays(rays), 1.0, True)[1][0].keys()))
+        res["state_dict_keys"] = np.array(list(model.nerf_mlp.state_dict().keys()))
+        if train:
+            res["specdens_grad_is_none"] = np.array([model.nerf_mlp.raw_specular_density.weight.grad is None,
+                                                     model.nerf_mlp.raw_specular_density.bias.grad is None])
+        res["specdens_w"], res["specdens_b"] = w, b
+        res["bindings"] = np.array(bindings)
+        res["param_kw"] = np.array([pk.get("seed", 0), pk.get("bias_scale", 0.0), pk.get("sharpen", 1.0), pk.get("roughness_bias", 0.0)])
+        for k, v in rays.items():
+            res["rays_" + k] = v
+        res["gt_rgb"] = gt
+        if "grads" in res:
+            g = res.pop("grads")
+            res["grads_sub"] = g[::97].copy()
+            res["grads_tensor_l2"] = np.array([[np.linalg.norm(g[s.w_off:s.w_off + s.out_dim * s.in_dim]),
+                                                np.linalg.norm(g[s.b_off:s.b_off + s.out_dim])] for s in layout.PARAM_SPECS])
+        save(name, **res)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models", "posenc_models", "raydist_models", "basis_models", "mlp_basis"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models", "posenc_models", "raydist_models", "basis_models", "mlp_basis", "specdens_models"]
     for w in which:
         globals()["golden_" + w]()

@@ -104,6 +104,24 @@ def test_unsupported_configurations_raise(cfg):
     assert models.Model(config=cfg, dilation_bias=0.0025).dilation_bias == 0.0025      # built (host dilation)
 
 
+def test_specular_density_head_module_matches_the_reference(cfg):
+    """NerfMLP.enable_pred_specular_density: the module gains `raw_specular_density` where the reference's has it (state_dict names
+    and order captured from the reference: tests/golden/model_specdens_eval.npz), outside the canonical 46-tensor blob the kernels
+    take; a state_dict round trip carries it."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "model_specdens_eval.npz"))
+    mlp = models.NerfMLP(enable_pred_specular_density=True)
+    assert list(mlp.state_dict().keys()) == [str(k) for k in g["state_dict_keys"]]
+    assert tuple(mlp.raw_specular_density.weight.shape) == (1, 256) and mlp.num_params == layout.NUM_PARAMS
+    with torch.no_grad():
+        mlp.raw_specular_density.weight.copy_(torch.tensor(g["specdens_w"]))
+    mlp2 = models.NerfMLP(enable_pred_specular_density=True)
+    mlp2.load_state_dict(mlp.state_dict())
+    assert torch.equal(mlp2.raw_specular_density.weight, mlp.raw_specular_density.weight)
+    assert np.array_equal(mlp2.flat_params().detach().numpy(), mlp.flat_params().detach().numpy())
+    with pytest.raises(RuntimeError):                       # a module without the head does not take the extra tensors silently
+        models.NerfMLP().load_state_dict(mlp.state_dict())
+
+
 def test_variant_gate_matches_reference_status():
     """what the reference itself survives (tests/golden/variants_status.json, captured by
     make_golden.py `variants`) against this build's gate.  Both shipped mip-NeRF configs and the flag settings behind them
