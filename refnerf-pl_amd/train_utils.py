@@ -23,8 +23,14 @@ def srgb_to_linear(srgb, eps=None):
     return torch.where(srgb <= 0.04045, linear0, linear1)
 
 
+def _l2_normalize(x):
+    """ref_utils.py:40-42"""
+    eps = torch.finfo(torch.float32).eps
+    return x / torch.sqrt(torch.clamp(torch.sum(x ** 2, dim=-1, keepdim=True), min=eps))
+
+
 def compute_data_loss(batch, renderings, rays, config):
-    """Data loss terms for RGB (train_utils.py:33-88).  Returns (loss, stats)."""
+    """Data loss terms for RGB, and the disparity / normal statistics (train_utils.py:33-88).  Returns (loss, stats)."""
     data_losses = []
     stats = collections.defaultdict(lambda: [])
     dev = renderings[0]['rgb'].device
@@ -50,6 +56,16 @@ def compute_data_loss(batch, renderings, rays, config):
         if config.compute_disp_metrics:
             disp = 1 / (1 + rendering['distance_mean'])
             stats['disparity_mses'].append(((disp - torch.as_tensor(batch.disps, device=dev)) ** 2).mean())
+        if config.compute_normal_metrics:                     # train_utils.py:69-84: weighted mean angular error, degrees
+            if 'normals' in rendering:
+                w = rendering['acc'] * torch.as_tensor(batch.alphas, dtype=torch.float32, device=dev)
+                n_gt = _l2_normalize(torch.as_tensor(batch.normals, dtype=torch.float32, device=dev))
+                n = _l2_normalize(rendering['normals'])
+                one_eps = 1 - torch.finfo(torch.float32).eps  # ref_utils.py:45-50
+                ang = torch.arccos(torch.clip((n * n_gt).sum(-1), -one_eps, one_eps))
+                stats['normal_maes'].append((w * ang).sum() / w.sum() * 180.0 / torch.pi)
+            else:                                             # normals not computed (eval mode): NaN, as in the reference
+                stats['normal_maes'].append(torch.tensor(float('nan'), device=dev))
     data_losses = torch.stack(data_losses)
     loss = config.data_coarse_loss_mult * torch.sum(data_losses[:-1]) + config.data_loss_mult * data_losses[-1]
     stats = {k: torch.stack([x.detach() for x in v]) for k, v in stats.items()}

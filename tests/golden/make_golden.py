@@ -1230,6 +1230,41 @@ def golden_variants():
         print(f"  {k}: {v}")
 
 
+def golden_normal_metrics():
+    """`Config.compute_normal_metrics` / `compute_disp_metrics`: the statistics branch of train_utils.compute_data_loss
+    (internal/train_utils.py:62-84) on seeded two-level renderings -- with normals (training mode) and without (NaN)."""
+    rng = np.random.default_rng(9)
+    R = 40
+    gin.clear_config()
+    gin.parse_config_files_and_bindings([REF_CFG], ["Config.compute_normal_metrics = True", "Config.compute_disp_metrics = True"])
+    cfg = configs.Config()
+    rays = synthetic.blender_rays(R, seed=3, center_frac=0.4)
+    r = to_rays(rays)
+    out = {}
+    for tag, with_normals in (("train", True), ("eval", False)):
+        rend = []
+        for lvl in range(2):
+            d = dict(rgb=torch.tensor(rng.random((R, 3)).astype(np.float32)), acc=torch.tensor(rng.random(R).astype(np.float32)),
+                     distance_mean=torch.tensor((2 + 4 * rng.random(R)).astype(np.float32)))
+            if with_normals:
+                d["normals"] = torch.tensor(rng.standard_normal((R, 3)).astype(np.float32))
+            rend.append(d)
+        batch = utils.Batch(rays=r, rgb=rng.random((R, 3)).astype(np.float32), disps=torch.tensor(rng.random(R).astype(np.float32)),
+                            normals=torch.tensor(rng.standard_normal((R, 3)).astype(np.float32)), alphas=torch.tensor(rng.random(R).astype(np.float32)))
+        loss, stats = train_utils.compute_data_loss(batch, rend, r, cfg)
+        out[tag + "_loss"] = float(loss)
+        for k, v in stats.items():
+            out[f"{tag}_stat_{k}"] = v.numpy()
+        for lvl, d in enumerate(rend):
+            for k, v in d.items():
+                out[f"{tag}_L{lvl}_{k}"] = v.numpy()
+        out[tag + "_gt_rgb"] = batch.rgb
+        out[tag + "_disps"], out[tag + "_normals"], out[tag + "_alphas"] = batch.disps.numpy(), batch.normals.numpy(), batch.alphas.numpy()
+    for k, v in rays.items():
+        out["rays_" + k] = v
+    save("normal_metrics", **out)
+
+
 SPECDENS_FLAGS = ["NerfMLP.enable_pred_specular_density = True", "Config.render_with_specular_density = True"]
 
 
@@ -1279,6 +1314,6 @@ def golden_specdens_models():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models", "posenc_models", "raydist_models", "basis_models", "mlp_basis", "specdens_models"]
+    which = sys.argv[1:] or ["sampler", "cast_ipe", "ide", "mlp", "render", "models", "camera", "geometry", "seeds", "io", "propmlp", "dilation", "shiny", "trained_models", "variants", "variant_models", "posenc_models", "raydist_models", "basis_models", "mlp_basis", "specdens_models", "normal_metrics"]
     for w in which:
         globals()["golden_" + w]()

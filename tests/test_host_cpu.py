@@ -417,3 +417,28 @@ def test_bench_stdout_carries_exactly_one_line(tmp_path):
     assert "roofline" in line and "cpu_baseline" in line and len(lines[0]) < 4096
     assert "python-level noise" in r.stderr and "fd-level noise" in r.stderr and "C stdio noise" in r.stderr
     assert "BENCH_FULL " in r.stderr and os.path.exists(tmp_path / "gpurun_out" / "bench_full.json")
+
+
+def test_data_loss_statistics_match_the_reference():
+    """`Config.compute_normal_metrics` / `compute_disp_metrics`: the statistics branch of train_utils.compute_data_loss
+    (internal/train_utils.py:62-84; VERDICT r4 missing 5) against the reference's own values on seeded renderings
+    (tests/golden/normal_metrics.npz): weighted mean angular error of the normals in degrees per level, NaN when the
+    renderings carry no normals (eval mode), disparity MSE, and the loss itself."""
+    from refnerf_pl_amd import train_utils, utils
+    g = np.load(os.path.join(ROOT, "tests", "golden", "normal_metrics.npz"))
+    configs.clear_config()
+    configs.parse_config_files_and_bindings([os.path.join(ROOT, "configs", "refnerf_blender.gin")],
+                                            ["Config.compute_normal_metrics = True", "Config.compute_disp_metrics = True"])
+    c = configs.Config()
+    rays = utils.rays_from_dict({k[5:]: g[k] for k in g.files if k.startswith("rays_")}, torch.device("cpu"))
+    for tag in ("train", "eval"):
+        rend = [{k: torch.tensor(g[f"{tag}_L{lvl}_{k}"]) for k in ("rgb", "acc", "distance_mean", "normals") if f"{tag}_L{lvl}_{k}" in g.files}
+                for lvl in range(2)]
+        batch = utils.Batch(rays=rays, rgb=g[tag + "_gt_rgb"], disps=g[tag + "_disps"], normals=g[tag + "_normals"], alphas=g[tag + "_alphas"])
+        loss, stats = train_utils.compute_data_loss(batch, rend, rays, c)
+        assert float(loss) == pytest.approx(float(g[tag + "_loss"]), rel=1e-6)
+        assert sorted(stats) == sorted(k[len(tag) + 6:] for k in g.files if k.startswith(tag + "_stat_"))
+        for k, v in stats.items():
+            np.testing.assert_allclose(v.numpy(), g[f"{tag}_stat_{k}"], rtol=2e-6, atol=0, equal_nan=True, err_msg=f"{tag} {k}")
+    assert np.isnan(g["eval_stat_normal_maes"]).all() and np.isfinite(g["train_stat_normal_maes"]).all()
+    configs.clear_config()
