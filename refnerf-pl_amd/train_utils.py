@@ -29,83 +29,88 @@ def _l2_normalize(x):
     return x / torch.sqrt(torch.clamp(torch.sum(x ** 2, dim=-1, keepdim=True), min=eps))
 
 
+def _pixel_penalty(sq_err, config):
+    """per-channel penalty of the data term: plain L2 or Charbonnier (train_utils.py:53-61)"""
+    kind = config.data_loss_type
+    if kind == 'mse':
+        return sq_err
+    if kind == 'charb':
+        return torch.sqrt(sq_err + config.charb_padding ** 2)
+    assert False
+
+
+def _angular_error_deg(weight, a, b):
+    """weighted mean angle between unit vectors, in degrees (ref_utils.py:45-50)"""
+    lim = 1 - torch.finfo(torch.float32).eps
+    angle = torch.arccos(torch.clip((a * b).sum(-1), -lim, lim))
+    return (weight * angle).sum() / weight.sum() * 180.0 / torch.pi
+
+
+def _coarse_fine(per_level, n_levels, coarse_mult, fine_mult):
+    """sum over levels in level order with the coarse multiplier on all but the last level (the reference's accumulation order)"""
+    acc = 0.
+    for lvl, term in enumerate(per_level):
+        acc = acc + (fine_mult if lvl >= n_levels - 1 else coarse_mult) * term
+    return acc
+
+
 def compute_data_loss(batch, renderings, rays, config):
     """Data loss terms for RGB, and the disparity / normal statistics (train_utils.py:33-88).  Returns (loss, stats)."""
-    data_losses = []
-    stats = collections.defaultdict(lambda: [])
     dev = renderings[0]['rgb'].device
-    gt_all = torch.as_tensor(batch.rgb, dtype=torch.float32, device=dev)[..., :3]
-    lossmult = torch.as_tensor(rays.lossmult, dtype=torch.float32, device=dev)
-    lossmult = torch.broadcast_to(lossmult, gt_all.shape)
+    target = torch.as_tensor(batch.rgb, dtype=torch.float32, device=dev)[..., :3]
+    if config.supervised_by_linear_rgb:
+        target = srgb_to_linear(target)
+    # per-ray weight of the residual (mosaic masks, multiscale up-weighting: rays.lossmult), one copy per channel
+    ray_w = torch.broadcast_to(torch.as_tensor(rays.lossmult, dtype=torch.float32, device=dev), target.shape)
     if config.disable_multiscale_loss:
-        lossmult = torch.ones_like(lossmult)
-    for rendering in renderings:
-        gt_rgb = gt_all
-        if config.supervised_by_linear_rgb:
-            gt_rgb = srgb_to_linear(gt_rgb)
-        resid_sq = (rendering['rgb'] - gt_rgb) ** 2
-        denom = lossmult.sum()
-        stats['mses'].append((lossmult * resid_sq).sum() / denom)
-        if config.data_loss_type == 'mse':
-            data_loss = resid_sq
-        elif config.data_loss_type == 'charb':
-            data_loss = torch.sqrt(resid_sq + config.charb_padding ** 2)
-        else:
-            assert False
-        data_losses.append((lossmult * data_loss).sum() / denom)
-        if config.compute_disp_metrics:
-            disp = 1 / (1 + rendering['distance_mean'])
-            stats['disparity_mses'].append(((disp - torch.as_tensor(batch.disps, device=dev)) ** 2).mean())
-        if config.compute_normal_metrics:                     # train_utils.py:69-84: weighted mean angular error, degrees
-            if 'normals' in rendering:
-                w = rendering['acc'] * torch.as_tensor(batch.alphas, dtype=torch.float32, device=dev)
-                n_gt = _l2_normalize(torch.as_tensor(batch.normals, dtype=torch.float32, device=dev))
-                n = _l2_normalize(rendering['normals'])
-                one_eps = 1 - torch.finfo(torch.float32).eps  # ref_utils.py:45-50
-                ang = torch.arccos(torch.clip((n * n_gt).sum(-1), -one_eps, one_eps))
-                stats['normal_maes'].append((w * ang).sum() / w.sum() * 180.0 / torch.pi)
+        ray_w = torch.ones_like(ray_w)
+    norm = ray_w.sum()
+    per_level, stats = [], collections.defaultdict(list)
+    for out in renderings:
+        sq_err = (out['rgb'] - target) ** 2
+        stats['mses'].append((ray_w * sq_err).sum() / norm)
+        per_level.append((ray_w * _pixel_penalty(sq_err, config)).sum() / norm)
+        if config.compute_disp_metrics:                       # train_utils.py:62-67 (disparity from the mean distance)
+            disparity = 1 / (1 + out['distance_mean'])
+            stats['disparity_mses'].append(((disparity - torch.as_tensor(batch.disps, device=dev)) ** 2).mean())
+        if config.compute_normal_metrics:                     # train_utils.py:69-84
+            if 'normals' in out:
+                w = out['acc'] * torch.as_tensor(batch.alphas, dtype=torch.float32, device=dev)
+                stats['normal_maes'].append(_angular_error_deg(
+                    w, _l2_normalize(out['normals']), _l2_normalize(torch.as_tensor(batch.normals, dtype=torch.float32, device=dev))))
             else:                                             # normals not computed (eval mode): NaN, as in the reference
                 stats['normal_maes'].append(torch.tensor(float('nan'), device=dev))
-    data_losses = torch.stack(data_losses)
-    loss = config.data_coarse_loss_mult * torch.sum(data_losses[:-1]) + config.data_loss_mult * data_losses[-1]
-    stats = {k: torch.stack([x.detach() for x in v]) for k, v in stats.items()}
-    return loss, stats
+    per_level = torch.stack(per_level)
+    loss = config.data_coarse_loss_mult * torch.sum(per_level[:-1]) + config.data_loss_mult * per_level[-1]
+    return loss, {k: torch.stack([x.detach() for x in v]) for k, v in stats.items()}
 
 
 def orientation_loss(rays, model, ray_history, config):
-    """Orientation regulariser of Ref-NeRF (train_utils.py:165-183)."""
-    total_loss = 0.
-    for i, ray_results in enumerate(ray_history):
-        w = ray_results['weights']
-        n = ray_results[config.orientation_loss_target]
-        if n is None:
+    """Orientation regulariser of Ref-NeRF (train_utils.py:165-183): normals facing away from the camera, weighted by the
+    sample's rendering weight."""
+    terms = []
+    for level in ray_history:
+        normals = level[config.orientation_loss_target]
+        if normals is None:
             raise ValueError('Normals cannot be None if orientation loss is on.')
-        v = -torch.as_tensor(rays.viewdirs, dtype=torch.float32, device=w.device)
-        n_dot_v = (n * v[..., None, :]).sum(dim=-1)
-        loss = torch.mean((w * torch.clamp(n_dot_v, max=0.0) ** 2).sum(dim=-1))
-        if i < model.num_levels - 1:
-            total_loss += config.orientation_coarse_loss_mult * loss
-        else:
-            total_loss += config.orientation_loss_mult * loss
-    return total_loss
+        weights = level['weights']
+        to_camera = -torch.as_tensor(rays.viewdirs, dtype=torch.float32, device=weights.device)
+        facing = (normals * to_camera[..., None, :]).sum(dim=-1)
+        terms.append(torch.mean((weights * torch.clamp(facing, max=0.0) ** 2).sum(dim=-1)))
+    return _coarse_fine(terms, model.num_levels, config.orientation_coarse_loss_mult, config.orientation_loss_mult)
 
 
 def predicted_normal_loss(model, ray_history, config):
-    """Predicted-normal supervision of Ref-NeRF (train_utils.py:186-204)."""
-    total_loss = 0.
-    for i, ray_results in enumerate(ray_history):
-        w = ray_results['weights']
-        n = ray_results['normals']
-        n_pred = ray_results['normals_pred']
-        if n is None or n_pred is None:
+    """Predicted-normal supervision of Ref-NeRF (train_utils.py:186-204): 1 - cos between the density normals and the predicted
+    ones, weighted by the sample's rendering weight."""
+    terms = []
+    for level in ray_history:
+        n_density, n_mlp = level['normals'], level['normals_pred']
+        if n_density is None or n_mlp is None:
             raise ValueError('Predicted normals and gradient normals cannot be None if '
                              'predicted normal loss is on.')
-        loss = torch.mean((w * (1.0 - torch.sum(n * n_pred, dim=-1))).sum(dim=-1))
-        if i < model.num_levels - 1:
-            total_loss += config.predicted_normal_coarse_loss_mult * loss
-        else:
-            total_loss += config.predicted_normal_loss_mult * loss
-    return total_loss
+        terms.append(torch.mean((level['weights'] * (1.0 - torch.sum(n_density * n_mlp, dim=-1))).sum(dim=-1)))
+    return _coarse_fine(terms, model.num_levels, config.predicted_normal_coarse_loss_mult, config.predicted_normal_loss_mult)
 
 
 class _FusedRefNerfLosses(torch.autograd.Function):
