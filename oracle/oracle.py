@@ -11,7 +11,14 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "librefnerf_oracle.so")
+# oracle/oracle_f64.py executes this very file with _REAL_F64 set: the same binding over librefnerf_oracle_f64.so (the
+# restatement compiled with the real type switched to double, refnerf_oracle_f64.h), float64 arrays in and out
+_F64 = bool(globals().get("_REAL_F64", False))
+_LIB_NAME = "librefnerf_oracle_f64.so" if _F64 else "librefnerf_oracle.so"
+_LIB_PATH = os.path.join(_HERE, _LIB_NAME)
+_REAL = C.c_double if _F64 else getattr(C, "c_float")
+_NP = np.float64 if _F64 else getattr(np, "float32")
+_SZ = 8 if _F64 else 4
 
 WIDTH, DEPTH = 256, 8
 SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 4}
@@ -19,12 +26,12 @@ SRGB_MODES = {"none": 0, "linear": 1, "norm_linear": 2, "srgb": 3, "norm_srgb": 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "refnerf_oracle.c")
-    hdr = os.path.join(_HERE, "refnerf_oracle.h")
+    deps = [src, os.path.join(_HERE, "refnerf_oracle.h"), os.path.join(_HERE, "refnerf_oracle_f64.h"),
+            os.path.join(os.path.dirname(_HERE), "include", "refnerf_detmath.h")]
     stale = (not os.path.exists(_LIB_PATH)
-             or (os.path.exists(src) and os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))))
+             or (os.path.exists(src) and os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(d) for d in deps if os.path.exists(d))))
     if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "librefnerf_oracle.so"],
-                              stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", _LIB_NAME], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
@@ -32,12 +39,12 @@ class LevelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_samples", "n_in", "training", "compute_extras", "srgb_mapping",
         "srgb_mapping_normalization", "render_srgb_mode", "opaque_background",
-        "ray_shape", "ide_mode", "raydist", "disable_integration")] + [(n, C.c_float) for n in (
+        "ray_shape", "ide_mode", "raydist", "disable_integration")] + [(n, _REAL) for n in (
             "anneal", "resample_padding", "s_near", "s_far", "density_bias",
             "roughness_bias", "rgb_premultiplier", "rgb_bias", "rgb_padding", "bg_rgb")]
 
 
-_FP = C.POINTER(C.c_float)
+_FP = C.POINTER(_REAL)
 
 
 class Rays(C.Structure):
@@ -61,8 +68,8 @@ class LevelOut(C.Structure):
 
 
 class SampleOut(C.Structure):
-    _fields_ = [("density", C.c_float), ("roughness", C.c_float)] + [
-        (n, C.c_float * 3) for n in ("rgb", "normals", "normals_pred", "grad_pred", "tint", "diffuse", "specular")]
+    _fields_ = [("density", _REAL), ("roughness", _REAL)] + [
+        (n, _REAL * 3) for n in ("rgb", "normals", "normals_pred", "grad_pred", "tint", "diffuse", "specular")]
 
 
 _lib = None
@@ -74,15 +81,15 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.rn_level_forward.restype = C.c_int
-        _lib.rn_s_to_t.restype = C.c_float
-        _lib.rn_s_to_t.argtypes = [C.c_float] * 3
-        _lib.rn_linear_to_srgb.restype = C.c_float
-        _lib.rn_linear_to_srgb.argtypes = [C.c_float]
+        _lib.rn_s_to_t.restype = _REAL
+        _lib.rn_s_to_t.argtypes = [_REAL] * 3
+        _lib.rn_linear_to_srgb.restype = _REAL
+        _lib.rn_linear_to_srgb.argtypes = [_REAL]
     return _lib
 
 
 def _f(a):
-    a = np.ascontiguousarray(a, dtype=np.float32)
+    a = np.ascontiguousarray(a, dtype=_NP)
     return a, a.ctypes.data_as(_FP)
 
 
@@ -99,7 +106,7 @@ def default_cfg(**kw) -> LevelCfg:
 
 
 def linspace_u(n):
-    u = np.empty(n, np.float32)
+    u = np.empty(n, _NP)
     lib().rn_linspace_u(C.c_int(n), u.ctypes.data_as(_FP))
     return u
 
@@ -107,13 +114,13 @@ def linspace_u(n):
 def resample_logits(t, w, anneal=1.0, padding=0.01):
     t, tp = _f(t)
     w, wp = _f(w)
-    out = np.empty(w.shape, np.float32)
+    out = np.empty(w.shape, _NP)
     M = w.shape[-1]
     for r in range(int(np.prod(w.shape[:-1], dtype=np.int64))):
-        lib().rn_resample_logits(C.cast(C.addressof(tp.contents) + 4 * r * (M + 1), _FP),
-                                 C.cast(C.addressof(wp.contents) + 4 * r * M, _FP), C.c_int(M),
-                                 C.c_float(anneal), C.c_float(padding),
-                                 C.cast(out.ctypes.data + 4 * r * M, _FP))
+        lib().rn_resample_logits(C.cast(C.addressof(tp.contents) + _SZ * r * (M + 1), _FP),
+                                 C.cast(C.addressof(wp.contents) + _SZ * r * M, _FP), C.c_int(M),
+                                 _REAL(anneal), _REAL(padding),
+                                 C.cast(out.ctypes.data + _SZ * r * M, _FP))
     return out
 
 
@@ -122,11 +129,11 @@ def sample_intervals(t, w_logits, n, smin=0.0, smax=1.0):
     t, _ = _f(t)
     w_logits, _ = _f(w_logits)
     R, M = w_logits.shape
-    sd = np.empty((R, n + 1), np.float32)
+    sd = np.empty((R, n + 1), _NP)
     bi = np.empty((R, n), np.int32)
     for r in range(R):
         lib().rn_sample_intervals(t[r].ctypes.data_as(_FP), w_logits[r].ctypes.data_as(_FP),
-                                  C.c_int(M), C.c_int(n), C.c_float(smin), C.c_float(smax),
+                                  C.c_int(M), C.c_int(n), _REAL(smin), _REAL(smax),
                                   sd[r].ctypes.data_as(_FP), bi[r].ctypes.data_as(C.POINTER(C.c_int32)))
     return sd, bi
 
@@ -135,16 +142,16 @@ def cast_samples(origins, directions, radii, tdist, ray_shape=0):
     """-> lifted means [R,N,3], lifted vars [R,N,3], means xyz [R,N,3]."""
     o, _ = _f(origins)
     d, _ = _f(directions)
-    rad = np.ascontiguousarray(radii, np.float32).reshape(-1)
+    rad = np.ascontiguousarray(radii, _NP).reshape(-1)
     td, _ = _f(tdist)
     R, N1 = td.shape
-    lm = np.empty((R, N1 - 1, 3), np.float32)
+    lm = np.empty((R, N1 - 1, 3), _NP)
     lv = np.empty_like(lm)
     mx = np.empty_like(lm)
     for r in range(R):
         for i in range(N1 - 1):
-            lib().rn_cast_sample(o[r].ctypes.data_as(_FP), d[r].ctypes.data_as(_FP), C.c_float(rad[r]),
-                                 C.c_float(td[r, i]), C.c_float(td[r, i + 1]), C.c_int(ray_shape),
+            lib().rn_cast_sample(o[r].ctypes.data_as(_FP), d[r].ctypes.data_as(_FP), _REAL(rad[r]),
+                                 _REAL(td[r, i]), _REAL(td[r, i + 1]), C.c_int(ray_shape),
                                  lm[r, i].ctypes.data_as(_FP), lv[r, i].ctypes.data_as(_FP),
                                  mx[r, i].ctypes.data_as(_FP))
     return lm, lv, mx
@@ -154,7 +161,7 @@ def ipe(lmean, lvar):
     lm, _ = _f(lmean)
     lv, _ = _f(lvar)
     flat_m, flat_v = lm.reshape(-1, 3), lv.reshape(-1, 3)
-    out = np.empty((flat_m.shape[0], 96), np.float32)
+    out = np.empty((flat_m.shape[0], 96), _NP)
     for i in range(flat_m.shape[0]):
         lib().rn_ipe(flat_m[i].ctypes.data_as(_FP), flat_v[i].ctypes.data_as(_FP), out[i].ctypes.data_as(_FP))
     return out.reshape(lm.shape[:-1] + (96,))
@@ -171,10 +178,10 @@ def ide(xyz, kappa_inv, mode="stable"):
                              out[i].ctypes.data_as(C.POINTER(C.c_double)))
         return out
     fn = lib().rn_ide_stable_f32 if mode == "stable" else lib().rn_ide_ref_f32
-    x = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
-    out = np.empty((x.shape[0], 72), np.float32)
+    x = np.ascontiguousarray(xyz, _NP).reshape(-1, 3)
+    out = np.empty((x.shape[0], 72), _NP)
     for i in range(x.shape[0]):
-        fn(x[i].ctypes.data_as(_FP), C.c_float(kap[i]), out[i].ctypes.data_as(_FP))
+        fn(x[i].ctypes.data_as(_FP), _REAL(kap[i]), out[i].ctypes.data_as(_FP))
     return out
 
 
@@ -186,9 +193,9 @@ def mlp_samples(params, cfg, lmean, lvar, viewdirs):
     v, _ = _f(viewdirs)
     S = lm.shape[0]
     names = ("rgb", "normals", "normals_pred", "grad_pred", "tint", "diffuse", "specular")
-    res = {n: np.empty((S, 3), np.float32) for n in names}
-    res["density"] = np.empty(S, np.float32)
-    res["roughness"] = np.empty(S, np.float32)
+    res = {n: np.empty((S, 3), _NP) for n in names}
+    res["density"] = np.empty(S, _NP)
+    res["roughness"] = np.empty(S, _NP)
     so = SampleOut()
     for i in range(S):
         lib().rn_mlp_sample(pp, C.byref(cfg), lm[i].ctypes.data_as(_FP), lv[i].ctypes.data_as(_FP),
@@ -196,7 +203,7 @@ def mlp_samples(params, cfg, lmean, lvar, viewdirs):
         res["density"][i] = so.density
         res["roughness"][i] = so.roughness
         for n in names:
-            res[n][i] = np.array(getattr(so, n)[:], np.float32)
+            res[n][i] = np.array(getattr(so, n)[:], _NP)
     return res
 
 
@@ -205,7 +212,7 @@ def alpha_weights(density, tdist, dirs, opaque_background=False):
     td, _ = _f(tdist)
     d, _ = _f(dirs)
     R, N = dn.shape
-    out = np.empty((R, N), np.float32)
+    out = np.empty((R, N), _NP)
     for r in range(R):
         lib().rn_alpha_weights(dn[r].ctypes.data_as(_FP), td[r].ctypes.data_as(_FP), d[r].ctypes.data_as(_FP),
                                C.c_int(N), C.c_int(int(opaque_background)), out[r].ctypes.data_as(_FP))
@@ -232,12 +239,12 @@ def render_rays(density, tdist, dirs, far, rgb=None, diffuse=None, specular=None
             opt.append(ap)
     cfg = default_cfg(n_samples=N, training=int(normals is not None), **cfg_kw)
     out = LevelOut()
-    res = {"weights": np.zeros((R, N), np.float32), "r_rgb": np.zeros((R, 3), np.float32),
-           "r_diffuse": np.zeros((R, 3), np.float32), "r_specular": np.zeros((R, 3), np.float32),
-           "r_distance": np.zeros(R, np.float32), "r_acc": np.zeros(R, np.float32),
-           "r_normals": np.zeros((R, 3), np.float32), "r_normals_pred": np.zeros((R, 3), np.float32),
-           "r_tint": np.zeros((R, 3), np.float32), "r_roughness": np.zeros(R, np.float32),
-           "r_distance_mean": np.zeros(R, np.float32)}
+    res = {"weights": np.zeros((R, N), _NP), "r_rgb": np.zeros((R, 3), _NP),
+           "r_diffuse": np.zeros((R, 3), _NP), "r_specular": np.zeros((R, 3), _NP),
+           "r_distance": np.zeros(R, _NP), "r_acc": np.zeros(R, _NP),
+           "r_normals": np.zeros((R, 3), _NP), "r_normals_pred": np.zeros((R, 3), _NP),
+           "r_tint": np.zeros((R, 3), _NP), "r_roughness": np.zeros(R, _NP),
+           "r_distance_mean": np.zeros(R, _NP)}
     for k, a in res.items():
         setattr(out, k, a.ctypes.data_as(_FP))
     res["r_percentiles"] = np.zeros((R, 3), np.float64)
@@ -252,7 +259,7 @@ def _rays_struct(rays: dict):
     keep = {}
     rs = Rays()
     for name in ("origins", "directions", "viewdirs", "radii", "near", "far"):
-        arr = np.ascontiguousarray(np.asarray(rays[name], np.float32))
+        arr = np.ascontiguousarray(np.asarray(rays[name], _NP))
         keep[name] = arr
         setattr(rs, name, arr.ctypes.data_as(_FP))
     return rs, keep
@@ -282,7 +289,7 @@ def level_forward(params, cfg: LevelCfg, rays: dict, sdist_in, weights_in, n_thr
             continue
         if name in ("normals", "r_normals") and not cfg.training:
             continue
-        res[name] = np.zeros(shp, np.float32)
+        res[name] = np.zeros(shp, _NP)
         setattr(out, name, res[name].ctypes.data_as(_FP))
     res["bin_idx"] = np.zeros((R, N), np.int32)
     out.bin_idx = res["bin_idx"].ctypes.data_as(C.POINTER(C.c_int32))
@@ -301,8 +308,8 @@ def model_forward(params, rays: dict, num_levels=2, num_prop_samples=128, num_ne
     R = np.asarray(rays["origins"]).shape[0]
     s_near = cfg_kw.get("s_near", 0.0)
     s_far = cfg_kw.get("s_far", 1.0)
-    sdist = np.tile(np.array([[s_near, s_far]], np.float32), (R, 1))
-    weights = np.ones((R, 1), np.float32)
+    sdist = np.tile(np.array([[s_near, s_far]], _NP), (R, 1))
+    weights = np.ones((R, 1), _NP)
     outs = []
     for lvl in range(num_levels):
         n = num_prop_samples if lvl < num_levels - 1 else num_nerf_samples
@@ -314,7 +321,7 @@ def model_forward(params, rays: dict, num_levels=2, num_prop_samples=128, num_ne
 
 
 class LossCfg(C.Structure):
-    _fields_ = [("data_mult", C.c_float), ("orientation_mult", C.c_float), ("normal_mult", C.c_float)]
+    _fields_ = [("data_mult", _REAL), ("orientation_mult", _REAL), ("normal_mult", _REAL)]
 
 
 def model_train(params, rays: dict, gt_rgb, num_levels=2, num_prop_samples=128, num_nerf_samples=128,
@@ -329,9 +336,9 @@ def model_train(params, rays: dict, gt_rgb, num_levels=2, num_prop_samples=128, 
     R = keep["origins"].shape[0]
     gt, gtp = _f(np.asarray(gt_rgb)[..., :3].reshape(R, 3))
     lm, lmp = _f(np.asarray(rays["lossmult"]).reshape(R))
-    grads = np.zeros(p.shape[0], np.float32)
-    sdist = np.tile(np.array([[cfg_kw.get("s_near", 0.0), cfg_kw.get("s_far", 1.0)]], np.float32), (R, 1))
-    weights = np.ones((R, 1), np.float32)
+    grads = np.zeros(p.shape[0], _NP)
+    sdist = np.tile(np.array([[cfg_kw.get("s_near", 0.0), cfg_kw.get("s_far", 1.0)]], _NP), (R, 1))
+    weights = np.ones((R, 1), _NP)
     losses = {"data": 0.0, "orientation": 0.0, "normal": 0.0}
     levels = []
     for lvl in range(num_levels):
@@ -341,8 +348,8 @@ def model_train(params, rays: dict, gt_rgb, num_levels=2, num_prop_samples=128, 
         lc = LossCfg(data_mults[1] if fine else data_mults[0], orientation_mults[1] if fine else orientation_mults[0],
                      normal_mults[1] if fine else normal_mults[0])
         out = LevelOut()
-        res = {"sdist": np.zeros((R, n + 1), np.float32), "weights": np.zeros((R, n), np.float32),
-               "r_rgb": np.zeros((R, 3), np.float32)}
+        res = {"sdist": np.zeros((R, n + 1), _NP), "weights": np.zeros((R, n), _NP),
+               "r_rgb": np.zeros((R, 3), _NP)}
         for k, a in res.items():
             setattr(out, k, a.ctypes.data_as(_FP))
         loss3 = (C.c_double * 3)()
@@ -392,7 +399,7 @@ def level_backward(params, cfg: LevelCfg, rays: dict, sdist_in, weights_in, seed
         hold.append(a)
         setattr(st, "g_" + k, ap)
     if grads is None:
-        grads = np.zeros(p.shape[0], np.float32)
+        grads = np.zeros(p.shape[0], _NP)
     rc = lib().rn_level_backward(pp, C.byref(cfg), C.byref(rs), C.c_int(R), sdp, wp, C.byref(st),
                                  grads.ctypes.data_as(_FP), C.c_int(n_threads))
     if rc != 0:

@@ -9,16 +9,26 @@
  * fp32 IEEE arithmetic in the reference's operation order; compile with
  *   gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC
  */
-#include "refnerf_oracle.h"
-#include "../include/refnerf_detmath.h"
-
 #include <float.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#endif
+#include "../include/refnerf_detmath.h"
+typedef float rn_f32;   /* stays fp32 in the float64 build: the reference's fp32-derived constants (linspace, 100 pi, pi/2) */
+/* -DRN_ORACLE_F64 (oracle/Makefile: librefnerf_oracle_f64.so): the SAME source with every fp32 quantity and libm
+ * call switched to float64 -- the "truth" build that gates fp32 rounding error (of the reference's arithmetic and
+ * of the HIP kernels alike) in tests/.  The fp32 build is untouched by it. */
+#ifdef RN_ORACLE_F64
+#include "refnerf_oracle_f64.h"
+#endif
+#include "refnerf_oracle.h"
 
 #define EPS32 1.1920928955078125e-07f /* torch.finfo(float32).eps */
 
@@ -76,21 +86,21 @@ void rn_level_cfg_default(rn_level_cfg *c) {
  *   pad = 1/(2N); u = linspace(pad, 1 - pad - eps, N). */
 void rn_linspace_u(int n, float *u) {
   double pad = 1.0 / (2.0 * n);
-  float start = (float)pad;
-  float end = (float)(1.0 - pad - (double)EPS32);
+  rn_f32 start = (rn_f32)pad;
+  rn_f32 end = (rn_f32)(1.0 - pad - (double)EPS32);
   if (n == 1) { u[0] = start; return; }
-  float step = (end - start) / (float)(n - 1);
+  rn_f32 step = (end - start) / (rn_f32)(n - 1);
   int half = n / 2;
-  for (int i = 0; i < n; ++i)
-    u[i] = (i < half) ? fmaf(step, (float)i, start)
-                      : fmaf(-step, (float)(n - 1 - i), end);
+  for (int i = 0; i < n; ++i)     /* fp32 in both builds: the quantiles are constants of the reference */
+    u[i] = (i < half) ? __builtin_fmaf(step, (rn_f32)i, start)
+                      : __builtin_fmaf(-step, (rn_f32)(n - 1 - i), end);
 }
 
 /* models.py:200-203 */
 void rn_resample_logits(const float *t, const float *w, int M, float anneal,
                         float padding, float *logits) {
   for (int i = 0; i < M; ++i)
-    logits[i] = (t[i + 1] > t[i]) ? anneal * logf(w[i] + padding) : -INFINITY;
+    logits[i] = (t[i + 1] > t[i]) ? anneal * rn_det_logf(w[i] + padding) : -INFINITY;   /* shared with the kernels */
 }
 
 static float nan_to_num0(float x) { /* torch.nan_to_num(x, 0) */
@@ -232,7 +242,7 @@ void rn_cast_sample(const float *o, const float *d, float radius, float t0,
 /* math.py:22-34: sin(where(|x| < 100pi, x, x % 100pi)); torch `%` is the
  * floored remainder, with the scalar cast to fp32. */
 static float safe_arg(float x) {
-  const float T = (float)(100.0 * M_PI);
+  const float T = (rn_f32)(100.0 * M_PI);       /* the scalar is cast to fp32 by torch (also in the float64 build) */
   if (fabsf(x) < T) return x;
   float m = fmodf(x, T);
   if (m != 0.0f && (m < 0.0f)) m += T;
@@ -241,7 +251,7 @@ static float safe_arg(float x) {
 
 /* coord.py:107-126 (integrated_pos_enc, min_deg=0, max_deg=16) + 102-104. */
 void rn_ipe(const float *lmean, const float *lvar, float *feat) {
-  const float HALF_PI = (float)(0.5 * M_PI);
+  const float HALF_PI = (rn_f32)(0.5 * M_PI);
   for (int j = 0; j < RN_IPE_DEG; ++j) {
     float sc = ldexpf(1.0f, j), sc2 = ldexpf(1.0f, 2 * j);
     for (int b = 0; b < 3; ++b) {
@@ -356,7 +366,7 @@ void rn_ide_tables(float *c, float *a, float *b) {
 #define RN_POSENC_DEG 5
 void rn_posenc_slots_f32(const float *xyz, float *out) {
   for (int q = 0; q < RN_IDE_DIM; ++q) out[q] = 0.0f;
-  const float half_pi = (float)(0.5 * 3.14159265358979323846);
+  const float half_pi = (rn_f32)(0.5 * 3.14159265358979323846);
   for (int i = 0; i < 3; ++i) out[i] = xyz[i];
   for (int j = 0; j < RN_POSENC_DEG; ++j)
     for (int i = 0; i < 3; ++i) {
@@ -366,7 +376,7 @@ void rn_posenc_slots_f32(const float *xyz, float *out) {
     }
 }
 static void posenc_slots_grad(const float *xyz, const float *g_out, float *g_xyz) {
-  const float half_pi = (float)(0.5 * 3.14159265358979323846);
+  const float half_pi = (rn_f32)(0.5 * 3.14159265358979323846);
   for (int i = 0; i < 3; ++i) {
     float g = g_out[i];
     for (int j = 0; j < RN_POSENC_DEG; ++j) {
@@ -429,9 +439,6 @@ float rn_linear_to_srgb(float x) {
  * the bias (nn.Linear = addmm(bias, x, W^T)).  Weights are held transposed
  * ([in][out]) so the chain vectorises across outputs; the per-output
  * summation order (k ascending, one rounding per fma) is unchanged. */
-#if defined(__AVX2__) && defined(__FMA__)
-#include <immintrin.h>
-#endif
 #define RN_SB 8 /* samples per block */
 
 typedef struct rn_model {
@@ -456,7 +463,31 @@ static void model_free(rn_model *m) { free(m->T); }
 /* X: [S][ldx], Y: [S][ldy]; Wt: [in][out]; out multiple of 16 uses AVX2. */
 static void dense_block(const float *Wt, const float *b, const float *X, int ldx, int in,
                         int out, float *Y, int ldy, int S, int relu) {
-#if defined(__AVX2__) && defined(__FMA__)
+#if defined(__AVX2__) && defined(__FMA__) && defined(RN_ORACLE_F64)
+  if (out % 8 == 0) {                                  /* float64 build: the same k-ordered chains, 4 lanes per vector */
+    for (int ob = 0; ob < out; ob += 8) {
+      __m256d a0[RN_SB], a1[RN_SB];
+      __m256d b0 = _mm256_loadu_pd(b + ob), b1 = _mm256_loadu_pd(b + ob + 4);
+      for (int s = 0; s < S; ++s) { a0[s] = b0; a1[s] = b1; }
+      for (int k = 0; k < in; ++k) {
+        __m256d w0 = _mm256_loadu_pd(Wt + (size_t)k * out + ob);
+        __m256d w1 = _mm256_loadu_pd(Wt + (size_t)k * out + ob + 4);
+        for (int s = 0; s < S; ++s) {
+          __m256d xs = _mm256_broadcast_sd(X + (size_t)s * ldx + k);
+          a0[s] = _mm256_fmadd_pd(w0, xs, a0[s]);
+          a1[s] = _mm256_fmadd_pd(w1, xs, a1[s]);
+        }
+      }
+      __m256d z = _mm256_setzero_pd();
+      for (int s = 0; s < S; ++s) {
+        if (relu) { a0[s] = _mm256_max_pd(a0[s], z); a1[s] = _mm256_max_pd(a1[s], z); }
+        _mm256_storeu_pd(Y + (size_t)s * ldy + ob, a0[s]);
+        _mm256_storeu_pd(Y + (size_t)s * ldy + ob + 4, a1[s]);
+      }
+    }
+    return;
+  }
+#elif defined(__AVX2__) && defined(__FMA__)
   if (out % 16 == 0) {
     for (int ob = 0; ob < out; ob += 16) {
       __m256 a0[RN_SB], a1[RN_SB];
@@ -546,7 +577,7 @@ static void mlp_block(const rn_model *M, const rn_level_cfg *cfg, const float *l
         }
       }
       /* through the IPE (coord.py:119-126): d/dx sin(r(x)) = cos(r(x)) */
-      const float HALF_PI = (float)(0.5 * M_PI);
+      const float HALF_PI = (rn_f32)(0.5 * M_PI);
       float gl[3] = {0, 0, 0};
       for (int j = 0; j < RN_IPE_DEG; ++j) {
         float sc = ldexpf(1.0f, j), sc2 = ldexpf(1.0f, 2 * j);
@@ -716,15 +747,15 @@ static void composite_ray(const rn_level_cfg *cfg, const rn_sample_out *so, cons
   float bg_w = fmaxf(0.0f, 1.0f - acc);
   for (int c = 0; c < 3; ++c) { rgb[c] += bg_w * cfg->bg_rgb; dif[c] += bg_w * cfg->bg_rgb; spc[c] += bg_w * cfg->bg_rgb; }
   render_map(cfg->render_srgb_mode, rgb, dif, spc);
-  if (out->r_rgb) memcpy(out->r_rgb + 3 * (size_t)r, rgb, 12);
-  if (out->r_diffuse) memcpy(out->r_diffuse + 3 * (size_t)r, dif, 12);
-  if (out->r_specular) memcpy(out->r_specular + 3 * (size_t)r, spc, 12);
+  if (out->r_rgb) memcpy(out->r_rgb + 3 * (size_t)r, rgb, 3 * sizeof(float));
+  if (out->r_diffuse) memcpy(out->r_diffuse + 3 * (size_t)r, dif, 3 * sizeof(float));
+  if (out->r_specular) memcpy(out->r_specular + 3 * (size_t)r, spc, 3 * sizeof(float));
   if (out->r_distance) out->r_distance[r] = dist;
   if (out->r_acc) out->r_acc[r] = acc;
   if (cfg->compute_extras) {
-    if (out->r_normals && cfg->training) memcpy(out->r_normals + 3 * (size_t)r, nrm, 12);
-    if (out->r_normals_pred) memcpy(out->r_normals_pred + 3 * (size_t)r, nrp, 12);
-    if (out->r_tint) memcpy(out->r_tint + 3 * (size_t)r, tnt, 12);
+    if (out->r_normals && cfg->training) memcpy(out->r_normals + 3 * (size_t)r, nrm, 3 * sizeof(float));
+    if (out->r_normals_pred) memcpy(out->r_normals_pred + 3 * (size_t)r, nrp, 3 * sizeof(float));
+    if (out->r_tint) memcpy(out->r_tint + 3 * (size_t)r, tnt, 3 * sizeof(float));
     if (out->r_roughness) out->r_roughness[r] = rgh;
     if (out->r_distance_mean) {
       float e = expf(logd / fmaxf(EPS32, acc));
@@ -1133,7 +1164,7 @@ int rn_level_train(const float *params, const rn_level_cfg *cfg_in, const rn_ray
       for (int c = 0; c < 3; ++c) { rgb[c] += bg_w * cfg->bg_rgb; pre[c] = rgb[c]; }
       float dif_[3] = {0, 0, 0}, spc_[3] = {0, 0, 0};
       render_map(cfg->render_srgb_mode, rgb, dif_, spc_);
-      if (out && out->r_rgb) memcpy(out->r_rgb + 3 * (size_t)r, rgb, 12);
+      if (out && out->r_rgb) memcpy(out->r_rgb + 3 * (size_t)r, rgb, 3 * sizeof(float));
       float g_rgb[3];
       for (int c = 0; c < 3; ++c) {
         float res = rgb[c] - gt_rgb[3 * r + c];
