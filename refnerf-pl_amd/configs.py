@@ -218,12 +218,15 @@ class Config:
     render_spline_smoothness: float = .03
     # build-side knobs (not in the reference).  hip_precision = arithmetic of the MLP contractions of inference levels:
     # 'f32' (exact fp32 MFMA chains: the strict parity mode and the default of THIS CLASS -- no operand-range limit), 'f16x2'
-    # (split-operand f16 MFMA: the parity-grade fast mode of record, <= 1e-4 RGB vs the reference also on trained weights, 4x
-    # faster; hidden activations beyond 65504 turn into NaN outputs), 'bf16' / 'f16' (throughput modes: within 1e-4 on
+    # (split-operand f16 MFMA: the parity-grade fast mode of record -- on trained weights 99.99 % of the rays within 1e-4 RGB of
+    # the reference, single grazing rays up to 1.8e-4 where the reference's own fp32 rounding is that far from its float64
+    # value (the f32 mode likewise) --, 4x faster; hidden activations beyond 65504 turn into NaN
+    # outputs), 'bf16' / 'f16' (throughput modes: within 1e-4 on
     # random-init networks only).  The shipped configs/refnerf_*.gin set all three knobs to 'f16x2' (INTEGRATION.md section A).
     hip_precision: str = 'f32'
     hip_train_precision: str = 'f32'  # MLP chains of the training forward: 'f32' (exact) | 'f16x2' (split f16: 22-bit products, parity-grade, ~3x faster) | 'bf16' (throughput mode)
     hip_bwd_precision: str = 'f32'  # transposed GEMM chains of the backward: 'f32' (exact) | 'f16x2' (split f16, parity-grade) | 'bf16' (throughput mode)
+    hip_check_finite: bool = True  # train_utils.compute_losses watches every total loss (one device flag per step, read a step later: no synchronisation) and raises FloatingPointError on a non-finite one -- the operand-range limit of the 16-bit chains made loud
     hip_fused_losses: bool = False  # data (mse) + orientation + predicted-normal losses of a level as ONE fused kernel each way (train_utils.fused_refnerf_losses)
     hip_flat_grads: bool = False  # route the backward's gradient to MLP.flat_parameter().grad (one tensor) instead of the 46 nn.Parameters
     # weight-gradient GEMM of the backward.  'bf16x3' (default) = the 16-bit-MFMA GEMM that goes with the chains: after f32 chains

@@ -93,10 +93,6 @@ struct Pipe {
   int dma_left;      /* chunks still to be DMA'd by this workgroup */
   int lane, wave, h;
   long long t_vm, t_bar;   /* debug (REFNERF_PROF): cycles spent in the DMA wait / in the barrier */
-#ifdef REFNERF_EXP_L2PF
-  char *dma_dst;           /* this wave's LDS-DMA destination inside a slot (waves 6 / 7: 3 KB of dummy LDS each; REFNERF_LDS_PAD >= 6400 at launch) */
-  int slot_mask;           /* ~0, or 0 for the waves whose destination does not move with the slot */
-#endif
 };
 
 /* LDS-DMA of one 17 KB chunk into the ring slot at `slot_off`.  Wave w moves the
@@ -121,31 +117,17 @@ struct Pipe {
 #define REFNERF_BARE_BARRIER 0
 #endif
 #if REFNERF_BARE_BARRIER
-#define RN_RENDEZVOUS() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
+/* (round 6) the wavefront-scope fences emit no instruction, but without them the register allocator spills 129-154 VGPRs in
+ * these kernels: round 5's "bare barrier is 11 % slower" was that spill.  Measured with the fences (0 spills): f16x2 3.86 ->
+ * 3.86 ms per C2 step, bf16 2.077 -> 2.067: the lgkmcnt(0) drain of __syncthreads()' fence costs nothing here; it stays. */
+#define RN_RENDEZVOUS() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #else
 #define RN_RENDEZVOUS() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
-#endif
-#if defined(REFNERF_EXP_L2PF) && !defined(REFNERF_L2PF_PLAINRDV)
-/* one asm statement: no control flow for the compiler (a wave-uniform branch in the unrolled chunk body spills > 100 registers) */
-#define RN_RENDEZVOUS_P(p) asm volatile("s_cmp_lt_u32 %0, 6\n\ts_cbranch_scc0 .Lrdv%=\n\ts_waitcnt vmcnt(0)\n.Lrdv%=:\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" :: "s"((p).wave) : "memory", "scc")
-#else
-#define RN_RENDEZVOUS_P(p) RN_RENDEZVOUS()
 #endif
 template <bool SPLIT = false>
 __device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off, int piece = -1) {
   if (p.dma_left > 0) {
-#ifdef REFNERF_EXP_L2PF
-    /* experiment, branch-free: every wave issues the same three LDS-DMA instructions.  Waves 0-5 move their pieces of the chunk;
-     * waves 6 / 7 (no pieces of their own) run REFNERF_EXP_L2PF chunks AHEAD of the stream with one 128-byte line per lane
-     * (wave 6: lines lane, lane + 8, lane + 16 of the chunk; wave 7: 80 lines further) into 2 x 3 KB of dummy LDS, so that the
-     * stream's L2 misses are taken outside the rendezvous' wait -- these two waves meet the barrier without draining vmcnt */
-    if constexpr (SPLIT) {
-      lptr_t dst = (lptr_t)(p.dma_dst + (slot_off & p.slot_mask));
-      if (piece < 0 || piece == 0) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 0, REFNERF_DMA_AUX);
-      if (piece < 0 || piece == 1) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 1024, REFNERF_DMA_AUX);
-      if ((piece < 0 || piece == 2) && p.wave != 5) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 2048, REFNERF_DMA_AUX);
-    } else
-#endif
     if (p.wave < 6) {
 #ifndef REFNERF_EXP_NODMA
       lptr_t dst = (lptr_t)(p.wbuf + slot_off + p.wave * 3072);
@@ -269,7 +251,7 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], cons
       p.t_vm += t1 - t0;
       p.t_bar += t2 - t1;
 #else
-      RN_RENDEZVOUS_P(p);
+      RN_RENDEZVOUS();
 #endif
       issue_chunk<SPLIT>(p, p.fil_off, REFNERF_BF_SPREAD ? 0 : -1);
     }
@@ -293,7 +275,8 @@ template <bool SPLIT = false>
 __device__ __forceinline__ void idle_pass(Pipe &p) {
 #pragma unroll 1
   for (int c = 0; c < (SPLIT ? SPPACKED.chunks_per_pass : BFPACKED.chunks_per_pass); ++c) {
-    RN_RENDEZVOUS_P(p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     issue_chunk<SPLIT>(p, p.fil_off);
     const int t = p.cur_off;
     p.cur_off = p.nxt_off;
@@ -697,7 +680,7 @@ __device__ __forceinline__ void sq_chunk(Pipe &p, sq_v8 (&fr)[SQ_NF], const v4uu
       p.t_vm += t1 - t0;
       p.t_bar += t2 - t1;
 #else
-      RN_RENDEZVOUS_P(p);
+      RN_RENDEZVOUS();
 #endif
       issue_chunk<true>(p, p.fil_off, REFNERF_BF_SPREAD ? 0 : -1);
       if (PRE && REFNERF_SQ_PREBIAS) {
@@ -826,16 +809,6 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
   RN_STAMPW(A, 0);
 #ifdef REFNERF_PROF_WAITS
   if (A.prof && blockIdx.x == (gridDim.x >> 1) && lane == 0) A.prof[wave * 32 + 22] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef REFNERF_EXP_L2PF
-  p.dma_dst = WB + wave * 3072;
-  p.slot_mask = ~0;
-  if (wave >= 6) {
-    p.src = reinterpret_cast<const char *>(A.packed) + (size_t)REFNERF_EXP_L2PF * BF_CHUNK_BYTES + (wave - 6) * (80 * 128) + lane * 128;
-    p.seq = REFNERF_EXP_L2PF;
-    p.dma_dst = reinterpret_cast<char *>(NRM + 8 + rpw * 12 + 4) + (wave - 6) * 3072;
-    p.slot_mask = 0;
-  }
 #endif
   issue_chunk<true>(p, p.cur_off);                           /* overlaps with the resampler */
   issue_chunk<true>(p, p.nxt_off);

@@ -161,7 +161,16 @@ def render_image_sharded(render_fn, rays: utils.Rays, config, group=None):
         part = utils.Rays(*[getattr(mine, f.name)[i0:i0 + config.render_chunk_size] for f in fields(mine)])
         renderings, _ = render_fn(part)
         chunks.append({k: utils.recursive_detach(v) for k, v in renderings[-1].items() if not k.startswith("ray_")})
-    local = utils.merge_chunks(chunks) if chunks else {}
+    if chunks:
+        local = utils.merge_chunks(chunks)
+    elif world > 1:
+        # a rank without rays (fewer pixels than ranks) still has to join the collective with the same column table: it renders
+        # the image's first ray for the keys / dtypes / shapes and contributes zero rows
+        probe = utils.Rays(*[getattr(flat, f.name)[:1] for f in fields(flat)])
+        renderings, _ = render_fn(probe)
+        local = {k: utils.recursive_detach(v)[:0] for k, v in renderings[-1].items() if not k.startswith("ray_")}
+    else:
+        local = {}
     global LAST_IMAGE_COLLECTIVES
     LAST_IMAGE_COLLECTIVES = 0
     if world == 1:
@@ -195,5 +204,6 @@ def render_image_sharded(render_fn, rays: utils.Rays, config, group=None):
     full = torch.cat([g[:e - b] for g, (b, e) in zip(gathered, sizes)], dim=0)
     out = {}
     for (k, off, nb, dt, tail) in cols:
-        out[k] = full[:, off:off + nb].contiguous().view(dt).reshape((height, width) + tail)
+        # (clone, not contiguous(): a one-row slice IS contiguous at a byte offset that need not be aligned for `dt`)
+        out[k] = full[:, off:off + nb].clone().view(dt).reshape((height, width) + tail)
     return out

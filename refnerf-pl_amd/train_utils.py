@@ -409,4 +409,54 @@ def compute_losses(model, batch, rays, renderings, ray_history, config, renderin
         losses['weights_entropy'] = weights_entropy_loss(model, renderings, ray_history, config, warmup_ratio)
     total = torch.sum(torch.stack([torch.as_tensor(v, dtype=torch.float32, device=data_loss.device)
                                    for v in losses.values()]))
+    if getattr(config, 'hip_check_finite', True):
+        _FINITE_GUARD.watch(total, config)
     return total, losses, stats
+
+
+class _FiniteGuard:
+    """Loud failure for the operand-range limit of the 16-bit chain modes (include/refnerf_hip.h: beyond |x| = 65504 a split-f16
+    unit becomes inf - inf and the level's outputs NaN).  No per-step synchronisation: every total is reduced to one flag on
+    the device and copied to pinned host memory asynchronously; the flag of step k is read when step k + 1 asks (its copy has
+    long completed by then), or on `flush()`.  Raises FloatingPointError naming the knobs that lift the limit."""
+
+    def __init__(self):
+        self.pending = None      # (host flag, event, step number)
+        self.step = 0
+
+    def _raise(self, step, config):
+        raise FloatingPointError(
+            f"non-finite training loss at step {step} of this process (hip_train_precision = {getattr(config, 'hip_train_precision', '?')!r}, "
+            f"hip_bwd_precision = {getattr(config, 'hip_bwd_precision', '?')!r}): the split-f16 / f16 / bf16 chains hold operands up to 65504 only -- "
+            "set Config.hip_precision = Config.hip_train_precision = Config.hip_bwd_precision = 'f32' (exact fp32 MFMA chains, no "
+            "operand-range limit), or Config.hip_check_finite = False to train on regardless")
+
+    def flush(self, config=None):
+        if self.pending is not None:
+            flag, event, step = self.pending
+            self.pending = None
+            if event is not None:
+                event.synchronize()
+            if not bool(flag.item()):
+                self._raise(step, config)
+
+    def watch(self, total, config):
+        self.flush(config)                      # the previous step's flag: its copy was queued a whole step ago
+        self.step += 1
+        ok = torch.isfinite(total.detach())
+        if total.is_cuda:
+            flag = torch.empty((), dtype=torch.bool, pin_memory=True)
+            flag.copy_(ok, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            self.pending = (flag, event, self.step)
+        elif not bool(ok):
+            self._raise(self.step, config)
+
+
+_FINITE_GUARD = _FiniteGuard()
+
+
+def flush_finite_check(config=None):
+    """raise now if the LAST watched training loss was not finite (call at the end of a run / before a checkpoint)"""
+    _FINITE_GUARD.flush(config)

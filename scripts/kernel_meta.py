@@ -16,10 +16,18 @@ def kernel_meta(lib):
         # the device code objects sit in the .hip_fatbin section as a clang offload bundle
         fat = os.path.join(td, "fat.bin")
         subprocess.check_call([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
-        co = os.path.join(td, "gfx950.co")
-        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", f"--output={co}",
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], stderr=subprocess.DEVNULL)
-        notes = subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", co], text=True)
+        # one bundle per translation unit, concatenated in the section
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(magic, blob)]
+        notes = ""
+        for i, st in enumerate(starts):
+            part = os.path.join(td, f"fat{i}.bin")
+            open(part, "wb").write(blob[st:(starts[i + 1] if i + 1 < len(starts) else len(blob))])
+            co = os.path.join(td, f"gfx950_{i}.co")
+            subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={part}", f"--output={co}",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], stderr=subprocess.DEVNULL)
+            notes += subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", co], text=True)
     for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
         blk = ".agpr_count:" + blk
         g = lambda k: (re.search(r"\." + k + r":\s+(\S+)", blk) or [None, "?"])[1]

@@ -103,6 +103,13 @@ def _worker(rank, world, port, tmp):
     assert torch.equal(out["acc"].reshape(-1), ref[-1]["acc"])
     assert out["distance_median"].dtype == torch.float64 and torch.equal(out["distance_median"].reshape(-1), ref[-1]["distance_median"])
     assert distributed.LAST_IMAGE_COLLECTIVES == 1       # ONE all_gather per image, whatever the number of outputs
+    # a 1 x 1 image on two ranks: one rank has no ray at all, yet joins the collective with the same column table; and a single
+    # gathered row must come apart at byte offsets that are not float64-aligned
+    one = utils.rays_from_dict({k: np.asarray(v)[:1].reshape(1, 1, -1) for k, v in rd.items()})
+    out1 = distributed.render_image_sharded(_fake_render, one, cfg)
+    ref1, _ = _fake_render(utils.rays_from_dict({k: np.asarray(v)[:1] for k, v in rd.items()}))
+    assert out1["rgb"].shape == (1, 1, 3) and torch.equal(out1["rgb"].reshape(-1, 3), ref1[-1]["rgb"])
+    assert out1["distance_median"].dtype == torch.float64 and torch.equal(out1["distance_median"].reshape(-1), ref1[-1]["distance_median"])
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")

@@ -276,9 +276,10 @@ def test_f16x2_through_the_model_api(hip):
 
 
 # ---------------------------------------------------------------- split-f16 chains in the training forward
+@pytest.mark.parametrize("wgrad", ["bf16x3", "f16"])       # 22-bit GEMM inputs / one half ('f16': what the shipped configs select)
 @pytest.mark.parametrize("bwd", ["f32", "f16x2"])
 @pytest.mark.parametrize("name", ["model_blender_sharp_train", "model_llff_linear_train", "model_shiny_train", "model_trained_train"])
-def test_f16x2_chain_training_step_vs_reference(hip, name, bwd):
+def test_f16x2_chain_training_step_vs_reference(hip, O, name, bwd, wgrad):
     """Config.hip_train_precision = hip_bwd_precision = 'f16x2': the split-f16 training kernels (round 5: REFNERF_ACT_SQ
     activations, two-product backward, f16 weight-gradient GEMM) against the REFERENCE's own losses and autograd gradients on the
     golden training fixtures, the trained-like one included.  Same bars as the exact-fp32 chains (test_training_step_gradients):
@@ -297,7 +298,8 @@ def test_f16x2_chain_training_step_vs_reference(hip, name, bwd):
         configs.clear_config()
         configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
                                                 bindings + [f"Config.hip_train_precision = '{mode}'",
-                                                            f"Config.hip_bwd_precision = '{'f16x2' if mode == 'f16x2' else bwd}'"])
+                                                            f"Config.hip_bwd_precision = '{'f16x2' if mode == 'f16x2' else bwd}'",
+                                                            f"Config.hip_wgrad_mode = '{wgrad}'"])
         cfg = configs.Config()
         model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
         model.nerf_mlp.load_flat_params(params_from_golden(g))
@@ -307,8 +309,21 @@ def test_f16x2_chain_training_step_vs_reference(hip, name, bwd):
         total, terms, _ = train_utils.compute_losses(model, batch, rays, rend, hist, cfg)
         total.backward()
         grads = torch.cat([p.grad.flatten() for p in model.nerf_mlp.ordered_parameters()]).cpu().numpy()
-        res[mode] = (grads, float(total.detach()), rend[1]["rgb"].detach().cpu().numpy(), hist[1]["normals"].detach().cpu().numpy())
-    grads, total, rgb_l1, normals = res["f16x2"]
+        res[mode] = (grads, float(total.detach()), rend[1]["rgb"].detach().cpu().numpy(), hist[1]["normals"].detach().cpu().numpy(),
+                     [hist[L]["normals"].detach().cpu().numpy() for L in range(2)])
+    grads, total, rgb_l1, normals, normals_per_level = res["f16x2"]
+    # row a10 in the mode of record (models.py:603-609): the density-gradient normals of the split-f16 training forward, per
+    # sample, against the oracle and against the reference's own ray_history -- the statistics of
+    # test_training_forward_density_normals (the normal is ill-conditioned where the density gradient is tiny: bulk tight, tail loose)
+    kw_o, lv_o = cfg_from_bindings(g["bindings"])
+    orc = O.model_forward(params_from_golden(g), rays_from_golden(g), training=1, **lv_o, **kw_o)
+    nstat = {}
+    for L in range(2):
+        for tag, refn, bulk, tail in (("oracle", orc[L]["normals"], 2e-5, 0.99), ("reference", g[f"L{L}_h_normals"], 1e-4, 0.97)):
+            err = np.abs(normals_per_level[L] - refn.reshape(normals_per_level[L].shape)).max(-1)
+            nstat[f"L{L}_normals_median_err_vs_{tag}"] = float(np.median(err))
+            nstat[f"L{L}_normals_frac_under_1e-3_vs_{tag}"] = float(np.mean(err < 1e-3))
+            assert np.median(err) < bulk and np.mean(err < 1e-3) > tail, (name, L, tag, nstat)
     ref = g["grads_sub"]
     rel = float(np.linalg.norm(grads[::97] - ref) / np.linalg.norm(ref))
     rel32 = float(np.linalg.norm(res["f32"][0][::97] - ref) / np.linalg.norm(ref))
@@ -320,8 +335,8 @@ def test_f16x2_chain_training_step_vs_reference(hip, name, bwd):
     nerr = float(np.abs(normals - res["f32"][3]).max())
     print(f"{name} f16x2 chains vs reference: gradient rel-L2 {rel:.2e} (f32 chains {rel32:.2e}; between the modes {rel_modes:.2e}), "
           f"worst tensor-norm error {worst:.2e}, loss rel {lrel:.2e}, RGB L-inf {rgb:.2e}, density normals vs f32 chains {nerr:.2e}")
-    _record("f16x2_chain_training_vs_reference/" + name, dict(grad_rel_l2=rel, grad_rel_l2_f32_chains=rel32, grad_rel_l2_between_modes=rel_modes,
-                                                              worst_tensor_norm_err=float(worst), loss_rel=lrel, rgb_linf=rgb))
+    _record(f"f16x2_chain_training_vs_reference/{name}/bwd={bwd}/wgrad={wgrad}", dict(grad_rel_l2=rel, grad_rel_l2_f32_chains=rel32, grad_rel_l2_between_modes=rel_modes,
+                                                              worst_tensor_norm_err=float(worst), loss_rel=lrel, rgb_linf=rgb, **nstat))
     trained = name.startswith("model_trained")
     assert rel < (1e-3 if trained else 2e-4), rel
     assert rel32 < (1e-3 if trained else 2e-4), (bwd, rel32)       # the f32 forward with the f32 / split-on-fp32-rows backward
@@ -533,8 +548,9 @@ def test_f16x2_operand_range(hip):
     assert float(torch.isnan(res["r_rgb"]).float().mean()) > 0.5
 
 
-@pytest.mark.parametrize("chains,fused", [("f32", False), ("f16x2", False), ("f16x2", True)])
-def test_twenty_optimiser_steps_follow_the_reference(hip, chains, fused):
+@pytest.mark.parametrize("chains,fused,wgrad", [("f32", False, "bf16x3"), ("f16x2", False, "bf16x3"), ("f16x2", True, "bf16x3"),
+                                                ("f16x2", False, "f16"), ("f16x2", True, "f16")])
+def test_twenty_optimiser_steps_follow_the_reference(hip, chains, fused, wgrad):
     """the whole loop, not single steps: the first 20 Adam steps of the REFERENCE from the seeded init on fixed batches
     (tests/golden/trajectory.npz) against Model + torch.optim.Adam here -- per-step losses and the accumulated parameter
     update.  Exercises the weight re-pack after every step, the gradient path into the parameters (per-tensor and the flat
@@ -547,7 +563,7 @@ def test_twenty_optimiser_steps_follow_the_reference(hip, chains, fused):
     configs.clear_config()
     configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")], [
         f"Model.num_prop_samples = {int(n_samples)}", f"Model.num_nerf_samples = {int(n_samples)}",
-        f"Config.hip_train_precision = '{chains}'", f"Config.hip_bwd_precision = '{chains}'"] +
+        f"Config.hip_train_precision = '{chains}'", f"Config.hip_bwd_precision = '{chains}'", f"Config.hip_wgrad_mode = '{wgrad}'"] +
         (["Config.hip_flat_grads = True"] if fused else []))
     cfg = configs.Config()
     model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
@@ -573,8 +589,10 @@ def test_twenty_optimiser_steps_follow_the_reference(hip, chains, fused):
     upd = (model.nerf_mlp.flat_params().detach().cpu().numpy() - init)[::97]
     rel_u = float(np.linalg.norm(upd - g["update_sub"]) / np.linalg.norm(g["update_sub"]))
     print(f"[{chains} chains, fused={fused}] worst per-step loss deviation {worst:.2e}; accumulated update vs the reference's: rel-L2 {rel_u:.2e}")
-    _record(f"trajectory/{chains}/fused={fused}", dict(worst_loss_rel=worst, update_rel_l2=rel_u))
-    assert rel_u < 1e-2          # measured 7e-4 (f32 chains) / 4.6e-3 (split-f16 chains of round 5; round 4: 1.3e-3): Adam's 1 / sqrt(v) on tiny gradients
+    _record(f"trajectory/{chains}/fused={fused}/wgrad={wgrad}", dict(worst_loss_rel=worst, update_rel_l2=rel_u))
+    # measured 7e-4 (f32 chains) / 4.6e-3 (split-f16 chains of round 5: two-product backward, 11-bit deltas; round 4: 1.3e-3) --
+    # Adam's 1 / sqrt(v) on tiny gradients.  Bars at ~2x the measured values, so that further drift is caught
+    assert rel_u < (1.5e-3 if chains == "f32" else 9e-3), rel_u
     configs.clear_config()
 
 

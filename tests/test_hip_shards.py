@@ -228,6 +228,32 @@ def test_two_rank_launcher_on_one_gpu(hip, config, extra):
     assert line["config"]["rays_per_gpu"] * 2 == line["config"]["total_rays"]
 
 
+@pytest.mark.parametrize("config,extra", [("C4", []), ("C5", ["--rays", "2048"])])
+def test_two_gpu_rccl_launch_when_two_devices(hip, config, extra):
+    """the driver's 8-GPU run must not be the first multi-rank RCCL run.  When the box has >= 2 GPUs, the
+    driver's own command line for N = 2 -- `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`, one rank
+    per device, backend "nccl" = RCCL over xGMI (C4: sharded eval, no data-path collective; C5: the gradient all-reduce in the
+    step) -- must report both ranks from the process group.  Skipped on the one-GPU boxes of this pool (device_count() does not
+    initialise the GPU on this image)."""
+    import socket
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: the multi-rank RCCL path is exercised by the driver's scaling run")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "REFNERF_BENCH_BACKEND", "REFNERF_BENCH_SHARE_GPU")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-image"] + extra, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["n_ranks_seen"] == 2
+    assert np.isfinite(line["value"]) and line["value"] > 0
+
+
 def test_rccl_one_rank_group_runs_the_gradient_collectives(hip):
     """RCCL itself on the box (the reference's DDP runs on it, train.py:84-88): ONE fresh child process
     creates a one-rank "nccl" group on cuda:0 and runs distributed.allreduce_gradients (flat blob and per-parameter path,

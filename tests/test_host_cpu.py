@@ -442,3 +442,19 @@ def test_data_loss_statistics_match_the_reference():
             np.testing.assert_allclose(v.numpy(), g[f"{tag}_stat_{k}"], rtol=2e-6, atol=0, equal_nan=True, err_msg=f"{tag} {k}")
     assert np.isnan(g["eval_stat_normal_maes"]).all() and np.isfinite(g["train_stat_normal_maes"]).all()
     configs.clear_config()
+
+
+def test_non_finite_loss_guard_is_loud_one_step_later():
+    """the 16-bit chain modes turn operands beyond 65504 into NaN outputs; train_utils.compute_losses watches every
+    total (Config.hip_check_finite, default on) and raises FloatingPointError naming the knobs that lift the limit.  On the
+    CPU the check is immediate; on a device the flag of step k is read when step k + 1 asks (no synchronisation)."""
+    import torch
+    from refnerf_pl_amd import configs, train_utils
+    cfg = configs.Config()
+    assert cfg.hip_check_finite is True
+    guard = train_utils._FiniteGuard()
+    guard.watch(torch.tensor(1.0), cfg)
+    with pytest.raises(FloatingPointError, match="hip_train_precision"):
+        guard.watch(torch.tensor(float("nan")), cfg)
+    guard.watch(torch.tensor(2.0), cfg)          # usable afterwards
+    train_utils.flush_finite_check(cfg)          # nothing pending on the module's own guard: no-op
