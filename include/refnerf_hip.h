@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define REFNERF_ABI_VERSION 10  /* v10: REFNERF_IMAGE_F16X2_TRAIN + REFNERF_ACT_SQ (training levels of REFNERF_PREC_F16X2 on the eval kernel's skeleton: d_packed of refnerf_level_forward_train / refnerf_level_backward is the train image then); v9: REFNERF_ACT_F16X2 (split-f16 ACT / DELTA formats of the split-f16 training chains), refnerf_activations_format; v8: cfg.ipe_groups, refnerf_pack_weights_basis (general IPE bases: icosahedron); v7: REFNERF_PREC_F16X2 (split-operand f16: the parity-grade 16-bit inference mode); v6: cfg.dir_enc (REFNERF_DIRENC_*), cfg.raydist (REFNERF_RAYDIST_*), cfg.disable_integration; v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
+#define REFNERF_ABI_VERSION 11  /* v11: refnerf_level_image (which weight image a level configuration expects as d_packed) + the library remembers the kind of every image it packs and refuses a mismatching d_packed; v10: REFNERF_IMAGE_F16X2_TRAIN + REFNERF_ACT_SQ (training levels of REFNERF_PREC_F16X2 on the eval kernel's skeleton: d_packed of refnerf_level_forward_train / refnerf_level_backward is the train image then); v9: REFNERF_ACT_F16X2 (split-f16 ACT / DELTA formats of the split-f16 training chains), refnerf_activations_format; v8: cfg.ipe_groups, refnerf_pack_weights_basis (general IPE bases: icosahedron); v7: REFNERF_PREC_F16X2 (split-operand f16: the parity-grade 16-bit inference mode); v6: cfg.dir_enc (REFNERF_DIRENC_*), cfg.raydist (REFNERF_RAYDIST_*), cfg.disable_integration; v5: refnerf_render_rays, REFNERF_PREC_F16, refnerf_get_timing_family, refnerf_losses_forward / _backward; v4: cfg.wgrad_mode, refnerf_level_saved.activations_format, bf16-chain training modes */
 #define REFNERF_NUM_PARAMS 1110158 /* canonical fp32 blob, nerf_mlp.* state_dict order */
 
 enum {
@@ -291,6 +291,14 @@ typedef struct refnerf_level_grads {
  * activations rounded to bf16 once per layer (RGB within 1e-4 of the f32 mode); REFNERF_PREC_F32 is the parity mode. */
 size_t refnerf_activation_workspace_bytes(int32_t R, int32_t n_samples);
 int refnerf_activations_format(const refnerf_level_cfg *cfg);   /* REFNERF_ACT_* of refnerf_level_forward_train(cfg), -1 for NULL */
+/* v11: the weight image refnerf_level_forward / _forward_train / _backward expect as `d_packed` for this configuration -- the
+ * `precision` argument to pass to refnerf_pack_weights (REFNERF_PREC_* or REFNERF_IMAGE_F16X2_TRAIN; a general IPE basis:
+ * REFNERF_PREC_F32 through refnerf_pack_weights_basis), -1 for NULL.  One rule, inside the library (it depends on
+ * cfg->training, cfg->precision, cfg->ipe_groups and on the REFNERF_LEGACY_F16X2_TRAIN switch the library itself reads).
+ * The library also remembers, per device pointer, the kind of every image refnerf_pack_weights* wrote: a level entry handed a
+ * pointer it packed as ANOTHER kind returns REFNERF_EINVAL instead of streaming garbage (pointers it never packed -- a
+ * caller's own copy of an image -- are taken on trust). */
+int refnerf_level_image(const refnerf_level_cfg *cfg);
 int refnerf_level_forward_train(const void *d_packed, const refnerf_level_cfg *cfg,
                                 const refnerf_rays *rays, int32_t R,
                                 const float *d_sdist_in, const float *d_weights_in,

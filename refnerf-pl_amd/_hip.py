@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X2 = 0, 1, 2, 3
 IMAGE_F16X2_TRAIN = 4   # REFNERF_IMAGE_F16X2_TRAIN: the weight image of the REFNERF_PREC_F16X2 training kernels (built-in basis)
 ACT_F32, ACT_BF16, ACT_F16X2, ACT_SQ = 0, 1, 2, 3   # REFNERF_ACT_*
-ABI_VERSION = 10  # REFNERF_ABI_VERSION
+ABI_VERSION = 11  # REFNERF_ABI_VERSION
 # debug knob, read once by the library as well: the round-4 training kernels of the f16x2 mode (REFNERF_ACT_F16X2, f32 image)
 LEGACY_F16X2_TRAIN = os.environ.get("REFNERF_LEGACY_F16X2_TRAIN", "0") not in ("", "0")
 WGRAD_F32, WGRAD_BF16X3, WGRAD_F16 = 0, 1, 2
@@ -98,6 +98,8 @@ def lib():
         L.refnerf_level_forward.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
                                             _FP, _FP, C.POINTER(LevelOut), _FP]
         L.refnerf_activations_format.argtypes = [C.POINTER(LevelCfg)]
+        L.refnerf_level_image.argtypes = [C.POINTER(LevelCfg)]
+        L.refnerf_level_image.restype = C.c_int
         L.refnerf_activation_workspace_bytes.restype = C.c_size_t
         L.refnerf_activation_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
         L.refnerf_level_forward_train.argtypes = [_FP, C.POINTER(LevelCfg), C.POINTER(RaysStruct), C.c_int32,
@@ -172,11 +174,10 @@ def level_image(precision: int, training: bool = False, ipe_groups: int = 0) -> 
     """Which weight image refnerf_level_forward / _forward_train / _backward expect as `d_packed` for a level configuration:
     inference levels the image of their precision mode (a general IPE basis: the f32 image), training levels the f32 image --
     except REFNERF_PREC_F16X2 on the built-in basis, whose training kernels stream their own image (REFNERF_IMAGE_F16X2_TRAIN)."""
-    if ipe_groups > 1:
-        return PREC_F32
-    if training:
-        return IMAGE_F16X2_TRAIN if (precision == PREC_F16X2 and not LEGACY_F16X2_TRAIN) else PREC_F32
-    return precision
+    # one rule, inside the library (ABI v11: refnerf_level_image; it reads the REFNERF_LEGACY_F16X2_TRAIN switch itself)
+    cfg = LevelCfg()
+    cfg.precision, cfg.training, cfg.ipe_groups = int(precision), int(bool(training)), int(ipe_groups)
+    return int(lib().refnerf_level_image(C.byref(cfg)))
 
 
 def packed_weights_bytes(precision=PREC_F32) -> int:

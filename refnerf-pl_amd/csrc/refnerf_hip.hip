@@ -614,8 +614,56 @@ size_t refnerf_packed_weights_bytes(int precision) {
   return 0;
 }
 
+/* ---- which image a device pointer holds (v11): recorded by the pack entries, checked by the level entries ---- */
+#include <mutex>
+#include <unordered_map>
+namespace {
+constexpr int IMAGE_KIND_BASIS = 0x100;      /* + REFNERF_PREC_F32: the extended image of refnerf_pack_weights_basis */
+std::mutex g_image_mu;
+std::unordered_map<const void *, int> g_image_kind;
+void remember_image(const void *p, int kind) {
+  std::lock_guard<std::mutex> lk(g_image_mu);
+  g_image_kind[p] = kind;
+}
+const char *image_name(int kind) {
+  switch (kind) {
+    case REFNERF_PREC_F32: return "REFNERF_PREC_F32";
+    case REFNERF_PREC_BF16: return "REFNERF_PREC_BF16";
+    case REFNERF_PREC_F16: return "REFNERF_PREC_F16";
+    case REFNERF_PREC_F16X2: return "REFNERF_PREC_F16X2";
+    case REFNERF_IMAGE_F16X2_TRAIN: return "REFNERF_IMAGE_F16X2_TRAIN";
+    case IMAGE_KIND_BASIS + REFNERF_PREC_F32: return "REFNERF_PREC_F32 (general basis)";
+    default: return "?";
+  }
+}
+/* 0, or REFNERF_EINVAL when the library itself packed `p` as something else than this level streams */
+int check_image(const void *p, const refnerf_level_cfg *cfg, const char *who) {
+  const int want = refnerf_level_image(cfg) + (cfg->ipe_groups > 1 ? IMAGE_KIND_BASIS : 0);
+  int have = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_image_mu);
+    auto it = g_image_kind.find(p);
+    if (it != g_image_kind.end()) have = it->second;
+  }
+  if (have < 0 || have == want) return REFNERF_OK;
+  /* (the plain f32 image in place of the extended one reads past its end; the extended one in place of the plain one is a superset) */
+  if (have == IMAGE_KIND_BASIS + REFNERF_PREC_F32 && want == REFNERF_PREC_F32) return REFNERF_OK;
+  snprintf(g_err, sizeof(g_err), "%s: d_packed was packed as the %s image, this level configuration streams the %s image (refnerf_level_image)",
+           who, image_name(have), image_name(want));
+  return REFNERF_EINVAL;
+}
+}  // namespace
+
+int refnerf_level_image(const refnerf_level_cfg *cfg) {
+  if (!cfg) return -1;
+  if (cfg->ipe_groups > 1) return REFNERF_PREC_F32;
+  if (cfg->training) return (cfg->precision == REFNERF_PREC_F16X2 && !legacy_f16x2_train()) ? REFNERF_IMAGE_F16X2_TRAIN : REFNERF_PREC_F32;
+  return cfg->precision;
+}
+
 int refnerf_pack_weights(const float *d_params, void *d_packed, int precision, void *stream) {
   if (!d_params || !d_packed) return fail(REFNERF_EINVAL, "refnerf_pack_weights: null pointer%s");
+  remember_image(d_packed, precision);
   if (precision == REFNERF_PREC_F32) {
     dim3 grid(64, 3 * rn::NUM_OPS + 3 * rn::NUM_TOPS + 1);
     hipLaunchKernelGGL(rn::pack_weights_f32, grid, dim3(256), 0, (hipStream_t)stream, d_params, (float *)d_packed);
@@ -651,6 +699,7 @@ int refnerf_pack_weights_basis(const float *d_params, const float *d_basis, int 
     return fail(REFNERF_EUNSUPPORTED, "refnerf_pack_weights_basis builds the REFNERF_PREC_F32 image (levels with REFNERF_PREC_F32 or REFNERF_PREC_F16X2 run on it); the plain bf16 / f16 images have no direction groups%s");
   const int rc = refnerf_pack_weights(d_params, d_packed, precision, stream);
   if (rc) return rc;
+  remember_image(d_packed, IMAGE_KIND_BASIS + REFNERF_PREC_F32);
   hipLaunchKernelGGL(rn::pack_weights_ext, dim3(32, 1 + 8 * rn::EXT_GROUPS), dim3(256), 0, (hipStream_t)stream, d_params, d_basis, ipe_groups, (float *)d_packed);
   HIP_TRY(hipGetLastError());
   return REFNERF_OK;
@@ -731,6 +780,7 @@ static int level_forward_impl(const void *d_packed, const refnerf_level_cfg *cfg
   const bool gb_split = gbasis && cfg->precision == REFNERF_PREC_F16X2;
   /* training + F16X2 on the built-in basis: the round-5 kernels on the eval kernel's skeleton (refnerf_sq_train.hip);
    * d_packed is the REFNERF_IMAGE_F16X2_TRAIN image, the activations REFNERF_ACT_SQ */
+  if (int irc = check_image(d_packed, cfg, "refnerf_level_forward")) return irc;
   if (cfg->training && cfg->precision == REFNERF_PREC_F16X2 && !gbasis && !d_act && !legacy_f16x2_train())
     return fail(REFNERF_EINVAL, "a training level in REFNERF_PREC_F16X2 runs through refnerf_level_forward_train: its kernel keeps the ReLU sign words and "
                                 "the bottleneck rows in the activation buffer (d_packed: the REFNERF_IMAGE_F16X2_TRAIN image)%s");
@@ -966,6 +1016,14 @@ int refnerf_level_backward(const void *d_packed, const refnerf_level_cfg *cfg, c
     return fail(REFNERF_EINVAL, "refnerf_level_backward: unknown wgrad_mode%s");
   if (cfg->wgrad_mode == REFNERF_WGRAD_F16 && saved->activations_format != REFNERF_ACT_SQ)
     return fail(REFNERF_EUNSUPPORTED, "wgrad_mode = REFNERF_WGRAD_F16 belongs to the REFNERF_PREC_F16X2 training kernels (REFNERF_ACT_SQ activations, written with the same wgrad_mode)%s");
+  {
+    /* the backward streams the image of the TRAINING level it belongs to, whatever cfg->training says */
+    refnerf_level_cfg tc = *cfg;
+    tc.training = 1;
+    /* (the split-f16 backward on fp32 rows -- an exact-fp32 forward, or a general basis -- reads the f32 image) */
+    if (tc.precision == REFNERF_PREC_F16X2 && saved->activations_format == REFNERF_ACT_F32) tc.precision = REFNERF_PREC_F32;
+    if (int irc = check_image(d_packed, &tc, "refnerf_level_backward")) return irc;
+  }
   if (!saved->d_sdist || !saved->d_density || !saved->d_rgb || !saved->d_weights || !grads->d_g_r_rgb)
     return fail(REFNERF_EINVAL, "refnerf_level_backward: null saved tensor / rendering gradient%s");
   if (!saved->d_activations)

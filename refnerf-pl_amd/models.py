@@ -498,7 +498,7 @@ class _LevelFunction(torch.autograd.Function):
         # unconditionally -- an optimiser step always changes the weights, but not every optimiser bumps the tensors'
         # version counters (fused Adam does not), and the pack is 16 us
         # (the split-f16 chains on the built-in basis: their own image -- forward + transposed operands as one chunk stream)
-        image = _hip.IMAGE_F16X2_TRAIN if (cfg.precision == _hip.PREC_F16X2 and not mlp.ipe_groups and not _hip.LEGACY_F16X2_TRAIN) else _hip.PREC_F32
+        image = _hip.level_image(cfg.precision, True, mlp.ipe_groups)        # the library's own rule (refnerf_level_image)
         # (the levels of ONE Model.__call__ share the image of their MLP: no optimiser step can fall between them)
         reuse = holder.get("call_images")
         packed = reuse.get((id(mlp), image)) if reuse is not None else None

@@ -1677,3 +1677,27 @@ def test_specular_density_stage_entry_and_errors(hip):
     with pytest.raises(ValueError, match="useless"):                      # models.py:478-480
         models.NerfMLP(enable_pred_specular_density=True, use_diffuse_color=False)
     configs.clear_config()
+
+
+def test_mismatched_weight_image_is_refused(hip):
+    """ABI v11: the library remembers the kind of every image it packs; a level handed a pointer it packed as another
+    kind returns REFNERF_EINVAL (it used to stream the wrong bytes: out-of-bounds LDS-DMA reads) -- forward and backward."""
+    from refnerf_pl_amd import synthetic
+    P = torch.tensor(synthetic.make_params(0, 0.05, 20.0), device=DEV)
+    rays = dev_rays(synthetic.blender_rays(8, seed=4, center_frac=0.4))
+    sd, w = torch.tensor([[0.0, 1.0]], device=DEV).repeat(8, 1), torch.ones((8, 1), device=DEV)
+    f32_image = hip.pack_weights(P, precision=hip.PREC_F32)
+    cfg = hip.default_cfg(n_samples=32, n_in=1, precision=hip.PREC_F16X2)
+    with pytest.raises(hip.HipLibraryError, match="refnerf_level_image"):
+        hip.level_forward(f32_image, cfg, rays, sd, w)
+    tcfg = hip.default_cfg(n_samples=32, n_in=1, precision=hip.PREC_F16X2, training=1, compute_extras=0)
+    eval_image = hip.pack_weights(P, precision=hip.PREC_F16X2)
+    if not hip.LEGACY_F16X2_TRAIN:
+        with pytest.raises(hip.HipLibraryError, match="REFNERF_IMAGE_F16X2_TRAIN"):
+            hip.level_forward(eval_image, tcfg, rays, sd, w, history=True, save_activations=True)
+    good = hip.pack_weights(P, precision=hip.level_image(hip.PREC_F16X2, True))
+    res = hip.level_forward(good, tcfg, rays, sd, w, history=True, save_activations=True)
+    with pytest.raises(hip.HipLibraryError, match="refnerf_level_backward"):
+        hip.level_backward(eval_image, tcfg, rays, res, torch.full((8, 3), 1e-2, device=DEV), None, None, torch.zeros(hip.NUM_PARAMS, device=DEV))
+    # a re-pack of the same buffer as another kind is what counts from then on
+    hip.level_backward(good, tcfg, rays, res, torch.full((8, 3), 1e-2, device=DEV), None, None, torch.zeros(hip.NUM_PARAMS, device=DEV))

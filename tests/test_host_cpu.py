@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.lib()
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.refnerf_abi_version() == 10
+    assert lib.refnerf_abi_version() == 11
     assert _hip.packed_weights_bytes(_hip.PREC_F32) > 4 * layout.NUM_PARAMS
     # 17 KB chunks (+ 2 chunks of tail pad the ring may prefetch into): 150 for the plain 16-bit images, 206 for the split-f16 one
     # (133 spatial + heads chunks on the 16x16x32 layout, streamed twice per pass, + 73 directional: refnerf_layout.h)
@@ -458,3 +458,19 @@ def test_non_finite_loss_guard_is_loud_one_step_later():
         guard.watch(torch.tensor(float("nan")), cfg)
     guard.watch(torch.tensor(2.0), cfg)          # usable afterwards
     train_utils.flush_finite_check(cfg)          # nothing pending on the module's own guard: no-op
+
+
+def test_level_image_rule_lives_in_the_library():
+    """ABI v11: which weight image a level configuration streams is ONE rule inside the library
+    (refnerf_level_image; _hip.level_image only forwards to it) -- a pure host function, checked here without a GPU."""
+    import ctypes as C
+    import refnerf_pl_amd  # noqa: F401
+    from refnerf_pl_amd import _hip
+    assert _hip.lib().refnerf_level_image(None) == -1
+    F32, BF16, F16, F16X2 = _hip.PREC_F32, _hip.PREC_BF16, _hip.PREC_F16, _hip.PREC_F16X2
+    for prec in (F32, BF16, F16, F16X2):
+        assert _hip.level_image(prec, False) == prec                     # inference: the image of the mode
+        assert _hip.level_image(prec, False, 7) == F32                   # a general IPE basis: the (extended) f32 image
+    assert _hip.level_image(F32, True) == F32 and _hip.level_image(BF16, True) == F32      # the f32 image carries the bf16 chain ops
+    assert _hip.level_image(F16X2, True) == (F32 if _hip.LEGACY_F16X2_TRAIN else _hip.IMAGE_F16X2_TRAIN)
+    assert _hip.level_image(F16X2, True, 7) == F32
