@@ -316,11 +316,12 @@ __device__ __forceinline__ void posenc_grad(float x, float y, float z, G g, floa
   const float half_pi = (float)(0.5 * 3.14159265358979323846);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    float acc = g(i);
+    float dep = 0.0f;
+    float acc = g(i, dep);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const float sc = (float)(1 << j), sx = d[i] * sc;
-      acc += sc * (cosf(sx) * g(3 + 3 * j + i) + cosf(sx + half_pi) * g(IDE_TERMS + 3 * j + i));
+      acc += sc * (cosf(sx) * g(3 + 3 * j + i, dep) + cosf(sx + half_pi) * g(IDE_TERMS + 3 * j + i, dep));
     }
     gxyz[i] = acc;
   }
@@ -368,11 +369,15 @@ __device__ __forceinline__ void colour_map_backward(const float pre[3], bool nor
 }
 
 /* Gradient of ide_eval (stable form) w.r.t. (x,y,z) and kappa_inv.
- * g(q) = upstream gradient of output q (0..35 real parts, 36..71 imaginary). */
+ * g(q, dep) = upstream gradient of output q (0..35 real parts, 36..71 imaginary); `dep` is the recurrence value the read is
+ * needed for: a caller that wants its 72 reads issued where they are used (not hoisted to the front and parked in scratch) ties
+ * the read's address to it (asm volatile("" : "+v"(addr), "+v"(dep))). */
 template <typename G>
 __device__ __forceinline__ void ide_grad(float x, float y, float z, float kappa_inv, G g, float (&gxyz)[3], float &gkappa) {
-  const float att1 = expf(-1.0f * kappa_inv), att2 = expf(-3.0f * kappa_inv), att4 = expf(-10.0f * kappa_inv);
-  const float att8 = expf(-36.0f * kappa_inv), att16 = expf(-136.0f * kappa_inv);
+  float att1 = expf(-1.0f * kappa_inv), att2 = expf(-3.0f * kappa_inv), att4 = expf(-10.0f * kappa_inv);
+  float att8 = expf(-36.0f * kappa_inv), att16 = expf(-136.0f * kappa_inv);
+  /* (pinned here: sunk to their first uses, the five exponentials make every product in front of them wait -- in scratch) */
+  asm volatile("" : "+v"(att1), "+v"(att2), "+v"(att4), "+v"(att8), "+v"(att16));
   float pr = 1.0f, pi = 0.0f, prm1 = 0.0f, pim1 = 0.0f;
   float gx = 0.0f, gy = 0.0f, gz = 0.0f, gk = 0.0f;
 #pragma unroll
@@ -387,18 +392,23 @@ __device__ __forceinline__ void ide_grad(float x, float y, float z, float kappa_
       else {
         tl = IDE_A[m][l] * (z * tm1 - IDE_B[m][l] * tm2);
         dl = IDE_A[m][l] * (tm1 + z * dm1 - IDE_B[m][l] * dm2);
+        /* (pinned: program order, one degree at a time.  Pure arithmetic is not ordered by sched_barrier -- left to itself the
+         * instruction selector runs the whole T recurrence of an order m first and parks every T_l for the derivative recurrence
+         * behind it: 77 scratch stores / 92 loads per sample in level_bwd_sq, round 6) */
+        asm volatile("" : "+v"(tl), "+v"(dl));
         tm2 = tm1; tm1 = tl; dm2 = dm1; dm1 = dl;
       }
       if (l == 1 || l == 2 || l == 4 || l == 8 || l == 16) {
         const int idx = (l == 1 ? 0 : l == 2 ? 2 : l == 4 ? 5 : l == 8 ? 10 : 19) + m;
         const float sigma = (float)(0.5 * l * (l + 1));
         const float att = (l == 1 ? att1 : l == 2 ? att2 : l == 4 ? att4 : l == 8 ? att8 : att16);
-        const float gre = g(idx), gim = g(IDE_TERMS + idx);
+        const float gre = g(idx, tl), gim = g(IDE_TERMS + idx, tl);
         const float s = tl * att;
         const float gs = gre * pr + gim * pi;
         gpr += gre * s; gpi += gim * s;
         gz += gs * att * dl;
         gk += gs * tl * (-sigma * att);
+        asm volatile("" : "+v"(gz), "+v"(gk), "+v"(gpr), "+v"(gpi));      /* accumulate now */
       }
     }
     if (m > 0) {

@@ -522,7 +522,7 @@ __device__ __forceinline__ void level_bwd_body(const BwdArgs &A) {
     {
       float g_ref[3], g_rough;
       const int xhi = tile_hi(col);              /* rows >= 128 of the tile through one laundered base (tile_idx) */
-      auto gq = [&](int q) { return X[tile_idx(BNECK + q, col, xhi)]; };
+      auto gq = [&](int q, float &) { return X[tile_idx(BNECK + q, col, xhi)]; };
       if (cfg.dir_enc == REFNERF_DIRENC_POSENC) { posenc_grad(sh.refd[0], sh.refd[1], sh.refd[2], gq, g_ref); g_rough = 0.0f; }   /* coord.pos_enc: no roughness */
       else ide_grad(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, gq, g_ref, g_rough);
       const float g_dot = X[tile_idx(BNECK + IDE_DIM, col, xhi)];

@@ -255,7 +255,11 @@ __device__ __forceinline__ void resample_phase(const LevelArgs &A, float *scratc
     /* models.py:200-203 */
     #pragma clang loop unroll(disable)
     for (int i = lane; i < M; i += 64)
+#ifdef REFNERF_EXP_LOGF_OCML      /* A/B only: the device libm's logf (rounds 1-5) */
+      lg[i] = (t_in[i + 1] > t_in[i]) ? cfg.anneal * logf(wg[i] + cfg.resample_padding) : -INFINITY;
+#else
       lg[i] = (t_in[i + 1] > t_in[i]) ? cfg.anneal * rn_det_logf(wg[i] + cfg.resample_padding) : -INFINITY;   /* shared with the oracle: bit-identical logits */
+#endif
     wave_sync();
     float *sd = TD + rl * (N + 1);
     sample_intervals_wave<EXACT>(t_in, lg, cw, c, M, N, cfg.s_near, cfg.s_far, sd,

@@ -222,8 +222,10 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
         float e_dl[3], e_sp[3], spl[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          e_dl[i] = (valid2 && A.g_s_diffuse) ? A.g_s_diffuse[gsc * 3 + i] : 0.0f;
-          e_sp[i] = (valid2 && A.g_s_specular) ? A.g_s_specular[gsc * 3 + i] : 0.0f;
+          /* (gsc is clamped: the load itself is unconditional per lane, a wave-uniform branch on the pointer only) */
+          const float ld = A.g_s_diffuse ? A.g_s_diffuse[gsc * 3 + i] : 0.0f, ls = A.g_s_specular ? A.g_s_specular[gsc * 3 + i] : 0.0f;
+          e_dl[i] = valid2 ? ld : 0.0f;
+          e_sp[i] = valid2 ? ls : 0.0f;
           spl[i] = H.sh.tint[i] * sg[i];
         }
         if (cfg.srgb_mapping) {
@@ -235,7 +237,8 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        H.g_tint[i] = g_sp[i] * sg[i] + ((valid2 && A.g_s_tint) ? A.g_s_tint[gsc * 3 + i] : 0.0f);
+        const float lt = A.g_s_tint ? A.g_s_tint[gsc * 3 + i] : 0.0f;
+        H.g_tint[i] = g_sp[i] * sg[i] + (valid2 ? lt : 0.0f);
         H.g_raw_rgb[i] = (g_sp[i] * H.sh.tint[i]) * sg[i] * (1.0f - sg[i]) * cfg.rgb_premultiplier;
         H.g_raw_diff[i] = g_dl[i] * dl[i] * (1.0f - dl[i]);
       }
@@ -358,8 +361,12 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
           asm volatile("" : "+v"(mxb));
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            hbn[2 * ob][e] = pk_f16(vv[2 * e], vv[2 * e + 1]);
-            hbn[2 * ob + 1][e] = pk_f16(vv[8 + 2 * e], vv[8 + 2 * e + 1]);
+            /* (pinned: MachineSink otherwise moves the conversions to their first use behind the IDE backward and the sixteen
+             * fp32 values of every slice wait for them in scratch -- 64 of the 160 spilled registers of round 5) */
+            unsigned q0 = pk_f16(vv[2 * e], vv[2 * e + 1]), q1 = pk_f16(vv[8 + 2 * e], vv[8 + 2 * e + 1]);
+            asm volatile("" : "+v"(q0), "+v"(q1));
+            hbn[2 * ob][e] = q0;
+            hbn[2 * ob + 1][e] = q1;
           }
         } else {
           int cg = col_v + 4 * h_v * BT;
@@ -381,6 +388,7 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
       /* ===== IDE, reflection, predicted normal, head activations backward (models.py:611-686) ===== */
       HeadState H;
       head_state(H);
+      __builtin_amdgcn_sched_barrier(0);      /* (the phase is 11 k VALU instructions: one scheduling region of it fills 256 registers by itself) */
       const SampleHeads &sh = H.sh;
       const float (&v)[3] = H.v;
       const float (&gsv)[SQ_NGS] = H.gsv;
@@ -390,9 +398,16 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
       float g_ref[3], g_rough;
       int ci = col_v;
       asm volatile("" : "+v"(ci));
-      auto gq = [&](int q) { return GI[q * BT + ci]; };
+      /* (the read's address is tied to the recurrence value it is needed for: the 72 reads stay where they are used instead of
+       *  being hoisted in front of the recurrences and parked in scratch) */
+      auto gq = [&](int q, float &dep) {
+        int c2 = ci;
+        asm volatile("" : "+v"(c2), "+v"(dep));
+        return GI[q * BT + c2];
+      };
       if (cfg.dir_enc == REFNERF_DIRENC_POSENC) { posenc_grad(sh.refd[0], sh.refd[1], sh.refd[2], gq, g_ref); g_rough = 0.0f; }
       else ide_grad(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, gq, g_ref, g_rough);
+      __builtin_amdgcn_sched_barrier(0);
       const float g_dot = GI[IDE_DIM * BT + ci];
       const float w3[3] = {-v[0], -v[1], -v[2]};
       const float ndw = (sh.npred[0] * w3[0] + sh.npred[1] * w3[1]) + sh.npred[2] * w3[2];
