@@ -321,7 +321,9 @@ __device__ __forceinline__ void posenc_grad(float x, float y, float z, G g, floa
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const float sc = (float)(1 << j), sx = d[i] * sc;
-      acc += sc * (cosf(sx) * g(3 + 3 * j + i, dep) + cosf(sx + half_pi) * g(IDE_TERMS + 3 * j + i, dep));
+      /* (|sx| <= 16 |d|: the reduced kernels, 1.5 ulp -- the library's cosf carries its Payne-Hanek path and 16 registers of it
+       *  into every caller) */
+      acc += sc * (cos_reduced(sx) * g(3 + 3 * j + i, dep) + cos_reduced(sx + half_pi) * g(IDE_TERMS + 3 * j + i, dep));
     }
     gxyz[i] = acc;
   }

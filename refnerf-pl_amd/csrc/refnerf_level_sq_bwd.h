@@ -163,7 +163,10 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
       /* a wave whose 32 samples are all past the end keeps the stream going */
       if (gs_pass + wave * 32 >= A.S) { tq_idle_pass<true>(p); continue; }
     }
-    int col_v = col, h_v = h;
+    /* (lane constants of the pass from a lane index formed here: carried from the kernel's entry they sit in scratch) */
+    const int lane_p = fresh_lane();
+    const int lane = lane_p;                /* (shadows the entry value for the cycle stamps of the pass) */
+    int col_v = wave * 32 + (lane_p & 31), h_v = lane_p >> 5;
     asm volatile("" : "+v"(col_v), "+v"(h_v));
     const long long gs = gs_pass + col_v;
     const bool valid = gs < A.S;
@@ -538,10 +541,13 @@ __device__ __forceinline__ void level_bwd_sq_body(const SqBwdArgs &A) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  RN_STAMPW(A, 9);
+  {
+    const int lane = fresh_lane();          /* (shadows the entry value: that one then dies in front of the pass loop) */
+    RN_STAMPW(A, 9);
 #ifdef REFNERF_PROF_WAITS
-  if (A.prof && blockIdx.x == (gridDim.x >> 1) && lane == 0) { A.prof[wave * 32 + 20] = p.t_vm; A.prof[wave * 32 + 21] = p.t_bar; }
+    if (A.prof && blockIdx.x == (gridDim.x >> 1) && lane == 0) { A.prof[wave * 32 + 20] = p.t_vm; A.prof[wave * 32 + 21] = p.t_bar; }
 #endif
+  }
 }
 
 __global__ __launch_bounds__(BF_NTHREADS) void level_bwd_sq(const SqBwdArgs A) { level_bwd_sq_body(A); }

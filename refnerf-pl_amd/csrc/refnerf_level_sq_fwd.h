@@ -65,6 +65,13 @@ __device__ __forceinline__ unsigned win_load(const BlkWin &w, unsigned voff, int
   asm volatile("" : "+v"(voff));
   return __builtin_amdgcn_raw_buffer_load_b32(w.rs, voff + (unsigned)iunit * 256u, sunit * 256, 0);
 }
+/* this lane's index within the wave, formed HERE: asm volatile is neither hoisted out of a loop nor merged with the kernel's
+ * entry value -- a lane constant derived from it lives from this point on, not across every trunk in front of it */
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 /* a unit index the compiler must treat as a run-time scalar */
 __device__ __forceinline__ int opaque_s(int x) {
   asm volatile("" : "+s"(x));
@@ -97,11 +104,15 @@ __device__ __forceinline__ void tq_rendezvous(Pipe &p) {
 template <bool BWD>
 __device__ __forceinline__ void tq_issue(Pipe &p, int slot_off, int piece = -1) {
   if (p.dma_left > 0) {
-    if (p.wave < 6) {
-      lptr_t dst = (lptr_t)(p.wbuf + slot_off + p.wave * 3072);
+    /* (the wave index is laundered: its comparisons are then formed here -- one s_cmp each -- instead of being hoisted to the
+     *  kernel's entry as lane masks, which end up as VGPR booleans in scratch once the SGPRs run out) */
+    int wv = p.wave;
+    asm volatile("" : "+s"(wv));
+    if (wv < 6) {
+      lptr_t dst = (lptr_t)(p.wbuf + slot_off + wv * 3072);
       if (piece < 0 || piece == 0) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 0, REFNERF_DMA_AUX);
       if (piece < 0 || piece == 1) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 1024, REFNERF_DMA_AUX);
-      if ((piece < 0 || piece == 2) && p.wave < 5) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 2048, REFNERF_DMA_AUX);
+      if ((piece < 0 || piece == 2) && wv < 5) __builtin_amdgcn_global_load_lds((gptr_t)p.src, dst, 16, 2048, REFNERF_DMA_AUX);
     }
     if (piece >= 0 && piece < 2) return;
     p.src += BF_CHUNK_BYTES;
