@@ -13,6 +13,8 @@ import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "librefnerf_hip.so")
+if os.environ.get("REFNERF_LIB"):      # A/B builds of the library (scripts/build_*_variant.sh -> ab/*.so): a debug knob, never a fallback
+    LIB_PATH = os.path.abspath(os.environ["REFNERF_LIB"])
 
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X2 = 0, 1, 2, 3
 IMAGE_F16X2_TRAIN = 4   # REFNERF_IMAGE_F16X2_TRAIN: the weight image of the REFNERF_PREC_F16X2 training kernels (built-in basis)

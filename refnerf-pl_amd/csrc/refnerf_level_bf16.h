@@ -1011,6 +1011,9 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
     for (int e = 0; e < 16; ++e) { R0[e] = (v4uu){0, 0, 0, 0}; R1[e] = (v4uu){0, 0, 0, 0}; }
     {
     /* P4: head activations, reflection, IDE (k' = IDE index; half 0 real, half 1 imaginary) */
+    /* (ring variant, round 6: the phase's half-wave index from a lane index formed here -- what depends on the kernel's entry
+     *  value is hoisted in front of the pass loop and parked in scratch; the plain kernel keeps its proven allocation) */
+    const int h4 = RINGPS ? (fresh_lane() >> 5) : h;
     char *xs = Xb + col * 16;
     {
       SampleHeads sh;
@@ -1018,15 +1021,15 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
       float ide[40];
 #pragma unroll
       for (int q = 36; q < 40; ++q) ide[q] = 0.0f;
-      if (cfg.dir_enc == REFNERF_DIRENC_POSENC) posenc_eval<false, true>(sh.refd[0], sh.refd[1], sh.refd[2], h, [&](int q, float val) { ide[q] = val; });
-      else ide_eval<false>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h, [&](int q, float val) { ide[q] = val; });
-      if (h == 0) ide[36] = sh.dot;
+      if (cfg.dir_enc == REFNERF_DIRENC_POSENC) posenc_eval<false, true>(sh.refd[0], sh.refd[1], sh.refd[2], h4, [&](int q, float val) { ide[q] = val; });
+      else ide_eval<false>(sh.refd[0], sh.refd[1], sh.refd[2], sh.rough, h4, [&](int q, float val) { ide[q] = val; });
+      if (h4 == 0) ide[36] = sh.dot;
 #pragma unroll
       for (int q = 0; q < 5; ++q) {
         v8mm pk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pk[e] = (mm_t)ide[q * 8 + e];
-        *reinterpret_cast<v8mm *>(xs + (5 * h + q) * BT * 16) = pk;
+        *reinterpret_cast<v8mm *>(xs + (5 * h4 + q) * BT * 16) = pk;
       }
     }
     wave_sync();
@@ -1044,16 +1047,18 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
     v16f acc;
     bf_chunk<MM, BF_REG, 0, true, true>(p, ad, R1, bn, acc);
     float raw_rgb[3];
+    const int lane6 = RINGPS ? fresh_lane() : lane;
+    const int n6 = RINGPS ? (lane6 & 31) : n, h6 = RINGPS ? (lane6 >> 5) : h;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n, 64);
+    for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n6, 64);
     int g_w, rl_w; bool valid;
     locate(g_w, rl_w, valid);
-    int lane_w = lane, pass_w = pass0;
+    int lane_w = lane6, pass_w = pass0;
     asm volatile("" : "+v"(lane_w), "+s"(pass_w));
-    if (valid && h == 0) {                                                            /* P6 */
+    if (valid && h6 == 0) {                                                           /* P6 */
       SampleHeads sh;
       load_heads(sh);
-      colour_store<false, NPS_EVAL, PSM, true>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
+      colour_store<false, NPS_EVAL, PSM, true, RINGPS>(A, sh, raw_rgb, PS, PX, n_tot, g_w, RINGPS ? wave * 32 + n6 : col);
     }
     wave_sync();
     history_flush<NPS_EVAL, PSM>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);

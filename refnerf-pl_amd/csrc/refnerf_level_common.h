@@ -228,6 +228,15 @@ __device__ __forceinline__ void sample_intervals_wave(const float *t_in, float *
   __builtin_amdgcn_wave_barrier();
 }
 
+/* this lane's index within the wave, formed HERE (round 6): asm volatile is neither hoisted out of a loop nor merged with the
+ * kernel's entry value -- a lane constant derived from it lives from this point on, not across every trunk in front of it (in
+ * scratch, once the kernel sits at its register limit) */
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 __device__ __forceinline__ void st3(float *base, size_t idx, float a, float b, float c) {
   if (base) { base[idx * 3 + 0] = a; base[idx * 3 + 1] = b; base[idx * 3 + 2] = c; }
 }
@@ -324,7 +333,9 @@ __device__ __forceinline__ int ps_row(int g) { return PSM ? (g & PSM) : g; }
 
 /* FAST_SRGB: the 5/12 power of the sRGB curve through v_log_f32 / v_exp_f32 (2-3 ulp) instead of the library powf (nine
  * calls of ~100 instructions per sample); set by the split-f16 kernel, whose other transcendentals stay libm-accurate */
-template <bool FAST = false, int NP = NPS_TRAIN, int PSM = 0, bool FAST_SRGB = FAST>
+/* PAD_HERE: rgb_padding is laundered, so that the padding scale is formed here (two VALU instructions) instead of at the kernel's
+ * entry, from where it rides in a VGPR -- in scratch -- to this phase (the split-f16 training forward, round 6) */
+template <bool FAST = false, int NP = NPS_TRAIN, int PSM = 0, bool FAST_SRGB = FAST, bool PAD_HERE = false>
 __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHeads &s, const float raw_rgb[3],
                                              float *PS, float *PX, int n_tot, int g_sample, int gcol) {
   const int g = ps_row<PSM>(g_sample);
@@ -353,9 +364,11 @@ __device__ __forceinline__ void colour_store(const LevelArgs &A, const SampleHea
 #pragma unroll
     for (int i = 0; i < 3; ++i) { dif[i] = dif_lin[i]; spc[i] = spec_lin[i]; }
   }
-  const float pad_scale = (float)(1.0 + 2.0 * (double)cfg.rgb_padding);
+  float pad = cfg.rgb_padding;
+  if (PAD_HERE) asm volatile("" : "+s"(pad));
+  const float pad_scale = (float)(1.0 + 2.0 * (double)pad);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] * pad_scale - cfg.rgb_padding;
+  for (int i = 0; i < 3; ++i) rgb[i] = rgb[i] * pad_scale - pad;
   PS[g * NP + PS_DENSITY] = s.density;
   PS[g * NP + PS_ROUGH] = s.rough;
 #pragma unroll

@@ -65,13 +65,6 @@ __device__ __forceinline__ unsigned win_load(const BlkWin &w, unsigned voff, int
   asm volatile("" : "+v"(voff));
   return __builtin_amdgcn_raw_buffer_load_b32(w.rs, voff + (unsigned)iunit * 256u, sunit * 256, 0);
 }
-/* this lane's index within the wave, formed HERE: asm volatile is neither hoisted out of a loop nor merged with the kernel's
- * entry value -- a lane constant derived from it lives from this point on, not across every trunk in front of it */
-__device__ __forceinline__ int fresh_lane() {
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
-}
 /* a unit index the compiler must treat as a run-time scalar */
 __device__ __forceinline__ int opaque_s(int x) {
   asm volatile("" : "+s"(x));
@@ -132,10 +125,14 @@ __device__ __forceinline__ void tq_rotate(Pipe &p) {
   p.nxt_off = p.fil_off;
   p.fil_off = t;
 }
+/* (round 6) the forward's extra workgroup barrier between the second run's VJP and the directional phase (see P4): an idle wave
+ * joins it at the same place in the barrier sequence, behind the 2 TR_RUN rendezvous of the two runs */
+__device__ __forceinline__ void tq_phase_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <bool BWD>
 __device__ __forceinline__ void tq_idle_pass(Pipe &p) {
 #pragma unroll 1
   for (int c = 0; c < (BWD ? TR_BWD : TR_FWD_PASS); ++c) {
+    if (!BWD && c == 2 * TR_RUN) tq_phase_barrier();
     tq_rendezvous<0>(p);
     tq_issue<BWD>(p, p.fil_off);
     tq_rotate(p);
@@ -772,6 +769,11 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
       RN_STAMPW(A, 7 + phase * 4);
     }
     RN_STAMPW(A, 12);
+    /* (round 6) the IDE planes this phase writes (columns 32 w .. 32 w + 31 of k-groups 0..9) are the IPE planes of OTHER waves'
+     * runs (columns 16 u .. of the hi / lo halves), where the VJP keeps its d feature / d mean factors and reads the last eight of
+     * them BEHIND the final rendezvous of the run: every wave is through with them before any wave overwrites them.  (The window was
+     * a few hundred cycles against this phase's ~10 k of arithmetic in front of its first store -- never observed, not excluded.) */
+    tq_phase_barrier();
 #pragma unroll
     for (int e = 0; e < 16; ++e) { R0[e] = (v4uu){0, 0, 0, 0}; R1[e] = (v4uu){0, 0, 0, 0}; }
     {

