@@ -63,8 +63,12 @@ int main(int argc, char **argv) {
   float *d_params = dmalloc<float>(REFNERF_NUM_PARAMS);
   HIP_OK(hipMemcpy(d_params, params.data(), REFNERF_NUM_PARAMS * sizeof(float), hipMemcpyHostToDevice));
   void *d_packed = nullptr;
-  // training levels read the f32 image; the split-f16 chains (built-in IPE basis) stream their own (ABI v10)
-  const int image = chains == REFNERF_PREC_F16X2 ? REFNERF_IMAGE_F16X2_TRAIN : REFNERF_PREC_F32;
+  // which weight image a training level of this arithmetic streams: the library's own rule (ABI v11: refnerf_level_image)
+  refnerf_level_cfg icfg;
+  refnerf_level_cfg_default(&icfg);
+  icfg.training = 1;
+  icfg.precision = chains;
+  const int image = refnerf_level_image(&icfg);
   HIP_OK(hipMalloc(&d_packed, refnerf_packed_weights_bytes(image)));
   RN_OK(refnerf_pack_weights(d_params, d_packed, image, nullptr));
 

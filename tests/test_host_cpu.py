@@ -474,3 +474,32 @@ def test_level_image_rule_lives_in_the_library():
     assert _hip.level_image(F32, True) == F32 and _hip.level_image(BF16, True) == F32      # the f32 image carries the bf16 chain ops
     assert _hip.level_image(F16X2, True) == (F32 if _hip.LEGACY_F16X2_TRAIN else _hip.IMAGE_F16X2_TRAIN)
     assert _hip.level_image(F16X2, True, 7) == F32
+
+
+def test_every_roofline_names_its_profile():
+    """every PMC-derived figure of a bench line is reproducible from THIS round's committed profiles --
+    profiles/traffic.json holds entries of one round only, the per-kernel summary each entry was condensed from exists under
+    profiles/<round>/, and bench.py's roofline helpers name that file (`traffic_source`, `pmc_source`) for the headline kernel, the
+    C3 ring variant and the kernels of the training step."""
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    rounds = {v["round"] for k, v in prof.items() if not k.startswith("_")}
+    assert rounds == {"r06"}, rounds
+    for key in prof:
+        if key.startswith("_"):
+            continue
+        kernel, _, cfg = key.partition("@")
+        f = os.path.join(root, "profiles", "r06", f"pmc_{kernel.split('::')[-1]}{'_' + cfg if cfg else ''}.csv")
+        assert os.path.exists(f), f
+    assert os.path.exists(os.path.join(root, "profiles", "r06", "kernel_stats.csv")) and os.path.exists(os.path.join(root, "profiles", "r06", "kernel_stats_C3.csv"))
+    for kernel, cfg, rays, n in (("rn::level_fwd_f16x2", "C2", 4096, 128), ("rn::level_fwd_f16x2_ring", "C3", 8192, 192),
+                                 ("rn::level_fwd_train_sq_h", "C2", 4096, 128), ("rn::level_bwd_sq", "C2", 4096, 128),
+                                 ("rn::wgrad_sq256_kernel", "C2", 4096, 128)):
+        r = bench.mfma_roofline("f16x2", kernel, 2.0, 1, 1e12, cfg, rays, n)
+        assert r["traffic"] and "profiles/r06/pmc_" in r["traffic_source"], (kernel, r)
+        assert "profiles/r06/pmc_" in r.get("pmc_source", ""), (kernel, r)
+    line = bench.compact_line({"metric": "m", "value": 1.0, "dtype": "f16x2", "roofline": bench.mfma_roofline("f16x2", "rn::level_fwd_f16x2", 2.0, 1, 1e12, "C2", 4096, 128),
+                               "timed_blocks": {"blocks": 5, "reported": "median", "ms_per_step": [1, 2, 3, 4, 5]}})
+    assert line["roofline"]["pmc_source"].startswith("profiles/r06/pmc_level_fwd_f16x2.csv") and line["timed_blocks"]["blocks"] == 5
