@@ -68,7 +68,12 @@ constexpr bool ENC_FAST = true;
 constexpr int BT = 256;                               /* samples per pass: 8 waves x 32 */
 constexpr int BF_NW = 8;                              /* waves per workgroup */
 constexpr int BF_NTHREADS = 64 * BF_NW;
-constexpr int BF_RING_BYTES = 3 * BF_CHUNK_BYTES;     /* 51 KB */
+/* REFNERF_RING_SLOTS = 4 (round 6): a fourth ring slot = TWO chunk-times between the issue of a chunk's LDS-DMA and the rendezvous
+ * that certifies it (the 3-slot ring gives one) */
+#ifndef REFNERF_RING_SLOTS
+#define REFNERF_RING_SLOTS 3
+#endif
+constexpr int BF_RING_BYTES = REFNERF_RING_SLOTS * BF_CHUNK_BYTES;     /* 51 KB (68 KB with four slots) */
 constexpr int BF_X_BYTES = (IPE_DIM / 8) * BT * 16;   /* 12 k-groups x 256 x 16 B = 48 KB */
 #ifndef REFNERF_BF_AF
 #define REFNERF_BF_AF 2
@@ -90,6 +95,7 @@ struct Pipe {
   const char *xps;   /* split mode: this lane's B fragment in the IPE planes of a run (hi plane; the lo plane (BT / 2) * 16 bytes behind) */
   int seq;           /* split mode: chunks issued so far in this pass (the spatial section is streamed twice) */
   int cur_off, nxt_off, fil_off;   /* ring slots: being consumed / landed next / free */
+  int nx2_off;                     /* four-slot ring: the chunk behind `nxt` (in flight or landed) */
   int dma_left;      /* chunks still to be DMA'd by this workgroup */
   int lane, wave, h;
   long long t_vm, t_bar;   /* debug (REFNERF_PROF): cycles spent in the DMA wait / in the barrier */
@@ -116,7 +122,12 @@ struct Pipe {
 #ifndef REFNERF_BARE_BARRIER
 #define REFNERF_BARE_BARRIER 0
 #endif
-#if REFNERF_BARE_BARRIER
+#if REFNERF_RING_SLOTS == 4
+/* four slots: chunk c + 1 must have landed, chunk c + 2 (<= 3 pieces per wave, wave 5: 2) may still fly: vmcnt(2) certifies c + 1 for
+ * every wave (loads return in order).  No __syncthreads(): its fence is vmcnt(0); wavefront-scope fences keep the allocator sane. */
+#define RN_RENDEZVOUS() do { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#elif REFNERF_BARE_BARRIER
 /* (round 6) the wavefront-scope fences emit no instruction, but without them the register allocator spills 129-154 VGPRs in
  * these kernels: round 5's "bare barrier is 11 % slower" was that spill.  Measured with the fences (0 spills): f16x2 3.86 ->
  * 3.86 ms per C2 step, bf16 2.077 -> 2.067: the lgkmcnt(0) drain of __syncthreads()' fence costs nothing here; it stays. */
@@ -125,6 +136,17 @@ struct Pipe {
 #else
 #define RN_RENDEZVOUS() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 #endif
+__device__ __forceinline__ void ring_rotate(Pipe &p) {
+  const int t = p.cur_off;
+  p.cur_off = p.nxt_off;
+#if REFNERF_RING_SLOTS == 4
+  p.nxt_off = p.nx2_off;
+  p.nx2_off = p.fil_off;
+#else
+  p.nxt_off = p.fil_off;
+#endif
+  p.fil_off = t;
+}
 template <bool SPLIT = false>
 __device__ __forceinline__ void issue_chunk(Pipe &p, int slot_off, int piece = -1) {
   if (p.dma_left > 0) {
@@ -261,10 +283,7 @@ __device__ __forceinline__ void bf_chunk(Pipe &p, typename MM::v8 (&a)[AF], cons
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  const int t = p.cur_off;
-  p.cur_off = p.nxt_off;
-  p.nxt_off = p.fil_off;
-  p.fil_off = t;
+  ring_rotate(p);
 }
 
 /* A wave whose 32 samples of this pass are all past the end (the partly filled last pass of a workgroup: N = 192 puts 384
@@ -275,13 +294,9 @@ template <bool SPLIT = false>
 __device__ __forceinline__ void idle_pass(Pipe &p) {
 #pragma unroll 1
   for (int c = 0; c < (SPLIT ? SPPACKED.chunks_per_pass : BFPACKED.chunks_per_pass); ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    RN_RENDEZVOUS();
     issue_chunk<SPLIT>(p, p.fil_off);
-    const int t = p.cur_off;
-    p.cur_off = p.nxt_off;
-    p.nxt_off = p.fil_off;
-    p.fil_off = t;
+    ring_rotate(p);
   }
 }
 
@@ -357,13 +372,16 @@ __device__ __forceinline__ void level_fwd_mm(const LevelArgs &A) {
   p.src_end = p.src + (size_t)BFPACKED.chunks_per_pass * BF_CHUNK_BYTES;
   p.wbuf = WB;
   p.xp = Xb + (h * BT + col) * 16;
-  p.cur_off = 0; p.nxt_off = BF_CHUNK_BYTES; p.fil_off = 2 * BF_CHUNK_BYTES;
+  p.cur_off = 0; p.nxt_off = BF_CHUNK_BYTES; p.nx2_off = 2 * BF_CHUNK_BYTES; p.fil_off = (REFNERF_RING_SLOTS - 1) * BF_CHUNK_BYTES;
   p.dma_left = n_pass * BFPACKED.chunks_per_pass;
   p.lane = lane; p.wave = wave; p.h = h;
   p.t_vm = 0; p.t_bar = 0;
   RN_STAMPW(A, 0);
   issue_chunk(p, p.cur_off);                                 /* overlaps with the resampler */
   issue_chunk(p, p.nxt_off);
+#if REFNERF_RING_SLOTS == 4
+  issue_chunk(p, p.nx2_off);
+#endif
 
   resample_phase<BF_NW, false>(A, reinterpret_cast<float *>(Xb), TD, NRM, ray0, wave, lane);   /* P0 */
   RN_STAMPW(A, 1);
@@ -695,10 +713,7 @@ __device__ __forceinline__ void sq_chunk(Pipe &p, sq_v8 (&fr)[SQ_NF], const v4uu
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  const int t = p.cur_off;
-  p.cur_off = p.nxt_off;
-  p.nxt_off = p.fil_off;
-  p.fil_off = t;
+  ring_rotate(p);
 }
 /* piece q (0..3) of a slice's epilogue: accumulator values (2 q, 2 q + 1) of the eight a lane holds -> NaN-propagating ReLU,
  * hi / lo split -> dword q of the next layer's H and L fragments of k-step `slice` */
@@ -802,7 +817,7 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
    * reads k-group 4 s + b of k-step s: hi plane, the lo plane (BT / 2) * 16 bytes behind */
   p.xps = Xb + ((lane >> 4) * BT + wave * 16 + (lane & 15)) * 16;
   p.seq = 0;
-  p.cur_off = 0; p.nxt_off = BF_CHUNK_BYTES; p.fil_off = 2 * BF_CHUNK_BYTES;
+  p.cur_off = 0; p.nxt_off = BF_CHUNK_BYTES; p.nx2_off = 2 * BF_CHUNK_BYTES; p.fil_off = (REFNERF_RING_SLOTS - 1) * BF_CHUNK_BYTES;
   p.dma_left = n_pass * SPPACKED.chunks_per_pass;
   p.lane = lane; p.wave = wave; p.h = h;
   p.t_vm = 0; p.t_bar = 0;
@@ -812,6 +827,9 @@ __device__ __forceinline__ void level_fwd_split(const LevelArgs &A) {
 #endif
   issue_chunk<true>(p, p.cur_off);                           /* overlaps with the resampler */
   issue_chunk<true>(p, p.nxt_off);
+#if REFNERF_RING_SLOTS == 4
+  issue_chunk<true>(p, p.nx2_off);
+#endif
 
   resample_phase<BF_NW, true>(A, reinterpret_cast<float *>(Xb), TD, NRM, ray0, wave, lane);   /* P0: bit-exact CDF */
   /* (the EXACT resampler leaves the ray geometry to its caller: park it here as the plain kernel's does) */
