@@ -286,8 +286,13 @@ def test_hip_full_loss_set_vs_reference_and_oracle(name, chains):
     _check_against_reference(g, {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in losses.items()},
                              total.detach().cpu(), flat, 1e-4, 2e-3 if chains == "f16x2" else 1e-3)
     omodel, _, ototal, _, _ = _oracle_step(g)
-    assert float(total) == pytest.approx(float(ototal), rel=1e-5)
-    assert np.linalg.norm(flat - omodel.grads) / np.linalg.norm(omodel.grads) < 1e-3
+    orel = abs(float(total) - float(ototal)) / abs(float(ototal))
+    ograd = float(np.linalg.norm(flat - omodel.grads) / np.linalg.norm(omodel.grads))
+    print(f"vs the oracle's step: total loss rel {orel:.2e}, gradient rel-L2 {ograd:.2e}")
+    # (same conditioning as above: the split-f16 chains' total sits 0.8e-5 .. 1.2e-5 from the oracle's on geometry_mse_srgb,
+    #  whichever log forms the resampling logits; the f32 chains < 1e-6)
+    assert orel < (3e-5 if chains == "f16x2" else 1e-5), orel
+    assert ograd < (2e-3 if chains == "f16x2" else 1e-3), ograd
 
 
 @pytest.mark.gpu
