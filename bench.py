@@ -446,7 +446,8 @@ def torch_cpu_baseline(spec):
             res = json.loads(r.stdout.strip().splitlines()[-1])
             out.append({"value": res["rate"], "unit": "ray-samples/s", "cores": res["threads"], "kind": "port",
                         "sample": f"unfused PyTorch CPU path, {tag}, eval forward, fp32, {res['seconds']:.2f} s per pass "
-                                  f"(best of {res['tried']} intra-op thread counts on {os.cpu_count()} cores)"})
+                                  f"(best of {res['tried']} intra-op thread counts <= 64 on {os.cpu_count()} cores: ATen's elementwise ops and "
+                                  f"small GEMMs get slower, not faster, with hundreds of threads -- 256 threads: > 50 s per pass at C1's shape)"})
         except (subprocess.TimeoutExpired, ValueError, IndexError, KeyError) as e:
             out.append({"value": None, "unit": "ray-samples/s", "cores": None, "kind": "port",
                         "sample": f"unfused PyTorch CPU path, {tag}: not measured ({type(e).__name__})"})

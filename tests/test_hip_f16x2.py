@@ -765,3 +765,46 @@ def test_shipped_config_runs_the_mode_of_record(hip):
     assert torch.equal(out["shipped"], out["f16x2"]) and not torch.equal(out["shipped"], out["f32"])
     assert float((out["shipped"] - out["f32"]).abs().max()) < 1e-4
     configs.clear_config()
+
+
+def test_non_finite_training_loss_is_loud(hip):
+    """weights that push hidden activations of the split-f16 chains beyond 65504 turn the level's outputs into NaN; the
+    loss assembly (train_utils.compute_losses, Config.hip_check_finite) raises FloatingPointError one step later at the latest
+    (its device flag is read without a synchronisation when the next step asks) and names the knobs that lift the limit; the
+    exact-fp32 chains train through the same weights."""
+    import os
+    import torch
+    from refnerf_pl_amd import configs, layout, models, synthetic, train_utils, utils
+    P = synthetic.make_params(seed=0, bias_scale=0.05, sharpen=1.0)
+    for name in ("spatial_net.2", "spatial_net.3"):
+        sp = layout.SPEC_BY_NAME[name]
+        P[sp.w_off:sp.w_off + sp.out_dim * sp.in_dim] *= 3000.0
+    nxt = layout.SPEC_BY_NAME["spatial_net.4"]
+    P[nxt.w_off:nxt.w_off + nxt.out_dim * nxt.in_dim] /= 9e6
+    rays_np = synthetic.blender_rays(64, seed=2, center_frac=0.6)
+    gt = synthetic.target_rgb(64, seed=5)
+    for chains in ("f16x2", "f32"):
+        configs.clear_config()
+        configs.parse_config_files_and_bindings([os.path.join(os.path.dirname(__file__), "..", "configs", "refnerf_blender.gin")],
+                                                ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 64",
+                                                 f"Config.hip_train_precision = '{chains}'", f"Config.hip_bwd_precision = '{chains}'"])
+        cfg = configs.Config()
+        model = models.construct_model(utils.dummy_rays(), cfg).to(DEV).train()
+        model.nerf_mlp.load_flat_params(P)
+        rays = utils.rays_from_dict(dict(rays_np), DEV)
+        batch = utils.Batch(rays=rays, rgb=gt)
+        train_utils.flush_finite_check(cfg)
+
+        def step():
+            rend, hist = model(rays, 1.0, False)
+            return train_utils.compute_losses(model, batch, rays, rend, hist, cfg)[0]
+        if chains == "f16x2":
+            total = step()
+            assert not bool(torch.isfinite(total))
+            with pytest.raises(FloatingPointError, match="hip_train_precision"):
+                step()                                   # the flag of the step before is read here
+                train_utils.flush_finite_check(cfg)      # (not reached)
+        else:
+            assert bool(torch.isfinite(step())) and bool(torch.isfinite(step()))
+            train_utils.flush_finite_check(cfg)
+    configs.clear_config()
