@@ -218,9 +218,9 @@ class Config:
     render_spline_smoothness: float = .03
     # build-side knobs (not in the reference).  hip_precision = arithmetic of the MLP contractions of inference levels:
     # 'f32' (exact fp32 MFMA chains: the strict parity mode and the default of THIS CLASS -- no operand-range limit), 'f16x2'
-    # (split-operand f16 MFMA: the parity-grade fast mode of record -- on trained weights 99.99 % of the rays within 1e-4 RGB of
-    # the reference, single grazing rays up to 1.8e-4 where the reference's own fp32 rounding is that far from its float64
-    # value (the f32 mode likewise) --, 4x faster; hidden activations beyond 65504 turn into NaN
+    # (split-operand f16 MFMA: the parity-grade fast mode of record -- on trained weights within 1e-4 RGB of the reference on all
+    # but single grazing rays of a batch (<= 2 of 8192, up to 1.8e-4), where the reference's own fp32 rounding is that far from its
+    # float64 value (the f32 mode likewise) --, 4x faster; hidden activations beyond 65504 turn into NaN
     # outputs), 'bf16' / 'f16' (throughput modes: within 1e-4 on
     # random-init networks only).  The shipped configs/refnerf_*.gin set all three knobs to 'f16x2' (INTEGRATION.md section A).
     hip_precision: str = 'f32'
