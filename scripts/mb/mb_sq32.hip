@@ -76,9 +76,12 @@ __global__ __launch_bounds__(64 * NW) void trunk(const char *img, float *out, lo
   for (int t = 0; t < TILES; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) { R0[t][e] = (v4u){0x3c003c00u + lane + t, 0x3800u + e, 0x34003400u, 0x3c00u}; R1[t][e] = (v4u){0, 0, 0, 0}; }
-  v8h fr[4];
+#ifndef NFR
+#define NFR 4        /* fragment ring depth in pieces: 4 = one k-step ahead (shipped), 8 = two */
+#endif
+  v8h fr[NFR];
 #pragma unroll
-  for (int d = 0; d < 4; ++d) fr[d] = *reinterpret_cast<const v8h *>(WB + 1024 + lane * 16 + d * 1024);
+  for (int d = 0; d < NFR; ++d) fr[d] = *reinterpret_cast<const v8h *>(WB + 1024 + lane * 16 + d * 1024);
 
   /* one chunk: 4 k-steps x [WhT0 H | WhT1 H | WlT0 H | WlT1 H | WhT0 L | WhT1 L] per tile; pieces 4 s .. 4 s + 3; HALF = 0 / 1 = SQ_A / SQ_B */
   auto chunk = [&](const v4u (&in)[TILES][16], Acc (&acc)[TILES], int half, auto &&hook) {
@@ -92,24 +95,31 @@ __global__ __launch_bounds__(64 * NW) void trunk(const char *img, float *out, lo
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
           const v8h b = __builtin_bit_cast(v8h, in[t][2 * (4 * half + s) + (lo ? 1 : 0)]);
-          if (j & 1) acc[t].t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[piece], b, acc[t].t1, 0, 0, 0);
-          else acc[t].t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[piece], b, acc[t].t0, 0, 0, 0);
+          if (j & 1) acc[t].t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[(4 * s + piece) % NFR], b, acc[t].t1, 0, 0, 0);
+          else acc[t].t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[(4 * s + piece) % NFR], b, acc[t].t0, 0, 0, 0);
         }
         /* release: pieces 2, 3 after j = 2, 3 (their last use), pieces 0, 1 after j = 4, 5 */
         const int rel = j == 2 ? 2 : (j == 3 ? 3 : (j == 4 ? 0 : (j == 5 ? 1 : -1)));
         if (rel >= 0) {
-          const int q = 4 * s + rel + 4;
-          fr[rel] = q < 16 ? *reinterpret_cast<const v8h *>(c + q * 1024) : *reinterpret_cast<const v8h *>(n + (q - 16) * 1024);
+          const int q = 4 * s + rel + NFR;
+          /* (NFR = 8: the ring runs into the next chunk from k-step 2 on -- behind the rendezvous of k-step 1, as it must) */
+          fr[(4 * s + rel) % NFR] = q < 16 ? *reinterpret_cast<const v8h *>(c + q * 1024) : *reinterpret_cast<const v8h *>(n + (q - 16) * 1024);
         }
         hook(6 * s + j);
         if (s == 1 && j == 5) {          /* mid-chunk rendezvous: chunk c + 1 landed for every wave, slot of c - 1 free */
 #ifndef NOBAR
+#ifdef BAREBAR
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
 #endif
+#endif
           issue(fil);
         }
+#ifndef NOSCHED
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
     const int tmp = cur; cur = nxt; nxt = fil; fil = tmp;
