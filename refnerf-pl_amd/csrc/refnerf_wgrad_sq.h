@@ -507,13 +507,285 @@ __device__ __forceinline__ void wgrad_sq256_body(const WgradSqArgs &A, int slice
   }
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Round 6: the one-half jobs WITHOUT the conversion pass (wgrad_sq256_raw_body).  The ring holds the operands as they lie in
+ * HBM -- pair units: one dword = rows 2p, 2p + 1 of one sample -- and every wave turns pair units into MFMA operands when it
+ * loads its fragments: a lane's eight dwords of pair row p are the k-halves of rows 2p AND 2p + 1, so the even rows of 32 pair
+ * rows are one 32-row operand block and the odd rows the next (v_perm_b32; the common factor K / c_s as the halves (f_2t,
+ * f_2t+1) multiplies the operand dword of samples 2t, 2t + 1).  No T, no second barrier, no LDS round trip of the converted
+ * tile, and the LDS that T took is a fourth ring slot.
+ * Ring slot = [D: 128 pair rows x 128 B | A: 128 pair rows x 128 B | c: 8 waves x 128 B]; 16-B chunk c of pair row p at chunk
+ * c ^ (p & 7) (the DMA lane picks its global chunk accordingly: the swizzle is free).
+ * What bounds the compute side is the SIMD's one issue port: a k-step is 16 MFMAs (32 cycles each) + ~100 VALU instructions
+ * per wave, two waves per SIMD in lockstep (one barrier per k-step).  Measured on the way (docs/EXPERIMENTS.md section 11): the
+ * conversion at fragment-load time but phase by phase (loads, wait, convert, 8 MFMAs) 2.17 -> 1.89 ms; the same with the loads
+ * half a k-step ahead but the MFMAs still back to back: 2.04 (VALU time and MFMA time simply add); every MFMA followed by the
+ * 4 - 8 VALU instructions that fit under it, the D fragment of the NEXT half k-step among them: 1.75; scalar DMA bases, the
+ * second factor on a scalar branch, bias sums on one wave per SIMD only: 1.71 ms = 0.67 of 8 TB/s (DMA alone: 1.63).
+ * ------------------------------------------------------------------------------------------------------------------------- */
+constexpr int SQ3_NS = 4;
+#ifndef REFNERF_SQ3_SPLIT
+#define REFNERF_SQ3_SPLIT 32768.0f     /* (a smaller power of two sends every k-step through the two-factor path: a test build, same arithmetic) */
+#endif
+constexpr float SQ3_SPLIT = REFNERF_SQ3_SPLIT;
+constexpr int SQ3_OP = 128 * 128;                       /* one operand of a k-step: 128 pair rows x 32 samples x 4 B */
+constexpr int SQ3_SLOT = 2 * SQ3_OP + 8 * 128;
+constexpr int SQ3_FS = SQ3_NS * SQ3_SLOT;               /* per wave: two buffers of a k-step's factors as halves, f and g: 2 x 2 x 64 B */
+constexpr int SQ3_LDS = SQ3_FS + 8 * 256;
+static_assert(SQ3_NS == 4 && SQ3_LDS <= SQ2_LDS, "inside the kernel's LDS");
+typedef _Float16 sqw_h2 __attribute__((ext_vector_type(2)));
+
+#ifdef REFNERF_EXPERIMENT_SQ3_NOMFMA
+#define SQ3_MFMA(a, b, c, x, y, z) ({ asm volatile("" ::"v"(a), "v"(b)); (c); })
+#else
+#define SQ3_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
+#endif
+/* BIAS: this wave carries the bias sums of its 64 rows (the waves of column half 0 of a job with a bias: one per SIMD) */
+template <bool BIAS>
+__device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int slice, int ji, const float *__restrict__ kmin_all) {
+  extern __shared__ __attribute__((aligned(16))) char wbs[];
+  constexpr int NS = SQ3_NS, VM = 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, sl = lane & 31;
+  const int wm = wave & 3, wn = wave >> 2;      /* (waves w and w + 4 share a SIMD: one of each column half) */
+  const WJob J = WJOBS_SQ.job[ji].j;
+  const int a_unit = WJOBS_SQ.job[ji].a_unit;
+  const bool halfrows = WJOBS_SQ.job[ji].half != 0;
+  const long long k_begin = (long long)slice * A.k_per_slice;
+  long long k_end = k_begin + A.k_per_slice;
+  const long long s_pad = (A.S + RB - 1) / RB * RB;
+  if (k_end > s_pad) k_end = s_pad;
+  const int nsteps = (int)((k_end - k_begin + SQ2_KT - 1) / SQ2_KT);
+  const int lid = del_layer_id(J.d_row);
+  const float kmin = kmin_all[lid];
+  const bool have = kmin < INFINITY;
+
+  v16f acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  float bsum[2] = {0.0f, 0.0f};
+
+  /* DMA: lane -> pair row 64 q + tid / 8 of both operands, global chunk (tid & 7) ^ (row & 7), LDS chunk tid & 7 */
+  const int p0 = tid >> 3, c4 = (((tid & 7) ^ (p0 & 7)) & 7) * 4;
+  const int aup = halfrows ? 1 : 2;
+  const int dlast = (J.n_out - 1) / 2, alast = (J.n_in - 1) / 2;
+  /* address = a scalar base (matrix + the k-step's place in it: the same for every lane, SALU work) + a lane offset that
+   * never changes (32 bits: the units of one 64-sample block span < 1 MB) */
+  unsigned doff[2], aoff[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pd = min(p0 + 64 * q, dlast), pa = min(p0 + 64 * q, alast);
+    doff[q] = (unsigned)(((J.d_row / 2 + pd) * RB + c4) * 4);
+    aoff[q] = (unsigned)(((a_unit + pa * aup) * RB + c4) * 4);
+  }
+  const unsigned coff = (unsigned)(((DQ_C + lid) * RB + (lane & 7) * 4) * 4);
+  const char *dmat = reinterpret_cast<const char *>(A.delta), *amat = reinterpret_cast<const char *>(A.act);
+  const int kh0 = __builtin_amdgcn_readfirstlane((int)(k_begin >> 5)), nst = __builtin_amdgcn_readfirstlane(nsteps);
+  auto issue = [&](int s, int slot) {
+    const int kh = kh0 + (s < nst ? s : nst - 1);                    /* k / 32: 64-sample block kh / 2, half kh & 1 */
+    const char *db = dmat + ((long long)(kh >> 1) * (DQ_UNITS * RB * 4) + (kh & 1) * 128);
+    const char *ab = amat + ((long long)(kh >> 1) * (AQ_UNITS * RB * 4) + (kh & 1) * 128);
+    char *base = wbs + slot * SQ3_SLOT + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      __builtin_amdgcn_global_load_lds((sq2_gptr)(db + doff[q]), (sq2_lptr)(base + q * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((sq2_gptr)(ab + aoff[q]), (sq2_lptr)(base + SQ3_OP + q * 8192), 16, 0, 0);
+    }
+    if (lane < 8) __builtin_amdgcn_global_load_lds((sq2_gptr)(db + coff), (sq2_lptr)(wbs + slot * SQ3_SLOT + 2 * SQ3_OP + wave * 128), 16, 0, 0);
+  };
+  /* fragment addresses: pair row (wm 32 + sl) of D, (wn 64 + jj 32 + sl) of A; logical chunk 4 kk + 2 h + e at ^ (sl & 7) */
+  const int x7 = sl & 7;
+  int choff[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) choff[kk][e] = (((4 * kk + 2 * h + e) ^ x7) & 7) << 4;
+  int rowD = (wm * 32 + sl) * 128, rowA = SQ3_OP + (wn * 64 + sl) * 128;
+  /* per wave, two buffers (k-step parity) of the k-step's factors as halves: f of sample k at + 2 k, g at + 64 + 2 k */
+  int fsl = SQ3_FS + wave * 256 + h * 16, fsw = SQ3_FS + wave * 256 + sl * 2, cvr = 2 * SQ3_OP + wave * 128 + sl * 4;
+  const unsigned one2 = 0x3c003c00u;
+  typedef unsigned v4uu __attribute__((ext_vector_type(4)));
+  auto frag = [](const v4uu w0, const v4uu w1, unsigned sel) {
+    v4uu r;
+    r[0] = __builtin_amdgcn_perm(w0[1], w0[0], sel);
+    r[1] = __builtin_amdgcn_perm(w0[3], w0[2], sel);
+    r[2] = __builtin_amdgcn_perm(w1[1], w1[0], sel);
+    r[3] = __builtin_amdgcn_perm(w1[3], w1[2], sel);
+    return r;
+  };
+  /* one half k-step (16 samples) of this wave's fragments as they lie in the ring: 6 x 16 B per lane */
+  struct Half { v4uu d0, d1, a[2][2]; };
+  struct Fac { v4uu f, g; };
+  auto load_half = [&](int so, int kk) {
+    Half H;
+    H.d0 = *reinterpret_cast<const v4uu *>(wbs + so + rowD + choff[kk][0]);
+    H.d1 = *reinterpret_cast<const v4uu *>(wbs + so + rowD + choff[kk][1]);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) H.a[jj][e] = *reinterpret_cast<const v4uu *>(wbs + so + rowA + jj * 4096 + choff[kk][e]);
+    return H;
+  };
+  auto load_fac = [&](int buf, int kk, bool with_g) {
+    Fac F;
+    F.f = *reinterpret_cast<const v4uu *>(wbs + fsl + buf * 128 + kk * 32);
+    F.g = F.f;
+    if (with_g) F.g = *reinterpret_cast<const v4uu *>(wbs + fsl + buf * 128 + kk * 32 + 64);
+    return F;
+  };
+  /* the k-step's 32 factors K / c_s, one per lane (both halves of the wave the same): f = min(x, 2^15) and -- a sample whose
+   * stored deltas are all below 1 -- g = x / 2^15, as halves; an operand dword after the unpair holds samples 2 t, 2 t + 1 of
+   * one row, so it takes the halves (f_2t, f_2t+1) as they lie */
+  auto put_factors = [&](float cvv, int s, int buf) {
+    const long long left = A.S - (k_begin + (long long)s * SQ2_KT);
+    const int lim = left < 0 ? 0 : (left > 32 ? 32 : (int)left);
+    const bool ok = have & (s < nst) & (sl < lim) & (cvv > 0.0f);   /* (s = nst: the loop's look-ahead past its last k-step -- factor 0) */
+    const float x = ok ? kmin * __builtin_amdgcn_rcpf(cvv) : 0.0f;
+    const float f = fminf(x, SQ3_SPLIT);
+    const bool big = x > SQ3_SPLIT;
+    const bool slow = __builtin_amdgcn_ballot_w64(big) != 0;          /* (seldom: the second factor costs 16 instructions per k-step) */
+    *reinterpret_cast<_Float16 *>(wbs + fsw + buf * 128) = (_Float16)f;
+    if (slow) *reinterpret_cast<_Float16 *>(wbs + fsw + buf * 128 + 64) = (_Float16)(big ? x * (1.0f / SQ3_SPLIT) : 1.0f);
+    return slow;
+  };
+  /* Hand-ordered half k-steps.  The two waves of a SIMD run in lockstep (one barrier per k-step), so a wave that issues its eight
+   * MFMAs back to back leaves the VALU port idle for 256 cycles and then both waves queue on it: measured, the VALU work and
+   * the MFMAs of a k-step simply ADD (1.41 ms of compute = 0.93 + 0.48).  Here every MFMA is followed by the 4 - 8 VALU
+   * instructions that fit under it: first the unpair of this half's own A fragments, then -- their loads issued at the top of
+   * the half -- the D fragment of the NEXT half (unpair, common factor, bias sums).  sched_barrier(0) after every group: the
+   * source order is the issue order. */
+  auto conv_d_part = [&](bool slow, const Half &H, const Fac &F, int t, v4uu &e4, v4uu &o4) {
+    const unsigned w0 = t < 2 ? H.d0[2 * t] : H.d1[2 * t - 4], w1 = t < 2 ? H.d0[2 * t + 1] : H.d1[2 * t - 3];
+    const unsigned ft = F.f[t], gt = F.g[t];
+    unsigned e = __builtin_amdgcn_perm(w1, w0, 0x05040100u), o = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+    e = sqw_pk_mul(e, ft);
+    o = sqw_pk_mul(o, ft);
+    if (__builtin_expect(slow, 0)) {      /* (a real branch on the scalar flag: the empty asm keeps it from becoming two selects) */
+      asm volatile("");
+      e = sqw_pk_mul(e, gt); o = sqw_pk_mul(o, gt);
+    }
+    if (BIAS) {
+      bsum[0] = __builtin_amdgcn_fdot2(__builtin_bit_cast(sqw_h2, e), __builtin_bit_cast(sqw_h2, one2), bsum[0], false);
+      bsum[1] = __builtin_amdgcn_fdot2(__builtin_bit_cast(sqw_h2, o), __builtin_bit_cast(sqw_h2, one2), bsum[1], false);
+    }
+    e4[t] = e; o4[t] = o;
+  };
+#define SQ3_SB() __builtin_amdgcn_sched_barrier(0)
+  /* MFMAs of the half whose operands are (dE, dO, H.a) + the D fragment of the half (Hn, Fn) -> (nE, nO) */
+  /* (so_next >= 0: (Hn, Fn) = the second half of the k-step in slot so_next, loaded here BEHIND the first MFMA -- the first
+   * unpair waits for lgkmcnt(0), which must not include loads issued a moment ago) */
+  auto half_step = [&](bool slow, const v4uu dE4, const v4uu dO4, const Half &H, Half &Hn, Fac &Fn, v4uu &nE, v4uu &nO, int so_next, int buf) {
+    const sqw_v8h dE = __builtin_bit_cast(sqw_v8h, dE4), dO = __builtin_bit_cast(sqw_v8h, dO4);
+    const sqw_v8h aE0 = __builtin_bit_cast(sqw_v8h, frag(H.a[0][0], H.a[0][1], 0x05040100u));
+    SQ3_SB();
+    acc[0][0] = SQ3_MFMA(dE, aE0, acc[0][0], 0, 0, 0);
+    if (so_next >= 0) { Hn = load_half(so_next, 1); Fn = load_fac(buf, 1, slow); }
+    const sqw_v8h aO0 = __builtin_bit_cast(sqw_v8h, frag(H.a[0][0], H.a[0][1], 0x07060302u));
+    SQ3_SB();
+    acc[1][0] = SQ3_MFMA(dO, aE0, acc[1][0], 0, 0, 0);
+    const sqw_v8h aE1 = __builtin_bit_cast(sqw_v8h, frag(H.a[1][0], H.a[1][1], 0x05040100u));
+    SQ3_SB();
+    acc[0][1] = SQ3_MFMA(dE, aO0, acc[0][1], 0, 0, 0);
+    const sqw_v8h aO1 = __builtin_bit_cast(sqw_v8h, frag(H.a[1][0], H.a[1][1], 0x07060302u));
+    SQ3_SB();
+    acc[1][1] = SQ3_MFMA(dO, aO0, acc[1][1], 0, 0, 0);
+    conv_d_part(slow, Hn, Fn, 0, nE, nO);
+    SQ3_SB();
+    acc[0][2] = SQ3_MFMA(dE, aE1, acc[0][2], 0, 0, 0);
+    conv_d_part(slow, Hn, Fn, 1, nE, nO);
+    SQ3_SB();
+    acc[1][2] = SQ3_MFMA(dO, aE1, acc[1][2], 0, 0, 0);
+    conv_d_part(slow, Hn, Fn, 2, nE, nO);
+    SQ3_SB();
+    acc[0][3] = SQ3_MFMA(dE, aO1, acc[0][3], 0, 0, 0);
+    conv_d_part(slow, Hn, Fn, 3, nE, nO);
+    SQ3_SB();
+    acc[1][3] = SQ3_MFMA(dO, aO1, acc[1][3], 0, 0, 0);
+    asm volatile("" : "+v"(nE), "+v"(nO));      /* (used here: or MachineSink carries the conversion off to the block of its first MFMA, behind the barrier) */
+    SQ3_SB();
+  };
+  auto opaque = [&] { asm volatile("" : "+v"(rowD), "+v"(rowA), "+v"(fsl), "+v"(fsw), "+v"(cvr), "+v"(choff[0][0]), "+v"(choff[0][1]), "+v"(choff[1][0]), "+v"(choff[1][1])); };
+  /* The loop runs half a k-step ahead of its MFMAs.  The barrier sits in the MIDDLE of k-step s: there every wave has its part
+   * of k-step s + 1 (own vmcnt) and has read the last of k-step s - 1, whose slot is re-armed with k-step s + 3. */
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s, s);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM * (NS - 2)) : "memory");
+  bool slow0 = put_factors(*reinterpret_cast<const float *>(wbs + cvr), 0, 0);
+  Half R0 = load_half(0, 0);
+  v4uu dE, dO, nE, nO;
+  {
+    const Fac F0 = load_fac(0, 0, slow0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) conv_d_part(slow0, R0, F0, t, dE, dO);
+  }
+#pragma unroll 1
+  for (int s = 0; s < nst; ++s) {
+    opaque();
+    const int b = s & 1, so0 = (s & 3) * SQ3_SLOT, so1 = ((s + 1) & 3) * SQ3_SLOT;
+    Half R1;
+    Fac F1;
+    half_step(slow0, dE, dO, R0, R1, F1, nE, nO, so0, b);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM * (NS - 3)) : "memory");
+    const float cvv = *reinterpret_cast<const float *>(wbs + so1 + cvr);     /* (on its way while the DMA addresses are made) */
+    SQ3_SB();
+#ifndef REFNERF_EXPERIMENT_SQ3_NODMA
+    issue(s + NS - 1, (s + NS - 1) & 3);
+#endif
+    SQ3_SB();
+    slow0 = put_factors(cvv, s + 1, b ^ 1);
+    SQ3_SB();
+    R0 = load_half(so1, 0);
+    Fac F0 = load_fac(b ^ 1, 0, slow0);
+    SQ3_SB();
+    half_step(slow0, nE, nO, R1, R0, F0, dE, dO, -1, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* (the re-armed slots' DMA before the workgroup gives its LDS back) */
+  const float inv = have ? 1.0f / kmin : 0.0f;
+  float *part = A.part + (size_t)slice * NUM_PARAMS;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int colk = wn * 128 + (j >> 1) * 64 + 2 * sl + (j & 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + i;
+        if (orow < J.n_out && colk < J.n_in) part[wjob_row_off(J, orow) + colk] = acc[i][j][r] * inv;
+      }
+    }
+  if (BIAS) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float sum = bsum[i];
+      sum += __shfl_xor(sum, 32, 64);
+      const int orow = wm * 64 + 2 * sl + i;
+      if (h == 0 && orow < J.n_out) part[wjob_bias_off(J, orow)] = sum * inv;
+    }
+  }
+}
+
 /* grid = jobs x slices workgroups of 512 threads, the heaviest jobs first.  (Slices per job in proportion to the job's bytes --
  * two even rounds of ~495 workgroups -- measured SLOWER, 3.9 against 3.3 ms: a k-step of a light job costs the same MFMA and
  * conversion time as a heavy one's, so its few long workgroups became the tail: docs/EXPERIMENTS.md section 10.) */
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_sq256_kernel(const WgradSqArgs A, int slices, const float *__restrict__ kmin_all, int act11) {
+#ifdef REFNERF_EXPERIMENT_SQ2_SLICE_MAJOR
+  const int slice = blockIdx.x / WJOBS_SQ.n, tix = blockIdx.x - slice * WJOBS_SQ.n;
+#else
   const int tix = blockIdx.x / slices, slice = blockIdx.x - tix * slices;
+#endif
   const int ji = SQ2_ORDER.o[tix];
+#ifndef REFNERF_SQ2_CONVERT_PASS
+  if (WJOBS_SQ.job[ji].half != 0 || act11 != 0) {
+    if (threadIdx.x < 256 && WJOBS_SQ.job[ji].j.b_off >= 0) wgrad_sq256_raw_body<true>(A, slice, ji, kmin_all);
+    else wgrad_sq256_raw_body<false>(A, slice, ji, kmin_all);
+  }
+#else
   if (WJOBS_SQ.job[ji].half != 0 || act11 != 0) wgrad_sq256_body<true>(A, slice, ji, kmin_all);
+#endif
   else wgrad_sq256_body<false>(A, slice, ji, kmin_all);
 }
 

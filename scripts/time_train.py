@@ -14,6 +14,8 @@ from refnerf_pl_amd import utils
 model, cfg, blob = bench.build_model(args, spec, dev)
 if os.environ.get("REFNERF_WGRAD_MODE"):
     cfg.hip_wgrad_mode = os.environ["REFNERF_WGRAD_MODE"]
+if os.environ.get("REFNERF_NO_FINITE_CHECK"):
+    cfg.hip_check_finite = False          # timing-only builds (-DREFNERF_EXPERIMENT_*) compute garbage
 rays = utils.rays_from_dict(bench.make_rays(spec, spec["rays"], seed=1), dev)
 sync = torch.cuda.synchronize
 for mode in (sys.argv[1:] or ["f32", "f16x2", "bf16"]):
