@@ -540,6 +540,8 @@ typedef _Float16 sqw_h2 __attribute__((ext_vector_type(2)));
 #else
 #define SQ3_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
 #endif
+/* this wave's part of the k-step that is due has landed (KSTEPS younger ones may still fly), then everybody's */
+#define SQ3_WAIT_BARRIER(KSTEPS) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM * (KSTEPS)) : "memory")
 /* BIAS: this wave carries the bias sums of its 64 rows (the waves of column half 0 of a job with a bias: one per SIMD) */
 template <bool BIAS>
 __device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int slice, int ji, const float *__restrict__ kmin_all) {
@@ -713,7 +715,7 @@ __device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int s
    * of k-step s + 1 (own vmcnt) and has read the last of k-step s - 1, whose slot is re-armed with k-step s + 3. */
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) issue(s, s);
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM * (NS - 2)) : "memory");
+  SQ3_WAIT_BARRIER(NS - 2);
   bool slow0 = put_factors(*reinterpret_cast<const float *>(wbs + cvr), 0, 0);
   Half R0 = load_half(0, 0);
   v4uu dE, dO, nE, nO;
@@ -728,8 +730,10 @@ __device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int s
     const int b = s & 1, so0 = (s & 3) * SQ3_SLOT, so1 = ((s + 1) & 3) * SQ3_SLOT;
     Half R1;
     Fac F1;
+#ifndef REFNERF_EXPERIMENT_SQ3_NOCOMPUTE
     half_step(slow0, dE, dO, R0, R1, F1, nE, nO, so0, b);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM * (NS - 3)) : "memory");
+#endif
+    SQ3_WAIT_BARRIER(NS - 3);
     const float cvv = *reinterpret_cast<const float *>(wbs + so1 + cvr);     /* (on its way while the DMA addresses are made) */
     SQ3_SB();
 #ifndef REFNERF_EXPERIMENT_SQ3_NODMA
@@ -741,7 +745,9 @@ __device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int s
     R0 = load_half(so1, 0);
     Fac F0 = load_fac(b ^ 1, 0, slow0);
     SQ3_SB();
+#ifndef REFNERF_EXPERIMENT_SQ3_NOCOMPUTE
     half_step(slow0, nE, nO, R1, R0, F0, dE, dO, -1, 0);
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* (the re-armed slots' DMA before the workgroup gives its LDS back) */
   const float inv = have ? 1.0f / kmin : 0.0f;

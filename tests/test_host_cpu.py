@@ -503,3 +503,30 @@ def test_every_roofline_names_its_profile():
     line = bench.compact_line({"metric": "m", "value": 1.0, "dtype": "f16x2", "roofline": bench.mfma_roofline("f16x2", "rn::level_fwd_f16x2", 2.0, 1, 1e12, "C2", 4096, 128),
                                "timed_blocks": {"blocks": 5, "reported": "median", "ms_per_step": [1, 2, 3, 4, 5]}})
     assert line["roofline"]["pmc_source"].startswith("profiles/r06/pmc_level_fwd_f16x2.csv") and line["timed_blocks"]["blocks"] == 5
+
+
+def test_scratch_of_the_training_kernels_is_what_design_md_states():
+    """Code-object metadata of the built library (scripts/kernel_meta.py: private_segment_fixed_size = scratch bytes per lane,
+    read with llvm-readelf -- no GPU needed): the backward of the mode of record and the weight-gradient GEMM hold every value
+    in registers (round 5: 640 B/lane in the backward), the eval kernels of the three 16-bit modes likewise; the training
+    forward's 152 B/lane is the figure DESIGN.md accounts for.  A build that regresses fails here, before any timing."""
+    import importlib.util
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("no llvm-readelf on this host")
+    spec = importlib.util.spec_from_file_location("kernel_meta", os.path.join(here, "scripts", "kernel_meta.py"))
+    km = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(km)
+    meta = {k: v for k, v in km.kernel_meta(_hip.LIB_PATH).items()}
+
+    def scratch(fragment):
+        hits = [int(v["private_segment_fixed_size"]) for k, v in meta.items() if fragment in k]
+        assert hits, fragment
+        return max(hits)
+
+    assert scratch("level_bwd_sq") == 0
+    assert scratch("wgrad_sq256_kernel") == 0
+    assert scratch("wgrad_sq_kernel") == 0
+    for eval_kernel in ("level_fwd_f16x2ENS", "level_fwd_bf16ENS", "level_fwd_f16ENS"):
+        assert scratch(eval_kernel) == 0, eval_kernel
+    assert scratch("level_fwd_train_sq") <= 152
