@@ -343,7 +343,7 @@ int wgrad(const float *d_act, const float *d_delta, long long S, long long pitch
   /* REFNERF_WGRAD_SQ_TILE=128: the four-wave 128 x 128 tiles (measurement aid; the default 256 x 256 tile fetches every operand once) */
   static const bool tile128 = [] { const char *e = getenv("REFNERF_WGRAD_SQ_TILE"); return e && atoi(e) == 128; }();
   SQ_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_kmin, 0x7f800000, 32, st));
-  hipLaunchKernelGGL(rn::delta_kappa_min, dim3(rn::DSC_ROWS, 64), dim3(256), 0, st, d_delta, S, d_kmin);
+  hipLaunchKernelGGL(rn::delta_kappa_min, dim3(256), dim3(256), 0, st, d_delta, S, d_kmin);
   rn::WgradSqArgs w;
   w.act = d_act; w.delta = d_delta; w.S = S; w.k_per_slice = k_per_slice; w.part = d_part;
   long tslot = -1;

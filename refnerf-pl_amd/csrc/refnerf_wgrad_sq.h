@@ -37,18 +37,38 @@ constexpr WJobsSq make_wjobs_sq() {
 constexpr WJobsSq WJOBS_SQ = make_wjobs_sq();
 
 /* K[lid] = min over the valid samples of the kappa unit of layer id `lid`; kmin[] pre-set to +inf bits.
- * grid = (DSC_ROWS, 64) x 256 threads; positive floats order like their bit patterns, so one atomicMin per block. */
+ * The DSC_ROWS kappa units of a 64-sample block are adjacent (4.5 KB): a wave takes whole blocks, lane = sample, all rows
+ * in flight at once (one row per workgroup column walked the matrix eighteen times in 256-byte steps: 62 us at C2).
+ * grid = any x 256 threads; positive floats order like their bit patterns: atomicMin on the bits. */
 __global__ __launch_bounds__(256) void delta_kappa_min(const float *__restrict__ delta, long long S, float *kmin) {
-  const int lid = blockIdx.x;
-  const float *row = delta + (long long)(DQ_K + lid) * RB;
-  float m = INFINITY;
-  for (long long s = (long long)blockIdx.y * blockDim.x + threadIdx.x; s < S; s += (long long)gridDim.y * blockDim.x) {
-    const float c = row[rb_col(s, DQ_UNITS)];
-    m = (c > 0.0f) ? fminf(m, c) : m;
-  }
+  const int lane = threadIdx.x & 63;
+  const long long nblk = (S + RB - 1) / RB, nw = (long long)gridDim.x * 4;
+  float m[DSC_ROWS];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m < INFINITY) atomicMin(reinterpret_cast<int *>(kmin) + lid, __builtin_bit_cast(int, m));
+  for (int lid = 0; lid < DSC_ROWS; ++lid) m[lid] = INFINITY;
+  for (long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); b < nblk; b += nw) {
+    const float *p = delta + (b * DQ_UNITS + DQ_K) * RB + lane;
+    const bool ok = b * RB + lane < S;
+    float c[DSC_ROWS];
+#pragma unroll
+    for (int lid = 0; lid < DSC_ROWS; ++lid) c[lid] = p[lid * RB];
+#pragma unroll
+    for (int lid = 0; lid < DSC_ROWS; ++lid) m[lid] = (ok && c[lid] > 0.0f) ? fminf(m[lid], c[lid]) : m[lid];
+  }
+  /* one atomic per workgroup and row (atomics on one address queue up in the L2: 2048 waves x 18 rows of them took 0.3 ms) */
+  __shared__ float wm[4][DSC_ROWS];
+#pragma unroll
+  for (int lid = 0; lid < DSC_ROWS; ++lid) {
+    float v = m[lid];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    if (lane == 0) wm[threadIdx.x >> 6][lid] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < DSC_ROWS) {
+    const float v = fminf(fminf(wm[0][threadIdx.x], wm[1][threadIdx.x]), fminf(wm[2][threadIdx.x], wm[3][threadIdx.x]));
+    if (v < INFINITY) atomicMin(reinterpret_cast<int *>(kmin) + threadIdx.x, __builtin_bit_cast(int, v));
+  }
 }
 
 typedef _Float16 sqw_v2h __attribute__((ext_vector_type(2)));
@@ -515,7 +535,10 @@ __device__ __forceinline__ void wgrad_sq256_body(const WgradSqArgs &A, int slice
  * f_2t+1) multiplies the operand dword of samples 2t, 2t + 1).  No T, no second barrier, no LDS round trip of the converted
  * tile, and the LDS that T took is a fourth ring slot.
  * Ring slot = [D: 128 pair rows x 128 B | A: 128 pair rows x 128 B | c: 8 waves x 128 B]; 16-B chunk c of pair row p at chunk
- * c ^ (p & 7) (the DMA lane picks its global chunk accordingly: the swizzle is free).
+ * c ^ ((p >> 1) & 7) (the DMA lane picks its global chunk accordingly: the swizzle is free).  Rows are 128 B and the LDS has 64
+ * banks: the 16 rows a quarter wave reads at one chunk are 8 row PAIRS, each pair the two halves of one 256-B bank line -- so the
+ * chunk is swizzled by the pair's number (swizzled by the row's own number, rows r and r + 8 met on the same banks: 44 % of the
+ * kernel's LDS cycles were bank conflicts, profiles/r06 of the first build).
  * What bounds the compute side is the SIMD's one issue port: a k-step is 16 MFMAs (32 cycles each) + ~100 VALU instructions
  * per wave, two waves per SIMD in lockstep (one barrier per k-step).  Measured on the way (docs/EXPERIMENTS.md section 11): the
  * conversion at fragment-load time but phase by phase (loads, wait, convert, 8 MFMAs) 2.17 -> 1.89 ms; the same with the loads
@@ -571,8 +594,8 @@ __device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int s
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
   float bsum[2] = {0.0f, 0.0f};
 
-  /* DMA: lane -> pair row 64 q + tid / 8 of both operands, global chunk (tid & 7) ^ (row & 7), LDS chunk tid & 7 */
-  const int p0 = tid >> 3, c4 = (((tid & 7) ^ (p0 & 7)) & 7) * 4;
+  /* DMA: lane -> pair row 64 q + tid / 8 of both operands, global chunk (tid & 7) ^ ((row >> 1) & 7), LDS chunk tid & 7 */
+  const int p0 = tid >> 3, c4 = (((tid & 7) ^ (p0 >> 1)) & 7) * 4;
   const int aup = halfrows ? 1 : 2;
   const int dlast = (J.n_out - 1) / 2, alast = (J.n_in - 1) / 2;
   /* address = a scalar base (matrix + the k-step's place in it: the same for every lane, SALU work) + a lane offset that
@@ -599,8 +622,8 @@ __device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int s
     }
     if (lane < 8) __builtin_amdgcn_global_load_lds((sq2_gptr)(db + coff), (sq2_lptr)(wbs + slot * SQ3_SLOT + 2 * SQ3_OP + wave * 128), 16, 0, 0);
   };
-  /* fragment addresses: pair row (wm 32 + sl) of D, (wn 64 + jj 32 + sl) of A; logical chunk 4 kk + 2 h + e at ^ (sl & 7) */
-  const int x7 = sl & 7;
+  /* fragment addresses: pair row (wm 32 + sl) of D, (wn 64 + jj 32 + sl) of A; logical chunk 4 kk + 2 h + e at ^ ((sl >> 1) & 7) */
+  const int x7 = (sl >> 1) & 7;
   int choff[2][2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk)

@@ -33,6 +33,25 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigne
   lo = pk(x0 - (float)h0, x1 - (float)h1);
 }
 struct Acc { v4f t0, t1; };
+#ifdef ASMFRAG
+/* -DASMFRAG: the A-fragment reads as inline asm, so that the compiler's counter pass does not see them (it waits for
+ * lgkmcnt(0) -- every read issued so far -- in front of each fragment's first use); the waits are placed by hand with the count
+ * of reads issued behind the fragment's own (LDS reads return in order) */
+__device__ __forceinline__ v8h frag_asm(unsigned addr, int off) {
+  v8h r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(0) : "memory");
+  (void)off;
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ v8h frag_asm_o(unsigned addr) {
+  v8h r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void frag_wait(v8h &f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
+#endif
 
 __global__ __launch_bounds__(64 * NW) void trunk(const char *img, float *out, long long *cyc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,6 +101,10 @@ __global__ __launch_bounds__(64 * NW) void trunk(const char *img, float *out, lo
   v8h fr[NFR];
 #pragma unroll
   for (int d = 0; d < NFR; ++d) fr[d] = *reinterpret_cast<const v8h *>(WB + 1024 + lane * 16 + d * 1024);
+#ifdef ASMFRAG
+  const unsigned lbase = (unsigned)(unsigned long long)(lptr_t)WB + 1024 + lane * 16;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 
   /* one chunk: 4 k-steps x [WhT0 H | WhT1 H | WlT0 H | WlT1 H | WhT0 L | WhT1 L] per tile; pieces 4 s .. 4 s + 3; HALF = 0 / 1 = SQ_A / SQ_B */
   auto chunk = [&](const v4u (&in)[TILES][16], Acc (&acc)[TILES], int half, auto &&hook) {
@@ -90,8 +113,25 @@ __global__ __launch_bounds__(64 * NW) void trunk(const char *img, float *out, lo
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
+#ifdef REORDER   /* [WhT0 H | WhT1 H | WhT0 L | WhT1 L | WlT0 H | WlT1 H]: the Wh pieces are released two MFMAs earlier, every piece is re-read >= 3 reads ahead of its use */
+        const int piece = j < 2 ? j : j - 2;
+        const bool lo = j == 2 || j == 3;
+#else
         const int piece = j < 4 ? j : j - 4;
         const bool lo = j >= 4;
+#endif
+#ifdef ASMFRAG
+        /* first use of a piece in this k-step: j = 0..3.  Reads issued behind its own: NFR = 4: 1, 0, 3, 3; each further
+         * k-step of ring depth adds 4 */
+#ifdef REORDER
+        if (j == 0 || j == 4 || j == 5) frag_wait<3 + (NFR - 4)>(fr[(4 * s + piece) % NFR]);
+        if (j == 1) frag_wait<2 + (NFR - 4)>(fr[(4 * s + piece) % NFR]);
+#else
+        if (j == 0) frag_wait<1 + (NFR - 4)>(fr[(4 * s + piece) % NFR]);
+        if (j == 1) frag_wait<0 + (NFR - 4)>(fr[(4 * s + piece) % NFR]);
+        if (j == 2 || j == 3) frag_wait<3 + (NFR - 4)>(fr[(4 * s + piece) % NFR]);
+#endif
+#endif
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
           const v8h b = __builtin_bit_cast(v8h, in[t][2 * (4 * half + s) + (lo ? 1 : 0)]);
@@ -99,11 +139,25 @@ __global__ __launch_bounds__(64 * NW) void trunk(const char *img, float *out, lo
           else acc[t].t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[(4 * s + piece) % NFR], b, acc[t].t0, 0, 0, 0);
         }
         /* release: pieces 2, 3 after j = 2, 3 (their last use), pieces 0, 1 after j = 4, 5 */
+#ifdef REORDER
+        const int rel = j >= 2 ? j - 2 : -1;
+#else
         const int rel = j == 2 ? 2 : (j == 3 ? 3 : (j == 4 ? 0 : (j == 5 ? 1 : -1)));
+#endif
         if (rel >= 0) {
           const int q = 4 * s + rel + NFR;
           /* (NFR = 8: the ring runs into the next chunk from k-step 2 on -- behind the rendezvous of k-step 1, as it must) */
+#ifdef ASMFRAG
+          {
+            const unsigned a = lbase + (q < 16 ? cur : nxt);
+            v8h r;
+            if (q < 16) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"((4 * s + rel + NFR) % 16 * 1024));
+            else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"((4 * s + rel + NFR - 16) % 16 * 1024));
+            fr[(4 * s + rel) % NFR] = r;
+          }
+#else
           fr[(4 * s + rel) % NFR] = q < 16 ? *reinterpret_cast<const v8h *>(c + q * 1024) : *reinterpret_cast<const v8h *>(n + (q - 16) * 1024);
+#endif
         }
         hook(6 * s + j);
         if (s == 1 && j == 5) {          /* mid-chunk rendezvous: chunk c + 1 landed for every wave, slot of c - 1 free */
