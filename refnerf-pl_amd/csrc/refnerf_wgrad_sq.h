@@ -286,6 +286,8 @@ __global__ __launch_bounds__(64 * SQW_NW) __attribute__((amdgpu_waves_per_eu(2))
  * k-steps (2 x 56 KB per CU) are in flight while a third is converted (unpair, common factor, transpose) into the fragment
  * layout T and multiplied.  LDS: T 48 KB + 2 x 56 KB = 160 KB (no lo operand: T 32 KB + 3 x 40 KB).  Jobs issued heaviest first.
  * Same arithmetic and slice order as wgrad_sq_kernel (the bias sums add in another order).
+ * (Round 6: the shipped kernel runs wgrad_sq256_raw_body below -- no conversion pass, no T; this body builds with
+ * -DREFNERF_SQ2_CONVERT_PASS for A/B runs.)
  * ------------------------------------------------------------------------------------------------------------------------- */
 constexpr int SQ2_KT = 32, SQ2_T = 256, SQ2_ROWB = SQ2_KT * 2;
 constexpr int SQ2_REG = SQ2_T * SQ2_ROWB;                      /* one operand of T: 16 KB */
@@ -545,6 +547,7 @@ __device__ __forceinline__ void wgrad_sq256_body(const WgradSqArgs &A, int slice
  * half a k-step ahead but the MFMAs still back to back: 2.04 (VALU time and MFMA time simply add); every MFMA followed by the
  * 4 - 8 VALU instructions that fit under it, the D fragment of the NEXT half k-step among them: 1.75; scalar DMA bases, the
  * second factor on a scalar branch, bias sums on one wave per SIMD only: 1.71 ms = 0.67 of 8 TB/s (DMA alone: 1.63).
+ * The 22-bit mode's spatial jobs (LO: a third operand, three 49 KB slots, four units of eight MFMAs per k-step): 3.19 -> 2.75 ms.
  * ------------------------------------------------------------------------------------------------------------------------- */
 constexpr int SQ3_NS = 4;
 #ifndef REFNERF_SQ3_SPLIT
@@ -566,10 +569,17 @@ typedef _Float16 sqw_h2 __attribute__((ext_vector_type(2)));
 /* this wave's part of the k-step that is due has landed (KSTEPS younger ones may still fly), then everybody's */
 #define SQ3_WAIT_BARRIER(KSTEPS) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM * (KSTEPS)) : "memory")
 /* BIAS: this wave carries the bias sums of its 64 rows (the waves of column half 0 of a job with a bias: one per SIMD) */
-template <bool BIAS>
+template <bool V> struct Sq3Tag { static constexpr bool value = V; };
+/* LO: the 22-bit mode's spatial jobs -- a third operand, the lo halves of the layer inputs (pair units one unit behind their hi
+ * units): slot = D | A_hi | A_lo | c = 49 KB, three slots, and a k-step is FOUR units of eight MFMAs (kk 0 hi, kk 0 lo, kk 1 hi,
+ * kk 1 lo): each unit's A fragments are loaded during the unit before, the D fragment of the next kk is converted during the lo unit */
+template <bool BIAS, bool LO>
 __device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int slice, int ji, const float *__restrict__ kmin_all) {
   extern __shared__ __attribute__((aligned(16))) char wbs[];
-  constexpr int NS = SQ3_NS, VM = 5;
+  constexpr int NS = LO ? 3 : SQ3_NS, VM = LO ? 7 : 5;
+  constexpr int NOP = LO ? 3 : 2;                     /* operands of a slot */
+  constexpr int SLOT = NOP * SQ3_OP + 8 * 128, FSB = NS * SLOT;
+  static_assert(FSB + 8 * 256 <= SQ2_LDS, "inside the kernel's LDS");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, sl = lane & 31;
   const int wm = wave & 3, wn = wave >> 2;      /* (waves w and w + 4 share a SIMD: one of each column half) */
@@ -614,13 +624,14 @@ __device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int s
     const int kh = kh0 + (s < nst ? s : nst - 1);                    /* k / 32: 64-sample block kh / 2, half kh & 1 */
     const char *db = dmat + ((long long)(kh >> 1) * (DQ_UNITS * RB * 4) + (kh & 1) * 128);
     const char *ab = amat + ((long long)(kh >> 1) * (AQ_UNITS * RB * 4) + (kh & 1) * 128);
-    char *base = wbs + slot * SQ3_SLOT + wave * 1024;
+    char *base = wbs + slot * SLOT + wave * 1024;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       __builtin_amdgcn_global_load_lds((sq2_gptr)(db + doff[q]), (sq2_lptr)(base + q * 8192), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((sq2_gptr)(ab + aoff[q]), (sq2_lptr)(base + SQ3_OP + q * 8192), 16, 0, 0);
+      if (LO) __builtin_amdgcn_global_load_lds((sq2_gptr)(ab + aoff[q] + RB * 4), (sq2_lptr)(base + 2 * SQ3_OP + q * 8192), 16, 0, 0);
     }
-    if (lane < 8) __builtin_amdgcn_global_load_lds((sq2_gptr)(db + coff), (sq2_lptr)(wbs + slot * SQ3_SLOT + 2 * SQ3_OP + wave * 128), 16, 0, 0);
+    if (lane < 8) __builtin_amdgcn_global_load_lds((sq2_gptr)(db + coff), (sq2_lptr)(wbs + slot * SLOT + NOP * SQ3_OP + wave * 128), 16, 0, 0);
   };
   /* fragment addresses: pair row (wm 32 + sl) of D, (wn 64 + jj 32 + sl) of A; logical chunk 4 kk + 2 h + e at ^ ((sl >> 1) & 7) */
   const int x7 = (sl >> 1) & 7;
@@ -631,7 +642,7 @@ __device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int s
     for (int e = 0; e < 2; ++e) choff[kk][e] = (((4 * kk + 2 * h + e) ^ x7) & 7) << 4;
   int rowD = (wm * 32 + sl) * 128, rowA = SQ3_OP + (wn * 64 + sl) * 128;
   /* per wave, two buffers (k-step parity) of the k-step's factors as halves: f of sample k at + 2 k, g at + 64 + 2 k */
-  int fsl = SQ3_FS + wave * 256 + h * 16, fsw = SQ3_FS + wave * 256 + sl * 2, cvr = 2 * SQ3_OP + wave * 128 + sl * 4;
+  int fsl = FSB + wave * 256 + h * 16, fsw = FSB + wave * 256 + sl * 2, cvr = NOP * SQ3_OP + wave * 128 + sl * 4;
   const unsigned one2 = 0x3c003c00u;
   typedef unsigned v4uu __attribute__((ext_vector_type(4)));
   auto frag = [](const v4uu w0, const v4uu w1, unsigned sel) {
@@ -734,43 +745,144 @@ __device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int s
     SQ3_SB();
   };
   auto opaque = [&] { asm volatile("" : "+v"(rowD), "+v"(rowA), "+v"(fsl), "+v"(fsw), "+v"(cvr), "+v"(choff[0][0]), "+v"(choff[0][1]), "+v"(choff[1][0]), "+v"(choff[1][1])); };
-  /* The loop runs half a k-step ahead of its MFMAs.  The barrier sits in the MIDDLE of k-step s: there every wave has its part
-   * of k-step s + 1 (own vmcnt) and has read the last of k-step s - 1, whose slot is re-armed with k-step s + 3. */
+  if constexpr (LO) {
+    /* ---- four units per k-step ---- */
+    struct A4 { v4uu a[2][2]; };
+    struct D2 { v4uu d0, d1; };
+    auto load_a = [&](int so, int kk, int op) {          /* op 1 = hi, 2 = lo */
+      A4 R;
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s) issue(s, s);
-  SQ3_WAIT_BARRIER(NS - 2);
-  bool slow0 = put_factors(*reinterpret_cast<const float *>(wbs + cvr), 0, 0);
-  Half R0 = load_half(0, 0);
-  v4uu dE, dO, nE, nO;
-  {
-    const Fac F0 = load_fac(0, 0, slow0);
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) conv_d_part(slow0, R0, F0, t, dE, dO);
-  }
+        for (int e = 0; e < 2; ++e) R.a[jj][e] = *reinterpret_cast<const v4uu *>(wbs + so + rowA + (op - 1) * SQ3_OP + jj * 4096 + choff[kk][e]);
+      return R;
+    };
+    auto load_d = [&](int so, int kk) {
+      D2 R;
+      R.d0 = *reinterpret_cast<const v4uu *>(wbs + so + rowD + choff[kk][0]);
+      R.d1 = *reinterpret_cast<const v4uu *>(wbs + so + rowD + choff[kk][1]);
+      return R;
+    };
+    auto conv = [&](bool slow, const D2 &Dr, const Fac &F, int t, v4uu &e4, v4uu &o4) {
+      Half Hh;
+      Hh.d0 = Dr.d0; Hh.d1 = Dr.d1;
+      conv_d_part(slow, Hh, F, t, e4, o4);
+    };
+    /* one unit: eight MFMAs (dE, dO) x the four operand blocks of Ar; `behind0()` = the loads issued behind the first MFMA;
+     * CONV: the D fragment (Dn, Fn) -> (nE, nO) behind MFMAs 4 .. 7 */
+    auto unit = [&](auto conv_tag, bool slow, const v4uu dE4, const v4uu dO4, const A4 &Ar, auto &&behind0, const D2 &Dn, const Fac &Fn, v4uu &nE, v4uu &nO) {
+      constexpr bool CONV = decltype(conv_tag)::value;
+      const sqw_v8h dE = __builtin_bit_cast(sqw_v8h, dE4), dO = __builtin_bit_cast(sqw_v8h, dO4);
+      const sqw_v8h aE0 = __builtin_bit_cast(sqw_v8h, frag(Ar.a[0][0], Ar.a[0][1], 0x05040100u));
+      SQ3_SB();
+      acc[0][0] = SQ3_MFMA(dE, aE0, acc[0][0], 0, 0, 0);
+      behind0();
+      const sqw_v8h aO0 = __builtin_bit_cast(sqw_v8h, frag(Ar.a[0][0], Ar.a[0][1], 0x07060302u));
+      SQ3_SB();
+      acc[1][0] = SQ3_MFMA(dO, aE0, acc[1][0], 0, 0, 0);
+      const sqw_v8h aE1 = __builtin_bit_cast(sqw_v8h, frag(Ar.a[1][0], Ar.a[1][1], 0x05040100u));
+      SQ3_SB();
+      acc[0][1] = SQ3_MFMA(dE, aO0, acc[0][1], 0, 0, 0);
+      const sqw_v8h aO1 = __builtin_bit_cast(sqw_v8h, frag(Ar.a[1][0], Ar.a[1][1], 0x07060302u));
+      SQ3_SB();
+      acc[1][1] = SQ3_MFMA(dO, aO0, acc[1][1], 0, 0, 0);
+      if (CONV) conv(slow, Dn, Fn, 0, nE, nO);
+      SQ3_SB();
+      acc[0][2] = SQ3_MFMA(dE, aE1, acc[0][2], 0, 0, 0);
+      if (CONV) conv(slow, Dn, Fn, 1, nE, nO);
+      SQ3_SB();
+      acc[1][2] = SQ3_MFMA(dO, aE1, acc[1][2], 0, 0, 0);
+      if (CONV) conv(slow, Dn, Fn, 2, nE, nO);
+      SQ3_SB();
+      acc[0][3] = SQ3_MFMA(dE, aO1, acc[0][3], 0, 0, 0);
+      if (CONV) conv(slow, Dn, Fn, 3, nE, nO);
+      SQ3_SB();
+      acc[1][3] = SQ3_MFMA(dO, aO1, acc[1][3], 0, 0, 0);
+      if (CONV) asm volatile("" : "+v"(nE), "+v"(nO));
+      SQ3_SB();
+    };
+    typedef Sq3Tag<true> Yes;
+    typedef Sq3Tag<false> No;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s, s);
+    SQ3_WAIT_BARRIER(NS - 2);
+    bool slow0 = put_factors(*reinterpret_cast<const float *>(wbs + cvr), 0, 0);
+    v4uu dE, dO, nE, nO;
+    A4 Ah = load_a(0, 0, 1), Al;
+    {
+      const D2 D0 = load_d(0, 0);
+      const Fac F0 = load_fac(0, 0, slow0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) conv(slow0, D0, F0, t, dE, dO);
+    }
+    int i0 = 0;                                       /* slot of k-step s */
+    D2 Dn; Fac Fn;
 #pragma unroll 1
-  for (int s = 0; s < nst; ++s) {
-    opaque();
-    const int b = s & 1, so0 = (s & 3) * SQ3_SLOT, so1 = ((s + 1) & 3) * SQ3_SLOT;
-    Half R1;
-    Fac F1;
-#ifndef REFNERF_EXPERIMENT_SQ3_NOCOMPUTE
-    half_step(slow0, dE, dO, R0, R1, F1, nE, nO, so0, b);
-#endif
-    SQ3_WAIT_BARRIER(NS - 3);
-    const float cvv = *reinterpret_cast<const float *>(wbs + so1 + cvr);     /* (on its way while the DMA addresses are made) */
-    SQ3_SB();
-#ifndef REFNERF_EXPERIMENT_SQ3_NODMA
-    issue(s + NS - 1, (s + NS - 1) & 3);
-#endif
-    SQ3_SB();
-    slow0 = put_factors(cvv, s + 1, b ^ 1);
-    SQ3_SB();
-    R0 = load_half(so1, 0);
-    Fac F0 = load_fac(b ^ 1, 0, slow0);
-    SQ3_SB();
-#ifndef REFNERF_EXPERIMENT_SQ3_NOCOMPUTE
-    half_step(slow0, nE, nO, R1, R0, F0, dE, dO, -1, 0);
-#endif
+    for (int s = 0; s < nst; ++s) {
+      opaque();
+      const int b = s & 1, i1 = i0 + 1 == NS ? 0 : i0 + 1, ia = i0 == 0 ? NS - 1 : i0 - 1;
+      const int so0 = i0 * SLOT, so1 = i1 * SLOT;
+      /* kk 0 hi: the lo fragments of kk 0 on their way */
+      unit(No{}, slow0, dE, dO, Ah, [&] { Al = load_a(so0, 0, 2); }, Dn, Fn, nE, nO);
+      /* kk 0 lo: D, factors and hi fragments of kk 1 on their way, its D fragment converted */
+      unit(Yes{}, slow0, dE, dO, Al, [&] { Dn = load_d(so0, 1); Fn = load_fac(b, 1, slow0); Ah = load_a(so0, 1, 1); }, Dn, Fn, nE, nO);
+      /* kk 1 hi */
+      unit(No{}, slow0, nE, nO, Ah, [&] { Al = load_a(so0, 1, 2); }, Dn, Fn, dE, dO);
+      SQ3_WAIT_BARRIER(NS - 3);
+      const float cvv = *reinterpret_cast<const float *>(wbs + so1 + cvr);
+      SQ3_SB();
+      issue(s + NS - 1, ia);
+      SQ3_SB();
+      const bool slow1 = put_factors(cvv, s + 1, b ^ 1);
+      SQ3_SB();
+      Dn = load_d(so1, 0);
+      Fn = load_fac(b ^ 1, 0, slow1);
+      Ah = load_a(so1, 0, 1);
+      SQ3_SB();
+      /* kk 1 lo: the next k-step's first D fragment converted */
+      unit(Yes{}, slow1, nE, nO, Al, [] {}, Dn, Fn, dE, dO);
+      slow0 = slow1;
+      i0 = i1;
+    }
+  } else {
+  /* The loop runs half a k-step ahead of its MFMAs.  The barrier sits in the MIDDLE of k-step s: there every wave has its part
+     * of k-step s + 1 (own vmcnt) and has read the last of k-step s - 1, whose slot is re-armed with k-step s + 3. */
+  #pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s, s);
+    SQ3_WAIT_BARRIER(NS - 2);
+    bool slow0 = put_factors(*reinterpret_cast<const float *>(wbs + cvr), 0, 0);
+    Half R0 = load_half(0, 0);
+    v4uu dE, dO, nE, nO;
+    {
+      const Fac F0 = load_fac(0, 0, slow0);
+  #pragma unroll
+      for (int t = 0; t < 4; ++t) conv_d_part(slow0, R0, F0, t, dE, dO);
+    }
+  #pragma unroll 1
+    for (int s = 0; s < nst; ++s) {
+      opaque();
+      const int b = s & 1, so0 = (s & 3) * SLOT, so1 = ((s + 1) & 3) * SLOT;     /* (NS = 4) */
+      Half R1;
+      Fac F1;
+  #ifndef REFNERF_EXPERIMENT_SQ3_NOCOMPUTE
+      half_step(slow0, dE, dO, R0, R1, F1, nE, nO, so0, b);
+  #endif
+      SQ3_WAIT_BARRIER(NS - 3);
+      const float cvv = *reinterpret_cast<const float *>(wbs + so1 + cvr);     /* (on its way while the DMA addresses are made) */
+      SQ3_SB();
+  #ifndef REFNERF_EXPERIMENT_SQ3_NODMA
+      issue(s + NS - 1, (s + NS - 1) & 3);
+  #endif
+      SQ3_SB();
+      slow0 = put_factors(cvv, s + 1, b ^ 1);
+      SQ3_SB();
+      R0 = load_half(so1, 0);
+      Fac F0 = load_fac(b ^ 1, 0, slow0);
+      SQ3_SB();
+  #ifndef REFNERF_EXPERIMENT_SQ3_NOCOMPUTE
+      half_step(slow0, nE, nO, R1, R0, F0, dE, dO, -1, 0);
+  #endif
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* (the re-armed slots' DMA before the workgroup gives its LDS back) */
   const float inv = have ? 1.0f / kmin : 0.0f;
@@ -807,15 +919,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tix = blockIdx.x / slices, slice = blockIdx.x - tix * slices;
 #endif
   const int ji = SQ2_ORDER.o[tix];
-#ifndef REFNERF_SQ2_CONVERT_PASS
-  if (WJOBS_SQ.job[ji].half != 0 || act11 != 0) {
-    if (threadIdx.x < 256 && WJOBS_SQ.job[ji].j.b_off >= 0) wgrad_sq256_raw_body<true>(A, slice, ji, kmin_all);
-    else wgrad_sq256_raw_body<false>(A, slice, ji, kmin_all);
-  }
-#else
-  if (WJOBS_SQ.job[ji].half != 0 || act11 != 0) wgrad_sq256_body<true>(A, slice, ji, kmin_all);
-#endif
+  const bool half = WJOBS_SQ.job[ji].half != 0 || act11 != 0;      /* no lo operand */
+#ifdef REFNERF_SQ2_CONVERT_PASS                                    /* round 5's bodies with their conversion pass (A/B builds) */
+  if (half) wgrad_sq256_body<true>(A, slice, ji, kmin_all);
   else wgrad_sq256_body<false>(A, slice, ji, kmin_all);
+#else
+  const bool bias = threadIdx.x < 256 && WJOBS_SQ.job[ji].j.b_off >= 0;     /* (waves 0-3 = column half 0) */
+  if (half) {
+    if (bias) wgrad_sq256_raw_body<true, false>(A, slice, ji, kmin_all);
+    else wgrad_sq256_raw_body<false, false>(A, slice, ji, kmin_all);
+  } else {
+    if (bias) wgrad_sq256_raw_body<true, true>(A, slice, ji, kmin_all);
+    else wgrad_sq256_raw_body<false, true>(A, slice, ji, kmin_all);
+  }
+#endif
 }
 
 }  // namespace rn
