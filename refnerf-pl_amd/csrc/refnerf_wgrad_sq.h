@@ -550,6 +550,10 @@ __device__ __forceinline__ void wgrad_sq256_body(const WgradSqArgs &A, int slice
  * The 22-bit mode's spatial jobs (LO: a third operand, three 49 KB slots, four units of eight MFMAs per k-step): 3.19 -> 2.75 ms.
  * ------------------------------------------------------------------------------------------------------------------------- */
 constexpr int SQ3_NS = 4;
+#ifndef REFNERF_SQ3_DMA_AUX
+#define REFNERF_SQ3_DMA_AUX 2      /* cache policy bits of the operand stream's LDS-DMA (sc0 = 1, nt = 2, sc1 = 16): every byte is read
+                                    * once, by one CU -- nt; measured 0.5-1 % against the default policy, sc1 none (EXPERIMENTS section 11) */
+#endif
 #ifndef REFNERF_SQ3_SPLIT
 #define REFNERF_SQ3_SPLIT 32768.0f     /* (a smaller power of two sends every k-step through the two-factor path: a test build, same arithmetic) */
 #endif
@@ -627,11 +631,11 @@ __device__ __forceinline__ void wgrad_sq256_raw_body(const WgradSqArgs &A, int s
     char *base = wbs + slot * SLOT + wave * 1024;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      __builtin_amdgcn_global_load_lds((sq2_gptr)(db + doff[q]), (sq2_lptr)(base + q * 8192), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((sq2_gptr)(ab + aoff[q]), (sq2_lptr)(base + SQ3_OP + q * 8192), 16, 0, 0);
-      if (LO) __builtin_amdgcn_global_load_lds((sq2_gptr)(ab + aoff[q] + RB * 4), (sq2_lptr)(base + 2 * SQ3_OP + q * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((sq2_gptr)(db + doff[q]), (sq2_lptr)(base + q * 8192), 16, 0, REFNERF_SQ3_DMA_AUX);
+      __builtin_amdgcn_global_load_lds((sq2_gptr)(ab + aoff[q]), (sq2_lptr)(base + SQ3_OP + q * 8192), 16, 0, REFNERF_SQ3_DMA_AUX);
+      if (LO) __builtin_amdgcn_global_load_lds((sq2_gptr)(ab + aoff[q] + RB * 4), (sq2_lptr)(base + 2 * SQ3_OP + q * 8192), 16, 0, REFNERF_SQ3_DMA_AUX);
     }
-    if (lane < 8) __builtin_amdgcn_global_load_lds((sq2_gptr)(db + coff), (sq2_lptr)(wbs + slot * SLOT + NOP * SQ3_OP + wave * 128), 16, 0, 0);
+    if (lane < 8) __builtin_amdgcn_global_load_lds((sq2_gptr)(db + coff), (sq2_lptr)(wbs + slot * SLOT + NOP * SQ3_OP + wave * 128), 16, 0, REFNERF_SQ3_DMA_AUX);
   };
   /* fragment addresses: pair row (wm 32 + sl) of D, (wn 64 + jj 32 + sl) of A; logical chunk 4 kk + 2 h + e at ^ ((sl >> 1) & 7) */
   const int x7 = (sl >> 1) & 7;
