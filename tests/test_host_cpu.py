@@ -530,3 +530,43 @@ def test_scratch_of_the_training_kernels_is_what_design_md_states():
     for eval_kernel in ("level_fwd_f16x2ENS", "level_fwd_bf16ENS", "level_fwd_f16ENS"):
         assert scratch(eval_kernel) == 0, eval_kernel
     assert scratch("level_fwd_train_sq") <= 152
+
+
+def test_wgrad_loops_hold_exactly_the_vector_memory_operations_their_waits_count(tmp_path):
+    """The weight-gradient GEMM (refnerf_wgrad_sq.h, wgrad_sq256_raw_body) certifies the arrival of a k-step with
+    `s_waitcnt vmcnt(VM * k)`: VM = the LDS-DMA instructions of one k-step and wave, counted in the source.  Any other vector-memory
+    instruction the compiler put into those loops (a scratch reload, a re-fetched constant) would shift the count and let a wave read
+    a ring slot before its data has landed.  This test compiles the translation unit to assembly (no GPU needed) and audits the four
+    loop instances: exactly 5 (one-half jobs) / 7 (22-bit jobs) `global_load_lds_dwordx4`, nothing else from the vector-memory
+    family, 16 / 32 MFMAs, and the one counted wait."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this host")
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(here, "refnerf-pl_amd", "csrc")
+    out = str(tmp_path / "sq_train.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-I" + os.path.join(here, "include"),
+                           "-I" + csrc, "-S", "--cuda-device-only", os.path.join(csrc, "refnerf_sq_train.hip"), "-o", out], stderr=subprocess.DEVNULL)
+    lines = open(out).read().split("\n")
+    st = next(i for i, l in enumerate(lines) if re.match(r"_ZN2rn18wgrad_sq256_kernel\w*:", l))
+    en = next(i for i in range(st, len(lines)) if ".amdhsa_kernel _ZN2rn18wgrad_sq256_kernel" in lines[i])
+    loops = []
+    for h in (i for i in range(st, en) if "Inner Loop Header" in lines[i]):
+        label = lines[h].split(":")[0]
+        back = [i for i in range(h, en) if re.search(r"s_c?branch\S*\s+" + re.escape(label) + r"\s*$", lines[i])]
+        if back:
+            loops.append([l.strip() for l in lines[h:back[-1] + 1] if l.strip() and not l.strip().startswith(";")])
+    assert len(loops) == 4, len(loops)           # {bias wave, other wave} x {one-half jobs, 22-bit jobs}
+    seen = set()
+    for body in loops:
+        vmem = [l.split()[0] for l in body if re.match(r"(global_|buffer_|scratch_|flat_)", l)]
+        mfma = sum(1 for l in body if l.startswith("v_mfma"))
+        waits = [l for l in body if "s_waitcnt" in l and "vmcnt" in l]
+        assert set(vmem) == {"global_load_lds_dwordx4"}, vmem
+        assert (mfma, len(vmem)) in ((16, 5), (32, 7)), (mfma, len(vmem))
+        assert waits == (["s_waitcnt vmcnt(5)"] if mfma == 16 else ["s_waitcnt vmcnt(0)"]), waits
+        seen.add(mfma)
+    assert seen == {16, 32}
+    shutil.rmtree(str(tmp_path), ignore_errors=True)
