@@ -552,7 +552,16 @@ __device__ __forceinline__ void composite_phase(const LevelArgs &A, const float 
       if (A.out.d_r_distance) A.out.d_r_distance[ray] = s_dist;
       if (A.out.d_r_acc) A.out.d_r_acc[ray] = acc;
       if (cfg.compute_extras) {
-        if (cfg.training) st3(A.out.d_r_normals, ray, s_nm[0], s_nm[1], s_nm[2]);
+        if (cfg.training) {
+          if (NP > PS_NORMALS) st3(A.out.d_r_normals, ray, s_nm[0], s_nm[1], s_nm[2]);
+          else {
+            /* (a kernel without the normals' record columns writes zeros: formed HERE -- as a constant triple the compiler
+             * materialises them in front of the pass loop and carries them through it, in scratch in the ring variants) */
+            float z = 0.0f;
+            asm volatile("" : "+v"(z));
+            st3(A.out.d_r_normals, ray, z, z, z);
+          }
+        }
         st3(A.out.d_r_normals_pred, ray, s_np[0], s_np[1], s_np[2]);
         st3(A.out.d_r_tint, ray, s_tn[0], s_tn[1], s_tn[2]);
         if (A.out.d_r_roughness) A.out.d_r_roughness[ray] = s_rgh;

@@ -527,7 +527,8 @@ def test_scratch_of_the_training_kernels_is_what_design_md_states():
     assert scratch("level_bwd_sq") == 0
     assert scratch("wgrad_sq256_kernel") == 0
     assert scratch("wgrad_sq_kernel") == 0
-    for eval_kernel in ("level_fwd_f16x2ENS", "level_fwd_bf16ENS", "level_fwd_f16ENS"):
+    for eval_kernel in ("level_fwd_f16x2ENS", "level_fwd_bf16ENS", "level_fwd_f16ENS",
+                        "level_fwd_f16x2_ringENS", "level_fwd_bf16_ringENS", "level_fwd_f16_ringENS"):      # (ring variants: 16 B until round 6)
         assert scratch(eval_kernel) == 0, eval_kernel
     assert scratch("level_fwd_train_sq") <= 152
 
