@@ -228,13 +228,18 @@ __device__ __forceinline__ void sample_intervals_wave(const float *t_in, float *
   __builtin_amdgcn_wave_barrier();
 }
 
-/* this lane's index within the wave, formed HERE (round 6): asm volatile is neither hoisted out of a loop nor merged with the
- * kernel's entry value -- a lane constant derived from it lives from this point on, not across every trunk in front of it (in
- * scratch, once the kernel sits at its register limit) */
+/* this lane's index within the wave, formed HERE (round 6): a lane constant derived from it lives from this point on, not from
+ * the kernel's entry across every trunk in front of it (in scratch, once the kernel sits at its register limit) */
 __device__ __forceinline__ int fresh_lane() {
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
+  /* The lane index from the mbcnt BUILTINS on an opaque zero: not hoistable, not merged with the kernel's entry value -- and made
+   * of instructions the compiler knows.  Round 6 first had the two v_mbcnt in an `asm volatile`: the hazard recogniser does not
+   * look inside inline asm, and where the allocator gave the asm's output a register of a just-issued MFMA's dead accumulator
+   * (the rgb slice: 13 of its 16 result registers are never read) the MFMA's late write-back raced the v_mbcnt -- a lane index
+   * that was sometimes an accumulator value (found by bisecting a rewrite of the training forward's P6 that failed from run to
+   * run: docs/EXPERIMENTS.md section 11).  No inline asm in this tree holds a vector instruction any more. */
+  int z = 0;
+  asm volatile("" : "+v"(z));
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
 }
 
 __device__ __forceinline__ void st3(float *base, size_t idx, float a, float b, float c) {
