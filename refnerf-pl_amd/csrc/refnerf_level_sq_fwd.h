@@ -65,6 +65,10 @@ __device__ __forceinline__ unsigned win_load(const BlkWin &w, unsigned voff, int
   asm volatile("" : "+v"(voff));
   return __builtin_amdgcn_raw_buffer_load_b32(w.rs, voff + (unsigned)iunit * 256u, sunit * 256, 0);
 }
+/* the cycle stamps of the training kernels take their lane test from a lane index formed at the stamp (and only when profiling
+ * is on): the kernel's entry value of `lane` need not survive to them */
+#undef RN_STAMPW
+#define RN_STAMPW(A, slot) do { asm volatile("; RNMARK " #slot); if ((A).prof && blockIdx.x == (gridDim.x >> 1) && fresh_lane() == 0) (A).prof[wave * 32 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 /* a unit index the compiler must treat as a run-time scalar */
 __device__ __forceinline__ int opaque_s(int x) {
   asm volatile("" : "+s"(x));
@@ -534,15 +538,19 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
   for (int d = 0; d < SQ_NF; ++d) ar[d] = lds_frag<MM>(WB + 1024 + lane * 16 + d * 1024);
 
   for (int pass0 = 0; pass0 < n_tot; pass0 += BT) {
-    int lane_v = lane;
-    asm volatile("" : "+v"(lane_v));
+    /* (round 6) lane constants are formed from a lane index taken where they are needed (fresh_lane: not hoistable, not merged
+     * with the kernel's entry value) */
     auto locate = [&](int &g, int &rl, bool &valid) {
-      int col_l = col, pass_l = pass0;
+      int col_l = wave * 32 + (fresh_lane() & 31), pass_l = pass0;
       asm volatile("" : "+v"(col_l), "+s"(pass_l));
       g = pass_l + col_l;
       rl = g / N;
       valid = (g < n_tot) && (ray0 + rl < A.R);
     };
+    /* the ring's upper entries do not cross a pass boundary (every run re-fetches them; the directional chunks keep AF fragments
+     * ahead): defined here on every path, or the last spatial chunk's stale pieces ride through the directional trunk in scratch */
+#pragma unroll
+    for (int d = AF; d < SQ_NF; ++d) asm volatile("" : "=v"(ar[d]));
     {
       const int g0 = pass0 + wave * 32;
       if (g0 >= n_tot || ray0 + g0 / N >= A.R) { tq_idle_pass<false>(p); continue; }
@@ -555,7 +563,7 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
     auto load_heads = [&](SampleHeads &sh) {
       int g, rl; bool valid;
       locate(g, rl, valid);
-      int ci = col, ro = (valid ? rl : 0) * 12;
+      int ci = wave * 32 + (fresh_lane() & 31), ro = (valid ? rl : 0) * 12;
       asm volatile("" : "+v"(ci), "+v"(ro));
       float v[3], gp[3], raw_dif[3], raw_tint[3];
 #pragma unroll
@@ -572,17 +580,26 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
     for (int phase = 0; phase < 2; ++phase) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) { R0[e] = (v4uu){0, 0, 0, 0}; R1[e] = (v4uu){0, 0, 0, 0}; }
-      /* the lane's sample of this run: 16 * phase + (lane & 15) of the wave's 32; b = lane >> 4 = its k-group */
-      const int i16 = lane_v & 15, bq = lane_v >> 4;
-      const int cs = wave * 32 + 16 * phase + i16;          /* pass column */
-      const int gs = pass0 + cs;
-      const int rls = gs / N, sis = gs - rls * N;
-      const bool vs = (gs < n_tot) && (ray0 + rls < A.R);
-      const unsigned voff_c = blk_voff(aw, gs_pass + cs, AQ_UNITS, vs);     /* (invalid: stays out of range with any lane part added) */
+      /* the lane's sample of this run: 16 * phase + (lane & 15) of the wave's 32; b = lane >> 4 = its k-group.  Formed per
+       * section of the run (IPE | trunk + heads | VJP) from a fresh lane index and laundered loop counters */
+      struct RunConsts { int i16, bq, cs, gs; bool vs; unsigned voff_c; };
+      auto run_consts = [&]() {
+        RunConsts c;
+        int ps = pass0, ph = phase;
+        asm volatile("" : "+s"(ps), "+s"(ph));
+        const int ln = fresh_lane();
+        c.i16 = ln & 15; c.bq = ln >> 4;
+        c.cs = wave * 32 + 16 * ph + c.i16;                 /* pass column */
+        c.gs = ps + c.cs;
+        const int rls = c.gs / N;
+        c.vs = (c.gs < n_tot) && (ray0 + rls < A.R);
+        c.voff_c = blk_voff(aw, (long long)ray0 * N + ps + c.cs, AQ_UNITS, c.vs);     /* (invalid: stays out of range with any lane part added) */
+        return c;
+      };
       /* lifted mean / variance of this lane's sample (recomputed by the VJP: nothing of it lives across the trunk) */
       auto lift = [&](float (&lm)[3], float (&lv)[3]) {
-        int ln = lane_v, ps = pass0, ph = phase;
-        asm volatile("" : "+v"(ln), "+s"(ps), "+s"(ph));
+        int ln = fresh_lane(), ps = pass0, ph = phase;
+        asm volatile("" : "+s"(ps), "+s"(ph));
         const int g2 = ps + wave * 32 + 16 * ph + (ln & 15);
         const int r2 = g2 / N, s2 = g2 - r2 * N;
         const bool v2 = (g2 < n_tot) && (ray0 + r2 < A.R);
@@ -598,6 +615,9 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
       };
       {
       /* P1: four lanes per sample, each 24 of the 96 IPE features (level_fwd_split) */
+      const RunConsts rc = run_consts();
+      const int i16 = rc.i16, bq = rc.bq;
+      const unsigned voff_c = rc.voff_c;
       const int hb = bq >> 1, qq = bq & 1;
       float lm[3], lv[3];
       lift(lm, lv);
@@ -630,11 +650,19 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
       RN_STAMPW(A, 18);
       wave_sync();
       RN_STAMPW(A, 3 + phase * 4);
+      {
+        /* the pipe's lane constants of the spatial section, from here (not from the kernel's entry) */
+        const int ln = fresh_lane();
+        p.lane = ln;
+        p.xps = Xb + ((ln >> 4) * BT + wave * 16 + (ln & 15)) * 16;
+      }
       if (phase == 0) {
 #pragma unroll
-        for (int d = AF; d < SQ_NF; ++d) ar[d] = lds_frag<MM>(p.wbuf + p.cur_off + 1024 + lane_v * 16 + d * 1024);
+        for (int d = AF; d < SQ_NF; ++d) ar[d] = lds_frag<MM>(p.wbuf + p.cur_off + 1024 + p.lane * 16 + d * 1024);
       }
-      const unsigned voff_sp = blk_voff_add(voff_c, 4 * bq), voff_h = blk_voff_add(voff_c, 2 * bq);
+      const RunConsts rt_ = run_consts();
+      const int bq = rt_.bq;
+      const unsigned voff_sp = blk_voff_add(rt_.voff_c, 4 * bq), voff_h = blk_voff_add(rt_.voff_c, 2 * bq);
       SqAcc accs[2];
       sq_bias_now(p, accs[1]);
       tq_layer<true, 0, ACT_LO>(p, ar, accs, false, R0, R0, aw, voff_sp, voff_h, AQ_SP, AQ_MASK);
@@ -666,8 +694,10 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
             }
           } else {
             tq_chunk<SQ_SC, true, false, 4>(p, ar, R1, acc, ha[ob & 1]);
-            int csl = wave * 32 + 16 * phase + (lane_v & 15) + 4 * bq * BT;
+            const RunConsts rh = run_consts();
+            int csl = rh.cs + 4 * rh.bq * BT;
             asm volatile("" : "+v"(csl));
+            const int bq = rh.bq;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
               if (4 * bq + i < HD_ROWS) HD[i * BT + csl] = acc.t0[i];
@@ -681,6 +711,10 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
          * 5 and 0 through d feature / d mean.  The sign words come back from ACT (this wave's own stores). */
         /* d feature / d mean of this lane's 24 IPE rows into its own columns of the IPE planes (dead since layer 5 of this run;
          * wave-private bytes: the next run's P1 of a wave that runs ahead cannot touch another wave's) */
+        const RunConsts rv = run_consts();
+        const int i16 = rv.i16, bq = rv.bq, gs = rv.gs;
+        const bool vs = rv.vs;
+        const unsigned voff_h = blk_voff_add(rv.voff_c, 2 * bq);
         char *dfac = Xb + (wave * 16 + i16) * 16 + bq * 4;
         {
           float lm[3], lv[3];
@@ -778,6 +812,10 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
     for (int e = 0; e < 16; ++e) { R0[e] = (v4uu){0, 0, 0, 0}; R1[e] = (v4uu){0, 0, 0, 0}; }
     {
     /* P4: head activations, reflection, IDE (32 samples per wave from here on) */
+    const int lane_d = fresh_lane();
+    const int h = lane_d >> 5, n = lane_d & 31, col = wave * 32 + n;      /* (shadow the entry values from here to the end of the pass) */
+    p.lane = lane_d; p.h = h;
+    p.xp = Xb + (h * BT + col) * 16;                                      /* the pipe's lane constants of the directional section */
     int g_w, rl_w; bool valid;
     locate(g_w, rl_w, valid);
     const unsigned voff_d = blk_voff(aw, gs_pass + col, AQ_UNITS, valid);
@@ -831,23 +869,28 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
     tq_bf_chunk<false, BF_REG, 0, true, TQ_VM_DIR_LAYER>(p, ad, R1, bn, acc);
     tq_bf_chunk<false, BF_REG, 0, false, 0>(p, ad, R1, bn, acc);
     float raw_rgb[3];
+    /* P6 forms its lane constants again (P4's would ride across the directional trunk in scratch) */
+    int lane_w = fresh_lane(), pass_w = pass0;
+    asm volatile("" : "+s"(pass_w));
+    const int n6 = lane_w & 31, col6 = wave * 32 + n6;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n, 64);
-    int lane_w = lane, pass_w = pass0;
-    asm volatile("" : "+v"(lane_w), "+s"(pass_w));
-    if (valid && h == 0) {                                                            /* P6 */
+    for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n6, 64);
+    int g6, rl6; bool valid6;
+    locate(g6, rl6, valid6);
+    if (valid6 && (lane_w >> 5) == 0) {                                               /* P6 */
       SampleHeads sh;
       load_heads(sh);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) sh.normals[i] = PS[g_w * NP + PS_NORMALS + i];     /* (the VJP's; colour_store writes them back) */
-      colour_store<false, NP, 0, true>(A, sh, raw_rgb, PS, PX, n_tot, g_w, col);
+      for (int i = 0; i < 3; ++i) sh.normals[i] = PS[g6 * NP + PS_NORMALS + i];      /* (the VJP's; colour_store writes them back) */
+      colour_store<false, NP, 0, true, true>(A, sh, raw_rgb, PS, PX, n_tot, g6, col6);
       /* what the backward needs of the forward: the raw scalar head rows and raw rgb */
-      int ci = col;
+      const unsigned voff_d6 = blk_voff(aw, (long long)ray0 * N + pass_w + col6, AQ_UNITS, valid6);
+      int ci = col6;
       asm volatile("" : "+v"(ci));
 #pragma unroll
-      for (int i = 0; i < 11; ++i) win_store(aw, voff_d, opaque_s(AQ_RAW), i, __builtin_bit_cast(unsigned, HD[i * BT + ci]));
+      for (int i = 0; i < 11; ++i) win_store(aw, voff_d6, opaque_s(AQ_RAW), i, __builtin_bit_cast(unsigned, HD[i * BT + ci]));
 #pragma unroll
-      for (int i = 0; i < 3; ++i) win_store(aw, voff_d, opaque_s(AQ_RAW), 11 + i, __builtin_bit_cast(unsigned, raw_rgb[i]));
+      for (int i = 0; i < 3; ++i) win_store(aw, voff_d6, opaque_s(AQ_RAW), 11 + i, __builtin_bit_cast(unsigned, raw_rgb[i]));
     }
     wave_sync();
     history_flush<NP, 0>(A, PS, PX, n_tot, pass_w + wave * 32, wave * 32, (size_t)ray0 * N + pass_w + wave * 32, lane_w);
@@ -857,7 +900,7 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  composite_phase<BF_NW, false, NP>(A, TD, XP, PS, n_tot, ray0, wave, lane, reinterpret_cast<float *>(WB), NRM);   /* P7 */
+  composite_phase<BF_NW, false, NP>(A, TD, XP, PS, n_tot, ray0, wave, fresh_lane(), reinterpret_cast<float *>(WB), NRM);   /* P7 */
 }
 
 __global__ __launch_bounds__(BF_NTHREADS) void level_fwd_train_sq(const LevelArgs A) { level_fwd_train_sq_body<true>(A); }
