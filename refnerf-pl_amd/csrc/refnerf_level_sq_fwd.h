@@ -318,14 +318,21 @@ __device__ __forceinline__ float tq_bound_scale(float m, float G) {
   e = e > 100 ? 100 : (e < -100 ? -100 : e);
   return (x > 0.0f) ? __builtin_ldexpf(1.0f, e) : 1.0f;
 }
+/* value `v` of lane `src` (ds_bpermute on an index formed here: HIP's __shfl / __shfl_xor take this lane's index from the
+ * kernel's entry, where it is computed once and then rides -- in scratch -- to every shuffle of the kernel) */
+__device__ __forceinline__ float tq_lane_read(float v, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v)));
+}
 /* largest value over the four lanes (b = 0..3) that hold one sample */
 __device__ __forceinline__ float tq_max4(float m) {
-  m = fmaxf(m, __shfl_xor(m, 16, 64));
-  return fmaxf(m, __shfl_xor(m, 32, 64));
+  const int ln = fresh_lane();
+  m = fmaxf(m, tq_lane_read(m, ln ^ 16));
+  return fmaxf(m, tq_lane_read(m, ln ^ 32));
 }
 __device__ __forceinline__ float tq_sum4(float s) {
-  s += __shfl_xor(s, 16, 64);
-  return s + __shfl_xor(s, 32, 64);
+  const int ln = fresh_lane();
+  s += tq_lane_read(s, ln ^ 16);
+  return s + tq_lane_read(s, ln ^ 32);
 }
 /* piece q of a transposed slice's epilogue: the recorded sign bits, the sample's factor, running max, hi / lo split */
 __device__ __forceinline__ void tq_vjp_piece(const SqAcc &a, int q, v4uu &oh, v4uu &ol, unsigned mk, int bit0, float rs, float &mx) {
@@ -442,6 +449,18 @@ __device__ __forceinline__ void tq_dir_layer(Pipe &p, MmF16::v8 (&a)[AF], int se
   unsigned mk[4] = {0u, 0u, 0u, 0u};
   unit = opaque_s(unit);
   mask_unit = opaque_s(mask_unit);
+  /* the skip layer's bottleneck fragments come back from ACT HERE (32 dwords per lane, L2 hits, once per pass): held from the
+   * first directional layer on they are 32 registers live across three layers, eight of them in scratch around the layer loop.
+   * (Loads in front of the layer's first rendezvous only make its counted vmcnt wait stricter.) */
+  v4uu bnl[8];
+  if constexpr (KIND0 == BF_REG) {
+    if (second == 2) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bnl[t][q] = win_load(aw, voff_h2, opaque_s(AQ_DIN + 16 * (t >> 1)), 8 * (t & 1) + 4 * (q >> 1) + (q & 1));
+    }
+  }
 #pragma unroll
   for (int ob = 0; ob < 8; ++ob) {
     v16f acc;
@@ -450,8 +469,8 @@ __device__ __forceinline__ void tq_dir_layer(Pipe &p, MmF16::v8 (&a)[AF], int se
     tq_bf_chunk<false, KIND0, REAL0, false, 0>(p, a, in, bn, acc);
     if constexpr (KIND0 == BF_REG) {
       if (second == 2) {
-        tq_bf_chunk<false, BF_BNLDS, BF_DIR_REAL_KS, false, 0>(p, a, in, bn, acc);
-        tq_bf_chunk<false, BF_BNLDS, BF_DIR_REAL_KS, false, 0>(p, a, in, bn, acc);
+        tq_bf_chunk<false, BF_BNLDS, BF_DIR_REAL_KS, false, 0>(p, a, in, bnl, acc);
+        tq_bf_chunk<false, BF_BNLDS, BF_DIR_REAL_KS, false, 0>(p, a, in, bnl, acc);
       }
     }
     tq_pack_acc(acc, out[2 * ob], out[2 * ob + 1], mk[ob >> 1], 16 * (ob & 1));
@@ -520,7 +539,7 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
                       : lane < 6 ? A.rays.d_directions[(size_t)ray * 3 + lane - 3]
                       : lane < 9 ? A.rays.d_viewdirs[(size_t)ray * 3 + lane - 6] : A.rays.d_radii[ray];
       RYw[lane] = val;
-      const float dx = __shfl(val, 3, 64), dy = __shfl(val, 4, 64), dz = __shfl(val, 5, 64);
+      const float dx = tq_lane_read(val, 3), dy = tq_lane_read(val, 4), dz = tq_lane_read(val, 5);
       if (lane == 0) NRM[rl] = sqrtf((dx * dx + dy * dy) + dz * dz);
     }
   }
@@ -874,7 +893,7 @@ __device__ __forceinline__ void level_fwd_train_sq_body(const LevelArgs &A) {
     asm volatile("" : "+s"(pass_w));
     const int n6 = lane_w & 31, col6 = wave * 32 + n6;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) raw_rgb[i] = __shfl(acc[i], n6, 64);
+    for (int i = 0; i < 3; ++i) raw_rgb[i] = tq_lane_read(acc[i], n6);
     int g6, rl6; bool valid6;
     locate(g6, rl6, valid6);
     if (valid6 && (lane_w >> 5) == 0) {                                               /* P6 */

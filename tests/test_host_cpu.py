@@ -509,7 +509,7 @@ def test_scratch_of_the_training_kernels_is_what_design_md_states():
     """Code-object metadata of the built library (scripts/kernel_meta.py: private_segment_fixed_size = scratch bytes per lane,
     read with llvm-readelf -- no GPU needed): the backward of the mode of record and the weight-gradient GEMM hold every value
     in registers (round 5: 640 B/lane in the backward), the eval kernels of the three 16-bit modes likewise; the training
-    forward's 48 B/lane (round 5: 152) is the figure DESIGN.md accounts for.  A build that regresses fails here, before any timing."""
+    forward of the mode of record likewise (round 5: 152 B/lane).  A build that regresses fails here, before any timing."""
     import importlib.util
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
@@ -530,7 +530,7 @@ def test_scratch_of_the_training_kernels_is_what_design_md_states():
     for eval_kernel in ("level_fwd_f16x2ENS", "level_fwd_bf16ENS", "level_fwd_f16ENS",
                         "level_fwd_f16x2_ringENS", "level_fwd_bf16_ringENS", "level_fwd_f16_ringENS"):      # (ring variants: 16 B until round 6)
         assert scratch(eval_kernel) == 0, eval_kernel
-    assert scratch("level_fwd_train_sq") <= 48          # (round 5: 152; what is left: DESIGN.md section 4)
+    assert scratch("level_fwd_train_sq") == 0           # (both flavours; round 5: 152)
 
 
 def test_wgrad_loops_hold_exactly_the_vector_memory_operations_their_waits_count(tmp_path):
